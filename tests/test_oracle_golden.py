@@ -1,0 +1,199 @@
+"""Pin the oracle (oracle/rdo_oracle.py) to golden vectors produced by the reference's own code
+(tools/make_golden.py).  CPU only.  Tolerances: bit-exact where the restatement runs the same torch ops,
+1e-6 relative where the vectorised form reorders nothing but goes through a different kernel."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import rdo_oracle as O
+
+T = torch.from_numpy
+
+
+@pytest.fixture(scope="module")
+def qz(golden_dir):
+    return np.load(os.path.join(golden_dir, "quantizers.npz"))
+
+
+@pytest.mark.parametrize("tag,tconv", [("conv", False), ("tconv", True), ("gdn", False), ("vec", False)])
+@pytest.mark.parametrize("method", ["max", "mse", "l1", "l2"])
+@pytest.mark.parametrize("cw", [True, False])
+@pytest.mark.parametrize("bits", [8, 4])
+def test_uaq_init_and_fakequant(qz, tag, tconv, method, cw, bits):
+    w = T(qz[f"w_{tag}"])
+    key = f"uaq_{tag}_{method}_{'cw' if cw else 'lw'}_{bits}"
+    delta, zp = O.uaq_init(w, bits, cw, method, tconv=tconv)
+    np.testing.assert_array_equal(delta.numpy().reshape(-1), qz[key + "_delta"].reshape(-1))
+    np.testing.assert_array_equal(zp.numpy().reshape(-1), qz[key + "_zp"].reshape(-1))
+    assert tuple(delta.shape) == tuple(qz[key + "_delta"].shape)
+    out = O.uaq_fakequant(w, delta, zp, 2 ** bits)
+    np.testing.assert_array_equal(out.numpy(), qz[key + "_out"])
+
+
+def test_uaq_gaussian(qz):
+    w = T(qz["w_conv"])
+    delta, zp = O.uaq_init(w, 8, False, "gaussian")
+    np.testing.assert_array_equal(delta.numpy(), qz["uaq_conv_gaussian_lw_8_delta"])
+    np.testing.assert_array_equal(zp.numpy(), qz["uaq_conv_gaussian_lw_8_zp"])
+
+
+@pytest.mark.parametrize("tag,tconv", [("conv", False), ("tconv", True), ("gdn", False)])
+def test_adaround(qz, tag, tconv):
+    w = T(qz[f"w_{tag}"])
+    delta, zp = O.uaq_init(w, 8, True, "max", tconv=tconv)
+    np.testing.assert_array_equal(O.adaround_init_alpha(w, delta).numpy(), qz[f"ada_{tag}_alpha0"])
+    alpha = T(qz[f"ada_{tag}_alpha"]).clone().requires_grad_(True)
+    soft = O.adaround_forward(w, alpha, delta, zp, 256, True)
+    np.testing.assert_array_equal(soft.detach().numpy(), qz[f"ada_{tag}_soft"])
+    (soft * T(qz[f"ada_{tag}_gy"])).sum().backward()
+    np.testing.assert_array_equal(alpha.grad.numpy(), qz[f"ada_{tag}_galpha"])
+    hard = O.adaround_forward(w, alpha.detach(), delta, zp, 256, False)
+    np.testing.assert_array_equal(hard.numpy(), qz[f"ada_{tag}_hard"])
+    for b in (20, 11.5, 2.0):
+        np.testing.assert_array_equal(O.round_loss_term(alpha.detach(), b, 0.01).numpy(),
+                                      qz[f"ada_{tag}_roundloss_b{b}"])
+
+
+@pytest.mark.parametrize("tag", ["a4", "a3", "a2"])
+def test_act_quant(qz, tag):
+    out = O.act_quant(T(qz[f"act_{tag}_in"]))
+    np.testing.assert_array_equal(out.numpy(), qz[f"act_{tag}_out"])
+
+
+def test_lp_loss_round_ste(qz):
+    p, t = T(qz["lp_pred"]), T(qz["lp_tgt"])
+    for e in (2.0, 1.0, 3.5):
+        np.testing.assert_array_equal(O.lp_loss(p, t, p=e).numpy(), qz[f"lp_none_{e}"])
+        np.testing.assert_array_equal(O.lp_loss(p, t, p=e, reduction="all").numpy(), qz[f"lp_all_{e}"])
+    np.testing.assert_array_equal(O.round_ste(p * 3).numpy(), qz["round_ste"])
+
+
+def test_temp_decay(golden_dir):
+    d = np.load(os.path.join(golden_dir, "temp_decay.npz"))
+    for t_max, warm in ((50, 0.2), (20000, 0.2), (10, 0.0)):
+        got = [float(O.linear_temp_decay(t, t_max, warm, 20, 2)) for t in range(1, t_max + 1)]
+        np.testing.assert_array_equal(np.array(got), d[f"b_{t_max}_{warm}"])
+
+
+# ----------------------------------------------------------------------------- blocks
+def _ops_from(fx, tag, names, mode):
+    ops = {}
+    for n in names:
+        if f"{tag}/{n}.weight" not in fx:
+            continue
+        w = T(fx[f"{tag}/{n}.weight"])
+        b = T(fx[f"{tag}/{n}.bias"]) if f"{tag}/{n}.bias" in fx else None
+        if n in ("gdn", "igdn"):
+            op = O.QOp(n, w, b)
+        else:
+            k = w.shape[-1]
+            stride = 2 if (n in ("conv1", "skip") and tag.startswith("rbws")) else 1
+            op = O.QOp("conv", w, b, stride=stride, padding=k // 2)
+        if f"{tag}/{n}.delta" in fx:
+            op.delta, op.zp = T(fx[f"{tag}/{n}.delta"]), T(fx[f"{tag}/{n}.zp"])
+        op.mode = mode
+        ops[n] = op
+    return ops
+
+
+BLOCK_OPS = {"rbws": ["conv1", "conv2", "gdn", "skip"], "rbws3": ["conv1", "conv2", "gdn", "skip"],
+             "rbu": ["subpel_conv", "conv", "igdn", "upsample"], "rb": ["conv1", "conv2", "skip"]}
+
+
+@pytest.mark.parametrize("tag", ["rbws", "rbws3", "rbu", "rb"])
+def test_block_forward(golden_dir, tag):
+    fx = np.load(os.path.join(golden_dir, "blocks.npz"))
+    kind = "rbws" if tag.startswith("rbws") else tag
+    x = T(fx[f"{tag}/x"])
+    for state, mode, aq in (("fp", "fp", False), ("w8", "uaq", False), ("w8a8", "uaq", True)):
+        ops = _ops_from(fx, tag, BLOCK_OPS[tag], mode)
+        if aq:
+            # reference: inner QuantModules with disable_act_quant=False and trained also act-quantise
+            # their own outputs (quant_layer.py:130-133): conv2+gdn / conv+igdn / skip / upsample[0].
+            y = _block_forward_w8a8(kind, ops, x)
+        else:
+            with torch.no_grad():
+                y = O.UNIT_FORWARD[kind](ops, x)
+        np.testing.assert_allclose(y.numpy(), fx[f"{tag}/y_{state}"], rtol=0, atol=0)
+
+
+def _block_forward_w8a8(kind, ops, x):
+    import torch.nn.functional as F
+    aq = O.act_quant
+    with torch.no_grad():
+        if kind == "rbws":
+            out = aq(F.leaky_relu(ops["conv1"](x), 0.01))
+            out = aq(ops["gdn"](aq(ops["conv2"](out))))
+            return aq(out + aq(ops["skip"](x)))
+        if kind == "rbu":
+            out = aq(F.leaky_relu(F.pixel_shuffle(ops["subpel_conv"](x), 2), 0.01))
+            out = aq(ops["igdn"](aq(ops["conv"](out))))
+            return aq(out + F.pixel_shuffle(aq(ops["upsample"](x)), 2))
+        out = aq(F.leaky_relu(ops["conv1"](x), 0.01))
+        out = aq(F.leaky_relu(ops["conv2"](out), 0.01))
+        return aq(out + x)
+
+
+# ----------------------------------------------------------------------------- the reconstruction loop
+UNIT_OPS = {"rbws": ["conv1", "conv2", "gdn", "skip"], "rb": ["conv1", "conv2", "skip"],
+            "rbu": ["subpel_conv", "conv", "igdn", "upsample"], "layer": ["layer"]}
+LAYER_GEOM = {"g_a.6": (2, 1), "g_s.7.0": (1, 1), "h_s.2.0": (1, 1), "entropy_parameters.0": (1, 0),
+              "context_prediction": (1, 2)}
+
+
+def _unit_ops(fx, tag, kind):
+    ops = {}
+    for n in UNIT_OPS[kind]:
+        if f"{tag}/{n}.weight" not in fx:
+            continue
+        w = T(fx[f"{tag}/{n}.weight"])
+        b = T(fx[f"{tag}/{n}.bias"]) if f"{tag}/{n}.bias" in fx else None
+        if n in ("gdn", "igdn"):
+            op = O.QOp(n, w, b)
+        elif kind == "layer":
+            s, p = LAYER_GEOM[tag]
+            op = O.QOp("conv", w, b, stride=s, padding=p, act="lrelu" if int(fx[f"{tag}/{n}.act"]) else None)
+        else:
+            stride = 2 if (kind == "rbws" and n in ("conv1", "skip")) else 1
+            op = O.QOp("conv", w, b, stride=stride, padding=w.shape[-1] // 2)
+        op.delta, op.zp = T(fx[f"{tag}/{n}.delta"]), T(fx[f"{tag}/{n}.zp"])
+        ops[n] = op
+    return ops
+
+
+@pytest.fixture(scope="module")
+def recon(golden_dir):
+    return np.load(os.path.join(golden_dir, "recon_toy.npz"))
+
+
+@pytest.mark.parametrize("tag,kind", [("g_a.0", "rbws"), ("g_a.1", "rb"), ("g_a.6", "layer"), ("g_s.1", "rbu"),
+                                      ("g_s.7.0", "layer"), ("h_s.2.0", "layer"), ("entropy_parameters.0", "layer"),
+                                      ("context_prediction", "layer")])
+def test_reconstruction_loop_matches_reference(recon, tag, kind):
+    """Replay the reference's layer_/block_reconstruction run (same caches, idx stream, QDrop uniforms)."""
+    fx = recon
+    _, _, B, iters = (int(v) for v in fx["meta"])
+    ops = _unit_ops(fx, tag, kind)
+    rand = T(fx[f"{tag}/rand"])
+    log = O.reconstruct_unit(kind, ops, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]),
+                             iters=iters, batch_size=B, idx_stream=fx[f"{tag}/idx"],
+                             mask_fn=lambda i, shape: rand[i] < 0.5, input_prob=0.5, weight=0.01, b_range=(20, 2),
+                             warmup=0.2, p=2.0, task_p=2.0)
+    np.testing.assert_allclose(np.array(log.total), fx[f"{tag}/loss"], rtol=1e-6, atol=1e-9)
+    for n, op in ops.items():
+        np.testing.assert_allclose(op.alpha.numpy(), fx[f"{tag}/{n}.alpha_final"], rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        y = O.UNIT_FORWARD[kind](ops, T(fx[f"{tag}/inp_q"])[:2])
+    np.testing.assert_allclose(y.numpy(), fx[f"{tag}/hard_out"], rtol=1e-5, atol=1e-6)
+
+
+def test_counter_rng_is_uniform_and_reproducible():
+    m1 = O.qdrop_keep_mask_nhwc(1005, 3, (2, 8, 16, 16), 0.5)
+    m2 = O.qdrop_keep_mask_nhwc(1005, 3, (2, 8, 16, 16), 0.5)
+    m3 = O.qdrop_keep_mask_nhwc(1005, 4, (2, 8, 16, 16), 0.5)
+    assert torch.equal(m1, m2) and not torch.equal(m1, m3)
+    assert abs(float(m1.float().mean()) - 0.5) < 0.03
+    assert bool(O.qdrop_keep_mask_nhwc(1, 0, (1, 4, 4, 4), 1.0).all())
+    assert not bool(O.qdrop_keep_mask_nhwc(1, 0, (1, 4, 4, 4), 0.0).any())
