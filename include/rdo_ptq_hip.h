@@ -1,0 +1,158 @@
+/*
+ * rdo_ptq_hip.h -- C ABI of librdoptq_hip.so: the MI355X (gfx950) kernels behind the RDO-PTQ calibration hot path.
+ *
+ * The reference (Eric-qi/RDO-PTQ, /root/reference/task-oriented-PTQ) has no FFI: its hot path is Python calling ATen /
+ * CompressAI ops.  Each entry point below names the reference call site it replaces.  All pointers are BORROWED device
+ * pointers (hipMalloc'ed by the caller, e.g. torch tensors), `stream` is a hipStream_t passed as void*, nothing is
+ * allocated or synchronised inside, no exceptions cross the boundary: every function returns 0 on success or a negative
+ * RDO_E* code, with a human-readable message available from rdo_last_error() (thread-local).
+ *
+ * Layouts (fp32 everywhere):
+ *   activations  NHWC  x[b][h][w][c]              (== torch channels_last of the reference's NCHW tensors)
+ *   conv weights OHWI  w[co][kh][kw][ci]          (== torch channels_last of the reference's OIHW weights)
+ *   dgrad weights      wd[ci][kh'][kw'][co] with taps flipped (kh' = KH-1-kh), produced by rdo_adaround_step / rdo_weight_dgrad_layout
+ *   GDN gamma    [i][j] row-major (i = output channel), beta [i]
+ */
+#ifndef RDO_PTQ_HIP_H
+#define RDO_PTQ_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RDO_OK 0
+#define RDO_EINVAL (-22)   /* bad argument / unsupported shape */
+#define RDO_EHIP (-5)      /* a HIP runtime call failed */
+#define RDO_ENOMEM (-12)   /* workspace too small */
+
+/* epilogue / prologue selectors for the conv kernels */
+enum {
+    RDO_EPI_NONE = 0,       /* out = acc + bias */
+    RDO_EPI_LRELU = 1,      /* out = leaky_relu(acc + bias, 0.01)                         quant_block.py:238,273,301,305 */
+    RDO_EPI_LRELU_BWD = 2,  /* out = acc * (aux > 0 ? 1 : 0.01)        (dgrad through a LeakyReLU whose OUTPUT is aux)    */
+    RDO_EPI_GDN = 3,        /* out = aux * rsqrt(acc + bias)                                      quant_layer.py:147-153 */
+    RDO_EPI_IGDN = 4        /* out = aux * sqrt(acc + bias)                                       quant_layer.py:147-153 */
+};
+
+typedef struct rdo_conv_desc {
+    int32_t B, H, W, Cin;        /* input  [B][H][W][Cin]   */
+    int32_t Ho, Wo, Cout;        /* output [B][Ho][Wo][Cout] */
+    int32_t KH, KW, stride, pad; /* square stride / symmetric zero padding, dilation 1, groups 1 */
+    int32_t epilogue;            /* RDO_EPI_*  */
+    int32_t square_input;        /* 1: the kernel squares x on load (GDN norm pool, quant_layer.py:147) */
+    int32_t add_residual;        /* 1: out += residual (after the activation)        quant_block.py:245,279,310 */
+} rdo_conv_desc;
+
+const char* rdo_version(void);
+const char* rdo_last_error(void);
+
+/* ---- K1/K2/K3: convolution as implicit GEMM on fp32 MFMA -------- replaces F.conv2d at quant_layer.py:123 (and the
+ * 1x1 `F.conv2d(x**2, gamma, beta)` of f_gdn, quant_layer.py:147).  `pre` (nullable) receives acc+bias before the
+ * epilogue (needed by the GDN backward).  dgrad of a stride-1 conv is this same entry point run on dY with `wd`. */
+int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
+                   const float* residual, float* out, float* pre, void* stream);
+
+/* weight gradient: dw[co][kh][kw][ci] = sum_m dy[m][co] * x[pix(m,kh,kw)][ci]  (autograd of quant_layer.py:123).
+ * Split over `nsplit` pixel chunks into `slabs[nsplit][Cout*KH*KW*Cin]` (deterministic; reduced by rdo_adaround_step or
+ * rdo_reduce_slabs).  rdo_conv2d_wgrad_nsplit() returns the split count the kernel wants for a shape. */
+int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d);
+int rdo_conv2d_wgrad(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, void* stream);
+int rdo_reduce_slabs(const float* slabs, int nsplit, int64_t numel, float* out, void* stream);
+
+/* ---- K4/K8/K10: AdaRound ---------------------------------------- quantizer.py:427-452, layer_opt.py:159-165,254,307 */
+typedef struct rdo_ada_desc {
+    int64_t numel;      /* weight elements, stored [rows][inner] with delta/zp per row (channel-wise dim 0) */
+    int32_t rows;       /* Cout (conv) or C (GDN gamma rows); 1 for layer-wise scales */
+    int32_t n_levels;   /* 2^bits */
+    int32_t reparam;    /* 1: weight is a GDN gamma -> emit gamma' = max(wq, bound)^2 - pedestal (and chain the gradient) */
+    float reparam_bound, reparam_pedestal;
+    int32_t KH, KW, Cin; /* for the dgrad layout of conv weights (0,0,0: do not emit wd; for gamma wd = transpose) */
+} rdo_ada_desc;
+
+/* alpha0 = -log((zeta-gamma)/(frac(w/delta)-gamma) - 1)                                    quantizer.py:454-462 */
+int rdo_adaround_init_alpha(const rdo_ada_desc* d, const float* w, const float* delta, float* alpha, void* stream);
+
+/* soft (soft!=0) or hard rounding forward into the kernel layouts wq (same layout as w) and wd (nullable). */
+int rdo_adaround_fwd(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,
+                     int soft, float* wq, float* wd, void* stream);
+
+/* per-iteration schedule row (host-precomputed, device-resident): the unit executor indexes it with *iter_ptr */
+typedef struct rdo_sched_row {
+    float b;            /* temperature, LinearTempDecay utils.py:37-54 */
+    float round_on;     /* 0 while count < warmup*iters (layer_opt.py:160-161), else 1 */
+    float step_size;    /* lr / (1 - beta1^t)          torch.optim.Adam */
+    float bc2_sqrt;     /* sqrt(1 - beta2^t) */
+} rdo_sched_row;
+
+/* Fused: reduce `nsplit` wgrad slabs (+ optional pre-reduced grad) -> dL/dwq -> chain through the soft quantiser (and the
+ * GDN re-parametrisation) -> + round-loss gradient -> Adam(beta1 .9, beta2 .999, eps 1e-8) on alpha -> next soft wq / wd.
+ * Accumulates weight*sum(1-|2h-1|^b) of the CURRENT alpha (before the update) into *round_loss_out (atomicAdd).
+ * `grad_scale` multiplies the data gradient (1/world_size after a sum all-reduce). */
+int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* slabs,
+                      int nsplit, float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr,
+                      float* alpha, float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out,
+                      void* stream);
+
+/* only the data-gradient half (slab reduce + chain rule -> dalpha_data), for the all-reduce bucket of the DP path */
+int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,
+                      const float* slabs, int nsplit, float* dalpha, void* stream);
+/* ... and the second half applied to an (all-reduced) dalpha bucket */
+int rdo_adaround_apply(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* dalpha,
+                       float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr,
+                       float* alpha, float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out,
+                       void* stream);
+
+/* ---- K5: nearest fake-quant of a weight (UniformAffineQuantizer.forward)                  quantizer.py:175-177 */
+int rdo_uaq_fakequant(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, float* wq, float* wd,
+                      void* stream);
+/* channel-wise 'max' init: delta[r] = max((max(x,0)-min(x,0))/(L-1), 1e-8), zp[r] = round(-min/delta) quantizer.py:281-298 */
+int rdo_uaq_init_minmax(const float* w, int32_t rows, int64_t inner, int32_t n_levels, float* delta, float* zp,
+                        void* stream);
+
+/* ---- K6: dynamic per-channel 8-bit activation quant-dequant (ActQuant)                    quantizer.py:81-117 */
+int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, float* out, float* ws_minmax /* 2*C floats */,
+                            void* stream);
+
+/* ---- K7: mini-batch assembly: out[b] = keep ? cache_q[idx[b]] : cache_fp[idx[b]], keep ~ counter RNG(seed, iter, i)
+ * replaces cached_inps[..][idx] + torch.where(torch.rand_like(x) < p, x_q, x_fp)                layer_opt.py:289-292 */
+int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr,
+                     int32_t B, int64_t per_image, float prob, uint32_t seed, float* out, void* stream);
+
+/* ---- K8: lp_loss(pred, tgt[idx]) forward + gradient, p = 2: loss = sum((pred-tgt)^2)/(npix), sum over channels
+ * grad = coef * 2 (pred - tgt) / npix ; `coef` = 2 reproduces rec_loss + (degenerate) task_loss of SURVEY 3.4.
+ * Adds `coef * loss` into loss_out[*iter_ptr]  (atomicAdd).                          quantizer.py:71-79, layer_opt.py:133,150 */
+int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
+                      int32_t B, int64_t per_image, int32_t C, float coef, float* grad, float* loss_out, void* stream);
+
+/* ---- K9: element-wise helpers on NHWC tensors */
+int rdo_lrelu_fwd(const float* x, int64_t n, float* out, void* stream);                         /* nn.LeakyReLU(0.01) */
+int rdo_lrelu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream);          /* out = g*(y>0?1:.01) */
+int rdo_pixel_shuffle(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t r, int32_t inverse, float* out,
+                      void* stream);                                                     /* F.pixel_shuffle quant_layer.py:109 */
+int rdo_add(const float* a, const float* b, int64_t n, float* out, void* stream);
+/* GDN backward, element-wise halves (the two 1x1 GEMMs go through rdo_conv2d_fwd / rdo_conv2d_wgrad):
+ *   t   = -1/2 g x n^-3/2 (GDN)  |  1/2 g x n^-1/2 (IGDN)
+ *   dx  = g n^-1/2 + 2 x acc (GDN)  |  g n^1/2 + 2 x acc (IGDN)    with acc = t . gamma'                         */
+int rdo_gdn_bwd_t(const float* g, const float* x, const float* norm, int64_t n, int32_t inverse, float* t, void* stream);
+int rdo_gdn_bwd_dx(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t inverse,
+                   float* dx, void* stream);
+int rdo_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t inverse, float* out, void* stream);
+int rdo_iter_advance(int32_t* iter_ptr, void* stream);
+
+/* ---- unit executor: a recorded sequence of the calls above, replayed per calibration iteration with no host work.
+ * Python records the per-iteration op list once per unit (layer_reconstruction / block_reconstruction, layer_opt.py:287-309);
+ * rdo_plan_run() enqueues `n_iters` iterations, through a captured hipGraph when `use_graph` != 0. */
+typedef struct rdo_plan rdo_plan;
+rdo_plan* rdo_plan_create(void);
+void rdo_plan_destroy(rdo_plan* p);
+int rdo_plan_begin_record(rdo_plan* p);      /* subsequent rdo_* calls on this thread are recorded instead of launched */
+int rdo_plan_end_record(rdo_plan* p);
+int rdo_plan_num_ops(const rdo_plan* p);
+int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RDO_PTQ_HIP_H */

@@ -1,0 +1,339 @@
+// K4 / K5 / K8(round) / K10 -- AdaRound soft quantiser forward + backward, rounding regulariser and Adam, fused into one
+// pass over the weight that also reduces the split-K wgrad slabs and emits next iteration's kernel-layout weights.
+//
+// Reference arithmetic being restated (task-oriented-PTQ/quantization):
+//   quantizer.py:437-449  w~ = (clamp(floor(w/d) + h(alpha) + zp, 0, L-1) - zp) * d        (soft)   | + (alpha>=0)  (hard)
+//   quantizer.py:451-452  h(alpha) = clamp(sigmoid(alpha) * 1.2 - 0.1, 0, 1)
+//   quantizer.py:454-462  alpha0 = -log(1.2 / (frac(w/d) + 0.1) - 1)
+//   layer_opt.py:159-165  round_loss = weight * sum(1 - (2|h - .5|)^b)
+//   layer_opt.py:254,307  torch.optim.Adam(lr=1e-3, betas=(.9,.999), eps=1e-8), one step per iteration
+//   quant_layer.py:142-146 (GDN gamma): gamma' = max(w~, bound)^2 - pedestal, LowerBound gradient rule (CompressAI)
+// This file is built with -ffp-contract=off so products and sums round separately, as the reference's op chain does.
+#include "rdo_common.h"
+
+namespace {
+
+constexpr float kGamma = -0.1f, kZeta = 1.1f;
+constexpr float kBeta1 = 0.9f, kBeta2 = 0.999f, kAdamEps = 1e-8f;
+
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + expf(-a)); }
+
+struct AdaArgs {
+    rdo_ada_desc d;
+    const float* w;
+    const float* delta;
+    const float* zp;
+    const float* slabs;     // [nsplit][numel] data gradient w.r.t. the kernel-layout weight (w~ or gamma')
+    int nsplit;
+    const float* dalpha_in; // apply mode: data gradient w.r.t. alpha (already chained)
+    float* dalpha_out;      // grad mode
+    float grad_scale, round_weight;
+    const rdo_sched_row* sched;
+    const int32_t* iter_ptr;
+    float* alpha;
+    float* m;
+    float* v;
+    float* wq;
+    float* wd;
+    float* round_loss_out;
+    int mode;               // 0 fused step, 1 grad only, 2 apply
+};
+
+__device__ __forceinline__ long wd_index(const rdo_ada_desc& d, long e) {
+    // e = ((co*KH + kh)*KW + kw)*Cin + ci  ->  ((ci*KH + KH-1-kh)*KW + KW-1-kw)*Cout + co
+    const int Cin = d.Cin, KW = d.KW, KH = d.KH;
+    long t = e / Cin;
+    const int ci = (int)(e - t * Cin);
+    const int kw = (int)(t % KW); t /= KW;
+    const int kh = (int)(t % KH);
+    const long co = t / KH;
+    return (((long)ci * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)) * d.rows + co;
+}
+
+// emit kernel-layout weight(s) from the quantised value
+__device__ __forceinline__ void emit(const rdo_ada_desc& d, long e, float q, float* wq, float* wd) {
+    float o = q;
+    if (d.reparam) {
+        const float lb = fmaxf(q, d.reparam_bound);
+        o = lb * lb - d.reparam_pedestal;
+    }
+    wq[e] = o;
+    if (wd && d.Cin > 0) wd[wd_index(d, e)] = o;
+}
+
+__global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
+    const rdo_ada_desc d = a.d;
+    const long inner = d.numel / d.rows;
+    const float Lm1 = (float)(d.n_levels - 1);
+    float b = 0.f, round_on = 0.f, step_size = 0.f, bc2 = 1.f;
+    int it = 0;
+    if (a.mode != 1) {
+        it = *a.iter_ptr;
+        const rdo_sched_row s = a.sched[it];
+        b = s.b; round_on = s.round_on; step_size = s.step_size; bc2 = s.bc2_sqrt;
+    }
+    float rl_local = 0.f;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(e / inner);
+        const float dl = a.delta[row], z = a.zp[row], wv = a.w[e];
+        float al = a.alpha[e];
+        const float xf = floorf(wv / dl);
+        const float sg = sigmoidf_(al);
+        const float hraw = sg * (kZeta - kGamma) + kGamma;
+        const float h = fminf(fmaxf(hraw, 0.f), 1.f);
+        const float xint = xf + h + z;       // (x_floor + h) + zp
+        const float pass_h = (hraw >= 0.f && hraw <= 1.f) ? 1.f : 0.f;
+        const float dh_da = pass_h * ((kZeta - kGamma) * (sg * (1.f - sg)));
+
+        float g_alpha;  // data gradient w.r.t. alpha
+        if (a.mode == 2) {
+            g_alpha = a.dalpha_in[e];
+        } else {
+            float g = 0.f;
+            for (int s = 0; s < a.nsplit; ++s) g += a.slabs[(long)s * d.numel + e];
+            if (d.reparam) {
+                const float q = (fminf(fmaxf(xint, 0.f), Lm1) - z) * dl;
+                const float lb = fmaxf(q, d.reparam_bound);
+                const float go = g * (2.f * lb);                      // d(lb^2)/dlb
+                g = (q >= d.reparam_bound || go < 0.f) ? go : 0.f;    // LowerBound backward
+            }
+            const float pass_q = (xint >= 0.f && xint <= Lm1) ? 1.f : 0.f;
+            g_alpha = (g * dl) * pass_q * dh_da;
+        }
+        if (a.mode == 1) {
+            a.dalpha_out[e] = g_alpha;
+            continue;
+        }
+        // rounding regulariser (value of the current alpha, gradient through h)
+        float g_total = g_alpha * a.grad_scale;
+        if (round_on != 0.f) {
+            const float u = fabsf(h - 0.5f) * 2.f;
+            rl_local += a.round_weight * (1.f - powf(u, b));
+            const float sgn = (h > 0.5f) ? 1.f : ((h < 0.5f) ? -1.f : 0.f);
+            const float dpow = (u > 0.f) ? b * powf(u, b - 1.f) : 0.f;
+            g_total += (-a.round_weight * dpow * 2.f * sgn) * dh_da;
+        }
+        // Adam (torch.optim.Adam defaults; alpha has no weight decay)
+        float mm = a.m[e], vv = a.v[e];
+        mm = mm + (g_total - mm) * (1.f - kBeta1);
+        vv = vv * kBeta2 + (1.f - kBeta2) * g_total * g_total;
+        const float denom = sqrtf(vv) / bc2 + kAdamEps;
+        al = al - step_size * (mm / denom);
+        a.m[e] = mm; a.v[e] = vv; a.alpha[e] = al;
+        // next iteration's soft weight
+        const float sg2 = sigmoidf_(al);
+        const float h2 = fminf(fmaxf(sg2 * (kZeta - kGamma) + kGamma, 0.f), 1.f);
+        const float q2 = (fminf(fmaxf(xf + h2 + z, 0.f), Lm1) - z) * dl;
+        emit(d, e, q2, a.wq, a.wd);
+    }
+    if (a.mode != 1 && a.round_loss_out) {
+        // block reduce, one atomic per block
+        __shared__ float red[4];
+        float vsum = rl_local;
+        for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t = red[0] + red[1] + red[2] + red[3];
+            if (t != 0.f) atomicAdd(a.round_loss_out + it, t);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void ada_fwd_kernel(rdo_ada_desc d, const float* w, const float* alpha, const float* delta,
+                                                      const float* zp, int mode /*0 hard,1 soft,2 nearest*/, float* wq,
+                                                      float* wd) {
+    const long inner = d.numel / d.rows;
+    const float Lm1 = (float)(d.n_levels - 1);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += (long)gridDim.x * blockDim.x) {
+        const int row = (int)(e / inner);
+        const float dl = delta[row], z = zp[row], wv = w[e];
+        float xint;
+        if (mode == 2) {
+            xint = rintf(wv / dl) + z;
+        } else {
+            const float xf = floorf(wv / dl);
+            float h;
+            if (mode == 1) {
+                h = fminf(fmaxf(sigmoidf_(alpha[e]) * (kZeta - kGamma) + kGamma, 0.f), 1.f);
+            } else {
+                h = alpha[e] >= 0.f ? 1.f : 0.f;
+            }
+            xint = xf + h + z;
+        }
+        emit(d, e, (fminf(fmaxf(xint, 0.f), Lm1) - z) * dl, wq, wd);
+    }
+}
+
+__global__ __launch_bounds__(256) void ada_init_kernel(rdo_ada_desc d, const float* w, const float* delta, float* alpha) {
+    const long inner = d.numel / d.rows;
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += (long)gridDim.x * blockDim.x) {
+        const float dl = delta[e / inner];
+        const float r = w[e] / dl;
+        const float rest = r - floorf(r);
+        alpha[e] = -logf((kZeta - kGamma) / (rest - kGamma) - 1.f);
+    }
+}
+
+// one block per row: min / max -> delta, zp  ('max' init, quantizer.py:281-298: min/max clamped through 0, python-double
+// arithmetic for the range, fp32 for the zero point)
+__global__ __launch_bounds__(256) void uaq_minmax_kernel(const float* w, long inner, int n_levels, float* delta, float* zp) {
+    const float* p = w + (long)blockIdx.x * inner;
+    float mn = 0.f, mx = 0.f;
+    for (long i = threadIdx.x; i < inner; i += blockDim.x) {
+        const float v = p[i];
+        mn = fminf(mn, v);
+        mx = fmaxf(mx, v);
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        mn = fminf(mn, __shfl_down(mn, o, 64));
+        mx = fmaxf(mx, __shfl_down(mx, o, 64));
+    }
+    __shared__ float smn[4], smx[4];
+    if ((threadIdx.x & 63) == 0) { smn[threadIdx.x >> 6] = mn; smx[threadIdx.x >> 6] = mx; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        mn = fminf(fminf(smn[0], smn[1]), fminf(smn[2], smn[3]));
+        mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
+        float dl = (float)(((double)mx - (double)mn) / (double)(n_levels - 1));
+        dl = fmaxf(dl, 1e-8f);
+        delta[blockIdx.x] = dl;
+        zp[blockIdx.x] = rintf((float)(-(double)mn) / dl);
+    }
+}
+
+__global__ __launch_bounds__(256) void reduce_slabs_kernel(const float* slabs, int nsplit, long numel, float* out) {
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < numel; e += (long)gridDim.x * blockDim.x) {
+        float g = 0.f;
+        for (int s = 0; s < nsplit; ++s) g += slabs[(long)s * numel + e];
+        out[e] = g;
+    }
+}
+
+inline unsigned grid_for(long n) {
+    long g = rdo::ceil_div(n, 256);
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+int check_desc(const rdo_ada_desc* d, const char* who) {
+    RDO_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    RDO_REQUIRE(d->numel > 0 && d->rows > 0 && d->numel % d->rows == 0, "%s: numel %ld not divisible by rows %d", who,
+                (long)d->numel, d->rows);
+    RDO_REQUIRE(d->n_levels >= 4 && d->n_levels <= 65536, "%s: n_levels %d unsupported", who, d->n_levels);
+    if (d->Cin > 0)
+        RDO_REQUIRE(d->KH > 0 && d->KW > 0 && (long)d->rows * d->KH * d->KW * d->Cin == d->numel,
+                    "%s: conv layout [%d][%d][%d][%d] does not match numel %ld", who, d->rows, d->KH, d->KW, d->Cin,
+                    (long)d->numel);
+    return RDO_OK;
+}
+
+int run_step(AdaArgs a, void* stream) {
+    return rdo::dispatch(
+        [a](hipStream_t s) {
+            hipLaunchKernelGGL(ada_step_kernel, dim3(grid_for(a.d.numel)), dim3(256), 0, s, a);
+            return rdo::check_launch("ada_step");
+        },
+        stream);
+}
+
+}  // namespace
+
+extern "C" {
+
+int rdo_adaround_init_alpha(const rdo_ada_desc* d, const float* w, const float* delta, float* alpha, void* stream) {
+    if (int rc = check_desc(d, "rdo_adaround_init_alpha")) return rc;
+    RDO_REQUIRE(w && delta && alpha, "rdo_adaround_init_alpha: null pointer");
+    const rdo_ada_desc dd = *d;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(ada_init_kernel, dim3(grid_for(dd.numel)), dim3(256), 0, s, dd, w, delta, alpha);
+            return rdo::check_launch("ada_init");
+        },
+        stream);
+}
+
+int rdo_adaround_fwd(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp, int soft,
+                     float* wq, float* wd, void* stream) {
+    if (int rc = check_desc(d, "rdo_adaround_fwd")) return rc;
+    RDO_REQUIRE(w && alpha && delta && zp && wq, "rdo_adaround_fwd: null pointer");
+    const rdo_ada_desc dd = *d;
+    const int mode = soft ? 1 : 0;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(ada_fwd_kernel, dim3(grid_for(dd.numel)), dim3(256), 0, s, dd, w, alpha, delta, zp, mode, wq, wd);
+            return rdo::check_launch("ada_fwd");
+        },
+        stream);
+}
+
+int rdo_uaq_fakequant(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, float* wq, float* wd,
+                      void* stream) {
+    if (int rc = check_desc(d, "rdo_uaq_fakequant")) return rc;
+    RDO_REQUIRE(w && delta && zp && wq, "rdo_uaq_fakequant: null pointer");
+    const rdo_ada_desc dd = *d;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(ada_fwd_kernel, dim3(grid_for(dd.numel)), dim3(256), 0, s, dd, w, (const float*)nullptr, delta, zp,
+                               2, wq, wd);
+            return rdo::check_launch("uaq_fakequant");
+        },
+        stream);
+}
+
+int rdo_uaq_init_minmax(const float* w, int32_t rows, int64_t inner, int32_t n_levels, float* delta, float* zp, void* stream) {
+    RDO_REQUIRE(w && delta && zp && rows > 0 && inner > 0 && n_levels >= 4, "rdo_uaq_init_minmax: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(uaq_minmax_kernel, dim3(rows), dim3(256), 0, s, w, (long)inner, n_levels, delta, zp);
+            return rdo::check_launch("uaq_minmax");
+        },
+        stream);
+}
+
+int rdo_reduce_slabs(const float* slabs, int nsplit, int64_t numel, float* out, void* stream) {
+    RDO_REQUIRE(slabs && out && nsplit >= 1 && numel > 0, "rdo_reduce_slabs: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(reduce_slabs_kernel, dim3(grid_for(numel)), dim3(256), 0, s, slabs, nsplit, (long)numel, out);
+            return rdo::check_launch("reduce_slabs");
+        },
+        stream);
+}
+
+int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* slabs, int nsplit,
+                      float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr, float* alpha,
+                      float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out, void* stream) {
+    if (int rc = check_desc(d, "rdo_adaround_step")) return rc;
+    RDO_REQUIRE(w && delta && zp && slabs && nsplit >= 1 && sched && iter_ptr && alpha && adam_m && adam_v && wq,
+                "rdo_adaround_step: null pointer");
+    AdaArgs a{};
+    a.d = *d; a.w = w; a.delta = delta; a.zp = zp; a.slabs = slabs; a.nsplit = nsplit; a.grad_scale = grad_scale;
+    a.round_weight = round_weight; a.sched = sched; a.iter_ptr = iter_ptr; a.alpha = alpha; a.m = adam_m; a.v = adam_v;
+    a.wq = wq; a.wd = wd; a.round_loss_out = round_loss_out; a.mode = 0;
+    return run_step(a, stream);
+}
+
+int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,
+                      const float* slabs, int nsplit, float* dalpha, void* stream) {
+    if (int rc = check_desc(d, "rdo_adaround_grad")) return rc;
+    RDO_REQUIRE(w && alpha && delta && zp && slabs && nsplit >= 1 && dalpha, "rdo_adaround_grad: null pointer");
+    AdaArgs a{};
+    a.d = *d; a.w = w; a.delta = delta; a.zp = zp; a.slabs = slabs; a.nsplit = nsplit; a.alpha = const_cast<float*>(alpha);
+    a.dalpha_out = dalpha; a.mode = 1;
+    return run_step(a, stream);
+}
+
+int rdo_adaround_apply(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* dalpha,
+                       float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr, float* alpha,
+                       float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out, void* stream) {
+    if (int rc = check_desc(d, "rdo_adaround_apply")) return rc;
+    RDO_REQUIRE(w && delta && zp && dalpha && sched && iter_ptr && alpha && adam_m && adam_v && wq,
+                "rdo_adaround_apply: null pointer");
+    AdaArgs a{};
+    a.d = *d; a.w = w; a.delta = delta; a.zp = zp; a.dalpha_in = dalpha; a.grad_scale = grad_scale;
+    a.round_weight = round_weight; a.sched = sched; a.iter_ptr = iter_ptr; a.alpha = alpha; a.m = adam_m; a.v = adam_v;
+    a.wq = wq; a.wd = wd; a.round_loss_out = round_loss_out; a.mode = 2;
+    return run_step(a, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,321 @@
+// K6 / K7 / K8(lp) / K9 -- HBM-bound element-wise stages of the calibration loop on NHWC fp32 tensors.
+// 16-byte (float4) accesses, grid-stride loops capped at ~2048 workgroups (MI355X: 256 CUs x 8).
+// Built with -ffp-contract=off (products and sums round separately, like the reference's op chains).
+#include "rdo_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+inline unsigned grid_for(long n, int per_thread = 1) {
+    long g = rdo::ceil_div(n, 256L * per_thread);
+    return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
+}
+
+__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
+    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
+    return x;
+}
+
+// ---- K7: gather + QDrop (layer_opt.py:289-292).  keep = u32(seed, iter, i) < floor(p * 2^32) takes the quantised-prefix input.
+__global__ __launch_bounds__(256) void gather_qdrop_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
+                                                           const int32_t* iter_ptr, int B, long per_image, unsigned long long thr,
+                                                           uint32_t seed, float* out) {
+    const int it = *iter_ptr;
+    const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
+    const long quads = per_image / 4;
+    const long total = (long)B * quads;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / quads);
+        const long off = (t - (long)b * quads) * 4;
+        const long src = (long)idx_table[(long)it * B + b] * per_image + off;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(cq + src);
+        const f32x4 f = *reinterpret_cast<const f32x4*>(cfp + src);
+        const uint32_t i0 = (uint32_t)((long)b * per_image + off);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = ((unsigned long long)lowbias32((i0 + e) ^ key) < thr) ? q[e] : f[e];
+        *reinterpret_cast<f32x4*>(out + (long)b * per_image + off) = o;
+    }
+}
+
+// ---- K8: p=2 lp_loss forward + gradient against the cached FP target rows
+__global__ __launch_bounds__(256) void lp2_kernel(const float* pred, const float* tgt, const int32_t* idx_table,
+                                                  const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef,
+                                                  float* grad, float* loss_out) {
+    const int it = *iter_ptr;
+    const long quads = per_image / 4;
+    const long total = (long)B * quads;
+    float acc = 0.f;
+    const float gs = coef * 2.f * inv_npix;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / quads);
+        const long off = (t - (long)b * quads) * 4;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pred + (long)b * per_image + off);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(tgt + (long)idx_table[(long)it * B + b] * per_image + off);
+        const f32x4 dd = p - y;
+        acc += (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+        *reinterpret_cast<f32x4*>(grad + (long)b * per_image + off) = dd * gs;
+    }
+    __shared__ float red[4];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out + it, (red[0] + red[1] + red[2] + red[3]) * inv_npix * coef);
+}
+
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* g, const float* y, long n4, float* out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x) {
+        const f32x4 gv = reinterpret_cast<const f32x4*>(g)[t], yv = reinterpret_cast<const f32x4*>(y)[t];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = yv[e] > 0.f ? gv[e] : 0.01f * gv[e];
+        reinterpret_cast<f32x4*>(out)[t] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void lrelu_fwd_kernel(const float* x, long n4, float* out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x) {
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[t];
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        reinterpret_cast<f32x4*>(out)[t] = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* a, const float* b, long n4, float* out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(out)[t] = reinterpret_cast<const f32x4*>(a)[t] + reinterpret_cast<const f32x4*>(b)[t];
+}
+
+// pixel shuffle on NHWC: out[b][h*r+dy][w*r+dx][c] = in[b][h][w][c*r*r + dy*r + dx]   (inverse: the other way round)
+__global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* x, int B, int H, int W, int C, int r, int inverse,
+                                                            float* out) {
+    // C = channels of the SHUFFLED (large) tensor; small tensor has C*r*r channels at HxW
+    const long total = (long)B * H * r * W * r * C;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        long u = t;
+        const int c = (int)(u % C); u /= C;
+        const int wo = (int)(u % (W * r)); u /= (W * r);
+        const int ho = (int)(u % (H * r));
+        const int b = (int)(u / (H * r));
+        const int h = ho / r, dy = ho - h * r, w = wo / r, dx = wo - w * r;
+        const long small = (((long)b * H + h) * W + w) * ((long)C * r * r) + (long)c * r * r + dy * r + dx;
+        if (inverse) out[small] = x[t]; else out[t] = x[small];
+    }
+}
+
+__global__ __launch_bounds__(256) void gdn_bwd_t_kernel(const float* g, const float* x, const float* nrm, long n, int inverse,
+                                                        float* t) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float nv = nrm[i];
+        // GDN: y = x n^-1/2 -> dy/dn = -1/2 x n^-3/2 ; IGDN: y = x n^1/2 -> dy/dn = 1/2 x n^-1/2
+        const float r = __frsqrt_rn(nv);
+        t[i] = inverse ? (0.5f * g[i] * x[i]) * r : (-0.5f * g[i] * x[i]) * (r * r * r);
+    }
+}
+
+__global__ __launch_bounds__(256) void gdn_bwd_dx_kernel(const float* g, const float* x, const float* nrm, const float* acc,
+                                                         long n, int inverse, float* dx) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float nv = nrm[i];
+        const float f = inverse ? __fsqrt_rn(nv) : __frsqrt_rn(nv);
+        dx[i] = g[i] * f + 2.f * x[i] * acc[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void nchw_nhwc_kernel(const float* x, int B, int C, int H, int W, int inverse, float* out) {
+    const long total = (long)B * C * H * W;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        long u = t;  // t indexes NHWC
+        const int c = (int)(u % C); u /= C;
+        const int w = (int)(u % W); u /= W;
+        const int h = (int)(u % H);
+        const int b = (int)(u / H);
+        const long nchw = (((long)b * C + c) * H + h) * W + w;
+        if (inverse) out[nchw] = x[t]; else out[t] = x[nchw];
+    }
+}
+
+__global__ void iter_advance_kernel(int32_t* it) { *it += 1; }
+
+// ---- K6: per-channel dynamic activation quantisation (NHWC: channel = fastest dim)
+__device__ __forceinline__ unsigned f2ord(float f) {
+    unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(unsigned o) {
+    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
+}
+
+__global__ __launch_bounds__(256) void aq_init_kernel(unsigned* ws, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) { ws[c] = 0xFFFFFFFFu; ws[C + c] = 0u; }
+}
+
+// each block scans a slab of pixels; thread handles channel (tid % Cblk) strided over pixels, then LDS column reduce
+__global__ __launch_bounds__(256) void aq_minmax_kernel(const float* x, long npix, int C, unsigned* ws) {
+    // one thread per (pixel-lane, channel) with channels fastest for coalescing
+    const int cpt = (C + 255) / 256;  // channels handled per thread when C > 256
+    const long pix_per_block = rdo::kWave;  // rows scanned per block step
+    for (int cc = 0; cc < cpt; ++cc) {
+        const int c = threadIdx.x + cc * 256;
+        if (c >= C) continue;
+        float mn = INFINITY, mx = -INFINITY;
+        for (long p = blockIdx.x; p < npix; p += gridDim.x) {
+            const float v = x[p * C + c];
+            mn = fminf(mn, v);
+            mx = fmaxf(mx, v);
+        }
+        atomicMin(ws + c, f2ord(mn));
+        atomicMax(ws + C + c, f2ord(mx));
+    }
+    (void)pix_per_block;
+}
+
+__global__ __launch_bounds__(256) void aq_apply_kernel(const float* x, long n, int C, const unsigned* ws, float* out) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float zp = ord2f(ws[c]);
+        const float rng = fmaxf(ord2f(ws[C + c]) - zp, 1e-6f);
+        const float xn = x[i] - zp;
+        const float q = rintf(fminf(fmaxf(xn / rng, -1.f), 1.f) * 255.f);
+        out[i] = (q / 255.f) * rng + zp;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
+                     int64_t per_image, float prob, uint32_t seed, float* out, void* stream) {
+    RDO_REQUIRE(cache_q && cache_fp && idx_table && iter_ptr && out, "rdo_gather_qdrop: null pointer");
+    RDO_REQUIRE(B > 0 && per_image > 0 && per_image % 4 == 0, "rdo_gather_qdrop: per_image (%ld) must be a multiple of 4",
+                (long)per_image);
+    RDO_REQUIRE((long)B * per_image < (1L << 32), "rdo_gather_qdrop: batch tensor exceeds the 32-bit RNG counter");
+    RDO_REQUIRE(prob >= 0.f && prob <= 1.f, "rdo_gather_qdrop: prob out of [0,1]");
+    double t = floor((double)prob * 4294967296.0);
+    const unsigned long long thr = (unsigned long long)(t > 4294967296.0 ? 4294967296.0 : t);
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(gather_qdrop_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, cache_q, cache_fp,
+                               idx_table, iter_ptr, B, (long)per_image, thr, seed, out);
+            return rdo::check_launch("gather_qdrop");
+        },
+        stream);
+}
+
+int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
+                      int64_t per_image, int32_t C, float coef, float* grad, float* loss_out, void* stream) {
+    RDO_REQUIRE(pred && tgt_cache && idx_table && iter_ptr && grad, "rdo_lp2_loss_grad: null pointer");
+    RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_lp2_loss_grad: bad shape");
+    const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(lp2_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, pred, tgt_cache, idx_table,
+                               iter_ptr, B, (long)per_image, inv_npix, coef, grad, loss_out);
+            return rdo::check_launch("lp2_loss_grad");
+        },
+        stream);
+}
+
+int rdo_lrelu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream) {
+    RDO_REQUIRE(g && y && out && n > 0 && n % 4 == 0, "rdo_lrelu_bwd: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, g, y, (long)(n / 4), out);
+            return rdo::check_launch("lrelu_bwd");
+        },
+        stream);
+}
+
+int rdo_lrelu_fwd(const float* x, int64_t n, float* out, void* stream) {
+    RDO_REQUIRE(x && out && n > 0 && n % 4 == 0, "rdo_lrelu_fwd: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, (long)(n / 4), out);
+            return rdo::check_launch("lrelu_fwd");
+        },
+        stream);
+}
+
+int rdo_add(const float* a, const float* b, int64_t n, float* out, void* stream) {
+    RDO_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "rdo_add: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, a, b, (long)(n / 4), out);
+            return rdo::check_launch("add");
+        },
+        stream);
+}
+
+int rdo_pixel_shuffle(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t r, int32_t inverse, float* out,
+                      void* stream) {
+    RDO_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && r > 0, "rdo_pixel_shuffle: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for((long)B * H * W * C * r * r)), dim3(256), 0, s, x, B, H, W, C, r,
+                               inverse, out);
+            return rdo::check_launch("pixel_shuffle");
+        },
+        stream);
+}
+
+int rdo_gdn_bwd_t(const float* g, const float* x, const float* norm, int64_t n, int32_t inverse, float* t, void* stream) {
+    RDO_REQUIRE(g && x && norm && t && n > 0, "rdo_gdn_bwd_t: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(gdn_bwd_t_kernel, dim3(grid_for(n)), dim3(256), 0, s, g, x, norm, (long)n, inverse, t);
+            return rdo::check_launch("gdn_bwd_t");
+        },
+        stream);
+}
+
+int rdo_gdn_bwd_dx(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t inverse, float* dx,
+                   void* stream) {
+    RDO_REQUIRE(g && x && norm && acc && dx && n > 0, "rdo_gdn_bwd_dx: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(gdn_bwd_dx_kernel, dim3(grid_for(n)), dim3(256), 0, s, g, x, norm, acc, (long)n, inverse, dx);
+            return rdo::check_launch("gdn_bwd_dx");
+        },
+        stream);
+}
+
+int rdo_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t inverse, float* out, void* stream) {
+    RDO_REQUIRE(x && out && B > 0 && C > 0 && H > 0 && W > 0, "rdo_nchw_to_nhwc: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(nchw_nhwc_kernel, dim3(grid_for((long)B * C * H * W)), dim3(256), 0, s, x, B, C, H, W, inverse, out);
+            return rdo::check_launch("nchw_to_nhwc");
+        },
+        stream);
+}
+
+int rdo_iter_advance(int32_t* iter_ptr, void* stream) {
+    RDO_REQUIRE(iter_ptr != nullptr, "rdo_iter_advance: null pointer");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(iter_advance_kernel, dim3(1), dim3(1), 0, s, iter_ptr);
+            return rdo::check_launch("iter_advance");
+        },
+        stream);
+}
+
+int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, float* out, float* ws_minmax, void* stream) {
+    RDO_REQUIRE(x && out && ws_minmax && npix > 0 && C > 0, "rdo_actquant_perchannel: bad argument");
+    unsigned* ws = reinterpret_cast<unsigned*>(ws_minmax);
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(aq_init_kernel, dim3((unsigned)rdo::ceil_div(C, 256)), dim3(256), 0, s, ws, C);
+            long g = npix < 1024 ? npix : 1024;
+            hipLaunchKernelGGL(aq_minmax_kernel, dim3((unsigned)g), dim3(256), 0, s, x, (long)npix, C, ws);
+            hipLaunchKernelGGL(aq_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, s, x, (long)npix * C, C, ws, out);
+            return rdo::check_launch("actquant_perchannel");
+        },
+        stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,48 @@
+// Shared host-side plumbing for librdoptq_hip.so: error reporting, op recording for the unit executor.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <functional>
+#include <string>
+#include <vector>
+
+#include "../../include/rdo_ptq_hip.h"
+
+namespace rdo {
+
+using Op = std::function<int(hipStream_t)>;
+
+struct Recorder {
+    bool active = false;
+    std::vector<Op>* sink = nullptr;
+};
+Recorder& recorder();                      // thread-local
+int set_error(int code, const char* fmt, ...);
+
+// Run `op` now on `stream`, or append it to the plan being recorded on this thread.
+inline int dispatch(Op op, void* stream) {
+    Recorder& r = recorder();
+    if (r.active) {
+        r.sink->push_back(std::move(op));
+        return RDO_OK;
+    }
+    return op(reinterpret_cast<hipStream_t>(stream));
+}
+
+inline int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_error(RDO_EHIP, "%s: %s", what, hipGetErrorString(e));
+    return RDO_OK;
+}
+
+#define RDO_REQUIRE(cond, ...)                                  \
+    do {                                                        \
+        if (!(cond)) return rdo::set_error(RDO_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+constexpr int kWave = 64;
+inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace rdo

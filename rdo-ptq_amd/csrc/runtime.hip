@@ -1,0 +1,108 @@
+// Error state, version, and the unit executor (recorded op list -> per-iteration replay / hipGraph).
+#include "rdo_common.h"
+
+namespace rdo {
+
+static thread_local std::string g_err;
+static thread_local Recorder g_rec;
+
+Recorder& recorder() { return g_rec; }
+
+int set_error(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+}  // namespace rdo
+
+struct rdo_plan {
+    std::vector<rdo::Op> ops;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    bool recording = false;
+};
+
+extern "C" {
+
+const char* rdo_version(void) { return "rdo-ptq-hip 0.1 (gfx950)"; }
+const char* rdo_last_error(void) { return rdo::g_err.c_str(); }
+
+rdo_plan* rdo_plan_create(void) { return new rdo_plan(); }
+
+void rdo_plan_destroy(rdo_plan* p) {
+    if (!p) return;
+    if (p->recording) { rdo::recorder().active = false; rdo::recorder().sink = nullptr; }
+    if (p->exec) (void)hipGraphExecDestroy(p->exec);
+    if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
+    delete p;
+}
+
+int rdo_plan_begin_record(rdo_plan* p) {
+    RDO_REQUIRE(p != nullptr, "plan is null");
+    RDO_REQUIRE(!rdo::recorder().active, "another plan is already recording on this thread");
+    p->ops.clear();
+    if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
+    if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+    p->recording = true;
+    rdo::recorder().active = true;
+    rdo::recorder().sink = &p->ops;
+    return RDO_OK;
+}
+
+int rdo_plan_end_record(rdo_plan* p) {
+    RDO_REQUIRE(p != nullptr && p->recording, "plan is not recording");
+    p->recording = false;
+    rdo::recorder().active = false;
+    rdo::recorder().sink = nullptr;
+    return RDO_OK;
+}
+
+int rdo_plan_num_ops(const rdo_plan* p) { return p ? (int)p->ops.size() : 0; }
+
+static int run_ops(rdo_plan* p, hipStream_t s) {
+    for (auto& op : p->ops) {
+        int rc = op(s);
+        if (rc != RDO_OK) return rc;
+    }
+    return RDO_OK;
+}
+
+int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream) {
+    RDO_REQUIRE(p != nullptr && !p->recording, "plan is null or still recording");
+    RDO_REQUIRE(n_iters >= 0, "n_iters < 0");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!use_graph) {
+        for (int i = 0; i < n_iters; ++i) {
+            int rc = run_ops(p, s);
+            if (rc != RDO_OK) return rc;
+        }
+        return RDO_OK;
+    }
+    if (!p->exec) {
+        // Capture one iteration on a private stream (the caller's stream may be the legacy default stream).
+        if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess)
+            return rdo::set_error(RDO_EHIP, "hipStreamCreate failed");
+        if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+            return rdo::set_error(RDO_EHIP, "hipStreamBeginCapture failed");
+        int rc = run_ops(p, p->cap_stream);
+        hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph);
+        if (rc != RDO_OK) return rc;
+        if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+        if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+    }
+    for (int i = 0; i < n_iters; ++i) {
+        hipError_t e = hipGraphLaunch(p->exec, s);
+        if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
+    }
+    return RDO_OK;
+}
+
+}  // extern "C"

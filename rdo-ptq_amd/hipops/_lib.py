@@ -1,0 +1,84 @@
+"""ctypes binding of librdoptq_hip.so (the C ABI declared in include/rdo_ptq_hip.h).
+
+The library is the only compute back end of this package: if it cannot be loaded, or a call fails, a RuntimeError is
+raised -- there is no CPU or eager-PyTorch fallback."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librdoptq_hip.so")
+
+EPI_NONE, EPI_LRELU, EPI_LRELU_BWD, EPI_GDN, EPI_IGDN = range(5)
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "pad", "epilogue",
+                                         "square_input", "add_residual")]
+
+
+class AdaDesc(C.Structure):
+    _fields_ = [("numel", C.c_int64), ("rows", C.c_int32), ("n_levels", C.c_int32), ("reparam", C.c_int32),
+                ("reparam_bound", C.c_float), ("reparam_pedestal", C.c_float), ("KH", C.c_int32), ("KW", C.c_int32),
+                ("Cin", C.c_int32)]
+
+
+class SchedRow(C.Structure):
+    _fields_ = [("b", C.c_float), ("round_on", C.c_float), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
+
+
+P = C.c_void_p
+_SIGS = {
+    "rdo_version": (C.c_char_p, []),
+    "rdo_last_error": (C.c_char_p, []),
+    "rdo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P]),
+    "rdo_conv2d_wgrad_nsplit": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rdo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), P, P, P, C.c_int, P]),
+    "rdo_reduce_slabs": (C.c_int, [P, C.c_int, C.c_int64, P, P]),
+    "rdo_adaround_init_alpha": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P]),
+    "rdo_adaround_fwd": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, P, P, P]),
+    "rdo_adaround_step": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P]),
+    "rdo_adaround_grad": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, C.c_int, P, P]),
+    "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P]),
+    "rdo_uaq_fakequant": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, P]),
+    "rdo_uaq_init_minmax": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, P, P, P]),
+    "rdo_actquant_perchannel": (C.c_int, [P, C.c_int64, C.c_int32, P, P, P]),
+    "rdo_gather_qdrop": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_float, C.c_uint32, P, P]),
+    "rdo_lp2_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, P, P, P]),
+    "rdo_lrelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
+    "rdo_lrelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
+    "rdo_pixel_shuffle": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
+    "rdo_add": (C.c_int, [P, P, C.c_int64, P, P]),
+    "rdo_gdn_bwd_t": (C.c_int, [P, P, P, C.c_int64, C.c_int32, P, P]),
+    "rdo_gdn_bwd_dx": (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, P, P]),
+    "rdo_nchw_to_nhwc": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
+    "rdo_iter_advance": (C.c_int, [P, P]),
+    "rdo_plan_create": (P, []),
+    "rdo_plan_destroy": (None, [P]),
+    "rdo_plan_begin_record": (C.c_int, [P]),
+    "rdo_plan_end_record": (C.c_int, [P]),
+    "rdo_plan_num_ops": (C.c_int, [P]),
+    "rdo_plan_run": (C.c_int, [P, C.c_int, C.c_int, P]),
+}
+EXPORTS = tuple(_SIGS)
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is missing."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
+                               f"`make -C rdo-ptq_amd/csrc` (no CPU fallback exists)")
+        h = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(h, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError(f"librdoptq_hip {what} failed ({rc}): {lib().rdo_last_error().decode()}")

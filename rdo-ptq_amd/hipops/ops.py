@@ -1,0 +1,242 @@
+"""Thin tensor-level wrappers over the C ABI (include/rdo_ptq_hip.h).
+
+Conventions: every tensor is a contiguous fp32 CUDA tensor; activations are NHWC `[B,H,W,C]`, conv weights OHWI
+`[Cout,KH,KW,Cin]` (the memory image of torch's channels_last OIHW weight).  Calls are enqueued on torch's current stream.
+When a plan is being recorded (hipops.plan.Plan.record()), the same calls are captured instead of launched."""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError(f"librdoptq_hip has no CPU path: tensor is on {t.device}")
+    if t.dtype not in (torch.float32, torch.int32) or not t.is_contiguous():
+        raise RuntimeError(f"librdoptq_hip needs contiguous fp32/int32 tensors, got {t.dtype} contiguous={t.is_contiguous()}")
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def conv_desc(x_shape, w_shape, stride, pad, epilogue=L.EPI_NONE, square_input=False, add_residual=False):
+    B, H, W, Cin = x_shape
+    Cout, KH, KW, Cin2 = w_shape
+    if Cin != Cin2:
+        raise ValueError(f"conv: input has {Cin} channels, weight expects {Cin2}")
+    Ho = (H + 2 * pad - KH) // stride + 1
+    Wo = (W + 2 * pad - KW) // stride + 1
+    return L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, epilogue, int(square_input), int(add_residual))
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, square_input=False,
+               out=None, pre=None):
+    d = conv_desc(x.shape, w.shape, stride, pad, epilogue, square_input, residual is not None)
+    if out is None:
+        out = torch.empty((d.B, d.Ho, d.Wo, d.Cout), device=x.device, dtype=torch.float32)
+    L.check(L.lib().rdo_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(aux), _ptr(residual), _ptr(out), _ptr(pre),
+                                   _stream()), "rdo_conv2d_fwd")
+    return out
+
+
+def wgrad_nsplit(x_shape, w_shape, stride, pad):
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    return int(L.lib().rdo_conv2d_wgrad_nsplit(C.byref(d)))
+
+
+def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, square_input=False, slabs=None):
+    d = conv_desc(x.shape, w_shape, stride, pad, square_input=square_input)
+    ns = int(L.lib().rdo_conv2d_wgrad_nsplit(C.byref(d))) if slabs is None else slabs.shape[0]
+    if slabs is None:
+        slabs = torch.empty((ns,) + tuple(w_shape), device=x.device, dtype=torch.float32)
+    L.check(L.lib().rdo_conv2d_wgrad(C.byref(d), _ptr(x), _ptr(dy), _ptr(slabs), ns, _stream()), "rdo_conv2d_wgrad")
+    return slabs
+
+
+def reduce_slabs(slabs, out=None):
+    ns = slabs.shape[0]
+    numel = slabs[0].numel()
+    if out is None:
+        out = torch.empty(slabs.shape[1:], device=slabs.device, dtype=torch.float32)
+    L.check(L.lib().rdo_reduce_slabs(_ptr(slabs), ns, numel, _ptr(out), _stream()), "rdo_reduce_slabs")
+    return out
+
+
+def ada_desc(w, n_levels=256, reparam=None, conv_layout=True):
+    """w: OHWI conv weight [Cout,KH,KW,Cin] or a GDN gamma [C,C]."""
+    if w.dim() == 4:
+        rows, KH, KW, Cin = w.shape
+    else:
+        rows, Cin = w.shape
+        KH = KW = 1
+    if not conv_layout:
+        KH = KW = Cin = 0
+    bound, ped = (reparam if reparam is not None else (0.0, 0.0))
+    return L.AdaDesc(w.numel(), rows, n_levels, int(reparam is not None), bound, ped, KH, KW, Cin)
+
+
+def adaround_init_alpha(d, w, delta, alpha=None):
+    alpha = torch.empty_like(w) if alpha is None else alpha
+    L.check(L.lib().rdo_adaround_init_alpha(C.byref(d), _ptr(w), _ptr(delta), _ptr(alpha), _stream()), "rdo_adaround_init_alpha")
+    return alpha
+
+
+def adaround_fwd(d, w, alpha, delta, zp, soft, wq=None, wd=None):
+    wq = torch.empty_like(w) if wq is None else wq
+    L.check(L.lib().rdo_adaround_fwd(C.byref(d), _ptr(w), _ptr(alpha), _ptr(delta), _ptr(zp), int(soft), _ptr(wq), _ptr(wd),
+                                     _stream()), "rdo_adaround_fwd")
+    return wq
+
+
+def uaq_fakequant(d, w, delta, zp, wq=None, wd=None):
+    wq = torch.empty_like(w) if wq is None else wq
+    L.check(L.lib().rdo_uaq_fakequant(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(wq), _ptr(wd), _stream()),
+            "rdo_uaq_fakequant")
+    return wq
+
+
+def uaq_init_minmax(w, n_levels):
+    rows = w.shape[0]
+    delta = torch.empty(rows, device=w.device, dtype=torch.float32)
+    zp = torch.empty_like(delta)
+    L.check(L.lib().rdo_uaq_init_minmax(_ptr(w), rows, w.numel() // rows, n_levels, _ptr(delta), _ptr(zp), _stream()),
+            "rdo_uaq_init_minmax")
+    return delta, zp
+
+
+def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_ptr, alpha, m, v, wq, wd, round_log):
+    L.check(L.lib().rdo_adaround_step(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(slabs), slabs.shape[0], grad_scale,
+                                      round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(alpha), _ptr(m), _ptr(v), _ptr(wq),
+                                      _ptr(wd), _ptr(round_log), _stream()), "rdo_adaround_step")
+
+
+def adaround_grad(d, w, alpha, delta, zp, slabs, dalpha):
+    L.check(L.lib().rdo_adaround_grad(C.byref(d), _ptr(w), _ptr(alpha), _ptr(delta), _ptr(zp), _ptr(slabs), slabs.shape[0],
+                                      _ptr(dalpha), _stream()), "rdo_adaround_grad")
+
+
+def adaround_apply(d, w, delta, zp, dalpha, grad_scale, round_weight, sched, iter_ptr, alpha, m, v, wq, wd, round_log):
+    L.check(L.lib().rdo_adaround_apply(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(dalpha), grad_scale, round_weight,
+                                       _ptr(sched), _ptr(iter_ptr), _ptr(alpha), _ptr(m), _ptr(v), _ptr(wq), _ptr(wd),
+                                       _ptr(round_log), _stream()), "rdo_adaround_apply")
+
+
+def actquant_perchannel(x, out=None, ws=None):
+    """x: [..., C] channels-last; per-channel dynamic 8-bit quant-dequant."""
+    Cc = x.shape[-1]
+    npix = x.numel() // Cc
+    out = torch.empty_like(x) if out is None else out
+    ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32) if ws is None else ws
+    L.check(L.lib().rdo_actquant_perchannel(_ptr(x), npix, Cc, _ptr(out), _ptr(ws), _stream()), "rdo_actquant_perchannel")
+    return out
+
+
+def gather_qdrop(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out):
+    per_image = cache_q[0].numel()
+    L.check(L.lib().rdo_gather_qdrop(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, per_image, prob, seed,
+                                     _ptr(out), _stream()), "rdo_gather_qdrop")
+    return out
+
+
+def lp2_loss_grad(pred, tgt_cache, idx_table, iter_ptr, coef, grad, loss_log):
+    B = pred.shape[0]
+    per_image = pred[0].numel()
+    L.check(L.lib().rdo_lp2_loss_grad(_ptr(pred), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
+                                      pred.shape[-1], coef, _ptr(grad), _ptr(loss_log), _stream()), "rdo_lp2_loss_grad")
+    return grad
+
+
+def lrelu(x, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().rdo_lrelu_fwd(_ptr(x), x.numel(), _ptr(out), _stream()), "rdo_lrelu_fwd")
+    return out
+
+
+def lrelu_bwd(g, y, out=None):
+    out = torch.empty_like(g) if out is None else out
+    L.check(L.lib().rdo_lrelu_bwd(_ptr(g), _ptr(y), g.numel(), _ptr(out), _stream()), "rdo_lrelu_bwd")
+    return out
+
+
+def add(a, b, out=None):
+    out = torch.empty_like(a) if out is None else out
+    L.check(L.lib().rdo_add(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream()), "rdo_add")
+    return out
+
+
+def pixel_shuffle(x, r, out=None):
+    """[B,H,W,C*r*r] -> [B,H*r,W*r,C]"""
+    B, H, W, CC = x.shape
+    Cc = CC // (r * r)
+    out = torch.empty((B, H * r, W * r, Cc), device=x.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_pixel_shuffle(_ptr(x), B, H, W, Cc, r, 0, _ptr(out), _stream()), "rdo_pixel_shuffle")
+    return out
+
+
+def pixel_unshuffle(x, r, out=None):
+    """[B,H*r,W*r,C] -> [B,H,W,C*r*r]  (gradient of pixel_shuffle)"""
+    B, Hr, Wr, Cc = x.shape
+    H, W = Hr // r, Wr // r
+    out = torch.empty((B, H, W, Cc * r * r), device=x.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_pixel_shuffle(_ptr(x), B, H, W, Cc, r, 1, _ptr(out), _stream()), "rdo_pixel_shuffle(inverse)")
+    return out
+
+
+def gdn_bwd_t(g, x, norm, inverse, out=None):
+    out = torch.empty_like(g) if out is None else out
+    L.check(L.lib().rdo_gdn_bwd_t(_ptr(g), _ptr(x), _ptr(norm), g.numel(), int(inverse), _ptr(out), _stream()), "rdo_gdn_bwd_t")
+    return out
+
+
+def gdn_bwd_dx(g, x, norm, acc, inverse, out=None):
+    out = torch.empty_like(g) if out is None else out
+    L.check(L.lib().rdo_gdn_bwd_dx(_ptr(g), _ptr(x), _ptr(norm), _ptr(acc), g.numel(), int(inverse), _ptr(out), _stream()),
+            "rdo_gdn_bwd_dx")
+    return out
+
+
+def nchw_to_nhwc(x, out=None):
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, H, W, Cc), device=x.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_nchw_to_nhwc(_ptr(x), B, Cc, H, W, 0, _ptr(out), _stream()), "rdo_nchw_to_nhwc")
+    return out
+
+
+def nhwc_to_nchw(x, out=None):
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_nchw_to_nhwc(_ptr(x), B, Cc, H, W, 1, _ptr(out), _stream()), "rdo_nchw_to_nhwc(inverse)")
+    return out
+
+
+def iter_advance(iter_ptr):
+    L.check(L.lib().rdo_iter_advance(_ptr(iter_ptr), _stream()), "rdo_iter_advance")
+
+
+def make_sched(iters, warmup, b_range, lr=1e-3, device="cuda"):
+    """Per-iteration schedule table (rdo_sched_row): LinearTempDecay (utils.py:37-54), round-loss gate
+    (layer_opt.py:159-161), Adam bias corrections.  Computed on the host in double precision."""
+    import math
+    rows = torch.empty((iters, 4), dtype=torch.float32)
+    t_max, start = iters, warmup * iters
+    loss_start = iters * warmup
+    for i in range(iters):
+        count = i + 1
+        if count < start:
+            b = float(b_range[0])
+        else:
+            rel_t = (count - start) / (t_max - start)
+            b = b_range[1] + (b_range[0] - b_range[1]) * max(0.0, 1 - rel_t)
+        on = 0.0 if count < loss_start else 1.0
+        if not on:
+            b = 0.0
+        rows[i, 0] = b
+        rows[i, 1] = on
+        rows[i, 2] = lr / (1 - 0.9 ** count)
+        rows[i, 3] = math.sqrt(1 - 0.999 ** count)
+    return rows.to(device)

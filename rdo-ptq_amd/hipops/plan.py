@@ -1,0 +1,41 @@
+"""Recorded op list executed natively (rdo_plan_* of include/rdo_ptq_hip.h): one call enqueues whole calibration
+iterations, optionally through a captured hipGraph -- no per-kernel Python or ctypes work in the hot loop."""
+import contextlib
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+class Plan:
+    def __init__(self):
+        self._h = C.c_void_p(L.lib().rdo_plan_create())
+        self._keep = []          # tensors referenced by recorded ops must outlive the plan
+
+    def keep(self, *tensors):
+        self._keep.extend(tensors)
+
+    @contextlib.contextmanager
+    def record(self):
+        L.check(L.lib().rdo_plan_begin_record(self._h), "rdo_plan_begin_record")
+        try:
+            yield self
+        finally:
+            L.check(L.lib().rdo_plan_end_record(self._h), "rdo_plan_end_record")
+
+    @property
+    def num_ops(self):
+        return int(L.lib().rdo_plan_num_ops(self._h))
+
+    def run(self, n_iters=1, graph=True):
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(L.lib().rdo_plan_run(self._h, int(n_iters), int(bool(graph)), s), "rdo_plan_run")
+
+    def __del__(self):
+        try:
+            if self._h:
+                L.lib().rdo_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass

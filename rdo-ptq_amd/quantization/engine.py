@@ -1,0 +1,368 @@
+"""Calibration engine: the AdaRound hot loop of one reconstruction unit as a recorded HIP op list.
+
+This replaces the Python/autograd loop body of the reference (`for i in range(iters)` at
+/root/reference/task-oriented-PTQ/quantization/layer_opt.py:287-309 and block_opt.py:287-311):
+
+    idx -> gather cached (x_q, x_fp) -> QDrop mix -> unit forward with soft-rounded weights -> rec + task + round loss
+        -> backward -> Adam on the rounding logits alpha
+
+Forward, the hand-derived backward, the loss and the optimiser are enqueued as one native plan per iteration
+(hipops.plan.Plan -> rdo_plan_run, hipGraph replay), with every per-iteration scalar (temperature b, Adam bias corrections,
+mini-batch indices) read on the device from tables indexed by a device-side iteration counter: zero host work or syncs
+inside the loop.  Units: a bare conv `QuantModule` ('layer') and the Cheng2020 blocks QuantRB / QuantRBWS / QuantRBU.
+
+Loss = round + rec + task exactly as the reference computes it for Sequential-indexed CompressAI models, where the task
+term degenerates to a second copy of the reconstruction term: `coef = 2`.
+
+Data parallel (world_size > 1): each rank holds its shard of the caches; per iteration the chained data-gradient of all
+alphas of the unit is written into one flat bucket, all-reduced (RCCL over xGMI, SUM) and applied with scale 1/world_size;
+the rounding regulariser is data independent and is added locally after the reduction."""
+import math
+from collections import OrderedDict
+
+import torch
+
+from hipops import _lib as L
+from hipops import ops
+from hipops.plan import Plan
+
+from .quant_layer import QuantModule
+from .quantizer import AdaRoundQuantizer, to_rows
+
+UNIT_KINDS = ("layer", "rb", "rbws", "rbu")
+
+
+class _Op:
+    """Device state of one trainable QuantModule inside a unit."""
+
+    def __init__(self, name, qm: QuantModule, need_dgrad: bool):
+        self.name, self.qm, self.need_dgrad = name, qm, need_dgrad
+        self.is_gdn = qm.kind == "gdn"
+        if qm.kind not in ("conv", "gdn"):
+            raise NotImplementedError(f"calibration engine: QuantModule kind '{qm.kind}' is not supported yet")
+        wq = qm.weight_quantizer
+        if not wq.inited:
+            wq(qm.weight)                      # lazy scale init, as the reference's first forward would do
+        if not wq.channel_wise:
+            raise NotImplementedError("calibration engine: layer-wise (non channel-wise) scales are not built yet")
+        w = qm.org_weight.detach()
+        self.w = to_rows(w)                    # OHWI or [C,C]
+        dev = self.w.device
+        self.rows = self.w.shape[0]
+        self.delta = wq.delta.reshape(-1).to(dev).contiguous()
+        self.zp = wq.zero_point.reshape(-1).to(dev).contiguous()
+        self.n_levels = wq.n_levels
+        if self.is_gdn:
+            self.inverse = bool(qm.fwd_kwargs["inverse"])
+            self.beta, reparam = qm.gdn_constants()
+            self.beta = self.beta.to(dev).contiguous()
+            self.desc = ops.ada_desc(self.w, self.n_levels, reparam=reparam)
+            self.stride, self.pad, self.K = 1, 0, 1
+            self.w4 = (self.rows, 1, 1, self.rows)
+            self.bias = None
+        else:
+            self.stride, self.pad = qm.conv_geometry()
+            self.K = self.w.shape[1]
+            self.desc = ops.ada_desc(self.w, self.n_levels)
+            self.w4 = tuple(self.w.shape)
+            self.bias = None if qm.bias is None else qm.bias.detach().contiguous()
+        self.alpha = torch.empty_like(self.w)
+        self.m = torch.zeros_like(self.w)
+        self.v = torch.zeros_like(self.w)
+        self.wq = torch.empty_like(self.w)
+        # wd: dgrad layout for convs, transpose for gamma (always needed: GDN backward uses gamma'^T)
+        self.wd = torch.empty_like(self.w) if (need_dgrad or self.is_gdn) else None
+        ops.adaround_init_alpha(self.desc, self.w, self.delta, self.alpha)
+        ops.adaround_fwd(self.desc, self.w, self.alpha, self.delta, self.zp, True, self.wq, self.wd)
+        self.slabs = None
+
+    def wq4(self):
+        return self.wq.reshape(self.w4)
+
+    def wd4(self):
+        # [ci][kh][kw][co] for convs, gamma'^T viewed [C][1][1][C]
+        co, kh, kw, ci = self.w4
+        return self.wd.reshape(ci, kh, kw, co)
+
+    def numel(self):
+        return self.w.numel()
+
+
+class UnitEngine:
+    def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
+                 warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
+                 use_graph=True):
+        if kind not in UNIT_KINDS:
+            raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
+        for t in (cache_q, cache_fp, cache_out):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4):
+                raise RuntimeError("calibration engine: caches must be contiguous fp32 NHWC CUDA tensors")
+        self.kind, self.mods = kind, modules
+        self.cq, self.cf, self.co = cache_q, cache_fp, cache_out
+        self.B, self.iters = int(batch_size), int(iters)
+        self.weight, self.input_prob, self.seed = float(weight), float(input_prob), int(seed) & 0xFFFFFFFF
+        self.include_act = include_act_func
+        self.use_graph = use_graph
+        self.dev = cache_q.device
+        n = cache_q.shape[0]
+        if idx_table is None:
+            # same CPU-generator stream as the reference: one torch.randperm(n) per iteration (layer_opt.py:289)
+            idx_table = torch.stack([torch.randperm(n)[:self.B] for _ in range(self.iters)])
+        idx_table = torch.as_tensor(idx_table).to(torch.int32)
+        if tuple(idx_table.shape) != (self.iters, self.B):
+            raise ValueError(f"idx_table must be [{self.iters},{self.B}], got {tuple(idx_table.shape)}")
+        if int(idx_table.max()) >= n or int(idx_table.min()) < 0:
+            raise ValueError("idx_table refers to images outside the cache")
+        self.idx = idx_table.to(self.dev).contiguous()
+        self.sched = ops.make_sched(self.iters, warmup, b_range, lr, self.dev)
+        self.it = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        self.loss_log = torch.zeros(self.iters, device=self.dev)
+        self.round_log = torch.zeros(self.iters, device=self.dev)
+        self.group = group
+        self.world = 1
+        if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
+            self.world = torch.distributed.get_world_size(group)
+        self._build_ops()
+        self._alloc()
+        self._record()
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _build_ops(self):
+        m, k = self.mods, self.kind
+        o = OrderedDict()
+        if k == "layer":
+            o["layer"] = _Op("layer", m["layer"], False)
+        elif k == "rb":
+            o["conv1"] = _Op("conv1", m["conv1"], False)
+            o["conv2"] = _Op("conv2", m["conv2"], True)
+            if m.get("skip") is not None:
+                o["skip"] = _Op("skip", m["skip"], False)
+        elif k == "rbws":
+            o["conv1"] = _Op("conv1", m["conv1"], False)
+            o["conv2"] = _Op("conv2", m["conv2"], True)
+            o["gdn"] = _Op("gdn", m["gdn"], False)
+            if m.get("skip") is not None:
+                o["skip"] = _Op("skip", m["skip"], False)
+        elif k == "rbu":
+            o["subpel_conv"] = _Op("subpel_conv", m["subpel_conv"], False)
+            o["conv"] = _Op("conv", m["conv"], True)
+            o["igdn"] = _Op("igdn", m["igdn"], False)
+            o["upsample"] = _Op("upsample", m["upsample"], False)
+        for op in o.values():
+            if op.need_dgrad and (op.stride != 1 or 2 * op.pad != op.K - 1):
+                raise NotImplementedError("calibration engine: dgrad is built for stride-1 'same' convolutions only")
+        self.ops = o
+        if self.world > 1:
+            total = sum(op.numel() for op in o.values())
+            self.bucket = torch.zeros(total, device=self.dev)
+            off = 0
+            for op in o.values():
+                op.dalpha = self.bucket[off:off + op.numel()]
+                off += op.numel()
+
+    def _buf(self, *shape):
+        return torch.empty(shape, device=self.dev, dtype=torch.float32)
+
+    def _out_hw(self, op, H, W):
+        return (H + 2 * op.pad - op.K) // op.stride + 1, (W + 2 * op.pad - op.K) // op.stride + 1
+
+    def _alloc(self):
+        B = self.B
+        _, H, W, Cin = self.cq.shape
+        self.x_in = self._buf(B, H, W, Cin)
+        o, t = self.ops, {}
+        if self.kind == "layer":
+            op = o["layer"]
+            Ho, Wo = self._out_hw(op, H, W)
+            t["y"] = self._buf(B, Ho, Wo, op.rows)
+            t["dy"] = self._buf(B, Ho, Wo, op.rows)
+            t["dpre"] = self._buf(B, Ho, Wo, op.rows)
+        elif self.kind == "rb":
+            C = o["conv1"].rows
+            for n_ in ("h1", "pre2", "out", "dout", "dpre2", "dh1"):
+                t[n_] = self._buf(B, H, W, C)
+            if "skip" in o:
+                t["sk"] = self._buf(B, H, W, C)
+        elif self.kind == "rbws":
+            c1 = o["conv1"]
+            Ho, Wo = self._out_hw(c1, H, W)
+            C = c1.rows
+            for n_ in ("h1", "c2", "norm", "out", "dout", "t", "acc", "dc2", "dh1"):
+                t[n_] = self._buf(B, Ho, Wo, C)
+            if "skip" in o:
+                t["sk"] = self._buf(B, Ho, Wo, C)
+        elif self.kind == "rbu":
+            sp = o["subpel_conv"]
+            C4 = sp.rows
+            r = int(self.mods["upscale"])
+            C = C4 // (r * r)
+            t["sp"] = self._buf(B, H, W, C4)           # lrelu(subpel conv) before the shuffle
+            t["h1"] = self._buf(B, H * r, W * r, C)
+            t["up"] = self._buf(B, H, W, C4)
+            t["ups"] = self._buf(B, H * r, W * r, C)
+            for n_ in ("c", "norm", "out", "dout", "t", "acc", "dc", "dh1"):
+                t[n_] = self._buf(B, H * r, W * r, C)
+            t["dsp"] = self._buf(B, H, W, C4)
+            t["dup"] = self._buf(B, H, W, C4)
+            self.r = r
+        self.t = t
+        for op in self.ops.values():
+            op.slabs = None     # allocated at record time when the activation shapes are known
+
+    def _slabs(self, op, x_shape):
+        ns = ops.wgrad_nsplit(tuple(x_shape), op.w4, op.stride, op.pad)
+        op.slabs = self._buf(ns, *op.w4)
+        return op.slabs
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _conv(self, op, x, out, epilogue=L.EPI_NONE, aux=None, residual=None, pre=None, square=False, bias=True):
+        b = (op.beta if op.is_gdn else op.bias) if bias else None
+        return ops.conv2d_fwd(x, op.wq4(), b, op.stride, op.pad, epilogue=epilogue, aux=aux, residual=residual,
+                              square_input=square, out=out, pre=pre)
+
+    def _wgrad(self, op, x, dy, square=False):
+        if op.slabs is None:
+            self._slabs(op, x.shape)
+        ops.conv2d_wgrad(x, dy, op.w4, op.stride, op.pad, square_input=square, slabs=op.slabs)
+
+    def _dgrad(self, op, dy, out, epilogue=L.EPI_NONE, aux=None):
+        return ops.conv2d_fwd(dy, op.wd4(), None, 1, op.K - 1 - op.pad, epilogue=epilogue, aux=aux, out=out)
+
+    def _loss(self, pred, grad):
+        ops.lp2_loss_grad(pred, self.co, self.idx, self.it, 2.0, grad, self.loss_log)
+
+    def _forward_backward(self):
+        o, t, x = self.ops, self.t, self.x_in
+        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x)
+        if self.kind == "layer":
+            op = o["layer"]
+            lrelu = self.include_act and op.qm.fused_lrelu()
+            if lrelu:
+                self._conv(op, x, t["y"], epilogue=L.EPI_LRELU)
+                self._loss(t["y"], t["dy"])
+                ops.lrelu_bwd(t["dy"], t["y"], t["dpre"])
+                self._wgrad(op, x, t["dpre"])
+            else:
+                if self.include_act and type(op.qm.activation_function).__name__ != "StraightThrough":
+                    raise NotImplementedError("calibration engine: only LeakyReLU(0.01) may be fused into a layer unit")
+                self._conv(op, x, t["y"])
+                self._loss(t["y"], t["dy"])
+                self._wgrad(op, x, t["dy"])
+        elif self.kind == "rb":
+            c1, c2 = o["conv1"], o["conv2"]
+            self._conv(c1, x, t["h1"], epilogue=L.EPI_LRELU)
+            res = x
+            if "skip" in o:
+                self._conv(o["skip"], x, t["sk"])
+                res = t["sk"]
+            self._conv(c2, t["h1"], t["out"], epilogue=L.EPI_LRELU, residual=res, pre=t["pre2"])
+            self._loss(t["out"], t["dout"])
+            if "skip" in o:
+                self._wgrad(o["skip"], x, t["dout"])
+            ops.lrelu_bwd(t["dout"], t["pre2"], t["dpre2"])
+            self._wgrad(c2, t["h1"], t["dpre2"])
+            self._dgrad(c2, t["dpre2"], t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+            self._wgrad(c1, x, t["dh1"])
+        elif self.kind == "rbws":
+            c1, c2, g = o["conv1"], o["conv2"], o["gdn"]
+            self._conv(c1, x, t["h1"], epilogue=L.EPI_LRELU)
+            self._conv(c2, t["h1"], t["c2"])
+            res = x
+            if "skip" in o:
+                self._conv(o["skip"], x, t["sk"])
+                res = t["sk"]
+            self._conv(g, t["c2"], t["out"], epilogue=L.EPI_GDN, aux=t["c2"], residual=res, pre=t["norm"], square=True)
+            self._loss(t["out"], t["dout"])
+            if "skip" in o:
+                self._wgrad(o["skip"], x, t["dout"])
+            self._gdn_backward(g, t["dout"], t["c2"], t["norm"], t["t"], t["acc"], t["dc2"], inverse=False)
+            self._wgrad(c2, t["h1"], t["dc2"])
+            self._dgrad(c2, t["dc2"], t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+            self._wgrad(c1, x, t["dh1"])
+        elif self.kind == "rbu":
+            sp, cv, g, up = o["subpel_conv"], o["conv"], o["igdn"], o["upsample"]
+            r = self.r
+            self._conv(sp, x, t["sp"], epilogue=L.EPI_LRELU)       # LeakyReLU commutes with the pixel shuffle
+            ops.pixel_shuffle(t["sp"], r, t["h1"])
+            self._conv(cv, t["h1"], t["c"])
+            self._conv(up, x, t["up"])
+            ops.pixel_shuffle(t["up"], r, t["ups"])
+            self._conv(g, t["c"], t["out"], epilogue=L.EPI_IGDN, aux=t["c"], residual=t["ups"], pre=t["norm"], square=True)
+            self._loss(t["out"], t["dout"])
+            ops.pixel_unshuffle(t["dout"], r, t["dup"])
+            self._wgrad(up, x, t["dup"])
+            self._gdn_backward(g, t["dout"], t["c"], t["norm"], t["t"], t["acc"], t["dc"], inverse=True)
+            self._wgrad(cv, t["h1"], t["dc"])
+            self._dgrad(cv, t["dc"], t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+            ops.pixel_unshuffle(t["dh1"], r, t["dsp"])
+            self._wgrad(sp, x, t["dsp"])
+
+    def _gdn_backward(self, g, dout, xin, norm, tbuf, acc, dx, inverse):
+        ops.gdn_bwd_t(dout, xin, norm, inverse, tbuf)
+        ops.conv2d_fwd(tbuf, g.wd4(), None, 1, 0, out=acc)           # t . gamma'  (wd = gamma'^T as [C][1][1][C])
+        ops.gdn_bwd_dx(dout, xin, norm, acc, inverse, dx)
+        self._wgrad(g, xin, tbuf, square=True)                        # dgamma'[k][i] = sum_m t_k x_i^2
+
+    def _record(self):
+        self.plan_a = Plan()
+        self.plan_b = None
+        with self.plan_a.record():
+            self._forward_backward()
+            if self.world == 1:
+                for op in self.ops.values():
+                    ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
+                                      op.alpha, op.m, op.v, op.wq, op.wd, self.round_log)
+                ops.iter_advance(self.it)
+            else:
+                for op in self.ops.values():
+                    ops.adaround_grad(op.desc, op.w, op.alpha, op.delta, op.zp, op.slabs, op.dalpha)
+        if self.world > 1:
+            self.plan_b = Plan()
+            with self.plan_b.record():
+                for op in self.ops.values():
+                    ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, 1.0 / self.world, self.weight, self.sched,
+                                       self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log)
+                ops.iter_advance(self.it)
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def run(self, n_iters=None):
+        """Enqueue `n_iters` (default: all remaining) calibration iterations on the current stream."""
+        done = getattr(self, "_done", 0)
+        n = self.iters - done if n_iters is None else int(n_iters)
+        if n < 0 or done + n > self.iters:
+            raise ValueError(f"cannot run {n} iterations: {done} of {self.iters} already done")
+        if self.world == 1:
+            self.plan_a.run(n, graph=self.use_graph)
+        else:
+            for _ in range(n):
+                self.plan_a.run(1, graph=self.use_graph)
+                torch.distributed.all_reduce(self.bucket, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                self.plan_b.run(1, graph=self.use_graph)
+        self._done = done + n
+        return n
+
+    def logs(self):
+        """(total, rec+task, round) per iteration as CPU tensors (synchronises)."""
+        rt = self.loss_log.clone()
+        if self.world > 1:
+            torch.distributed.all_reduce(rt, group=self.group)
+            rt /= self.world
+        rt = rt.cpu()
+        rd = self.round_log.cpu()
+        return rt + rd, rt, rd
+
+    def alpha_of(self, name):
+        """Trained alpha in the logical weight shape (OIHW view of the OHWI storage)."""
+        op = self.ops[name]
+        return op.alpha.permute(0, 3, 1, 2) if op.alpha.dim() == 4 else op.alpha
+
+    def finish(self):
+        """Hand the trained rounding back to the modules: AdaRoundQuantizer with hard targets, `trained` flags
+        (layer_opt.py:313-316 / block_opt.py:316-321)."""
+        for name, op in self.ops.items():
+            qm = op.qm
+            ada = AdaRoundQuantizer(uaq=qm.weight_quantizer, round_mode="learned_hard_sigmoid",
+                                    weight_tensor=qm.org_weight.data, alpha_rows=op.alpha)
+            ada.soft_targets = False
+            qm.weight_quantizer = ada
+            qm.act_quantizer.is_training = False

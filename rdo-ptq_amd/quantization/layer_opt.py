@@ -1,0 +1,16 @@
+"""`layer_reconstruction`: AdaRound optimisation of a single QuantModule (reference: quantization/layer_opt.py:175-320)."""
+import torch
+
+from .quant_layer import QuantModule
+from .quant_model import QuantModel
+from .recon import LossFunction, find_unquantized_module, reconstruct  # noqa: F401  (surface compatibility)
+from .utils import set_mode  # noqa: F401
+
+
+def layer_reconstruction(model: QuantModel, layer: QuantModule, layer_name: str, cali_data: torch.Tensor,
+                         batch_size: int = 32, iters: int = 20000, weight: float = 0.001, opt_mode: str = "mse",
+                         asym: bool = False, include_act_func: bool = True, b_range: tuple = (20, 2), warmup: float = 0.0,
+                         input_prob: float = 1.0, act_quant: bool = False, lr: float = 4e-5, p: float = 2.0, config=None,
+                         args=None):
+    reconstruct(model, layer, layer_name, cali_data, batch_size, iters, weight, opt_mode, asym, include_act_func, b_range,
+                warmup, input_prob, act_quant, lr, p, config, args, is_block=False)

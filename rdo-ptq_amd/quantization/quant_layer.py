@@ -1,0 +1,163 @@
+"""`QuantModule`: one fake-quantised layer (reference surface: quantization/quant_layer.py:11-138), forward on the
+HIP kernels.  Supported here: Conv2d (dilation 1, groups 1), Linear (as a 1x1 conv), GDN/IGDN (`f_gdn`, :142-154) and
+PixelShuffle; ConvTranspose2d / LayerNorm (Minnen2018 / Lu2022 paths) raise NotImplementedError until those rows of
+SURVEY 8(f) are built."""
+from typing import Union
+
+import torch
+import torch.nn as nn
+
+from hipops import _lib as L
+from hipops import ops
+from lic import GDN as _LicGDN
+
+from .quantizer import StraightThrough, UniformAffineQuantizer, to_rows
+
+try:  # recognise real CompressAI modules when that package is installed
+    from compressai.layers.gdn import GDN as _CaiGDN
+    GDN_TYPES = (_LicGDN, _CaiGDN)
+except Exception:  # pragma: no cover - compressai is absent in the build image
+    GDN_TYPES = (_LicGDN,)
+GDN = _LicGDN
+
+
+def _nhwc(x):
+    """NCHW tensor (any memory format) -> contiguous NHWC storage; free when x is channels_last."""
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw_view(y):
+    return y.permute(0, 3, 1, 2)
+
+
+def _sq(v):
+    a, b = (v, v) if isinstance(v, int) else tuple(v)
+    if a != b:
+        raise ValueError(f"only square stride/padding is supported, got {v}")
+    return int(a)
+
+
+class QuantModule(nn.Module):
+    def __init__(self, org_module: Union[nn.Conv2d, nn.ConvTranspose2d, nn.LayerNorm, nn.Linear, GDN, nn.PixelShuffle],
+                 weight_quant_params: dict = {}, act_quant_params: dict = {}, disable_act_quant: bool = False, se_module=None):
+        super().__init__()
+        self.if_layer_norm = self.if_tconv = self.is_ps = False
+        if isinstance(org_module, nn.ConvTranspose2d):
+            self.kind, self.if_tconv = "tconv", True
+            self.fwd_kwargs = dict(stride=org_module.stride, padding=org_module.padding,
+                                   output_padding=org_module.output_padding, dilation=org_module.dilation,
+                                   groups=org_module.groups)
+        elif isinstance(org_module, nn.Conv2d):
+            self.kind = "conv"
+            self.fwd_kwargs = dict(stride=org_module.stride, padding=org_module.padding, dilation=org_module.dilation,
+                                   groups=org_module.groups)
+        elif isinstance(org_module, nn.Linear):
+            self.kind, self.fwd_kwargs = "linear", dict()
+        elif isinstance(org_module, nn.LayerNorm):
+            self.kind, self.if_layer_norm = "layernorm", True
+            self.fwd_kwargs = dict(normalized_shape=org_module.normalized_shape)
+        elif isinstance(org_module, GDN_TYPES):
+            self.kind = "gdn"
+            self.fwd_kwargs = dict(inverse=org_module.inverse, gamma_reparam=org_module.gamma_reparam,
+                                   beta_reparam=org_module.beta_reparam)
+        elif isinstance(org_module, nn.PixelShuffle):
+            self.kind, self.is_ps = "ps", True
+            self.fwd_kwargs = org_module.upscale_factor
+        else:
+            raise ValueError("Not supported modules: {}".format(org_module))
+
+        if self.kind == "gdn":
+            self.weight, self.bias = org_module.gamma, org_module.beta
+        elif self.is_ps:
+            self.weight = self.bias = None
+        else:
+            self.weight, self.bias = org_module.weight, org_module.bias
+        self.org_weight = None if self.weight is None else self.weight.data.clone()
+        self.org_bias = None if self.bias is None else self.bias.data.clone()
+
+        self.use_weight_quant = False
+        self.use_act_quant = False
+        self.disable_act_quant = disable_act_quant
+        self.weight_quantizer = UniformAffineQuantizer(tconv=self.if_tconv, **weight_quant_params)
+        self.act_quantizer = UniformAffineQuantizer(tconv=self.if_tconv, **act_quant_params)
+        self.activation_function = nn.LeakyReLU(inplace=True) if self.is_ps else StraightThrough()
+        self.ignore_reconstruction = False
+        self.se_module = se_module
+        self.extra_repr = org_module.extra_repr
+        self.trained = False
+
+    # geometry helpers used by the calibration engine ----------------------------------------------------------------
+    def conv_geometry(self):
+        if self.kind != "conv":
+            raise ValueError(f"{self.kind} has no conv geometry")
+        kw = self.fwd_kwargs
+        if _sq(kw["dilation"]) != 1 or kw["groups"] != 1:
+            raise NotImplementedError("dilated / grouped convolutions are not on the supported path")
+        return _sq(kw["stride"]), _sq(kw["padding"])
+
+    def fused_lrelu(self):
+        return isinstance(self.activation_function, nn.LeakyReLU) and abs(self.activation_function.negative_slope - 0.01) < 1e-12
+
+    def gdn_constants(self):
+        """beta' (re-parametrised, fp32 tensor) and the gamma (bound, pedestal) pair."""
+        beta = self.fwd_kwargs["beta_reparam"](self.bias.detach() if self.use_weight_quant else self.org_bias)
+        g = self.fwd_kwargs["gamma_reparam"]
+        return beta.contiguous(), (float(g.lower_bound.bound), float(g.pedestal))
+
+    # forward --------------------------------------------------------------------------------------------------------
+    def _weights(self):
+        if self.use_weight_quant:
+            return self.weight_quantizer(self.weight), self.bias
+        return self.org_weight, self.org_bias
+
+    def forward(self, input: torch.Tensor):
+        if not input.is_cuda:
+            raise RuntimeError("QuantModule.forward runs on librdoptq_hip only: move the model and data to the GPU")
+        if self.is_ps:
+            y = ops.pixel_shuffle(_nhwc(input), int(self.fwd_kwargs))
+            return _nchw_view(ops.lrelu(y) if isinstance(self.activation_function, nn.LeakyReLU) else y)
+        weight, bias = self._weights()
+        bias = None if bias is None else bias.detach().contiguous()
+        fuse = self.fused_lrelu() and self.se_module is None
+        if self.kind == "conv":
+            stride, pad = self.conv_geometry()
+            y = ops.conv2d_fwd(_nhwc(input), to_rows(weight.detach()), bias, stride, pad,
+                               epilogue=L.EPI_LRELU if fuse else L.EPI_NONE)
+            out = _nchw_view(y)
+        elif self.kind == "gdn":
+            c = input.shape[1]
+            gp = self.fwd_kwargs["gamma_reparam"](weight.detach()).reshape(c, 1, 1, c).contiguous()
+            bp = self.fwd_kwargs["beta_reparam"](bias)
+            x = _nhwc(input)
+            y = ops.conv2d_fwd(x, gp, bp.contiguous(), 1, 0,
+                               epilogue=L.EPI_IGDN if self.fwd_kwargs["inverse"] else L.EPI_GDN, aux=x, square_input=True)
+            out = _nchw_view(y)
+        elif self.kind == "linear":
+            x = input.reshape(1, 1, -1, input.shape[-1]).contiguous()
+            w = weight.detach().reshape(weight.shape[0], 1, 1, weight.shape[1]).contiguous()
+            y = ops.conv2d_fwd(x, w, bias, 1, 0, epilogue=L.EPI_LRELU if fuse else L.EPI_NONE)
+            out = y.reshape(*input.shape[:-1], weight.shape[0])
+        else:
+            raise NotImplementedError(f"QuantModule({self.kind}) forward is not built yet (SURVEY 8f rows 3: Lu2022 / Minnen2018)")
+        if self.se_module is not None:
+            out = self.se_module(out)
+        if not fuse:
+            out = self.activation_function(out)
+        if self.disable_act_quant:
+            return out
+        if self.use_act_quant and self.trained:
+            out = self.act_quantizer(out, True)
+        return out
+
+    def set_quant_state(self, weight_quant: bool = False, act_quant: bool = False):
+        self.use_weight_quant = weight_quant
+        self.use_act_quant = act_quant
+
+
+def f_gdn(x, gamma, beta, inverse, gamma_reparam, beta_reparam):
+    """Functional GDN on the HIP conv kernel (reference: quant_layer.py:142-154)."""
+    c = x.shape[1]
+    xr = _nhwc(x)
+    y = ops.conv2d_fwd(xr, gamma_reparam(gamma).reshape(c, 1, 1, c).contiguous(), beta_reparam(beta).contiguous(), 1, 0,
+                       epilogue=L.EPI_IGDN if inverse else L.EPI_GDN, aux=xr, square_input=True)
+    return _nchw_view(y)

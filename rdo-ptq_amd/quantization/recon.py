@@ -1,0 +1,105 @@
+"""Shared body of `layer_reconstruction` / `block_reconstruction` (reference: layer_opt.py:175-320, block_opt.py:176-324).
+
+The choreography around the hot loop is the reference's; the loop itself runs on `engine.UnitEngine`."""
+import logging
+import time
+
+import torch
+
+from .engine import UnitEngine
+from .quant_block import BaseQuantBlock
+from .quant_layer import QuantModule, _nhwc
+from .utils import LinearTempDecay, save_inp_oup_data, set_mode
+
+_COOPS = ("g_a", "h_a", "h_s", "g_s")
+
+
+def find_unquantized_module(model, _name_="g_a", module_list=None, name_list=None):
+    """Switch every untrained unit to full precision and collect those of the current sub-coder (layer_opt.py:15-43).
+    For Sequential-indexed models the names never contain g_a/h_a/h_s/g_s, so the lists stay empty."""
+    module_list = [] if module_list is None else module_list
+    name_list = [] if name_list is None else name_list
+    for name, module in model.named_children():
+        if isinstance(module, (QuantModule, BaseQuantBlock)):
+            if not module.trained:
+                module.set_quant_state(False, False)
+                for tag in _COOPS:
+                    if tag in _name_ and tag in name:
+                        name_list.append(name)
+                        module_list.append(module)
+        else:
+            find_unquantized_module(module, _name_, module_list, name_list)
+    return module_list[1:], name_list[1:]
+
+
+class LossFunction:
+    """Host-side restatement of the objective, used for logging/inspection only -- the engine evaluates the same terms
+    on the device (layer_opt.py:87-173)."""
+
+    def __init__(self, unit, round_loss="relaxation", weight=1., rec_loss="mse", max_count=2000, b_range=(10, 2),
+                 decay_start=0.0, warmup=0.0, p=2., lmbda=None, metric=None):
+        self.unit, self.round_loss, self.weight, self.rec_loss = unit, round_loss, weight, rec_loss
+        self.loss_start = max_count * warmup
+        self.p, self.lmbda, self.metric = p, lmbda, metric
+        self.temp_decay = LinearTempDecay(max_count, rel_start_decay=warmup + (1 - warmup) * decay_start,
+                                          start_b=b_range[0], end_b=b_range[1])
+        self.count = 0
+
+
+def _unit_modules(unit):
+    """kind + the engine's module dict for a QuantModule or a Cheng2020 block."""
+    if isinstance(unit, QuantModule):
+        return "layer", {"layer": unit}
+    kind = getattr(unit, "unit_kind", None)
+    if kind == "rb":
+        return kind, {"conv1": unit.conv1, "conv2": unit.conv2, "skip": unit.skip}
+    if kind == "rbws":
+        return kind, {"conv1": unit.conv1, "conv2": unit.conv2, "gdn": unit.gdn, "skip": unit.skip}
+    if kind == "rbu":
+        return kind, {"subpel_conv": unit.subpel_conv[0], "conv": unit.conv, "igdn": unit.igdn,
+                      "upsample": unit.upsample[0], "upscale": unit.subpel_conv[1].upscale_factor}
+    raise NotImplementedError(f"reconstruction of {type(unit).__name__} is not built yet")
+
+
+def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, weight=0.01, opt_mode="mse", asym=False,
+                include_act_func=True, b_range=(20, 2), warmup=0.0, input_prob=1.0, act_quant=False, lr=4e-5, p=2.0,
+                config=None, args=None, is_block=False):
+    if opt_mode != "mse":
+        raise NotImplementedError("only opt_mode='mse' (the mode main2.py uses) is built")
+    task_p = getattr(args, "task_loss", 2.0) if args is not None else 2.0
+    if float(p) != 2.0 or float(task_p) != 2.0:
+        raise NotImplementedError("the HIP loss kernel implements p = task_loss = 2 (main2.py defaults)")
+    t0 = time.time()
+    # dynamic activation quantisation makes cached values depend on the caching batch: keep the reference's batch of 1 then
+    cache_bs = 1 if act_quant else max(1, min(32, cali_data.size(0)))
+    (inp_q, inp_fp), out_fp = save_inp_oup_data(model, unit, cali_data, asym, act_quant, batch_size=cache_bs, input_prob=True)
+    logging.info("Cached init time: {}".format(time.time() - t0))
+    module_list, name_list = find_unquantized_module(model, unit_name, [], [])
+    logging.info(name_list)
+    if module_list:
+        raise NotImplementedError("task loss through the rest of the sub-coder (Lu2022 naming) is not built yet")
+    model.set_quant_state(False, False)
+    set_mode(model, act_quant)
+    if not is_block and ("g_s7" in unit_name or "7" in unit_name):
+        logging.info("=======last layer, close activation quantization=======")
+        unit.set_quant_state(True, False)
+    else:
+        unit.set_quant_state(True, act_quant)
+    if not is_block and unit.org_weight is None:
+        return None                                   # PixelShuffle units carry nothing to train (layer_opt.py:245-246)
+    kind, mods = _unit_modules(unit)
+    # the CLI --lr is ignored by the reference (Adam default 1e-3, layer_opt.py:253-254); kept that way.
+    eng = UnitEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), batch_size=batch_size, iters=iters,
+                     weight=weight, b_range=b_range, warmup=warmup, input_prob=input_prob, lr=1e-3,
+                     seed=torch.initial_seed() ^ (hash(unit_name) & 0xFFFF), include_act_func=include_act_func)
+    eng.run()
+    if logging.getLogger().isEnabledFor(logging.INFO) and iters >= 500:
+        total, rt, rd = eng.logs()
+        for c in range(500, iters + 1, 500):
+            logging.info("Total loss:\t{:.3f} ( task:{:.3f}, rec:{:.3f}, round:{:.3f})\tcount={}".format(
+                float(total[c - 1]), float(rt[c - 1]) / 2, float(rt[c - 1]) / 2, float(rd[c - 1]), c))
+    eng.finish()
+    for m in ([unit] if not is_block else unit.modules()):
+        if isinstance(m, (QuantModule, BaseQuantBlock)):
+            m.trained = True
+    return eng

@@ -1,0 +1,93 @@
+"""Shared builders for the parity tests: turn golden-fixture tensors into oracle QOps and into product modules."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from oracle import rdo_oracle as O
+
+T = torch.from_numpy
+
+UNIT_OPS = {"rbws": ["conv1", "conv2", "gdn", "skip"], "rb": ["conv1", "conv2", "skip"],
+            "rbu": ["subpel_conv", "conv", "igdn", "upsample"], "layer": ["layer"]}
+LAYER_GEOM = {"g_a.6": (2, 1), "g_s.7.0": (1, 1), "h_s.2.0": (1, 1), "entropy_parameters.0": (1, 0),
+              "context_prediction": (1, 2)}
+RECON_UNITS = [("g_a.0", "rbws"), ("g_a.1", "rb"), ("g_a.6", "layer"), ("g_s.1", "rbu"), ("g_s.7.0", "layer"),
+               ("h_s.2.0", "layer"), ("entropy_parameters.0", "layer"), ("context_prediction", "layer")]
+WQ = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+AQ = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+
+
+def oracle_ops(fx, tag, kind):
+    ops = {}
+    for n in UNIT_OPS[kind]:
+        if f"{tag}/{n}.weight" not in fx:
+            continue
+        w = T(fx[f"{tag}/{n}.weight"])
+        b = T(fx[f"{tag}/{n}.bias"]) if f"{tag}/{n}.bias" in fx else None
+        if n in ("gdn", "igdn"):
+            op = O.QOp(n, w, b)
+        elif kind == "layer":
+            s, p = LAYER_GEOM[tag]
+            op = O.QOp("conv", w, b, stride=s, padding=p, act="lrelu" if int(fx[f"{tag}/{n}.act"]) else None)
+        else:
+            stride = 2 if (kind == "rbws" and n in ("conv1", "skip")) else 1
+            op = O.QOp("conv", w, b, stride=stride, padding=w.shape[-1] // 2)
+        op.delta, op.zp = T(fx[f"{tag}/{n}.delta"]), T(fx[f"{tag}/{n}.zp"])
+        ops[n] = op
+    return ops
+
+
+def _conv(w, b, stride, pad, dev):
+    co, ci, k, _ = w.shape
+    c = nn.Conv2d(ci, co, k, stride=stride, padding=pad, bias=b is not None)
+    with torch.no_grad():
+        c.weight.copy_(w)
+        if b is not None:
+            c.bias.copy_(b)
+    return c.to(dev)
+
+
+def product_unit(fx, tag, kind, dev="cuda"):
+    """-> (unit module of the product `quantization` package, engine kind, engine module dict) from fixture tensors."""
+    import lic
+    from quantization.quant_block import QuantRB, QuantRBU, QuantRBWS
+    from quantization.quant_layer import QuantModule
+    from quantization.recon import _unit_modules
+    g = lambda n: T(fx[f"{tag}/{n}"]) if f"{tag}/{n}" in fx else None
+    if kind == "layer":
+        s, p = LAYER_GEOM[tag]
+        qm = QuantModule(_conv(g("layer.weight"), g("layer.bias"), s, p, dev), WQ, AQ)
+        if int(fx[f"{tag}/layer.act"]):
+            qm.activation_function = nn.LeakyReLU(inplace=True)
+        unit = qm
+    else:
+        w1 = g("conv1.weight") if kind != "rbu" else g("conv.weight")
+        C = w1.shape[0]
+        if kind == "rb":
+            blk = lic.ResidualBlock(w1.shape[1], C)
+            names = {"conv1": blk.conv1, "conv2": blk.conv2}
+        elif kind == "rbws":
+            blk = lic.ResidualBlockWithStride(w1.shape[1], C, stride=2)
+            names = {"conv1": blk.conv1, "conv2": blk.conv2, "skip": blk.skip, "gdn": blk.gdn}
+        else:
+            cin = g("subpel_conv.weight").shape[1]
+            blk = lic.ResidualBlockUpsample(cin, C, 2)
+            names = {"subpel_conv": blk.subpel_conv[0], "conv": blk.conv, "upsample": blk.upsample[0], "igdn": blk.igdn}
+        with torch.no_grad():
+            for n, mod in names.items():
+                if n in ("gdn", "igdn"):
+                    mod.gamma.copy_(g(f"{n}.weight"))
+                    mod.beta.copy_(g(f"{n}.bias"))
+                else:
+                    mod.weight.copy_(g(f"{n}.weight"))
+                    mod.bias.copy_(g(f"{n}.bias"))
+        blk = blk.to(dev)
+        unit = {"rb": QuantRB, "rbws": QuantRBWS, "rbu": QuantRBU}[kind](blk, WQ, AQ)
+    unit = unit.to(dev)
+    k, mods = _unit_modules(unit)
+    assert k == kind
+    return unit, kind, mods
+
+
+def nhwc(a, dev="cuda"):
+    return T(np.ascontiguousarray(a.transpose(0, 2, 3, 1))).to(dev)

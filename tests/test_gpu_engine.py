@@ -1,0 +1,80 @@
+"""Hot-loop parity: the HIP calibration engine against the oracle's reconstruct_unit (which is itself pinned to the
+reference's layer_/block_reconstruction by tests/test_oracle_golden.py), on the toy-Cheng2020 golden caches with the same
+mini-batch index stream and the same counter-RNG QDrop masks.
+
+Tolerances (fp32, different reduction orders): per-iteration loss 2e-4 relative; alpha 2e-3 absolute after 12 Adam
+steps of 1e-3 (Adam normalises the gradient, so a noisy tiny gradient may move one element by up to lr per step);
+hard rounding decisions (alpha >= 0) must agree on >= 99.5 % of the weights."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import RECON_UNITS, nhwc, oracle_ops, product_unit, T
+
+pytestmark = pytest.mark.gpu
+SEED = 1005
+
+
+@pytest.fixture(scope="module")
+def recon(golden_dir):
+    return np.load(os.path.join(golden_dir, "recon_toy.npz"))
+
+
+@pytest.mark.parametrize("tag,kind", RECON_UNITS)
+@pytest.mark.parametrize("graph", [True, False])
+def test_engine_matches_oracle(recon, tag, kind, graph):
+    from oracle import rdo_oracle as O
+    from quantization.engine import UnitEngine
+    fx = recon
+    _, n_img, B, iters = (int(v) for v in fx["meta"])
+    idx = fx[f"{tag}/idx"]
+    # --- oracle
+    ops_o = oracle_ops(fx, tag, kind)
+    log = O.reconstruct_unit(kind, ops_o, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]), iters=iters,
+                             batch_size=B, idx_stream=idx,
+                             mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5), input_prob=0.5,
+                             weight=0.01, b_range=(20, 2), warmup=0.2)
+    # --- product
+    unit, k, mods = product_unit(fx, tag, kind)
+    eng = UnitEngine(k, mods, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]), batch_size=B,
+                     iters=iters, weight=0.01, b_range=(20, 2), warmup=0.2, input_prob=0.5, seed=SEED,
+                     idx_table=torch.from_numpy(idx), use_graph=graph)
+    # scales initialised by the HIP min/max kernel must equal the reference's
+    for n, op in eng.ops.items():
+        np.testing.assert_array_equal(op.delta.cpu().numpy(), fx[f"{tag}/{n}.delta"].reshape(-1))
+        np.testing.assert_array_equal(op.zp.cpu().numpy(), fx[f"{tag}/{n}.zp"].reshape(-1))
+    eng.run()
+    torch.cuda.synchronize()
+    total, rt, rd = eng.logs()
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(rd.numpy(), np.array(log.round), rtol=2e-4, atol=1e-7)
+    flips = tot = 0
+    for n, op in ops_o.items():
+        a_gpu = eng.alpha_of(n).cpu()
+        assert a_gpu.shape == op.alpha.shape
+        np.testing.assert_allclose(a_gpu.numpy(), op.alpha.numpy(), rtol=0, atol=2e-3)
+        flips += int(((a_gpu >= 0) != (op.alpha >= 0)).sum())
+        tot += a_gpu.numel()
+    assert flips <= 0.005 * tot, f"{flips}/{tot} rounding decisions differ"
+    # hand-back: hard-rounded forward of the trained unit through the module surface
+    eng.finish()
+    for m in unit.modules():
+        if hasattr(m, "trained"):
+            m.trained = True
+    unit.set_quant_state(True, False)
+    with torch.no_grad():
+        y = unit(T(fx[f"{tag}/inp_q"][:2]).cuda())
+        y_ref = O.UNIT_FORWARD[kind](ops_o, T(fx[f"{tag}/inp_q"][:2]))
+    torch.cuda.synchronize()
+    err = (y.cpu() - y_ref).abs().max() / (y_ref.abs().max() + 1e-12)
+    # a flipped rounding decision moves one weight by one step: allow the few flips counted above
+    assert float(err) < (5e-3 if flips else 2e-5), float(err)
+
+
+def test_engine_rejects_cpu_tensors(recon):
+    from quantization.engine import UnitEngine
+    fx = recon
+    with pytest.raises(RuntimeError):
+        UnitEngine("layer", {}, torch.zeros(2, 4, 4, 4), torch.zeros(2, 4, 4, 4), torch.zeros(2, 4, 4, 4), batch_size=1, iters=1)

@@ -1,0 +1,249 @@
+"""Per-kernel parity of the HIP library (through the C ABI) against torch fp64/fp32 references and the oracle.
+Tolerances are stated per test: fp32 MFMA accumulation is a k-ordered fmaf chain, so conv results differ from an fp64
+reference by ~1e-6 relative to sum|a*b|; element-wise kernels match the oracle to a few ulp."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hipops import ops as o
+    return o
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).abs().max() / (b.double().abs().max() + 1e-30))
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, K, stride, pad
+    (2, 16, 16, 32, 64, 3, 1, 1),
+    (2, 16, 16, 192, 192, 3, 1, 1),
+    (1, 32, 32, 192, 192, 3, 2, 1),
+    (2, 17, 13, 8, 8, 3, 1, 1),       # ragged, tiny channels (toy goldens)
+    (2, 16, 16, 3, 192, 3, 2, 1),     # first layer, Cin=3 (scalar loads)
+    (2, 16, 16, 192, 12, 3, 1, 1),    # g_s.7.0
+    (2, 8, 8, 768, 640, 1, 1, 0),     # entropy_parameters.0
+    (1, 16, 16, 192, 384, 5, 1, 2),   # context_prediction
+    (2, 16, 16, 192, 192, 1, 2, 0),   # skip 1x1 s2
+    (1, 8, 8, 192, 768, 3, 1, 1),     # subpel conv
+    (3, 5, 7, 36, 20, 5, 2, 2),       # everything ragged
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_matches_fp64(ops, case):
+    B, H, W, Cin, Cout, K, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=s, padding=p)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = w.permute(0, 2, 3, 1).contiguous().cuda()
+    out = ops.conv2d_fwd(xd, wd, b.cuda(), stride=s, pad=p)
+    torch.cuda.synchronize()
+    got = out.cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert _rel(got, ref) < 5e-6   # ~sqrt(K)*2^-24 for K up to 4800 (fp32 fmaf chain)
+
+
+def test_conv_fwd_epilogues(ops):
+    from hipops import _lib as L
+    g = torch.Generator().manual_seed(3)
+    B, H, W, Cc = 2, 12, 12, 64
+    x = torch.randn(B, H, W, Cc, generator=g).cuda()
+    w = (torch.randn(Cc, 3, 3, Cc, generator=g) / 24).cuda()
+    b = torch.randn(Cc, generator=g).cuda()
+    aux = torch.randn(B, H, W, Cc, generator=g).cuda()
+    res = torch.randn(B, H, W, Cc, generator=g).cuda()
+    base = ops.conv2d_fwd(x, w, b, 1, 1)
+    pre = torch.empty_like(base)
+    y = ops.conv2d_fwd(x, w, b, 1, 1, epilogue=L.EPI_LRELU, residual=res, pre=pre)
+    torch.testing.assert_close(pre, base, rtol=0, atol=0)
+    torch.testing.assert_close(y, F.leaky_relu(base, 0.01) + res, rtol=1e-6, atol=1e-6)
+    y = ops.conv2d_fwd(x, w, None, 1, 1, epilogue=L.EPI_LRELU_BWD, aux=aux)
+    nb = ops.conv2d_fwd(x, w, None, 1, 1)
+    torch.testing.assert_close(y, torch.where(aux > 0, nb, 0.01 * nb), rtol=1e-6, atol=1e-6)
+    # GDN-style: square on load, positive weights/bias, aux * rsqrt / sqrt
+    wp = w.abs()
+    bp = b.abs() + 0.5
+    n = ops.conv2d_fwd(x * x, wp, bp, 1, 1)
+    for epi, fn in ((L.EPI_GDN, torch.rsqrt), (L.EPI_IGDN, torch.sqrt)):
+        y = ops.conv2d_fwd(x, wp, bp, 1, 1, epilogue=epi, aux=aux, square_input=True)
+        torch.testing.assert_close(y, aux * fn(n), rtol=2e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_wgrad_matches_fp64(ops, case):
+    B, H, W, Cin, Cout, K, s, p = case
+    g = torch.Generator().manual_seed(hash(case) % 2**31 + 1)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    Ho, Wo = (H + 2 * p - K) // s + 1, (W + 2 * p - K) // s + 1
+    dy = torch.randn(B, Cout, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_weight(x.double(), (Cout, Cin, K, K), dy.double(), stride=s, padding=p)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    dyd = dy.permute(0, 2, 3, 1).contiguous().cuda()
+    slabs = ops.conv2d_wgrad(xd, dyd, (Cout, K, K, Cin), stride=s, pad=p)
+    dw = ops.reduce_slabs(slabs)
+    torch.cuda.synchronize()
+    got = dw.cpu().permute(0, 3, 1, 2)
+    assert _rel(got, ref) < 3e-6
+
+
+def test_conv_dgrad_via_flipped_weights(ops):
+    """dgrad of a stride-1 'same' conv == forward conv of dy with the wd layout emitted by rdo_adaround_fwd."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W, Ci, Co, K = 2, 10, 9, 32, 48, 3
+    x = torch.randn(B, Ci, H, W, generator=g, dtype=torch.float64, requires_grad=True)
+    w = torch.randn(Co, Ci, K, K, generator=g, dtype=torch.float64) / 17
+    dy = torch.randn(B, Co, H, W, generator=g, dtype=torch.float64)
+    F.conv2d(x, w, None, 1, 1).backward(dy)
+    w_ohwi = w.float().permute(0, 2, 3, 1).contiguous().cuda()
+    delta = torch.full((Co,), 1e-3).cuda()
+    zp = torch.full((Co,), 128.0).cuda()
+    d = ops.ada_desc(w_ohwi, n_levels=1 << 16)   # fine grid: fake-quant ~ identity is not needed, use wd of the quantised w
+    wq = torch.empty_like(w_ohwi)
+    wd = torch.empty(Ci, K, K, Co, device="cuda")
+    ops.uaq_fakequant(d, w_ohwi, delta, zp, wq, wd)
+    # reference dgrad with the same quantised weight
+    wq_oihw = wq.cpu().permute(0, 3, 1, 2).double()
+    x2 = x.detach().clone().requires_grad_(True)
+    F.conv2d(x2, wq_oihw, None, 1, 1).backward(dy)
+    dx = ops.conv2d_fwd(dy.float().permute(0, 2, 3, 1).contiguous().cuda(), wd, None, 1, K - 1 - 1)
+    torch.cuda.synchronize()
+    assert _rel(dx.cpu().permute(0, 3, 1, 2), x2.grad) < 2e-6
+
+
+def test_pixel_shuffle_roundtrip(ops):
+    x = torch.randn(2, 6, 5, 12 * 4).cuda()
+    y = ops.pixel_shuffle(x, 2)
+    ref = F.pixel_shuffle(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y, ref.contiguous(), rtol=0, atol=0)
+    torch.testing.assert_close(ops.pixel_unshuffle(y, 2), x, rtol=0, atol=0)
+
+
+def test_layout_and_small_ops(ops):
+    x = torch.randn(2, 5, 6, 8).cuda()
+    torch.testing.assert_close(ops.nchw_to_nhwc(x), x.permute(0, 2, 3, 1).contiguous(), rtol=0, atol=0)
+    torch.testing.assert_close(ops.nhwc_to_nchw(ops.nchw_to_nhwc(x)), x, rtol=0, atol=0)
+    g, y = torch.randn(4, 64).cuda(), torch.randn(4, 64).cuda()
+    torch.testing.assert_close(ops.lrelu_bwd(g, y), torch.where(y > 0, g, 0.01 * g), rtol=0, atol=0)
+    torch.testing.assert_close(ops.add(g, y), g + y, rtol=0, atol=0)
+
+
+def test_actquant_matches_oracle(ops):
+    from oracle import rdo_oracle as O
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(3, 24, 7, 9, generator=g) * 2
+    x[:, 5] = 0.75
+    ref = O.act_quant(x)
+    got = ops.actquant_perchannel(x.permute(0, 2, 3, 1).contiguous().cuda()).cpu().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref, rtol=0, atol=2e-7)
+
+
+def test_uaq_init_and_fakequant_match_oracle(ops):
+    from oracle import rdo_oracle as O
+    g = torch.Generator().manual_seed(10)
+    w = torch.randn(16, 8, 3, 3, generator=g) * 0.2
+    delta, zp = O.uaq_init(w, 8, True, "max")
+    wo = w.permute(0, 2, 3, 1).contiguous().cuda()
+    d_gpu, z_gpu = ops.uaq_init_minmax(wo, 256)
+    torch.testing.assert_close(d_gpu.cpu(), delta.view(-1), rtol=0, atol=0)
+    torch.testing.assert_close(z_gpu.cpu(), zp.view(-1), rtol=0, atol=0)
+    d = ops.ada_desc(wo)
+    wq = ops.uaq_fakequant(d, wo, d_gpu, z_gpu)
+    ref = O.uaq_fakequant(w, delta, zp, 256)
+    torch.testing.assert_close(wq.cpu().permute(0, 3, 1, 2), ref, rtol=0, atol=0)
+
+
+def test_adaround_fwd_init_match_oracle(ops):
+    from oracle import rdo_oracle as O
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(16, 8, 3, 3, generator=g) * 0.2
+    delta, zp = O.uaq_init(w, 8, True, "max")
+    a0 = O.adaround_init_alpha(w, delta)
+    wo = w.permute(0, 2, 3, 1).contiguous().cuda()
+    d = ops.ada_desc(wo)
+    dg, zg = delta.view(-1).cuda(), zp.view(-1).cuda()
+    alpha = ops.adaround_init_alpha(d, wo, dg)
+    torch.testing.assert_close(alpha.cpu().permute(0, 3, 1, 2), a0, rtol=2e-6, atol=2e-6)
+    al = (a0 + torch.randn(a0.shape, generator=g)).contiguous()
+    alg = al.permute(0, 2, 3, 1).contiguous().cuda()
+    for soft in (True, False):
+        ref = O.adaround_forward(w, al, delta, zp, 256, soft)
+        wd = torch.empty(8, 3, 3, 16, device="cuda")
+        got = ops.adaround_fwd(d, wo, alg, dg, zg, soft, wd=wd)
+        torch.testing.assert_close(got.cpu().permute(0, 3, 1, 2), ref, rtol=0, atol=float(delta.max()) * 1e-4)  # (floor + h + zp) rounds on the 2^-16 grid at |x_int| ~ 128
+        # wd[ci][kh'][kw'][co] = wq[co][K-1-kh'][K-1-kw'][ci]
+        torch.testing.assert_close(wd, got.flip(1, 2).permute(3, 1, 2, 0).contiguous(), rtol=0, atol=0)
+
+
+def test_gather_qdrop_and_lp2_match_oracle(ops):
+    from oracle import rdo_oracle as O
+    g = torch.Generator().manual_seed(12)
+    n, Cc, H, W, B, iters = 6, 8, 6, 5, 3, 4
+    cq = torch.randn(n, Cc, H, W, generator=g)
+    cf = torch.randn(n, Cc, H, W, generator=g)
+    tgt = torch.randn(n, Cc, H, W, generator=g)
+    idx = torch.stack([torch.randperm(n, generator=g)[:B] for _ in range(iters)]).int()
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = torch.empty(B, H, W, Cc, device="cuda")
+    grad = torch.empty_like(out)
+    log = torch.zeros(iters, device="cuda")
+    for i in range(iters):
+        ops.gather_qdrop(nh(cq), nh(cf), idx.cuda(), it, B, 0.5, 1005, out)
+        keep = O.qdrop_keep_mask_nhwc(1005, i, (B, Cc, H, W), 0.5)
+        ref = torch.where(keep, cq[idx[i].long()], cf[idx[i].long()])
+        torch.testing.assert_close(out.cpu().permute(0, 3, 1, 2), ref, rtol=0, atol=0)
+        ops.lp2_loss_grad(out, nh(tgt), idx.cuda(), it, 2.0, grad, log)
+        pr = ref.clone().requires_grad_(True)
+        t = tgt[idx[i].long()]
+        loss = O.lp_loss(pr, t, p=2.0) + O.lp_loss(pr, t, p=2.0)
+        loss.backward()
+        torch.testing.assert_close(grad.cpu().permute(0, 3, 1, 2), pr.grad, rtol=1e-6, atol=1e-8)
+        assert abs(float(log[i]) - float(loss)) < 1e-5 * abs(float(loss))
+        ops.iter_advance(it)
+    assert int(it.item()) == iters
+
+
+def test_gdn_forward_backward_match_oracle(ops):
+    """f_gdn (quant_layer.py:142-154) forward and its input/gamma gradients, composed from the conv kernels."""
+    from hipops import _lib as L
+    from oracle import rdo_oracle as O
+    g = torch.Generator().manual_seed(13)
+    B, Cc, H, W = 2, 32, 9, 7
+    for inverse in (False, True):
+        x = torch.randn(B, Cc, H, W, generator=g, requires_grad=True)
+        gamma = (0.1 * torch.eye(Cc) + 0.02 * torch.rand(Cc, Cc, generator=g)).sqrt().requires_grad_(True)
+        beta = (0.5 + torch.rand(Cc, generator=g)).sqrt()
+        gy = torch.randn(B, Cc, H, W, generator=g)
+        y = O.f_gdn(x, gamma, beta, inverse)
+        y.backward(gy)
+        gp = O._GAMMA_REPARAM(gamma.detach())
+        bp = O._BETA_REPARAM(beta)
+        nh = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().cuda()
+        xg, gyg = nh(x), nh(gy)
+        w1 = gp.reshape(Cc, 1, 1, Cc).contiguous().cuda()
+        w1t = gp.t().reshape(Cc, 1, 1, Cc).contiguous().cuda()
+        norm = torch.empty_like(xg)
+        yg = ops.conv2d_fwd(xg, w1, bp.cuda(), 1, 0, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN, aux=xg, square_input=True,
+                            pre=norm)
+        torch.testing.assert_close(yg.cpu().permute(0, 3, 1, 2), y.detach(), rtol=3e-6, atol=1e-6)
+        t = ops.gdn_bwd_t(gyg, xg, norm, inverse)
+        acc = ops.conv2d_fwd(t, w1t, None, 1, 0)
+        dx = ops.gdn_bwd_dx(gyg, xg, norm, acc, inverse)
+        torch.testing.assert_close(dx.cpu().permute(0, 3, 1, 2), x.grad, rtol=2e-5, atol=2e-6)
+        dgp = ops.reduce_slabs(ops.conv2d_wgrad(xg, t, (Cc, 1, 1, Cc), 1, 0, square_input=True)).reshape(Cc, Cc).cpu()
+        # chain through gamma' = max(gamma, bound)^2 - pedestal on the host for the comparison
+        bound = float(O._GAMMA_REPARAM.lower_bound.bound)
+        lb = torch.clamp(gamma.detach(), min=bound)
+        go = dgp * 2 * lb
+        dg = torch.where((gamma.detach() >= bound) | (go < 0), go, torch.zeros_like(go))
+        torch.testing.assert_close(dg, gamma.grad, rtol=2e-5, atol=2e-5)
+        x.grad = None
