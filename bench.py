@@ -1,0 +1,295 @@
+#!/usr/bin/env python3
+"""Benchmark of the RDO-PTQ calibration hot path on MI355X (BASELINE.json metric: calibration images/sec).
+
+Workload (BASELINE.json configs[1]): Cheng2020-anchor N=192, W8 channel-wise `max` init, task-oriented RDO-PTQ calibration,
+256 synthetic 256x256 calibration images per GPU, mini-batch B (default 4 = the reference's `--batch_size`, main2.py:31),
+input_prob 0.5, round-loss weight 0.01, warmup 0.2, b 20->2 (main2.py:50-62).
+
+A *step* is one calibration iteration (gather -> QDrop -> forward -> round+rec+task loss -> backward -> Adam on alpha;
+layer_opt.py:287-309) of EVERY one of the 29 reconstruction units of the model; calibration images/s = units * B * steps /
+wall time.  Caches (cached_inps / cached_outs of every unit) are resident in HBM before the timed region.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--images n] [--no-cpu-baseline]
+
+N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: one rank per GPU, each
+with its own calibration shard and mini-batch (weak scaling), the per-unit alpha-gradient bucket all-reduced over RCCL
+every iteration.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "rdo-ptq_amd"))
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # /opt/skills/guides/MI355X_MICROARCH.md, "Peak FP32 (matrix)"
+PEAK_HBM_GBS = 8000.0
+
+
+def log(*a):
+    if os.environ.get("RANK", "0") == "0":
+        print(f"[bench {time.strftime('%H:%M:%S')}]", *a, file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = max(1, min(n, int(float(q) / float(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = max(1, min(n, q // per))
+        except Exception:
+            pass
+    return n
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--images", type=int, default=256, help="calibration images per GPU")
+    ap.add_argument("--N", type=int, default=192, help="Cheng2020 channel width")
+    ap.add_argument("--crop", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=6, help="timed oracle iterations per unit for cpu_baseline")
+    return ap.parse_args()
+
+
+# ----------------------------------------------------------------------------- product side
+def seeded_model(N, seed, device):
+    import lic
+    torch.manual_seed(seed)
+    model = lic.Cheng2020Anchor(N=N)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():                       # non-degenerate GDN parameters (default init has gamma = 0.1*I)
+        for name, p in model.named_parameters():
+            if name.endswith("gamma"):
+                c = p.shape[0]
+                p.copy_(torch.sqrt(0.1 * torch.eye(c) + 0.002 * torch.rand(c, c, generator=g) + 2.0 ** -36))
+    return model.to(device).eval()
+
+
+def unit_list(qnn):
+    """(name, unit) in the order main2.py's recon_model visits them (main2.py:227-253)."""
+    from quantization import BaseQuantBlock, QuantModule
+    out = []
+
+    def walk(mod, prefix):
+        for n, c in mod.named_children():
+            if isinstance(c, (QuantModule, BaseQuantBlock)):
+                out.append((prefix + n, c))
+            else:
+                walk(c, prefix + n + ".")
+    walk(qnn.model, "")
+    return [(n, u) for n, u in out if not (isinstance(u, QuantModule) and u.org_weight is None)]
+
+
+def build_caches(qnn, units, cali, bs):
+    """Two hooked passes of the wrapped model per batch: full precision (x_fp, target) and W8-nearest (x_q)."""
+    n = cali.shape[0]
+    store = {name: [None, None, None] for name, _ in units}
+    state = {"pass": 0, "lo": 0}
+
+    def mk(name):
+        def hook(mod, inp, out):
+            lo = state["lo"]
+            def put(k, t):
+                t = t.detach().permute(0, 2, 3, 1)
+                if store[name][k] is None:
+                    store[name][k] = torch.empty((n,) + tuple(t.shape[1:]), device=t.device, dtype=torch.float32)
+                store[name][k][lo:lo + t.shape[0]].copy_(t)
+            if state["pass"] == 0:
+                put(1, inp[0]); put(2, out)
+            else:
+                put(0, inp[0])
+        return hook
+    handles = [u.register_forward_hook(mk(name)) for name, u in units]
+    with torch.no_grad():
+        for lo in range(0, n, bs):
+            state["lo"] = lo
+            x = cali[lo:lo + bs]
+            state["pass"] = 0
+            qnn.set_quant_state(False, False)
+            qnn(x)
+            state["pass"] = 1
+            qnn.set_quant_state(True, False)
+            qnn(x)
+    for h in handles:
+        h.remove()
+    return store
+
+
+def gpu_leg(a, rank, world, device):
+    from quantization import QuantModel
+    from quantization.engine import UnitEngine
+    from quantization.recon import _unit_modules
+    model = seeded_model(a.N, 1005, device)
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True).to(device).eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    g = torch.Generator().manual_seed(1005 + rank)
+    cali = torch.rand(a.images, 3, a.crop, a.crop, generator=g).to(device)
+    units = unit_list(qnn)
+    log(f"model + QuantModel ready, {len(units)} units; building caches for {a.images} images")
+    t0 = time.time()
+    caches = build_caches(qnn, units, cali, bs=16)
+    torch.cuda.synchronize()
+    t_cache = time.time() - t0
+    log(f"caches built in {t_cache:.1f}s; recording engines")
+    iters = a.warmup + a.steps + 1                     # +1: the event-profiled iteration after the timed region
+    gi = torch.Generator().manual_seed(77 + rank)
+    engines = []
+    for name, u in units:
+        kind, mods = _unit_modules(u)
+        cq, cf, co = caches[name]
+        idx = torch.stack([torch.randperm(a.images, generator=gi)[:a.batch] for _ in range(iters)])
+        engines.append((name, UnitEngine(kind, mods, cq, cf, co, batch_size=a.batch, iters=iters, weight=0.01,
+                                         b_range=(20, 2), warmup=0.2, input_prob=0.5, seed=1005 + rank, idx_table=idx,
+                                         use_graph=not a.no_graph)))
+    dist = torch.distributed if world > 1 else None
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    log("engines recorded; warm-up")
+    for _, e in engines:
+        e.run(a.warmup)
+    barrier()
+    log("timed region")
+    t0 = time.perf_counter()
+    for _, e in engines:
+        e.run(a.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    log(f"timed region done: {dt:.3f}s for {a.steps} steps")
+    # ---- roofline probe: one more iteration of every unit, each op bracketed by hipEvents on the launch stream
+    per_tag = {}
+    for _, e in engines:
+        info, ms = e.plan_a.op_info(), e.plan_a.profile()
+        e._done += 1
+        if e.plan_b is not None:
+            torch.distributed.all_reduce(e.bucket, group=e.group)
+            info += e.plan_b.op_info()
+            ms += e.plan_b.profile()
+        for (tag, fl, by), m in zip(info, ms):
+            d = per_tag.setdefault(tag, [0, 0.0, 0.0, 0.0])
+            d[0] += 1; d[1] += m; d[2] += fl; d[3] += by
+    # sanity: losses finite
+    for name, e in engines:
+        tot, _, _ = e.logs()
+        if not torch.isfinite(tot[:a.warmup + a.steps]).all():
+            raise RuntimeError(f"non-finite loss in unit {name}")
+    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache)
+
+
+# ----------------------------------------------------------------------------- CPU baseline (oracle = "port")
+def cpu_leg(a):
+    from oracle import lic_oracle as L
+    from oracle import rdo_oracle as O
+    from oracle.cheng_units import capture_io, schedule
+    torch.manual_seed(1005)
+    cores = usable_cores()
+    torch.set_num_threads(cores)
+    log(f"cpu baseline on {cores} threads (os.cpu_count()={os.cpu_count()})")
+    model = L.Cheng2020Anchor(N=a.N).eval()
+    sched = schedule(model)
+    n = a.batch
+    x = torch.rand(n, 3, a.crop, a.crop, generator=torch.Generator().manual_seed(1005))
+    io = capture_io(model, sched, x)
+    iters = 1 + a.cpu_iters
+    t_total, img_iters = 0.0, 0
+    for name, kind, ops, _ in sched:
+        inp, out = io[name]
+        inp_q = inp + 1e-3 * torch.randn_like(inp)
+        idx = [list(range(n))] * iters
+        times = []
+
+        def hook(_grads, times=times):
+            times.append(time.perf_counter())
+        t0 = time.perf_counter()
+        O.reconstruct_unit(kind, ops, inp_q, inp, out, iters=iters, batch_size=n, idx_stream=idx,
+                           mask_fn=lambda i, shape: torch.rand(shape) < 0.5, input_prob=0.5, weight=0.01,
+                           b_range=(20, 2), warmup=0.2, grad_hook=hook)
+        t1 = time.perf_counter()
+        # iteration 0 (incl. AdaRound init) is warm-up: time from its grad hook to the end, i.e. `cpu_iters` iterations
+        t_total += t1 - times[0]
+        img_iters += a.cpu_iters * n
+        log(f"  cpu {name}: {(t1 - times[0]) / a.cpu_iters:.2f} s/iter")
+    return dict(value=img_iters / t_total, unit="calibration images/s", cores=cores, kind="port",
+                sample=f"oracle/rdo_oracle.py reconstruct_unit on torch-CPU fp32, all {len(sched)} units x {a.cpu_iters} timed "
+                       f"iteration(s) after 1 warm-up, B={n}, {a.crop}x{a.crop}, {cores} threads")
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        torch.distributed.init_process_group("nccl", device_id=device)
+    res = gpu_leg(a, rank, world, device)
+    n_units, dt = res["n_units"], res["dt"]
+    value = n_units * a.batch * a.steps * world / dt
+    if rank == 0:
+        conv = {t: v for t, v in res["per_tag"].items() if t.startswith("conv_")}
+        dom = max(conv, key=lambda t: conv[t][1])
+        cnt, ms, fl, _ = conv[dom]
+        achieved = fl / (ms * 1e-3) / 1e12
+        kernels = {t: {"launches_per_step": v[0], "ms_per_step": round(v[1], 4),
+                       "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[2] else None,
+                       "gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[3] else None}
+                   for t, v in sorted(res["per_tag"].items(), key=lambda kv: -kv[1][1])}
+        out = {
+            "metric": "calibration images/sec (Cheng2020 W8A8 task-oriented RDO-PTQ, image-iterations over all units)",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"Cheng2020-anchor N={a.N} W8 channel-wise max-init RDO-PTQ calibration, {n_units} units, "
+                                   f"{a.images} calib images {a.crop}x{a.crop} per GPU, batch {a.batch} per GPU",
+                       "units": n_units, "batch_per_gpu": a.batch, "images_per_gpu": a.images,
+                       "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
+                       "cache_build_s": round(res["t_cache"], 2)},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
+                         "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3)},
+            "kernels": kernels,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_leg(a)
+            out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

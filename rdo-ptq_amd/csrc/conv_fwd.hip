@@ -223,17 +223,24 @@ int launch(const FwdArgs& a, hipStream_t s) {
     return rdo::check_launch("conv_fwd");
 }
 
-template <bool VEC>
-int launch_by_shape(const FwdArgs& a, hipStream_t s) {
-    if (a.Cout <= 32) return launch<128, 32, 4, 1, VEC>(a, s);
-    if (a.Cout <= 64 || (a.Cout % 192 != 0 && a.Cout % 64 == 0 && a.Cout < 192)) return launch<128, 64, 2, 2, VEC>(a, s);
+// tile instance for a shape: 0 -> 128x32, 1 -> 128x64, 2 -> 128x192
+int pick_tile(const FwdArgs& a) {
+    if (a.Cout <= 32) return 0;
+    if (a.Cout <= 64) return 1;
     // tiles of 192 output channels fit the N=192 family (192, 384, 768, 1152); otherwise 64-wide tiles waste less.
     const long waste192 = rdo::ceil_div(a.Cout, 192) * 192 - a.Cout;
     const long waste64 = rdo::ceil_div(a.Cout, 64) * 64 - a.Cout;
-    // small problems: prefer more workgroups
-    const long tiles192 = rdo::ceil_div(a.M, 128) * rdo::ceil_div(a.Cout, 192);
-    if (waste192 <= waste64 && tiles192 >= 192) return launch<128, 192, 2, 2, VEC>(a, s);
-    return launch<128, 64, 2, 2, VEC>(a, s);
+    const long tiles192 = rdo::ceil_div(a.M, 128) * rdo::ceil_div(a.Cout, 192);   // small problems: prefer more workgroups
+    return (waste192 <= waste64 && tiles192 >= 192) ? 2 : 1;
+}
+
+template <bool VEC>
+int launch_by_shape(const FwdArgs& a, hipStream_t s) {
+    switch (pick_tile(a)) {
+        case 0: return launch<128, 32, 4, 1, VEC>(a, s);
+        case 1: return launch<128, 64, 2, 2, VEC>(a, s);
+        default: return launch<128, 192, 2, 2, VEC>(a, s);
+    }
 }
 
 }  // namespace
@@ -259,6 +266,10 @@ extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const floa
     a.csteps = (d->Cin + BK - 1) / BK;
     a.epilogue = epi; a.square_input = d->square_input; a.add_residual = d->add_residual;
     const bool vec = (d->Cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16 == 0);
+    static const char* kTags[3] = {"conv_fwd_128x32", "conv_fwd_128x64", "conv_fwd_128x192"};
+    const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
+    const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout * (1 + (pre != nullptr) + (aux != nullptr) +
+                                (residual != nullptr)) + (double)a.Cout * a.KH * a.KW * a.Cin);
     return rdo::dispatch([a, vec](hipStream_t s) { return vec ? launch_by_shape<true>(a, s) : launch_by_shape<false>(a, s); },
-                         stream);
+                         stream, kTags[pick_tile(a)], flops, bytes);
 }

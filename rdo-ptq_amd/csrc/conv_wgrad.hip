@@ -227,5 +227,6 @@ extern "C" int rdo_conv2d_wgrad(const rdo_conv_desc* d, const float* x, const fl
             if (big) return vec ? launch<192, 192, true>(a, s) : launch<192, 192, false>(a, s);
             return vec ? launch<64, 64, true>(a, s) : launch<64, 64, false>(a, s);
         },
-        stream);
+        stream, big ? "conv_wgrad_192x192" : "conv_wgrad_64x64", 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW,
+        4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout + (double)nsplit * a.Cout * a.KH * a.KW * a.Cin));
 }

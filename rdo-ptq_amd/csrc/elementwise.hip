@@ -204,7 +204,7 @@ int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t*
                                idx_table, iter_ptr, B, (long)per_image, thr, seed, out);
             return rdo::check_launch("gather_qdrop");
         },
-        stream);
+        stream, "gather_qdrop", 0.0, 12.0 * B * per_image);
 }
 
 int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
@@ -218,7 +218,7 @@ int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* 
                                iter_ptr, B, (long)per_image, inv_npix, coef, grad, loss_out);
             return rdo::check_launch("lp2_loss_grad");
         },
-        stream);
+        stream, "lp2_loss_grad", 0.0, 12.0 * B * per_image);
 }
 
 int rdo_lrelu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream) {

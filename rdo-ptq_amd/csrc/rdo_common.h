@@ -12,7 +12,12 @@
 
 namespace rdo {
 
-using Op = std::function<int(hipStream_t)>;
+struct Op {
+    std::function<int(hipStream_t)> fn;
+    const char* tag;   // kernel family / tile instance, static string
+    double flops;      // algorithmic FLOPs of this launch (0 for byte-moving ops)
+    double bytes;      // algorithmic HBM bytes of this launch
+};
 
 struct Recorder {
     bool active = false;
@@ -22,13 +27,14 @@ Recorder& recorder();                      // thread-local
 int set_error(int code, const char* fmt, ...);
 
 // Run `op` now on `stream`, or append it to the plan being recorded on this thread.
-inline int dispatch(Op op, void* stream) {
+inline int dispatch(std::function<int(hipStream_t)> fn, void* stream, const char* tag = "op", double flops = 0.0,
+                    double bytes = 0.0) {
     Recorder& r = recorder();
     if (r.active) {
-        r.sink->push_back(std::move(op));
+        r.sink->push_back(Op{std::move(fn), tag, flops, bytes});
         return RDO_OK;
     }
-    return op(reinterpret_cast<hipStream_t>(stream));
+    return fn(reinterpret_cast<hipStream_t>(stream));
 }
 
 inline int check_launch(const char* what) {

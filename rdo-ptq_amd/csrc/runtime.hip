@@ -68,7 +68,7 @@ int rdo_plan_num_ops(const rdo_plan* p) { return p ? (int)p->ops.size() : 0; }
 
 static int run_ops(rdo_plan* p, hipStream_t s) {
     for (auto& op : p->ops) {
-        int rc = op(s);
+        int rc = op.fn(s);
         if (rc != RDO_OK) return rc;
     }
     return RDO_OK;
@@ -103,6 +103,35 @@ int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream) {
         if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
     }
     return RDO_OK;
+}
+
+int rdo_plan_op_info(const rdo_plan* p, int i, const char** tag, double* flops, double* bytes) {
+    RDO_REQUIRE(p && i >= 0 && i < (int)p->ops.size(), "rdo_plan_op_info: index out of range");
+    if (tag) *tag = p->ops[i].tag;
+    if (flops) *flops = p->ops[i].flops;
+    if (bytes) *bytes = p->ops[i].bytes;
+    return RDO_OK;
+}
+
+// One eager iteration with a hipEvent pair around every op: ms[i] = device time of op i on `stream`.  Synchronises.
+int rdo_plan_profile(rdo_plan* p, float* ms, void* stream) {
+    RDO_REQUIRE(p != nullptr && !p->recording && ms != nullptr, "rdo_plan_profile: bad argument");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    const size_t n = p->ops.size();
+    std::vector<hipEvent_t> ev(n + 1);
+    for (auto& e : ev)
+        if (hipEventCreate(&e) != hipSuccess) return rdo::set_error(RDO_EHIP, "hipEventCreate failed");
+    int rc = RDO_OK;
+    (void)hipEventRecord(ev[0], s);
+    for (size_t i = 0; i < n && rc == RDO_OK; ++i) {
+        rc = p->ops[i].fn(s);
+        (void)hipEventRecord(ev[i + 1], s);
+    }
+    if (hipStreamSynchronize(s) != hipSuccess && rc == RDO_OK) rc = rdo::set_error(RDO_EHIP, "hipStreamSynchronize failed");
+    if (rc == RDO_OK)
+        for (size_t i = 0; i < n; ++i) (void)hipEventElapsedTime(&ms[i], ev[i], ev[i + 1]);
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    return rc;
 }
 
 }  // extern "C"

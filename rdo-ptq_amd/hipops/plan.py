@@ -32,6 +32,22 @@ class Plan:
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L.check(L.lib().rdo_plan_run(self._h, int(n_iters), int(bool(graph)), s), "rdo_plan_run")
 
+    def op_info(self):
+        """[(tag, flops, bytes)] of the recorded ops."""
+        out = []
+        for i in range(self.num_ops):
+            tag, fl, by = C.c_char_p(), C.c_double(), C.c_double()
+            L.check(L.lib().rdo_plan_op_info(self._h, i, C.byref(tag), C.byref(fl), C.byref(by)), "rdo_plan_op_info")
+            out.append((tag.value.decode(), fl.value, by.value))
+        return out
+
+    def profile(self):
+        """Run ONE eager iteration with a hipEvent pair around every op -> per-op milliseconds (synchronises)."""
+        ms = (C.c_float * self.num_ops)()
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(L.lib().rdo_plan_profile(self._h, ms, s), "rdo_plan_profile")
+        return list(ms)
+
     def __del__(self):
         try:
             if self._h:
