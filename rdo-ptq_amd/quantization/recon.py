@@ -6,6 +6,7 @@ import time
 
 import torch
 
+from . import dp
 from .engine import UnitEngine
 from .quant_block import BaseQuantBlock
 from .quant_layer import QuantModule, _nhwc
@@ -69,6 +70,10 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     task_p = getattr(args, "task_loss", 2.0) if args is not None else 2.0
     if float(p) != 2.0 or float(task_p) != 2.0:
         raise NotImplementedError("the HIP loss kernel implements p = task_loss = 2 (main2.py defaults)")
+    rank, world_size = dp.world()
+    if world_size > 1:                      # data parallel: this rank calibrates on its shard with its share of the batch
+        cali_data = dp.shard(cali_data)
+        batch_size = max(1, batch_size // world_size)
     t0 = time.time()
     # dynamic activation quantisation makes cached values depend on the caching batch: keep the reference's batch of 1 then
     cache_bs = 1 if act_quant else max(1, min(32, cali_data.size(0)))

@@ -1,0 +1,85 @@
+"""world_size-2 (gloo, CPU) check of the data-parallel calibration step: averaging the alpha-gradient bucket across ranks
+that each hold half of the mini-batch reproduces the single-process run on the concatenated mini-batch."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import oracle_ops, T
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, golden, tag, kind, iters, out_q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for p in (root, os.path.join(root, "rdo-ptq_amd"), os.path.join(root, "tests")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import rdo_oracle as O
+    from quantization import dp
+    fx = np.load(golden)
+    n = fx[f"{tag}/inp_q"].shape[0]
+    lo, hi = dp.shard_range(n, rank, world)
+    assert dp.shard(T(fx[f"{tag}/inp_q"])).shape[0] == hi - lo
+    # global mini-batch of iteration i = images [i % 3, i % 3 + 3] -> one image from each rank's shard
+    gidx = [[i % 3, 3 + i % 3] for i in range(iters)]
+    rand = T(fx[f"{tag}/rand"])                       # [iters, 2, C, H, W] uniforms recorded from the reference run
+    ops = oracle_ops(fx, tag, kind)
+    O.reconstruct_unit(kind, ops, T(fx[f"{tag}/inp_q"])[lo:hi], T(fx[f"{tag}/inp_fp"])[lo:hi], T(fx[f"{tag}/out"])[lo:hi],
+                       iters=iters, batch_size=1, idx_stream=[[g[rank] - lo] for g in gidx],
+                       mask_fn=lambda i, shape: rand[i, rank:rank + 1] < 0.5,
+                       grad_hook=lambda grads: dp.allreduce_mean_(grads))
+    if rank == 0:
+        out_q.put({n_: op.alpha.numpy() for n_, op in ops.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("tag,kind", [("g_a.1", "rb"), ("g_a.6", "layer")])
+def test_two_rank_gradient_average_equals_single_rank(golden_dir, tag, kind):
+    from oracle import rdo_oracle as O
+    golden = os.path.join(golden_dir, "recon_toy.npz")
+    fx = np.load(golden)
+    iters = 6
+    gidx = [[i % 3, 3 + i % 3] for i in range(iters)]
+    rand = T(fx[f"{tag}/rand"])
+    ref_ops = oracle_ops(fx, tag, kind)
+    O.reconstruct_unit(kind, ref_ops, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]), iters=iters,
+                       batch_size=2, idx_stream=gidx, mask_fn=lambda i, shape: rand[i] < 0.5)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_run, args=(r, 2, port, golden, tag, kind, iters, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = q.get(timeout=240)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for n, op in ref_ops.items():
+        np.testing.assert_allclose(got[n], op.alpha.numpy(), rtol=0, atol=2e-6)
+
+
+def test_shard_range_covers_everything():
+    from quantization import dp
+    for n in (1, 7, 256, 2048):
+        for w in (1, 2, 3, 8):
+            edges = [dp.shard_range(n, r, w) for r in range(w)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
