@@ -187,8 +187,13 @@ def gpu_leg(a, rank, world, device):
     log(f"timed region done: {dt:.3f}s for {a.steps} steps")
     # ---- roofline probe: one more iteration of every unit, each op bracketed by hipEvents on the launch stream
     per_tag = {}
-    for _, e in engines:
+    for uname, e in engines:
         info, ms = e.plan_a.op_info(), e.plan_a.profile()
+        if os.environ.get("RDO_BENCH_PER_UNIT"):
+            agg = {}
+            for (tag, fl, by), m in zip(info, ms):
+                agg[tag] = agg.get(tag, 0.0) + m
+            log(f"  unit {uname:24s} {sum(ms):7.3f} ms  " + " ".join(f"{k}={v:.3f}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:5]))
         e._done += 1
         if e.plan_b is not None:
             torch.distributed.all_reduce(e.bucket, group=e.group)

@@ -52,7 +52,10 @@ const char* rdo_last_error(void);
  * 1x1 `F.conv2d(x**2, gamma, beta)` of f_gdn, quant_layer.py:147).  `pre` (nullable) receives acc+bias before the
  * epilogue (needed by the GDN backward).  dgrad of a stride-1 conv is this same entry point run on dY with `wd`. */
 int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
-                   const float* residual, float* out, float* pre, void* stream);
+                   const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats, void* stream);
+/* Small problems (few output tiles) are split over K into `workspace` (deterministic two-pass reduction).  Returns the
+ * number of floats the kernel would like for this shape (0 = no split); with a smaller / NULL workspace it does not split. */
+int64_t rdo_conv2d_fwd_workspace(const rdo_conv_desc* d);
 
 /* weight gradient: dw[co][kh][kw][ci] = sum_m dy[m][co] * x[pix(m,kh,kw)][ci]  (autograd of quant_layer.py:123).
  * Split over `nsplit` pixel chunks into `slabs[nsplit][Cout*KH*KW*Cin]` (deterministic; reduced by rdo_adaround_step or

@@ -34,13 +34,26 @@ def conv_desc(x_shape, w_shape, stride, pad, epilogue=L.EPI_NONE, square_input=F
     return L.ConvDesc(B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, epilogue, int(square_input), int(add_residual))
 
 
+_SCRATCH = {}       # device -> list of scratch tensors (kept alive: recorded plans hold raw pointers into them)
+
+
+def _scratch(device, n_floats):
+    """Split-K workspace shared by all convolutions of a device (launches are stream-ordered, so one buffer suffices)."""
+    pool = _SCRATCH.setdefault(device, [])
+    if not pool or pool[-1].numel() < n_floats:
+        pool.append(torch.empty(max(n_floats, 1 << 22), device=device, dtype=torch.float32))
+    return pool[-1]
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, square_input=False,
                out=None, pre=None):
     d = conv_desc(x.shape, w.shape, stride, pad, epilogue, square_input, residual is not None)
     if out is None:
         out = torch.empty((d.B, d.Ho, d.Wo, d.Cout), device=x.device, dtype=torch.float32)
+    need = int(L.lib().rdo_conv2d_fwd_workspace(C.byref(d)))
+    ws = _scratch(x.device, need) if need else None
     L.check(L.lib().rdo_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(aux), _ptr(residual), _ptr(out), _ptr(pre),
-                                   _stream()), "rdo_conv2d_fwd")
+                                   _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "rdo_conv2d_fwd")
     return out
 
 
