@@ -7,6 +7,12 @@
 // over one chunk of pixels and writes its partial tile into slab[chunk]; slabs are summed deterministically by the fused
 // AdaRound step (adaround.hip) or rdo_reduce_slabs.  Both operands are staged [32 pixels][channels] exactly as they lie in
 // NHWC memory (channels contiguous), so the MFMA fragments are plain conflict-free ds_read_b32 (lane = channel).
+//
+// Pipeline (same idea as conv_fwd.hip): a reduction step is 16 "slots" (pixel pairs) of TM*TN MFMAs; slot j also writes
+// staging quad j (data of step s+1, loaded a full step earlier) into the idle LDS buffer and re-issues its global load
+// for step s+2, and prefetches the next slot's fragments, so the matrix pipe stays fed from a single wave per SIMD.
+#include <utility>
+
 #include "rdo_common.h"
 
 namespace {
@@ -30,9 +36,9 @@ template <int TCO, int TCI, bool VEC>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     constexpr int WCO = TCO / 2, WCI = TCI / 2;  // 2x2 waves
     constexpr int TM = WCO / 32, TN = WCI / 32;
-    constexpr int YQ = PK * TCO / 4 / 256;  // dy quads per thread per step
-    constexpr int XQ = PK * TCI / 4 / 256;
-    static_assert(YQ >= 1 && XQ >= 1, "tile too small for 256 threads");
+    constexpr int YQ = TCO / 32, XQ = TCI / 32;  // staging quads per thread per step (one pixel row per thread)
+    constexpr int NQ = YQ + XQ;
+    static_assert(NQ <= 16, "one staging quad per slot");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ys = smem;                   // [2][PK][TCO]
@@ -41,6 +47,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 31, lh = lane >> 5;
     const int wco0 = (wave >> 1) * WCO, wci0 = (wave & 1) * WCI;
+    const int srow = tid >> 3, sq = tid & 7;   // staging: pixel row of the step, first quad column
 
     const int chunk = blockIdx.x;
     int t = blockIdx.y;
@@ -52,7 +59,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 
     const int mbeg = chunk * a.mchunk;
     const int mend = min(a.M, mbeg + a.mchunk);
-    const int nsteps = (mend - mbeg + PK - 1) / PK;
+    const int nsteps = mend > mbeg ? (mend - mbeg + PK - 1) / PK : 0;
+    const int HoWo = a.Ho * a.Wo;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -62,89 +70,106 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgArgs a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ry[YQ], rx[XQ];
-    const int HoWo = a.Ho * a.Wo;
-
-    auto load_step = [&](int s) {
-        const int mb = mbeg + s * PK;
-#pragma unroll
-        for (int j = 0; j < YQ; ++j) {
-            int e = tid + 256 * j;
-            int row = e / (TCO / 4), qd = e - row * (TCO / 4);
-            int m = mb + row, c = co0 + 4 * qd;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < mend) {
-                const float* p = a.dy + (long)m * a.Cout + c;
-                if (VEC) {
-                    if (c < a.Cout) v = *reinterpret_cast<const f32x4*>(p);
-                } else {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-                        if (c + k < a.Cout) v[k] = p[k];
-                }
-            }
-            ry[j] = v;
-        }
-#pragma unroll
-        for (int j = 0; j < XQ; ++j) {
-            int e = tid + 256 * j;
-            int row = e / (TCI / 4), qd = e - row * (TCI / 4);
-            int m = mb + row, c = ci0 + 4 * qd;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (m < mend) {
-                int b = m / HoWo;
-                int rem = m - b * HoWo;
-                int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-                int hi = ho * a.stride - a.pad + kh, wi = wo * a.stride - a.pad + kw;
-                if ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) {
-                    const float* p = a.x + (((long)b * a.H + hi) * a.W + wi) * a.Cin + c;
-                    if (VEC) {
-                        if (c < a.Cin) v = *reinterpret_cast<const f32x4*>(p);
-                    } else {
-#pragma unroll
-                        for (int k = 0; k < 4; ++k)
-                            if (c + k < a.Cin) v[k] = p[k];
-                    }
-                }
-            }
-            if (a.square_input) v = v * v;
-            rx[j] = v;
+    f32x4 rq[NQ];
+    unsigned okmask = 0;
+    // element offsets of this thread's pixel row for the step being loaded (-1: row masked / in the padding halo)
+    int yoff = -1, xoff = -1;
+    auto decode = [&](int s) {
+        const int m = mbeg + s * PK + srow;
+        if (m < mend) {
+            const int b = m / HoWo;
+            const int rem = m - b * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            const int hi = ho * a.stride - a.pad + kh, wi = wo * a.stride - a.pad + kw;
+            yoff = m * a.Cout;
+            xoff = ((unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W) ? ((b * a.H + hi) * a.W + wi) * a.Cin : -1;
+        } else {
+            yoff = xoff = -1;
         }
     };
-    auto store_step = [&](int buf) {
-        float* Y = Ys + buf * PK * TCO;
-        float* X = Xs + buf * PK * TCI;
+    auto load_quad = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        bool ok;
+        if constexpr (j < YQ) {
+            const int c = co0 + 4 * (sq + 8 * j);
+            ok = yoff >= 0 && c < a.Cout;
+            if (VEC) {
+                v = *reinterpret_cast<const f32x4*>(a.dy + (ok ? yoff + c : 0));
+            } else {
 #pragma unroll
-        for (int j = 0; j < YQ; ++j) *reinterpret_cast<f32x4*>(Y + (tid + 256 * j) * 4) = ry[j];
+                for (int k = 0; k < 4; ++k)
+                    if (ok && c + k < a.Cout) v[k] = a.dy[yoff + c + k];
+            }
+        } else {
+            const int c = ci0 + 4 * (sq + 8 * (j - YQ));
+            ok = xoff >= 0 && c < a.Cin;
+            if (VEC) {
+                v = *reinterpret_cast<const f32x4*>(a.x + (ok ? xoff + c : 0));
+            } else {
 #pragma unroll
-        for (int j = 0; j < XQ; ++j) *reinterpret_cast<f32x4*>(X + (tid + 256 * j) * 4) = rx[j];
+                for (int k = 0; k < 4; ++k)
+                    if (ok && c + k < a.Cin) v[k] = a.x[xoff + c + k];
+            }
+        }
+        rq[j] = v;
+        okmask = ok ? (okmask | (1u << j)) : (okmask & ~(1u << j));
+    };
+    auto store_quad = [&](auto jc, int buf) {
+        constexpr int j = decltype(jc)::value;
+        f32x4 v = ((okmask >> j) & 1u) ? rq[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (j < YQ) {
+            *reinterpret_cast<f32x4*>(Ys + buf * PK * TCO + srow * TCO + 4 * (sq + 8 * j)) = v;
+        } else {
+            if (a.square_input) v = v * v;
+            *reinterpret_cast<f32x4*>(Xs + buf * PK * TCI + srow * TCI + 4 * (sq + 8 * (j - YQ))) = v;
+        }
+    };
+    auto for_each_quad = [&](auto&& f) {
+        [&]<int... J>(std::integer_sequence<int, J...>) { (f(std::integral_constant<int, J>{}), ...); }
+        (std::make_integer_sequence<int, NQ>{});
     };
 
     if (nsteps > 0) {
-        load_step(0);
-        store_step(0);
+        decode(0);
+        for_each_quad([&](auto jc) { load_quad(jc); });
+        for_each_quad([&](auto jc) { store_quad(jc, 0); });
+        decode(nsteps > 1 ? 1 : 0);
+        for_each_quad([&](auto jc) { load_quad(jc); });
     }
     __syncthreads();
+
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < nsteps) load_step(s + 1);
         const float* Y = Ys + buf * PK * TCO;
         const float* X = Xs + buf * PK * TCI;
-#pragma unroll 4
-        for (int kk = 0; kk < PK / 2; ++kk) {
+        float fa[2][TM], fb[2][TN];
+        auto read_frags = [&](int kk, int set) {
             const int prow = 2 * kk + lh;
-            float fa[TM], fb[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[i] = Y[prow * TCO + wco0 + i * 32 + li];
+            for (int i = 0; i < TM; ++i) fa[set][i] = Y[prow * TCO + wco0 + i * 32 + li];
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[j] = X[prow * TCI + wci0 + j * 32 + li];
+            for (int j = 0; j < TN; ++j) fb[set][j] = X[prow * TCI + wci0 + j * 32 + li];
+        };
+        read_frags(0, 0);
+        decode(s + 2 < nsteps ? s + 2 : nsteps - 1);   // row offsets of the step whose loads are re-issued below
+        [&]<int... SL>(std::integer_sequence<int, SL...>) {
+            (([&] {
+                 if constexpr (SL + 1 < PK / 2) read_frags(SL + 1, (SL + 1) & 1);
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+                 for (int i = 0; i < TM; ++i)
 #pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i], fb[j], acc[i][j], 0, 0, 0);
+                     for (int j = 0; j < TN; ++j)
+                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[SL & 1][i], fb[SL & 1][j], acc[i][j], 0, 0, 0);
+                 if constexpr (SL < NQ) {
+                     store_quad(std::integral_constant<int, SL>{}, buf ^ 1);
+                     load_quad(std::integral_constant<int, SL>{});
+                 }
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
         }
-        if (s + 1 < nsteps) store_step(buf ^ 1);
+        (std::make_integer_sequence<int, PK / 2>{});
         __syncthreads();
     }
 
@@ -183,8 +208,16 @@ int launch(WgArgs a, hipStream_t s) {
     return rdo::check_launch("conv_wgrad");
 }
 
-// tile choice shared by the split heuristic and the launcher
-inline bool big_tiles(const rdo_conv_desc* d) { return d->Cout >= 160 && d->Cin >= 160; }
+// ---- tile / split selection (tools/sweep_wgrad.py) -----------------------------------------------------------------------
+int g_force_big = -1, g_force_ns = -1;   // tuning overrides (rdo_debug_force_wgrad_choice)
+
+// 192x192 tiles (3x3 MFMA tiles per wave, 96 KiB LDS, one workgroup per CU) need a long pixel reduction per workgroup
+// to pay off; with few output pixels the 64x64 tile (one MFMA tile per wave, 5 workgroups per CU) spreads the work wider.
+inline bool big_tiles(const rdo_conv_desc* d) {
+    if (g_force_big >= 0) return g_force_big != 0;
+    const long M = (long)d->B * d->Ho * d->Wo;
+    return d->Cout >= 160 && d->Cin >= 160 && M >= 8192;
+}
 
 inline int tiles_total(const rdo_conv_desc* d) {
     const int t = big_tiles(d) ? 192 : 64;
@@ -193,13 +226,19 @@ inline int tiles_total(const rdo_conv_desc* d) {
 
 }  // namespace
 
+extern "C" void rdo_debug_force_wgrad_choice(int big, int nsplit) {
+    g_force_big = big;
+    g_force_ns = nsplit;
+}
+
 extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d) {
     if (!d) return 1;
+    if (g_force_ns >= 1) return g_force_ns;
     const long M = (long)d->B * d->Ho * d->Wo;
-    // aim at ~1 workgroup per CU (the big tile uses 96 KiB of LDS), chunks of at least 256 pixels
-    const long target = big_tiles(d) ? 256 : 512;
+    // big tile: ~1 workgroup per CU; small tile: ~4 per CU.  Chunks of at least 128 pixels (4 reduction steps).
+    const long target = big_tiles(d) ? 256 : 1024;
     long ns = target / tiles_total(d);
-    const long max_by_m = rdo::ceil_div(M, 256);
+    const long max_by_m = rdo::ceil_div(M, 128);
     if (ns > max_by_m) ns = max_by_m;
     if (ns < 1) ns = 1;
     if (ns > 256) ns = 256;
@@ -210,6 +249,8 @@ extern "C" int rdo_conv2d_wgrad(const rdo_conv_desc* d, const float* x, const fl
                                 void* stream) {
     RDO_REQUIRE(d && x && dy && slabs, "rdo_conv2d_wgrad: null argument");
     RDO_REQUIRE(nsplit >= 1, "rdo_conv2d_wgrad: nsplit < 1");
+    RDO_REQUIRE((long)d->B * d->H * d->W * d->Cin < (1L << 31) && (long)d->B * d->Ho * d->Wo * d->Cout < (1L << 31),
+                "rdo_conv2d_wgrad: tensors of 2^31 or more elements are not supported (32-bit staging offsets)");
     WgArgs a;
     a.x = x; a.dy = dy; a.slabs = slabs;
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
