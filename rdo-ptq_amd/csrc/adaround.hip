@@ -16,7 +16,7 @@ namespace {
 constexpr float kGamma = -0.1f, kZeta = 1.1f;
 constexpr float kBeta1 = 0.9f, kBeta2 = 0.999f, kAdamEps = 1e-8f;
 
-__device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + expf(-a)); }
+__device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + __expf(-a)); }
 
 struct AdaArgs {
     rdo_ada_desc d;
@@ -61,9 +61,21 @@ __device__ __forceinline__ void emit(const rdo_ada_desc& d, long e, float q, flo
     if (wd && d.Cin > 0) wd[wd_index(d, e)] = o;
 }
 
-__global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
+// Tiled: a block owns 32 rows x 32 inner columns of one tap so that BOTH the forward-layout accesses (coalesced over the
+// inner/ci index) and the dgrad-layout store wd[ci][kh'][kw'][co] (coalesced over co, via an LDS transpose) are 128-byte
+// segments.  1024 threads: thread (ty = tid>>5, tx = tid&31) handles row ty, column tx (one element per thread keeps the
+// nsplit-deep slab reads of many elements in flight).
+__global__ __launch_bounds__(1024) void ada_step_kernel(AdaArgs a) {
     const rdo_ada_desc d = a.d;
-    const long inner = d.numel / d.rows;
+    const int taps = d.Cin > 0 ? d.KH * d.KW : 1;
+    const int cdim = (int)(d.numel / d.rows / taps);      // Cin for conv layouts, whole inner otherwise
+    const int ctiles = (cdim + 31) / 32;
+    int bid = blockIdx.x;
+    const int ct = bid % ctiles; bid /= ctiles;
+    const int tap = bid % taps;
+    const int rt = bid / taps;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int c = ct * 32 + tx;
     const float Lm1 = (float)(d.n_levels - 1);
     float b = 0.f, round_on = 0.f, step_size = 0.f, bc2 = 1.f;
     int it = 0;
@@ -72,9 +84,13 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
         const rdo_sched_row s = a.sched[it];
         b = s.b; round_on = s.round_on; step_size = s.step_size; bc2 = s.bc2_sqrt;
     }
+    __shared__ float tile[32][33];
     float rl_local = 0.f;
-    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < d.numel; e += (long)gridDim.x * blockDim.x) {
-        const int row = (int)(e / inner);
+    {
+        constexpr int k = 0;
+        const int row = rt * 32 + ty;
+        if (row < d.rows && c < cdim) {
+        const long e = ((long)row * taps + tap) * cdim + c;
         const float dl = a.delta[row], z = a.zp[row], wv = a.w[e];
         float al = a.alpha[e];
         const float xf = floorf(wv / dl);
@@ -102,16 +118,15 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
         }
         if (a.mode == 1) {
             a.dalpha_out[e] = g_alpha;
-            continue;
-        }
+        } else {
         // rounding regulariser (value of the current alpha, gradient through h)
         float g_total = g_alpha * a.grad_scale;
         if (round_on != 0.f) {
             const float u = fabsf(h - 0.5f) * 2.f;
-            rl_local += a.round_weight * (1.f - powf(u, b));
+            const float ub1 = (u > 0.f) ? __powf(u, b - 1.f) : 0.f;   // u^(b-1); u^b = u * u^(b-1)
+            rl_local += a.round_weight * (1.f - u * ub1);
             const float sgn = (h > 0.5f) ? 1.f : ((h < 0.5f) ? -1.f : 0.f);
-            const float dpow = (u > 0.f) ? b * powf(u, b - 1.f) : 0.f;
-            g_total += (-a.round_weight * dpow * 2.f * sgn) * dh_da;
+            g_total += (-a.round_weight * (b * ub1) * 2.f * sgn) * dh_da;
         }
         // Adam (torch.optim.Adam defaults; alpha has no weight decay)
         float mm = a.m[e], vv = a.v[e];
@@ -123,18 +138,33 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
         // next iteration's soft weight
         const float sg2 = sigmoidf_(al);
         const float h2 = fminf(fmaxf(sg2 * (kZeta - kGamma) + kGamma, 0.f), 1.f);
-        const float q2 = (fminf(fmaxf(xf + h2 + z, 0.f), Lm1) - z) * dl;
-        emit(d, e, q2, a.wq, a.wd);
+        float o = (fminf(fmaxf(xf + h2 + z, 0.f), Lm1) - z) * dl;
+        if (d.reparam) {
+            const float lb = fmaxf(o, d.reparam_bound);
+            o = lb * lb - d.reparam_pedestal;
+        }
+        a.wq[e] = o;
+        tile[ty + 8 * k][tx] = o;
+        }
+        }
     }
-    if (a.mode != 1 && a.round_loss_out) {
-        // block reduce, one atomic per block
-        __shared__ float red[4];
+    if (a.mode != 1 && a.wd && d.Cin > 0) {
+        __syncthreads();
+        // wd[ci][KH-1-kh][KW-1-kw][co]: thread (ty, tx) now writes column ci = ct*32 + ty, row co = rt*32 + tx
+        const int kh = tap / d.KW, kw = tap - kh * d.KW;
+        const int tapf = (d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw);
+        const int co = rt * 32 + tx, ci = ct * 32 + ty;
+        if (ci < cdim && co < d.rows) a.wd[((long)ci * taps + tapf) * d.rows + co] = tile[tx][ty];
+    }
+    if (a.mode != 1 && a.round_loss_out && round_on != 0.f) {
+        __shared__ float red[16];
         float vsum = rl_local;
         for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vsum;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float t = red[0] + red[1] + red[2] + red[3];
+            float t = 0.f;
+            for (int i = 0; i < 16; ++i) t += red[i];
             if (t != 0.f) atomicAdd(a.round_loss_out + it, t);
         }
     }
@@ -230,7 +260,10 @@ int check_desc(const rdo_ada_desc* d, const char* who) {
 int run_step(AdaArgs a, void* stream) {
     return rdo::dispatch(
         [a](hipStream_t s) {
-            hipLaunchKernelGGL(ada_step_kernel, dim3(grid_for(a.d.numel)), dim3(256), 0, s, a);
+            const int taps = a.d.Cin > 0 ? a.d.KH * a.d.KW : 1;
+            const long cdim = a.d.numel / a.d.rows / taps;
+            const long blocks = rdo::ceil_div(a.d.rows, 32) * taps * rdo::ceil_div(cdim, 32);
+            hipLaunchKernelGGL(ada_step_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, a);
             return rdo::check_launch("ada_step");
         },
         stream, "ada_step", 0.0, 4.0 * a.d.numel * ((a.mode == 2 ? 1 : a.nsplit) + 9.0));
