@@ -13,6 +13,8 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 constexpr float kGamma = -0.1f, kZeta = 1.1f;
 constexpr float kBeta1 = 0.9f, kBeta2 = 0.999f, kAdamEps = 1e-8f;
 
@@ -61,21 +63,11 @@ __device__ __forceinline__ void emit(const rdo_ada_desc& d, long e, float q, flo
     if (wd && d.Cin > 0) wd[wd_index(d, e)] = o;
 }
 
-// Tiled: a block owns 32 rows x 32 inner columns of one tap so that BOTH the forward-layout accesses (coalesced over the
-// inner/ci index) and the dgrad-layout store wd[ci][kh'][kw'][co] (coalesced over co, via an LDS transpose) are 128-byte
-// segments.  1024 threads: thread (ty = tid>>5, tx = tid&31) handles row ty, column tx (one element per thread keeps the
-// nsplit-deep slab reads of many elements in flight).
-__global__ __launch_bounds__(1024) void ada_step_kernel(AdaArgs a) {
+// One thread per 4 consecutive weight elements (16-byte accesses on every stream: w, alpha, m, v, nsplit slabs, wq).
+// The dgrad layout wd is produced afterwards by wd_transpose_kernel (LDS-tiled, coalesced on both sides).
+__global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
     const rdo_ada_desc d = a.d;
-    const int taps = d.Cin > 0 ? d.KH * d.KW : 1;
-    const int cdim = (int)(d.numel / d.rows / taps);      // Cin for conv layouts, whole inner otherwise
-    const int ctiles = (cdim + 31) / 32;
-    int bid = blockIdx.x;
-    const int ct = bid % ctiles; bid /= ctiles;
-    const int tap = bid % taps;
-    const int rt = bid / taps;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-    const int c = ct * 32 + tx;
+    const long inner = d.numel / d.rows;
     const float Lm1 = (float)(d.n_levels - 1);
     float b = 0.f, round_on = 0.f, step_size = 0.f, bc2 = 1.f;
     int it = 0;
@@ -84,89 +76,121 @@ __global__ __launch_bounds__(1024) void ada_step_kernel(AdaArgs a) {
         const rdo_sched_row s = a.sched[it];
         b = s.b; round_on = s.round_on; step_size = s.step_size; bc2 = s.bc2_sqrt;
     }
-    __shared__ float tile[32][33];
     float rl_local = 0.f;
-    {
-        constexpr int k = 0;
-        const int row = rt * 32 + ty;
-        if (row < d.rows && c < cdim) {
-        const long e = ((long)row * taps + tap) * cdim + c;
-        const float dl = a.delta[row], z = a.zp[row], wv = a.w[e];
-        float al = a.alpha[e];
-        const float xf = floorf(wv / dl);
-        const float sg = sigmoidf_(al);
-        const float hraw = sg * (kZeta - kGamma) + kGamma;
-        const float h = fminf(fmaxf(hraw, 0.f), 1.f);
-        const float xint = xf + h + z;       // (x_floor + h) + zp
-        const float pass_h = (hraw >= 0.f && hraw <= 1.f) ? 1.f : 0.f;
-        const float dh_da = pass_h * ((kZeta - kGamma) * (sg * (1.f - sg)));
-
-        float g_alpha;  // data gradient w.r.t. alpha
+    const long nq = d.numel / 4;   // host guarantees numel % 4 == 0
+    for (long qi = (long)blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += (long)gridDim.x * blockDim.x) {
+        const long e0 = qi * 4;
+        const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.w + e0);
+        f32x4 al4 = *reinterpret_cast<const f32x4*>(a.alpha + e0);
+        f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
         if (a.mode == 2) {
-            g_alpha = a.dalpha_in[e];
+            g4 = *reinterpret_cast<const f32x4*>(a.dalpha_in + e0);
         } else {
-            float g = 0.f;
-            for (int s = 0; s < a.nsplit; ++s) g += a.slabs[(long)s * d.numel + e];
-            if (d.reparam) {
-                const float q = (fminf(fmaxf(xint, 0.f), Lm1) - z) * dl;
-                const float lb = fmaxf(q, d.reparam_bound);
-                const float go = g * (2.f * lb);                      // d(lb^2)/dlb
-                g = (q >= d.reparam_bound || go < 0.f) ? go : 0.f;    // LowerBound backward
+            for (int s = 0; s < a.nsplit; ++s) g4 += *reinterpret_cast<const f32x4*>(a.slabs + (long)s * d.numel + e0);
+        }
+        f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, v4 = m4, o4 = m4;
+        if (a.mode != 1) {
+            m4 = *reinterpret_cast<const f32x4*>(a.m + e0);
+            v4 = *reinterpret_cast<const f32x4*>(a.v + e0);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int row = (int)((e0 + k) / inner);
+            const float dl = a.delta[row], z = a.zp[row], wv = wv4[k];
+            float al = al4[k];
+            const float xf = floorf(wv / dl);
+            const float sg = sigmoidf_(al);
+            const float hraw = sg * (kZeta - kGamma) + kGamma;
+            const float h = fminf(fmaxf(hraw, 0.f), 1.f);
+            const float xint = xf + h + z;       // (x_floor + h) + zp
+            const float pass_h = (hraw >= 0.f && hraw <= 1.f) ? 1.f : 0.f;
+            const float dh_da = pass_h * ((kZeta - kGamma) * (sg * (1.f - sg)));
+            float g_alpha = g4[k];  // mode 2: already the data gradient w.r.t. alpha
+            if (a.mode != 2) {
+                float g = g4[k];
+                if (d.reparam) {
+                    const float q = (fminf(fmaxf(xint, 0.f), Lm1) - z) * dl;
+                    const float lb = fmaxf(q, d.reparam_bound);
+                    const float go = g * (2.f * lb);                      // d(lb^2)/dlb
+                    g = (q >= d.reparam_bound || go < 0.f) ? go : 0.f;    // LowerBound backward
+                }
+                const float pass_q = (xint >= 0.f && xint <= Lm1) ? 1.f : 0.f;
+                g_alpha = (g * dl) * pass_q * dh_da;
             }
-            const float pass_q = (xint >= 0.f && xint <= Lm1) ? 1.f : 0.f;
-            g_alpha = (g * dl) * pass_q * dh_da;
+            if (a.mode == 1) {
+                o4[k] = g_alpha;
+                continue;
+            }
+            // rounding regulariser (value of the current alpha, gradient through h)
+            float g_total = g_alpha * a.grad_scale;
+            if (round_on != 0.f) {
+                const float u = fabsf(h - 0.5f) * 2.f;
+                const float ub1 = (u > 0.f) ? __powf(u, b - 1.f) : 0.f;   // u^(b-1); u^b = u * u^(b-1)
+                rl_local += a.round_weight * (1.f - u * ub1);
+                const float sgn = (h > 0.5f) ? 1.f : ((h < 0.5f) ? -1.f : 0.f);
+                g_total += (-a.round_weight * (b * ub1) * 2.f * sgn) * dh_da;
+            }
+            // Adam (torch.optim.Adam defaults; alpha has no weight decay)
+            float mm = m4[k], vv = v4[k];
+            mm = mm + (g_total - mm) * (1.f - kBeta1);
+            vv = vv * kBeta2 + (1.f - kBeta2) * g_total * g_total;
+            const float denom = sqrtf(vv) / bc2 + kAdamEps;
+            al = al - step_size * (mm / denom);
+            m4[k] = mm; v4[k] = vv; al4[k] = al;
+            // next iteration's soft weight
+            const float sg2 = sigmoidf_(al);
+            const float h2 = fminf(fmaxf(sg2 * (kZeta - kGamma) + kGamma, 0.f), 1.f);
+            float o = (fminf(fmaxf(xf + h2 + z, 0.f), Lm1) - z) * dl;
+            if (d.reparam) {
+                const float lb = fmaxf(o, d.reparam_bound);
+                o = lb * lb - d.reparam_pedestal;
+            }
+            o4[k] = o;
         }
         if (a.mode == 1) {
-            a.dalpha_out[e] = g_alpha;
+            *reinterpret_cast<f32x4*>(a.dalpha_out + e0) = o4;
         } else {
-        // rounding regulariser (value of the current alpha, gradient through h)
-        float g_total = g_alpha * a.grad_scale;
-        if (round_on != 0.f) {
-            const float u = fabsf(h - 0.5f) * 2.f;
-            const float ub1 = (u > 0.f) ? __powf(u, b - 1.f) : 0.f;   // u^(b-1); u^b = u * u^(b-1)
-            rl_local += a.round_weight * (1.f - u * ub1);
-            const float sgn = (h > 0.5f) ? 1.f : ((h < 0.5f) ? -1.f : 0.f);
-            g_total += (-a.round_weight * (b * ub1) * 2.f * sgn) * dh_da;
+            *reinterpret_cast<f32x4*>(a.m + e0) = m4;
+            *reinterpret_cast<f32x4*>(a.v + e0) = v4;
+            *reinterpret_cast<f32x4*>(a.alpha + e0) = al4;
+            *reinterpret_cast<f32x4*>(a.wq + e0) = o4;
         }
-        // Adam (torch.optim.Adam defaults; alpha has no weight decay)
-        float mm = a.m[e], vv = a.v[e];
-        mm = mm + (g_total - mm) * (1.f - kBeta1);
-        vv = vv * kBeta2 + (1.f - kBeta2) * g_total * g_total;
-        const float denom = sqrtf(vv) / bc2 + kAdamEps;
-        al = al - step_size * (mm / denom);
-        a.m[e] = mm; a.v[e] = vv; a.alpha[e] = al;
-        // next iteration's soft weight
-        const float sg2 = sigmoidf_(al);
-        const float h2 = fminf(fmaxf(sg2 * (kZeta - kGamma) + kGamma, 0.f), 1.f);
-        float o = (fminf(fmaxf(xf + h2 + z, 0.f), Lm1) - z) * dl;
-        if (d.reparam) {
-            const float lb = fmaxf(o, d.reparam_bound);
-            o = lb * lb - d.reparam_pedestal;
-        }
-        a.wq[e] = o;
-        tile[ty + 8 * k][tx] = o;
-        }
-        }
-    }
-    if (a.mode != 1 && a.wd && d.Cin > 0) {
-        __syncthreads();
-        // wd[ci][KH-1-kh][KW-1-kw][co]: thread (ty, tx) now writes column ci = ct*32 + ty, row co = rt*32 + tx
-        const int kh = tap / d.KW, kw = tap - kh * d.KW;
-        const int tapf = (d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw);
-        const int co = rt * 32 + tx, ci = ct * 32 + ty;
-        if (ci < cdim && co < d.rows) a.wd[((long)ci * taps + tapf) * d.rows + co] = tile[tx][ty];
     }
     if (a.mode != 1 && a.round_loss_out && round_on != 0.f) {
-        __shared__ float red[16];
+        __shared__ float red[4];
         float vsum = rl_local;
         for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vsum;
         __syncthreads();
         if (threadIdx.x == 0) {
-            float t = 0.f;
-            for (int i = 0; i < 16; ++i) t += red[i];
+            const float t = red[0] + red[1] + red[2] + red[3];
             if (t != 0.f) atomicAdd(a.round_loss_out + it, t);
         }
+    }
+}
+
+// wd[ci][KH-1-kh][KW-1-kw][co] = wq[co][kh][kw][ci]: 32x32 tiles through LDS, 128-byte segments on both sides
+__global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const float* wq, float* wd) {
+    const int taps = d.KH * d.KW, cdim = d.Cin;
+    const int ctiles = (cdim + 31) / 32;
+    int bid = blockIdx.x;
+    const int ct = bid % ctiles; bid /= ctiles;
+    const int tap = bid % taps;
+    const int rt = bid / taps;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    __shared__ float tile[32][33];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int row = rt * 32 + ty + 8 * k, c = ct * 32 + tx;
+        if (row < d.rows && c < cdim) tile[ty + 8 * k][tx] = wq[((long)row * taps + tap) * cdim + c];
+    }
+    __syncthreads();
+    const int kh = tap / d.KW, kw = tap - kh * d.KW;
+    const int tapf = (d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int ci = ct * 32 + ty + 8 * k, co = rt * 32 + tx;
+        if (ci < cdim && co < d.rows) wd[((long)ci * taps + tapf) * d.rows + co] = tile[tx][ty + 8 * k];
     }
 }
 
@@ -258,12 +282,14 @@ int check_desc(const rdo_ada_desc* d, const char* who) {
 }
 
 int run_step(AdaArgs a, void* stream) {
+    RDO_REQUIRE(a.d.numel % 4 == 0, "adaround step: numel (%ld) must be a multiple of 4", (long)a.d.numel);
     return rdo::dispatch(
         [a](hipStream_t s) {
-            const int taps = a.d.Cin > 0 ? a.d.KH * a.d.KW : 1;
-            const long cdim = a.d.numel / a.d.rows / taps;
-            const long blocks = rdo::ceil_div(a.d.rows, 32) * taps * rdo::ceil_div(cdim, 32);
-            hipLaunchKernelGGL(ada_step_kernel, dim3((unsigned)blocks), dim3(1024), 0, s, a);
+            hipLaunchKernelGGL(ada_step_kernel, dim3(grid_for(a.d.numel / 4)), dim3(256), 0, s, a);
+            if (a.mode != 1 && a.wd && a.d.Cin > 0) {
+                const long blocks = rdo::ceil_div(a.d.rows, 32) * a.d.KH * a.d.KW * rdo::ceil_div(a.d.Cin, 32);
+                hipLaunchKernelGGL(wd_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.d, (const float*)a.wq, a.wd);
+            }
             return rdo::check_launch("ada_step");
         },
         stream, "ada_step", 0.0, 4.0 * a.d.numel * ((a.mode == 2 ? 1 : a.nsplit) + 9.0));

@@ -216,7 +216,10 @@ int g_force_big = -1, g_force_ns = -1;   // tuning overrides (rdo_debug_force_wg
 inline bool big_tiles(const rdo_conv_desc* d) {
     if (g_force_big >= 0) return g_force_big != 0;
     const long M = (long)d->B * d->Ho * d->Wo;
-    return d->Cout >= 160 && d->Cin >= 160 && M >= 8192;
+    // a 1x1 conv has a single 192x192 tile: filling the chip with it would need hundreds of pixel splits, and every split
+    // is one more slab for the AdaRound step to read back -- use the small tile (9x more tiles, 9x fewer splits) instead
+    const long big_tiles_total = (long)d->KH * d->KW * rdo::ceil_div(d->Cout, 192) * rdo::ceil_div(d->Cin, 192);
+    return d->Cout >= 160 && d->Cin >= 160 && M >= 8192 && big_tiles_total >= 4;
 }
 
 inline int tiles_total(const rdo_conv_desc* d) {
@@ -241,7 +244,7 @@ extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d) {
     const long max_by_m = rdo::ceil_div(M, 128);
     if (ns > max_by_m) ns = max_by_m;
     if (ns < 1) ns = 1;
-    if (ns > 256) ns = 256;
+    if (ns > 64) ns = 64;
     return (int)ns;
 }
 
