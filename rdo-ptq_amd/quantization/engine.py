@@ -91,7 +91,7 @@ class _Op:
 class UnitEngine:
     def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
                  warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
-                 use_graph=True):
+                 use_graph=True, force_dp_split=False):
         if kind not in UNIT_KINDS:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
@@ -122,6 +122,8 @@ class UnitEngine:
         self.world = 1
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
             self.world = torch.distributed.get_world_size(group)
+        # the data-parallel op sequence (grad -> all-reduce -> apply) can be forced on a single rank to test it
+        self.split = self.world > 1 or force_dp_split
         self._build_ops()
         self._alloc()
         self._record()
@@ -152,7 +154,7 @@ class UnitEngine:
             if op.need_dgrad and (op.stride != 1 or 2 * op.pad != op.K - 1):
                 raise NotImplementedError("calibration engine: dgrad is built for stride-1 'same' convolutions only")
         self.ops = o
-        if self.world > 1:
+        if self.split:
             total = sum(op.numel() for op in o.values())
             self.bucket = torch.zeros(total, device=self.dev)
             off = 0
@@ -308,7 +310,7 @@ class UnitEngine:
         self.plan_b = None
         with self.plan_a.record():
             self._forward_backward()
-            if self.world == 1:
+            if not self.split:
                 for op in self.ops.values():
                     ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
                                       op.alpha, op.m, op.v, op.wq, op.wd, self.round_log)
@@ -316,7 +318,7 @@ class UnitEngine:
             else:
                 for op in self.ops.values():
                     ops.adaround_grad(op.desc, op.w, op.alpha, op.delta, op.zp, op.slabs, op.dalpha)
-        if self.world > 1:
+        if self.split:
             self.plan_b = Plan()
             with self.plan_b.record():
                 for op in self.ops.values():
@@ -331,12 +333,13 @@ class UnitEngine:
         n = self.iters - done if n_iters is None else int(n_iters)
         if n < 0 or done + n > self.iters:
             raise ValueError(f"cannot run {n} iterations: {done} of {self.iters} already done")
-        if self.world == 1:
+        if not self.split:
             self.plan_a.run(n, graph=self.use_graph)
         else:
             for _ in range(n):
                 self.plan_a.run(1, graph=self.use_graph)
-                torch.distributed.all_reduce(self.bucket, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                if self.world > 1:
+                    torch.distributed.all_reduce(self.bucket, op=torch.distributed.ReduceOp.SUM, group=self.group)
                 self.plan_b.run(1, graph=self.use_graph)
         self._done = done + n
         return n

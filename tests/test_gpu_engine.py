@@ -78,3 +78,23 @@ def test_engine_rejects_cpu_tensors(recon):
     fx = recon
     with pytest.raises(RuntimeError):
         UnitEngine("layer", {}, torch.zeros(2, 4, 4, 4), torch.zeros(2, 4, 4, 4), torch.zeros(2, 4, 4, 4), batch_size=1, iters=1)
+
+
+@pytest.mark.parametrize("tag,kind", [("g_a.0", "rbws"), ("g_s.1", "rbu"), ("g_a.6", "layer")])
+def test_dp_split_sequence_equals_fused_step(recon, tag, kind):
+    """The data-parallel op sequence (rdo_adaround_grad -> bucket -> rdo_adaround_apply, engine plan A / plan B) run on
+    one rank must reproduce the fused rdo_adaround_step path bit for bit (same kernels' arithmetic, different packaging)."""
+    from quantization.engine import UnitEngine
+    fx = recon
+    _, _, B, iters = (int(v) for v in fx["meta"])
+    res = []
+    for split in (False, True):
+        unit, k, mods = product_unit(fx, tag, kind)
+        eng = UnitEngine(k, mods, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]), batch_size=B,
+                         iters=iters, seed=SEED, idx_table=torch.from_numpy(fx[f"{tag}/idx"]), force_dp_split=split)
+        eng.run()
+        torch.cuda.synchronize()
+        res.append(({n: eng.alpha_of(n).clone() for n in eng.ops}, eng.logs()[0]))
+    for n in res[0][0]:
+        torch.testing.assert_close(res[0][0][n], res[1][0][n], rtol=0, atol=0)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=0)
