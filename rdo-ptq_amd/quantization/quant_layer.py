@@ -86,6 +86,15 @@ class QuantModule(nn.Module):
         self.extra_repr = org_module.extra_repr
         self.trained = False
 
+    def _apply(self, fn, *args, **kwargs):
+        """`.to()/.cuda()` also moves the detached FP copies (plain attributes in the reference, quant_layer.py:82-89)."""
+        super()._apply(fn, *args, **kwargs)
+        for name in ("org_weight", "org_bias"):
+            t = getattr(self, name, None)
+            if t is not None:
+                setattr(self, name, fn(t))
+        return self
+
     # geometry helpers used by the calibration engine ----------------------------------------------------------------
     def conv_geometry(self):
         if self.kind != "conv":
@@ -98,9 +107,15 @@ class QuantModule(nn.Module):
     def fused_lrelu(self):
         return isinstance(self.activation_function, nn.LeakyReLU) and abs(self.activation_function.negative_slope - 0.01) < 1e-12
 
+    @staticmethod
+    def _reparam(p, t):
+        """NonNegativeParametrizer forward, max(t, bound)^2 - pedestal, with the constants taken as Python floats: the
+        reparam modules live in `fwd_kwargs` (as in the reference), so `.to(device)` on the wrapper does not move them."""
+        return torch.clamp(t, min=float(p.lower_bound.bound)) ** 2 - float(p.pedestal)
+
     def gdn_constants(self):
         """beta' (re-parametrised, fp32 tensor) and the gamma (bound, pedestal) pair."""
-        beta = self.fwd_kwargs["beta_reparam"](self.bias.detach() if self.use_weight_quant else self.org_bias)
+        beta = self._reparam(self.fwd_kwargs["beta_reparam"], self.bias.detach() if self.use_weight_quant else self.org_bias)
         g = self.fwd_kwargs["gamma_reparam"]
         return beta.contiguous(), (float(g.lower_bound.bound), float(g.pedestal))
 
@@ -126,8 +141,8 @@ class QuantModule(nn.Module):
             out = _nchw_view(y)
         elif self.kind == "gdn":
             c = input.shape[1]
-            gp = self.fwd_kwargs["gamma_reparam"](weight.detach()).reshape(c, 1, 1, c).contiguous()
-            bp = self.fwd_kwargs["beta_reparam"](bias)
+            gp = self._reparam(self.fwd_kwargs["gamma_reparam"], weight.detach()).reshape(c, 1, 1, c).contiguous()
+            bp = self._reparam(self.fwd_kwargs["beta_reparam"], bias)
             x = _nhwc(input)
             y = ops.conv2d_fwd(x, gp, bp.contiguous(), 1, 0,
                                epilogue=L.EPI_IGDN if self.fwd_kwargs["inverse"] else L.EPI_GDN, aux=x, square_input=True)

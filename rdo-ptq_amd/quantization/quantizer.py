@@ -98,6 +98,14 @@ class UniformAffineQuantizer(nn.Module):
         self.prob = prob
         self.is_training = False
 
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        for name in ("delta", "zero_point"):
+            t = getattr(self, name, None)
+            if torch.is_tensor(t):
+                setattr(self, name, fn(t))
+        return self
+
     # -- scale initialisation -------------------------------------------------------------------------------------
     def _rows(self, x):
         wr = to_rows(x, self.tconv) if (self.channel_wise and x.dim() != 1) else x.reshape(1, -1).contiguous()
@@ -200,6 +208,14 @@ class AdaRoundQuantizer(nn.Module):
             logging.info("Init alpha to be FP32")
             alpha_rows = ops.adaround_init_alpha(self._desc(wr), wr, self._row_scales(wr)[0])
         self.alpha = nn.Parameter(self._unrows(alpha_rows, weight_tensor))
+
+    def _apply(self, fn, *args, **kwargs):
+        super()._apply(fn, *args, **kwargs)
+        for name in ("delta", "zero_point"):
+            t = getattr(self, name, None)
+            if torch.is_tensor(t):
+                setattr(self, name, fn(t))
+        return self
 
     def _rows(self, x):
         return to_rows(x, self.tconv) if (self.channel_wise and x.dim() != 1) else x.reshape(1, -1).contiguous()

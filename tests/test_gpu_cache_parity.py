@@ -1,0 +1,77 @@
+"""End-to-end parity of the cache-building path: product `QuantModel` + `save_inp_oup_data` on the GPU
+against the caches the REFERENCE built for the same toy Cheng2020 (tests/golden/recon_toy.npz: full model state, calibration
+images, and for each visited unit the reference's (inp_q, inp_fp, out) plus its trained alphas).
+
+Units are visited in the reference's recon_model order; after each one the reference's trained rounding (alpha_final) is
+installed so that the quantised prefix seen by later units is the same as in the reference run."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import AQ, WQ, T
+
+pytestmark = pytest.mark.gpu
+
+
+def _get(root, dotted):
+    m = root
+    for p in dotted.split("."):
+        m = m[int(p)] if p.isdigit() else getattr(m, p)
+    return m
+
+
+def test_save_inp_oup_data_matches_reference_caches(golden_dir):
+    import lic
+    from quantization import BaseQuantBlock, QuantModel, QuantModule
+    from quantization.quantizer import AdaRoundQuantizer, to_rows
+    from quantization.utils import save_inp_oup_data
+    fx = np.load(os.path.join(golden_dir, "recon_toy.npz"))
+    N, n_img, B, iters = (int(v) for v in fx["meta"])
+    torch.manual_seed(0)
+    qnn = QuantModel(lic.Cheng2020Anchor(N=N), WQ, AQ, is_cheng=True).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    with torch.no_grad():
+        for name, m in qnn.model.named_modules():
+            if isinstance(m, QuantModule) and m.org_weight is not None:
+                w = T(fx[f"org/{name}.weight"]).cuda()
+                m.weight.data.copy_(w); m.org_weight.copy_(w)
+                if m.org_bias is not None:
+                    b = T(fx[f"org/{name}.bias"]).cuda()
+                    m.bias.data.copy_(b); m.org_bias.copy_(b)
+        eb = qnn.model.entropy_bottleneck
+        for k, v in eb.state_dict().items():
+            v.copy_(T(fx[f"state/entropy_bottleneck.{k}"]).cuda())
+    cali = T(fx["cali"]).cuda()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])                                               # scale init (main2.py:194-198)
+    qnn.set_quant_state(True, False)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    wanted = {str(o).split("|")[0]: str(o).split("|")[1] for o in fx["order"]}
+    checked = 0
+    for full in (str(s) for s in fx["full_order"]):
+        unit = _get(qnn.model, full)
+        inner = [unit] if isinstance(unit, QuantModule) else [m for m in unit.modules() if isinstance(m, QuantModule)]
+        if full in wanted:
+            (inp_q, inp_fp), out = save_inp_oup_data(qnn, unit, cali, asym=True, act_quant=False, batch_size=2, input_prob=True)
+            for got, key in ((inp_q, "inp_q"), (inp_fp, "inp_fp"), (out, "out")):
+                ref = T(fx[f"{full}/{key}"])
+                assert tuple(got.shape) == tuple(ref.shape), (full, key)
+                err = float((got.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+                assert err < 3e-5, (full, key, err)
+            checked += 1
+            # install the reference's trained rounding for this unit
+            for n, m in (("layer", unit),) if isinstance(unit, QuantModule) else \
+                    [(nm.replace(".0", ""), mm) for nm, mm in unit.named_modules() if isinstance(mm, QuantModule) and not mm.is_ps]:
+                alpha = T(fx[f"{full}/{n}.alpha_final"]).cuda()
+                ada = AdaRoundQuantizer(uaq=m.weight_quantizer, round_mode="learned_hard_sigmoid",
+                                        weight_tensor=m.org_weight.data, alpha_rows=to_rows(alpha))
+                ada.soft_targets = False
+                m.weight_quantizer = ada
+        for m in ([unit] if isinstance(unit, QuantModule) else unit.modules()):
+            if isinstance(m, (QuantModule, BaseQuantBlock)):
+                m.trained = True
+    assert checked == len(wanted) == 8

@@ -319,6 +319,17 @@ def golden_recon(out_dir, iters=12):
               "h_s.2.0": "layer", "entropy_parameters.0": "layer", "context_prediction": "layer"}
     fx = {"cali": _np(cali), "meta": np.array([N, n_img, B, iters])}
     order = []
+    # full toy-model state (original FP parameters and buffers) so that another implementation can rebuild the very same
+    # QuantModel and replay the cache-building passes
+    for k, v in model.state_dict().items():
+        key = k.replace(".org_module", "")
+        fx["state/" + key] = _np(v)
+    for n_, m_ in qnn.model.named_modules():
+        if isinstance(m_, QuantModule) and m_.org_weight is not None:
+            fx["org/" + n_ + ".weight"] = _np(m_.org_weight)
+            if m_.org_bias is not None:
+                fx["org/" + n_ + ".bias"] = _np(m_.org_bias)
+    full_order = []
 
     qnn.set_quant_state(True, False)
     qnn.model.g_s[-1][0].set_quant_state(True, False)
@@ -327,6 +338,7 @@ def golden_recon(out_dir, iters=12):
         for name, m in mod.named_children():
             full = prefix + name
             if isinstance(m, (QuantModule, BaseQuantBlock)):
+                full_order.append(full)
                 if full not in wanted:
                     # the reference would train it; for the fixture mark it trained with nearest rounding
                     # so later units see a quantised prefix (same effect on set_mode()).
@@ -389,6 +401,7 @@ def golden_recon(out_dir, iters=12):
     finally:
         sys.stdout = _stdout
     fx["order"] = np.array(order)
+    fx["full_order"] = np.array(full_order)
     np.savez_compressed(os.path.join(out_dir, "recon_toy.npz"), **fx)
     print("recon_toy.npz", len(fx), "arrays")
 
