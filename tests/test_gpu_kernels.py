@@ -247,3 +247,56 @@ def test_gdn_forward_backward_match_oracle(ops):
         dg = torch.where((gamma.detach() >= bound) | (go < 0), go, torch.zeros_like(go))
         torch.testing.assert_close(dg, gamma.grad, rtol=2e-5, atol=2e-5)
         x.grad = None
+
+
+@pytest.mark.parametrize("tag,tconv", [("conv", False), ("tconv", True), ("gdn", False), ("vec", False)])
+@pytest.mark.parametrize("method", ["max", "mse", "l1", "l2"])
+@pytest.mark.parametrize("cw", [True, False])
+@pytest.mark.parametrize("bits", [8, 4])
+def test_product_uaq_matches_reference_goldens(golden_dir, tag, tconv, method, cw, bits):
+    """The drop-in UniformAffineQuantizer (HIP min/max + fake-quant kernels, vectorised search inits) against the vectors the
+    reference's own UniformAffineQuantizer produced (tests/golden/quantizers.npz)."""
+    import os
+    from quantization.quantizer import UniformAffineQuantizer
+    qz = np.load(os.path.join(golden_dir, "quantizers.npz"))
+    w = torch.from_numpy(qz[f"w_{tag}"]).cuda()
+    key = f"uaq_{tag}_{method}_{'cw' if cw else 'lw'}_{bits}"
+    q = UniformAffineQuantizer(n_bits=bits, channel_wise=cw, scale_method=method, tconv=tconv)
+    out = q(w)
+    torch.cuda.synchronize()
+    d_ref, z_ref = qz[key + "_delta"], qz[key + "_zp"]
+    np.testing.assert_allclose(q.delta.cpu().numpy().reshape(-1), d_ref.reshape(-1), rtol=2e-7, atol=0)
+    np.testing.assert_array_equal(q.zero_point.cpu().numpy().reshape(-1), z_ref.reshape(-1))
+    if cw and w.dim() > 1:
+        assert tuple(q.delta.shape) == tuple(d_ref.shape)
+    assert tuple(out.shape) == tuple(w.shape)
+    np.testing.assert_allclose(out.cpu().numpy(), qz[key + "_out"], rtol=3e-7, atol=float(d_ref.max()) * 1e-6)  # 1 ulp of delta scales every level
+
+
+@pytest.mark.parametrize("tag", ["a4", "a3", "a2"])
+def test_product_actquantizer_matches_reference_goldens(golden_dir, tag):
+    import os
+    from quantization.quantizer import ActQuantizer
+    qz = np.load(os.path.join(golden_dir, "quantizers.npz"))
+    out = ActQuantizer(torch.from_numpy(qz[f"act_{tag}_in"]).cuda())
+    np.testing.assert_allclose(out.cpu().numpy(), qz[f"act_{tag}_out"], rtol=0, atol=3e-7)
+
+
+@pytest.mark.parametrize("tag,tconv", [("conv", False), ("tconv", True), ("gdn", False)])
+def test_product_adaround_quantizer_matches_reference_goldens(golden_dir, tag, tconv):
+    import os
+    from quantization.quantizer import AdaRoundQuantizer, UniformAffineQuantizer
+    qz = np.load(os.path.join(golden_dir, "quantizers.npz"))
+    w = torch.from_numpy(qz[f"w_{tag}"]).cuda()
+    uaq = UniformAffineQuantizer(n_bits=8, channel_wise=True, scale_method="max", tconv=tconv)
+    uaq(w)
+    ada = AdaRoundQuantizer(uaq=uaq, round_mode="learned_hard_sigmoid", weight_tensor=w)
+    assert tuple(ada.alpha.shape) == tuple(w.shape)
+    np.testing.assert_allclose(ada.alpha.detach().cpu().numpy(), qz[f"ada_{tag}_alpha0"], rtol=3e-6, atol=3e-6)
+    with torch.no_grad():
+        ada.alpha.copy_(torch.from_numpy(qz[f"ada_{tag}_alpha"]).cuda())
+    tol = float(uaq.delta.max()) * 1e-4
+    ada.soft_targets = True
+    np.testing.assert_allclose(ada(w).cpu().numpy(), qz[f"ada_{tag}_soft"], rtol=0, atol=tol)
+    ada.soft_targets = False
+    np.testing.assert_allclose(ada(w).cpu().numpy(), qz[f"ada_{tag}_hard"], rtol=0, atol=tol)
