@@ -152,6 +152,7 @@ def gpu_leg(a, rank, world, device):
     torch.cuda.synchronize()
     t_cache = time.time() - t0
     log(f"caches built in {t_cache:.1f}s; recording engines")
+    force_dp = bool(os.environ.get("RDO_BENCH_FORCE_DP"))    # exercise the grad -> RCCL all-reduce -> apply sequence on 1 rank
     iters = a.warmup + a.steps + 1                     # +1: the event-profiled iteration after the timed region
     gi = torch.Generator().manual_seed(77 + rank)
     engines = []
@@ -161,8 +162,8 @@ def gpu_leg(a, rank, world, device):
         idx = torch.stack([torch.randperm(a.images, generator=gi)[:a.batch] for _ in range(iters)])
         engines.append((name, UnitEngine(kind, mods, cq, cf, co, batch_size=a.batch, iters=iters, weight=0.01,
                                          b_range=(20, 2), warmup=0.2, input_prob=0.5, seed=1005 + rank, idx_table=idx,
-                                         use_graph=not a.no_graph)))
-    dist = torch.distributed if world > 1 else None
+                                         use_graph=not a.no_graph, force_dp_split=force_dp)))
+    dist = torch.distributed if (world > 1 or force_dp) else None
 
     def barrier():
         torch.cuda.synchronize()
@@ -196,7 +197,8 @@ def gpu_leg(a, rank, world, device):
             log(f"  unit {uname:24s} {sum(ms):7.3f} ms  " + " ".join(f"{k}={v:.3f}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:5]))
         e._done += 1
         if e.plan_b is not None:
-            torch.distributed.all_reduce(e.bucket, group=e.group)
+            if torch.distributed.is_initialized():
+                torch.distributed.all_reduce(e.bucket, group=e.group)
             info += e.plan_b.op_info()
             ms += e.plan_b.profile()
         for (tag, fl, by), m in zip(info, ms):
@@ -257,8 +259,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    if world > 1:
-        torch.distributed.init_process_group("nccl", device_id=device)
+    if world > 1 or os.environ.get("RDO_BENCH_FORCE_DP"):
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        torch.distributed.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
     res = gpu_leg(a, rank, world, device)
     n_units, dt = res["n_units"], res["dt"]
     value = n_units * a.batch * a.steps * world / dt
@@ -271,6 +275,14 @@ def main():
                        "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[2] else None,
                        "gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[3] else None}
                    for t, v in sorted(res["per_tag"].items(), key=lambda kv: -kv[1][1])}
+        traffic, traffic_src = None, None
+        try:        # HBM-side bytes per launch of the dominant kernel from the last committed rocprofv3 --pmc passes
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+            if dom in tj:
+                traffic = round((2 * tj[dom]["fetch_mib_raw"] + tj[dom]["write_mib"]) * 1048576)
+                traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, bytes per launch)"
+        except Exception:
+            pass
         out = {
             "metric": "calibration images/sec (Cheng2020 W8A8 task-oriented RDO-PTQ, image-iterations over all units)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -282,7 +294,7 @@ def main():
                        "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
                        "cache_build_s": round(res["t_cache"], 2)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS,
-                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                         "unit": "TFLOP/s", "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
                          "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3)},
             "kernels": kernels,
@@ -291,7 +303,7 @@ def main():
             out["cpu_baseline"] = cpu_leg(a)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
         print(json.dumps(out))
-    if world > 1:
+    if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

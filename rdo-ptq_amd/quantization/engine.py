@@ -338,7 +338,7 @@ class UnitEngine:
         else:
             for _ in range(n):
                 self.plan_a.run(1, graph=self.use_graph)
-                if self.world > 1:
+                if self.world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized()):
                     torch.distributed.all_reduce(self.bucket, op=torch.distributed.ReduceOp.SUM, group=self.group)
                 self.plan_b.run(1, graph=self.use_graph)
         self._done = done + n
