@@ -144,6 +144,21 @@ int rdo_gdn_bwd_dx(const float* g, const float* x, const float* norm, const floa
 int rdo_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t inverse, float* out, void* stream);
 int rdo_iter_advance(int32_t* iter_ptr, void* stream);
 
+/* ---- K12: entropy-model likelihoods (eval rounding) and the rate / distortion sums -------------------------------------
+ * Element-wise on [n] fp32 (NHWC: channel = i % C).  `params` = per channel 58 floats [33 softplus(matrix) | 13 bias |
+ * 12 tanh(factor)] of CompressAI's EntropyBottleneck(filters=(3,3,3,3)); medians[C].       models/nic_cvt.py:297,300-308;
+ * losses/losses.py:15-35; test_datasets.py:21-33 */
+int rdo_factorized_likelihood_fwd(const float* z, const float* params, const float* medians, int64_t n, int32_t C, float* zhat,
+                                  float* lik, void* stream);
+int rdo_gaussian_likelihood_fwd(const float* y, const float* scales, const float* means /* nullable */, int64_t n,
+                                float scale_bound, float* yhat /* nullable */, float* lik, void* stream);
+/* gradients of grad_scale * sum(-log2 p) w.r.t. scales / means (y^ constant: straight-through rounding) */
+int rdo_gaussian_likelihood_bwd(const float* yhat, const float* scales, const float* means, int64_t n, float scale_bound,
+                                float grad_scale, float* dscales, float* dmeans, void* stream);
+int rdo_neg_log2_sum(const float* lik, int64_t n, float scale, float* out /* += */, void* stream);   /* bpp numerator */
+int rdo_sq_diff_sum(const float* a, const float* b, int64_t n, float scale, int32_t clamp01_a, float* out /* += */,
+                    void* stream);                                                                    /* MSE numerator */
+
 /* ---- unit executor: a recorded sequence of the calls above, replayed per calibration iteration with no host work.
  * Python records the per-iteration op list once per unit (layer_reconstruction / block_reconstruction, layer_opt.py:287-309);
  * rdo_plan_run() enqueues `n_iters` iterations, through a captured hipGraph when `use_graph` != 0. */

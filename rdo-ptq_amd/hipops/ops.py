@@ -231,6 +231,41 @@ def iter_advance(iter_ptr):
     L.check(L.lib().rdo_iter_advance(_ptr(iter_ptr), _stream()), "rdo_iter_advance")
 
 
+def factorized_likelihood(z_cl, params, medians):
+    """z_cl: [..., C] channels-last.  -> (z_hat, likelihood)"""
+    Cc = z_cl.shape[-1]
+    zhat, lik = torch.empty_like(z_cl), torch.empty_like(z_cl)
+    L.check(L.lib().rdo_factorized_likelihood_fwd(_ptr(z_cl), _ptr(params), _ptr(medians), z_cl.numel(), Cc, _ptr(zhat),
+                                                  _ptr(lik), _stream()), "rdo_factorized_likelihood_fwd")
+    return zhat, lik
+
+
+def gaussian_likelihood(y, scales, means=None, scale_bound=0.11):
+    yhat, lik = torch.empty_like(y), torch.empty_like(y)
+    L.check(L.lib().rdo_gaussian_likelihood_fwd(_ptr(y), _ptr(scales), _ptr(means), y.numel(), scale_bound, _ptr(yhat), _ptr(lik),
+                                                _stream()), "rdo_gaussian_likelihood_fwd")
+    return yhat, lik
+
+
+def gaussian_likelihood_bwd(yhat, scales, means, grad_scale=1.0, scale_bound=0.11):
+    ds, dm = torch.empty_like(scales), torch.empty_like(scales)
+    L.check(L.lib().rdo_gaussian_likelihood_bwd(_ptr(yhat), _ptr(scales), _ptr(means), yhat.numel(), scale_bound, grad_scale,
+                                                _ptr(ds), _ptr(dm), _stream()), "rdo_gaussian_likelihood_bwd")
+    return ds, dm
+
+
+def neg_log2_sum(lik, scale=1.0, out=None):
+    out = torch.zeros(1, device=lik.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_neg_log2_sum(_ptr(lik), lik.numel(), scale, _ptr(out), _stream()), "rdo_neg_log2_sum")
+    return out
+
+
+def sq_diff_sum(a, b, scale=1.0, clamp01=False, out=None):
+    out = torch.zeros(1, device=a.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_sq_diff_sum(_ptr(a), _ptr(b), a.numel(), scale, int(clamp01), _ptr(out), _stream()), "rdo_sq_diff_sum")
+    return out
+
+
 def make_sched(iters, warmup, b_range, lr=1e-3, device="cuda"):
     """Per-iteration schedule table (rdo_sched_row): LinearTempDecay (utils.py:37-54), round-loss gate
     (layer_opt.py:159-161), Adam bias corrections.  Computed on the host in double precision."""

@@ -6,6 +6,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from hipops import ops
+
 
 class EntropyBottleneck(nn.Module):
     def __init__(self, channels, init_scale=10.0, filters=(3, 3, 3, 3), tail_mass=1e-9, likelihood_bound=1e-9):
@@ -29,7 +31,23 @@ class EntropyBottleneck(nn.Module):
                 v = v + torch.tanh(getattr(self, f"_factor{i}")) * torch.tanh(v)
         return v
 
+    def kernel_params(self):
+        """[C, 58] = per channel [33 softplus(matrix) | 13 bias | 12 tanh(factor)] for rdo_factorized_likelihood_fwd."""
+        n = len(self.filters) + 1
+        c = self.channels
+        mats = [F.softplus(getattr(self, f"_matrix{i}")).reshape(c, -1) for i in range(n)]
+        bias = [getattr(self, f"_bias{i}").reshape(c, -1) for i in range(n)]
+        fac = [torch.tanh(getattr(self, f"_factor{i}")).reshape(c, -1) for i in range(n - 1)]
+        return torch.cat(mats + bias + fac, dim=1).contiguous()
+
     def forward(self, x):
+        if x.is_cuda and not self.training and self.filters == (3, 3, 3, 3) and x.dim() == 4:
+            # eval path on the HIP kernel (NHWC element-wise); training-time noise stays in torch (not on the PTQ path)
+            with torch.no_grad():
+                xc = x.permute(0, 2, 3, 1).contiguous()
+                zhat, lik = ops.factorized_likelihood(xc, self.kernel_params().detach(),
+                                                      self.quantiles[:, 0, 1].detach().contiguous())
+            return zhat.permute(0, 3, 1, 2), lik.permute(0, 3, 1, 2)
         order = [1, 0] + list(range(2, x.dim()))
         xt = x.permute(*order).contiguous()
         flat = xt.reshape(xt.shape[0], 1, -1)
@@ -55,6 +73,10 @@ class GaussianConditional(nn.Module):
         return torch.round(inputs - means) + means
 
     def forward(self, inputs, scales, means=None):
+        if inputs.is_cuda and not self.training and inputs.dim() == 4 and not torch.is_grad_enabled():
+            cl = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous()
+            yhat, lik = ops.gaussian_likelihood(cl(inputs), cl(scales), cl(means), self.scale_bound)
+            return yhat.permute(0, 3, 1, 2), lik.permute(0, 3, 1, 2)
         y = self.quantize(inputs, "noise" if self.training else "dequantize", means)
         v = (y if means is None else y - means).abs()
         s = scales.clamp_min(self.scale_bound)

@@ -100,3 +100,17 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(base, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", txt, re.M), f"{f} imports the oracle"
+
+
+def test_bd_rate_matches_reference(golden_dir):
+    """bd_rate.BD_RATE / BD_PSNR vs the reference's BD-rate.py (tests/golden/bd_rate.npz)."""
+    import warnings
+    import bd_rate
+    g = np.load(os.path.join(golden_dir, "bd_rate.npz"))
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for c in range(4):
+            a = [g[f"c{c}_{k}"] for k in ("R1", "P1", "R2", "P2")]
+            for pw in (0, 1):
+                np.testing.assert_allclose(bd_rate.BD_RATE(*a, piecewise=pw), g[f"c{c}_bdrate_{pw}"], rtol=1e-10)
+                np.testing.assert_allclose(bd_rate.BD_PSNR(*a, piecewise=pw), g[f"c{c}_bdpsnr_{pw}"], rtol=1e-10)

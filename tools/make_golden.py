@@ -437,6 +437,32 @@ def golden_blocks(out_dir):
     print("blocks.npz", len(fx), "arrays")
 
 
+def golden_bd(out_dir):
+    """BD_RATE / BD_PSNR of the reference's BD-rate.py (imported by file path) on synthetic RD curves."""
+    import importlib.util
+    import warnings
+    spec = importlib.util.spec_from_file_location("ref_bd_rate", os.path.join(REF, "BD-rate.py"))
+    bd = importlib.util.module_from_spec(spec)
+    if not hasattr(np, "trapz"):
+        np.trapz = np.trapezoid
+    spec.loader.exec_module(bd)
+    rng = np.random.default_rng(5)
+    fx = {}
+    for case in range(4):
+        r1 = np.sort(rng.uniform(0.1, 1.2, 6))
+        p1 = 28 + 6 * np.log(1 + 4 * r1) + rng.normal(0, 0.02, 6)
+        r2 = r1 * rng.uniform(1.0, 1.08)
+        p2 = p1 - rng.uniform(0.0, 0.4)
+        fx[f"c{case}_R1"], fx[f"c{case}_P1"], fx[f"c{case}_R2"], fx[f"c{case}_P2"] = r1, p1, r2, p2
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            for pw in (0, 1):
+                fx[f"c{case}_bdrate_{pw}"] = np.float64(bd.BD_RATE(r1, p1, r2, p2, piecewise=pw))
+                fx[f"c{case}_bdpsnr_{pw}"] = np.float64(bd.BD_PSNR(r1, p1, r2, p2, piecewise=pw))
+    np.savez_compressed(os.path.join(out_dir, "bd_rate.npz"), **fx)
+    print("bd_rate.npz", len(fx), "arrays")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
@@ -445,6 +471,7 @@ def main():
     _install_shims()
     sys.path.insert(0, REF)
     torch.set_num_threads(4)
+    golden_bd(a.out)
     golden_quantizers(a.out)
     golden_temp_decay(a.out)
     golden_model_surgery(a.out)
