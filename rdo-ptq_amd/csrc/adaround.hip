@@ -65,7 +65,9 @@ __device__ __forceinline__ void emit(const rdo_ada_desc& d, long e, float q, flo
 
 // One thread per 4 consecutive weight elements (16-byte accesses on every stream: w, alpha, m, v, nsplit slabs, wq).
 // The dgrad layout wd is produced afterwards by wd_transpose_kernel (LDS-tiled, coalesced on both sides).
+template <int W>   // W = 4: float4 streams (numel % 4 == 0); W = 1: scalar fallback for odd-sized tensors
 __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
+    typedef float vec_t __attribute__((ext_vector_type(W)));
     const rdo_ada_desc d = a.d;
     const long inner = d.numel / d.rows;
     const float Lm1 = (float)(d.n_levels - 1);
@@ -77,24 +79,24 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
         b = s.b; round_on = s.round_on; step_size = s.step_size; bc2 = s.bc2_sqrt;
     }
     float rl_local = 0.f;
-    const long nq = d.numel / 4;   // host guarantees numel % 4 == 0
+    const long nq = d.numel / W;
     for (long qi = (long)blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += (long)gridDim.x * blockDim.x) {
-        const long e0 = qi * 4;
-        const f32x4 wv4 = *reinterpret_cast<const f32x4*>(a.w + e0);
-        f32x4 al4 = *reinterpret_cast<const f32x4*>(a.alpha + e0);
-        f32x4 g4 = {0.f, 0.f, 0.f, 0.f};
+        const long e0 = qi * W;
+        const vec_t wv4 = *reinterpret_cast<const vec_t*>(a.w + e0);
+        vec_t al4 = *reinterpret_cast<const vec_t*>(a.alpha + e0);
+        vec_t g4 = wv4 * 0.f;
         if (a.mode == 2) {
-            g4 = *reinterpret_cast<const f32x4*>(a.dalpha_in + e0);
+            g4 = *reinterpret_cast<const vec_t*>(a.dalpha_in + e0);
         } else {
-            for (int s = 0; s < a.nsplit; ++s) g4 += *reinterpret_cast<const f32x4*>(a.slabs + (long)s * d.numel + e0);
+            for (int s = 0; s < a.nsplit; ++s) g4 += *reinterpret_cast<const vec_t*>(a.slabs + (long)s * d.numel + e0);
         }
-        f32x4 m4 = {0.f, 0.f, 0.f, 0.f}, v4 = m4, o4 = m4;
+        vec_t m4 = wv4 * 0.f, v4 = m4, o4 = m4;
         if (a.mode != 1) {
-            m4 = *reinterpret_cast<const f32x4*>(a.m + e0);
-            v4 = *reinterpret_cast<const f32x4*>(a.v + e0);
+            m4 = *reinterpret_cast<const vec_t*>(a.m + e0);
+            v4 = *reinterpret_cast<const vec_t*>(a.v + e0);
         }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
+        for (int k = 0; k < W; ++k) {
             const int row = (int)((e0 + k) / inner);
             const float dl = a.delta[row], z = a.zp[row], wv = wv4[k];
             float al = al4[k];
@@ -148,12 +150,12 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
             o4[k] = o;
         }
         if (a.mode == 1) {
-            *reinterpret_cast<f32x4*>(a.dalpha_out + e0) = o4;
+            *reinterpret_cast<vec_t*>(a.dalpha_out + e0) = o4;
         } else {
-            *reinterpret_cast<f32x4*>(a.m + e0) = m4;
-            *reinterpret_cast<f32x4*>(a.v + e0) = v4;
-            *reinterpret_cast<f32x4*>(a.alpha + e0) = al4;
-            *reinterpret_cast<f32x4*>(a.wq + e0) = o4;
+            *reinterpret_cast<vec_t*>(a.m + e0) = m4;
+            *reinterpret_cast<vec_t*>(a.v + e0) = v4;
+            *reinterpret_cast<vec_t*>(a.alpha + e0) = al4;
+            *reinterpret_cast<vec_t*>(a.wq + e0) = o4;
         }
     }
     if (a.mode != 1 && a.round_loss_out && round_on != 0.f) {
@@ -282,10 +284,13 @@ int check_desc(const rdo_ada_desc* d, const char* who) {
 }
 
 int run_step(AdaArgs a, void* stream) {
-    RDO_REQUIRE(a.d.numel % 4 == 0, "adaround step: numel (%ld) must be a multiple of 4", (long)a.d.numel);
+
     return rdo::dispatch(
         [a](hipStream_t s) {
-            hipLaunchKernelGGL(ada_step_kernel, dim3(grid_for(a.d.numel / 4)), dim3(256), 0, s, a);
+            if (a.d.numel % 4 == 0)
+                hipLaunchKernelGGL(ada_step_kernel<4>, dim3(grid_for(a.d.numel / 4)), dim3(256), 0, s, a);
+            else
+                hipLaunchKernelGGL(ada_step_kernel<1>, dim3(grid_for(a.d.numel)), dim3(256), 0, s, a);
             if (a.mode != 1 && a.wd && a.d.Cin > 0) {
                 const long blocks = rdo::ceil_div(a.d.rows, 32) * a.d.KH * a.d.KW * rdo::ceil_div(a.d.Cin, 32);
                 hipLaunchKernelGGL(wd_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.d, (const float*)a.wq, a.wd);

@@ -1,0 +1,78 @@
+"""The reference driver's flow (main2.py:145-290) on a toy Cheng2020 through the drop-in package only: QuantModel -> scale
+init -> recon_model over every unit with layer_/block_reconstruction -> W8 and W8A8 evaluation -> pickle round trip."""
+import io
+import math
+import types
+
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+
+
+def test_main2_flow_on_toy_model():
+    import lic
+    from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstruction, layer_reconstruction
+    from test_datasets import evaluate_images
+    torch.manual_seed(1005)
+    N, n_img, B, iters = 8, 8, 4, 30
+    model = lic.Cheng2020Anchor(N=N).cuda().eval()
+    g = torch.Generator().manual_seed(7)
+    cali = torch.rand(n_img, 3, 64, 64, generator=g).cuda()
+    test_imgs = [torch.rand(1, 3, 96, 80, generator=g) for _ in range(2)]
+    psnr_fp, bpp_fp = evaluate_images(model, test_imgs, p=64)
+
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
+                  warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    visited = []
+
+    def recon_model(m: nn.Module):
+        for name, module in m.named_children():
+            if isinstance(module, QuantModule):
+                visited.append(name)
+                layer_reconstruction(qnn, module, name, **kwargs)
+            elif isinstance(module, BaseQuantBlock):
+                visited.append(name)
+                block_reconstruction(qnn, module, name, **kwargs)
+            else:
+                recon_model(module)
+
+    qnn.set_quant_state(weight_quant=True, act_quant=False)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    recon_model(qnn)
+    assert len(visited) == 32
+    trained = [m for m in qnn.modules() if isinstance(m, QuantModule) and m.org_weight is not None]
+    assert all(m.trained and hasattr(m.weight_quantizer, "alpha") and not m.weight_quantizer.soft_targets for m in trained)
+
+    qnn.set_quant_state(weight_quant=True, act_quant=False)
+    psnr_w8, bpp_w8 = evaluate_images(qnn.eval(), test_imgs, p=64)
+    qnn.set_quant_state(weight_quant=True, act_quant=True)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    psnr_w8a8, bpp_w8a8 = evaluate_images(qnn.eval(), test_imgs, p=64)
+    for v in (psnr_fp, bpp_fp, psnr_w8, bpp_w8, psnr_w8a8, bpp_w8a8):
+        assert math.isfinite(v)
+    # 8-bit weights of a random-init toy model stay close to the FP model (the wrapped decoder output additionally goes
+    # through the reference's LeakyReLU-on-PixelShuffle quirk)
+    assert abs(psnr_w8 - psnr_fp) < 3.0 and abs(bpp_w8 - bpp_fp) < 0.2 * bpp_fp + 0.05
+
+    # the saved artefact is the pickled QuantModel (main2.py:285-290)
+    buf = io.BytesIO()
+    torch.save(qnn, buf)
+    buf.seek(0)
+    qnn2 = torch.load(buf, weights_only=False)
+    qnn2.set_quant_state(True, False)
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        a = qnn(cali[:2])["x_hat"]
+        b = qnn2(cali[:2])["x_hat"]
+    torch.testing.assert_close(a, b, rtol=0, atol=0)
