@@ -52,7 +52,16 @@ const char* rdo_last_error(void);
  * 1x1 `F.conv2d(x**2, gamma, beta)` of f_gdn, quant_layer.py:147).  `pre` (nullable) receives acc+bias before the
  * epilogue (needed by the GDN backward).  dgrad of a stride-1 conv is this same entry point run on dY with `wd`. */
 int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
-                   const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats, void* stream);
+                   const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
+                   const void* wplanes /* nullable: [3][Cout*KH*KW*Cin] bf16 from rdo_split_bf16x3(w) */, void* stream);
+/* Large problems can run on the bf16 MFMA at fp32-level accuracy: every fp32 operand is split EXACTLY into three bf16
+ * planes (x = x1 + x2 + x3) and the six significant cross products are accumulated in fp32 (dropped terms <= 3*2^-24 |x w|).
+ * Activations are split in the kernel's loader; the caller supplies the weight planes.  rdo_conv2d_fwd takes this path when
+ * `wplanes` is given and rdo_conv2d_fwd_uses_bf16x6(d) is 1; rdo_conv2d_fwd_bf16x6 forces it (Cin % 16 == 0). */
+int rdo_conv2d_fwd_uses_bf16x6(const rdo_conv_desc* d);
+int rdo_split_bf16x3(const float* w, int64_t n, void* planes /* 3*n bf16 */, void* stream);
+int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, const void* wplanes, const float* bias, const float* aux,
+                          const float* residual, float* out, float* pre, void* stream);
 /* Small problems (few output tiles) are split over K into `workspace` (deterministic two-pass reduction).  Returns the
  * number of floats the kernel would like for this shape (0 = no split); with a smaller / NULL workspace it does not split. */
 int64_t rdo_conv2d_fwd_workspace(const rdo_conv_desc* d);

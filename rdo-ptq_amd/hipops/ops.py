@@ -15,7 +15,7 @@ def _ptr(t):
         return None
     if not t.is_cuda:
         raise RuntimeError(f"librdoptq_hip has no CPU path: tensor is on {t.device}")
-    if t.dtype not in (torch.float32, torch.int32) or not t.is_contiguous():
+    if t.dtype not in (torch.float32, torch.int32, torch.int16) or not t.is_contiguous():
         raise RuntimeError(f"librdoptq_hip needs contiguous fp32/int32 tensors, got {t.dtype} contiguous={t.is_contiguous()}")
     return C.c_void_p(t.data_ptr())
 
@@ -45,15 +45,27 @@ def _scratch(device, n_floats):
     return pool[-1]
 
 
+def uses_bf16x6(x_shape, w_shape, stride, pad):
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    return bool(L.lib().rdo_conv2d_fwd_uses_bf16x6(C.byref(d)))
+
+
+def split_bf16x3(w, planes=None):
+    """fp32 tensor -> int16 tensor [3, *w.shape] holding the exact bf16 split w = p0 + p1 + p2."""
+    planes = torch.empty((3,) + tuple(w.shape), device=w.device, dtype=torch.int16) if planes is None else planes
+    L.check(L.lib().rdo_split_bf16x3(_ptr(w), w.numel(), _ptr(planes), _stream()), "rdo_split_bf16x3")
+    return planes
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, square_input=False,
-               out=None, pre=None):
+               out=None, pre=None, wplanes=None):
     d = conv_desc(x.shape, w.shape, stride, pad, epilogue, square_input, residual is not None)
     if out is None:
         out = torch.empty((d.B, d.Ho, d.Wo, d.Cout), device=x.device, dtype=torch.float32)
     need = int(L.lib().rdo_conv2d_fwd_workspace(C.byref(d)))
     ws = _scratch(x.device, need) if need else None
     L.check(L.lib().rdo_conv2d_fwd(C.byref(d), _ptr(x), _ptr(w), _ptr(bias), _ptr(aux), _ptr(residual), _ptr(out), _ptr(pre),
-                                   _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "rdo_conv2d_fwd")
+                                   _ptr(ws), ws.numel() if ws is not None else 0, _ptr(wplanes), _stream()), "rdo_conv2d_fwd")
     return out
 
 

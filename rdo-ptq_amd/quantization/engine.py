@@ -75,6 +75,23 @@ class _Op:
         ops.adaround_init_alpha(self.desc, self.w, self.delta, self.alpha)
         ops.adaround_fwd(self.desc, self.w, self.alpha, self.delta, self.zp, True, self.wq, self.wd)
         self.slabs = None
+        # exact bf16 three-way splits of the kernel-layout weights, (re)made after every update for the convs that run on
+        # the split-bf16 MFMA path (large problems only; decided by the library from the activation shape)
+        self.wq_planes = self.wd_planes = None
+
+    def enable_planes(self, fwd: bool, dgrad: bool):
+        """Allocate the plane buffers (called while the plan is being recorded: no kernel may run here; the engine fills them
+        once eagerly after recording and re-fills them inside the plan after every AdaRound step)."""
+        if fwd and self.wq_planes is None:
+            self.wq_planes = torch.empty((3,) + tuple(self.wq.shape), device=self.wq.device, dtype=torch.int16)
+        if dgrad and self.wd is not None and self.wd_planes is None:
+            self.wd_planes = torch.empty((3,) + tuple(self.wd.shape), device=self.wd.device, dtype=torch.int16)
+
+    def refresh_planes(self):
+        if self.wq_planes is not None:
+            ops.split_bf16x3(self.wq, self.wq_planes)
+        if self.wd_planes is not None:
+            ops.split_bf16x3(self.wd, self.wd_planes)
 
     def wq4(self):
         return self.wq.reshape(self.w4)
@@ -127,6 +144,8 @@ class UnitEngine:
         self._build_ops()
         self._alloc()
         self._record()
+        for op in self.ops.values():
+            op.refresh_planes()          # initial soft weights -> bf16 planes (eager, before the first iteration)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _build_ops(self):
@@ -219,8 +238,10 @@ class UnitEngine:
     # ------------------------------------------------------------------------------------------------------------------
     def _conv(self, op, x, out, epilogue=L.EPI_NONE, aux=None, residual=None, pre=None, square=False, bias=True):
         b = (op.beta if op.is_gdn else op.bias) if bias else None
+        if ops.uses_bf16x6(tuple(x.shape), op.w4, op.stride, op.pad):
+            op.enable_planes(True, False)
         return ops.conv2d_fwd(x, op.wq4(), b, op.stride, op.pad, epilogue=epilogue, aux=aux, residual=residual,
-                              square_input=square, out=out, pre=pre)
+                              square_input=square, out=out, pre=pre, wplanes=op.wq_planes)
 
     def _wgrad(self, op, x, dy, square=False):
         if op.slabs is None:
@@ -228,7 +249,10 @@ class UnitEngine:
         ops.conv2d_wgrad(x, dy, op.w4, op.stride, op.pad, square_input=square, slabs=op.slabs)
 
     def _dgrad(self, op, dy, out, epilogue=L.EPI_NONE, aux=None):
-        return ops.conv2d_fwd(dy, op.wd4(), None, 1, op.K - 1 - op.pad, epilogue=epilogue, aux=aux, out=out)
+        if ops.uses_bf16x6(tuple(dy.shape), tuple(op.wd4().shape), 1, op.K - 1 - op.pad):
+            op.enable_planes(False, True)
+        return ops.conv2d_fwd(dy, op.wd4(), None, 1, op.K - 1 - op.pad, epilogue=epilogue, aux=aux, out=out,
+                              wplanes=op.wd_planes)
 
     def _loss(self, pred, grad):
         ops.lp2_loss_grad(pred, self.co, self.idx, self.it, 2.0, grad, self.loss_log)
@@ -301,7 +325,9 @@ class UnitEngine:
 
     def _gdn_backward(self, g, dout, xin, norm, tbuf, acc, dx, inverse):
         ops.gdn_bwd_t(dout, xin, norm, inverse, tbuf)
-        ops.conv2d_fwd(tbuf, g.wd4(), None, 1, 0, out=acc)           # t . gamma'  (wd = gamma'^T as [C][1][1][C])
+        if ops.uses_bf16x6(tuple(tbuf.shape), tuple(g.wd4().shape), 1, 0):
+            g.enable_planes(False, True)
+        ops.conv2d_fwd(tbuf, g.wd4(), None, 1, 0, out=acc, wplanes=g.wd_planes)   # t . gamma'  (wd = gamma'^T as [C][1][1][C])
         ops.gdn_bwd_dx(dout, xin, norm, acc, inverse, dx)
         self._wgrad(g, xin, tbuf, square=True)                        # dgamma'[k][i] = sum_m t_k x_i^2
 
@@ -314,6 +340,7 @@ class UnitEngine:
                 for op in self.ops.values():
                     ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
                                       op.alpha, op.m, op.v, op.wq, op.wd, self.round_log)
+                    op.refresh_planes()
                 ops.iter_advance(self.it)
             else:
                 for op in self.ops.values():
@@ -324,6 +351,7 @@ class UnitEngine:
                 for op in self.ops.values():
                     ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, 1.0 / self.world, self.weight, self.sched,
                                        self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log)
+                    op.refresh_planes()
                 ops.iter_advance(self.it)
 
     # ------------------------------------------------------------------------------------------------------------------

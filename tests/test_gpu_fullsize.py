@@ -128,3 +128,26 @@ def test_full_size_rb_unit_step_matches_torch_autograd():
         # Adam's first step is lr * sign(g) for |g| >> eps: disagreements can only come from gradients at the noise level
         bad = (got - ref).abs() > 2e-4
         assert float(bad.float().mean()) < 2e-3, (k, float(bad.float().mean()))
+
+
+@pytest.mark.parametrize("H,Cin,Cout,K,s,p", [(128, N, N, 3, 1, 1), (64, N, 4 * N, 3, 1, 1), (128, N, N, 1, 1, 0)])
+def test_split_bf16_conv_path_has_fp32_accuracy(ops, H, Cin, Cout, K, s, p):
+    """The bf16x6 path rdo_conv2d_fwd takes for large problems: error vs an fp64 reference no larger than the fp32-MFMA
+    kernel's, and the three bf16 planes re-sum to the fp32 weights exactly."""
+    g = torch.Generator(device="cuda").manual_seed(H + Cout)
+    x = torch.randn(4, H, H, Cin, device="cuda", generator=g) * 3
+    w = torch.randn(Cout, K, K, Cin, device="cuda", generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    assert ops.uses_bf16x6(tuple(x.shape), tuple(w.shape), s, p)
+    planes = ops.split_bf16x3(w)
+    resum = sum((planes[i].to(torch.int32) << 16).view(torch.float32) for i in range(3))
+    assert torch.equal(resum, w)
+    y32 = ops.conv2d_fwd(x, w, b, s, p)
+    y6 = ops.conv2d_fwd(x, w, b, s, p, wplanes=planes)
+    ref = torch.nn.functional.conv2d(x[:1].permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), s, p)
+    ref = ref.permute(0, 2, 3, 1)
+    scale = float(ref.abs().max())
+    e32 = float((y32[:1].double() - ref).abs().max()) / scale
+    e6 = float((y6[:1].double() - ref).abs().max()) / scale
+    assert e6 < 4e-6 and e6 < 2.0 * e32 + 1e-7, (e6, e32)
+    assert float((y6 - y32).abs().max()) / scale < 6e-6
