@@ -71,6 +71,7 @@ int64_t rdo_conv2d_fwd_workspace(const rdo_conv_desc* d);
  * rdo_reduce_slabs).  rdo_conv2d_wgrad_nsplit() returns the split count the kernel wants for a shape. */
 int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d);
 int rdo_conv2d_wgrad(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, void* stream);
+int rdo_conv2d_wgrad_uses_bf16x6(const rdo_conv_desc* d);   /* 1: this shape runs on the split-bf16 MFMA path (fp32 accuracy) */
 int rdo_reduce_slabs(const float* slabs, int nsplit, int64_t numel, float* out, void* stream);
 
 /* ---- K4/K8/K10: AdaRound ---------------------------------------- quantizer.py:427-452, layer_opt.py:159-165,254,307 */

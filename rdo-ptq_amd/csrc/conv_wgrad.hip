@@ -229,6 +229,16 @@ inline int tiles_total(const rdo_conv_desc* d) {
 
 }  // namespace
 
+int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, int mchunk, hipStream_t s);
+
+// 1 when rdo_conv2d_wgrad runs this shape on the split-bf16 MFMA path (conv_wgrad_x6.hip): big-tile problems whose output
+// rows are a multiple of 4 pixels wide and whose channel counts allow 16-byte quads.  RDO_CONV_X6=0 disables it.
+extern "C" int rdo_conv2d_wgrad_uses_bf16x6(const rdo_conv_desc* d) {
+    static const bool enabled = !(getenv("RDO_CONV_X6") && atoi(getenv("RDO_CONV_X6")) == 0);
+    if (!d || !enabled || g_force_big == 0) return 0;
+    return big_tiles(d) && d->Wo % 4 == 0 && d->Cin % 4 == 0 && d->Cout % 4 == 0;
+}
+
 extern "C" void rdo_debug_force_wgrad_choice(int big, int nsplit) {
     g_force_big = big;
     g_force_ns = nsplit;
@@ -266,6 +276,13 @@ extern "C" int rdo_conv2d_wgrad(const rdo_conv_desc* d, const float* x, const fl
     const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) % 16 == 0);
     const bool big = big_tiles(d);
+    if (vec && rdo_conv2d_wgrad_uses_bf16x6(d)) {
+        const rdo_conv_desc dd = *d;
+        const int mchunk = a.mchunk;
+        return rdo::dispatch([=](hipStream_t s) { return rdo_launch_wgrad_x6(&dd, x, dy, slabs, nsplit, mchunk, s); }, stream,
+                             "conv_wgrad_x6_192x192", 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW,
+                             4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout + (double)nsplit * a.Cout * a.KH * a.KW * a.Cin));
+    }
     return rdo::dispatch(
         [a, vec, big](hipStream_t s) {
             if (big) return vec ? launch<192, 192, true>(a, s) : launch<192, 192, false>(a, s);

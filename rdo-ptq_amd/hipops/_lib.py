@@ -37,6 +37,7 @@ _SIGS = {
     "rdo_conv2d_fwd_workspace": (C.c_int64, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_wgrad_nsplit": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), P, P, P, C.c_int, P]),
+    "rdo_conv2d_wgrad_uses_bf16x6": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_reduce_slabs": (C.c_int, [P, C.c_int, C.c_int64, P, P]),
     "rdo_adaround_init_alpha": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P]),
     "rdo_adaround_fwd": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, P, P, P]),
