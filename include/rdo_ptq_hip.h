@@ -61,7 +61,8 @@ int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const
 int rdo_conv2d_fwd_uses_bf16x6(const rdo_conv_desc* d);
 int rdo_split_bf16x3(const float* w, int64_t n, void* planes /* 3*n bf16 */, void* stream);
 int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, const void* wplanes, const float* bias, const float* aux,
-                          const float* residual, float* out, float* pre, void* stream);
+                          const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats, void* stream);
+int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d);   /* K split this path uses for a shape (0: shape too small) */
 /* Small problems (few output tiles) are split over K into `workspace` (deterministic two-pass reduction).  Returns the
  * number of floats the kernel would like for this shape (0 = no split); with a smaller / NULL workspace it does not split. */
 int64_t rdo_conv2d_fwd_workspace(const rdo_conv_desc* d);

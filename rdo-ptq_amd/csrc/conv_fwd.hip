@@ -347,15 +347,16 @@ extern "C" const char* rdo_debug_force_fwd_choice(int tile, int ksplit) {
 }
 
 extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, const void* wplanes, const float* bias, const float* aux,
-                                     const float* residual, float* out, float* pre, void* stream);
+                                     const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
+                                     void* stream);
+extern "C" int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d);
 
-// 1 when rdo_conv2d_fwd would take the split-bf16 path for this shape if weight planes are supplied: large problems only
-// (>= 384 tiles of 128 x 192), channel counts the 16-deep bf16 MFMA step divides.  RDO_CONV_X6=0 disables it.
+// 1 when rdo_conv2d_fwd would take the split-bf16 path for this shape if weight planes are supplied: problems that fill the
+// chip with 128 x 192 tiles, split over K if necessary (rdo_conv2d_fwd_bf16x6_ksplit).  RDO_CONV_X6=0 disables it.
 extern "C" int rdo_conv2d_fwd_uses_bf16x6(const rdo_conv_desc* d) {
     static const bool enabled = !(getenv("RDO_CONV_X6") && atoi(getenv("RDO_CONV_X6")) == 0);
     if (!d || !enabled) return 0;
-    const long M = (long)d->B * d->Ho * d->Wo;
-    return d->Cin % 16 == 0 && d->Cout >= 160 && rdo::ceil_div(M, 128) * rdo::ceil_div(d->Cout, 192) >= 384;
+    return rdo_conv2d_fwd_bf16x6_ksplit(d) >= 1;
 }
 
 // floats of scratch the caller should provide so that small problems can be split over K (0: never needed)
@@ -363,7 +364,10 @@ extern "C" int64_t rdo_conv2d_fwd_workspace(const rdo_conv_desc* d) {
     if (!d) return 0;
     const FwdArgs a = make_args(d);
     const Choice c = choose(a, 1L << 40);
-    return c.ksplit > 1 ? (int64_t)c.ksplit * a.M * a.Cout : 0;
+    int64_t need = c.ksplit > 1 ? (int64_t)c.ksplit * a.M * a.Cout : 0;
+    const int ks6 = rdo_conv2d_fwd_uses_bf16x6(d) ? rdo_conv2d_fwd_bf16x6_ksplit(d) : 0;
+    if (ks6 > 1 && (int64_t)ks6 * a.M * a.Cout > need) need = (int64_t)ks6 * a.M * a.Cout;
+    return need;
 }
 
 extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
@@ -383,7 +387,7 @@ extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const floa
     RDO_REQUIRE(epi < RDO_EPI_LRELU_BWD || aux != nullptr, "rdo_conv2d_fwd: epilogue %d needs aux", epi);
     RDO_REQUIRE(!d->add_residual || residual != nullptr, "rdo_conv2d_fwd: add_residual without residual");
     if (wplanes && rdo_conv2d_fwd_uses_bf16x6(d))
-        return rdo_conv2d_fwd_bf16x6(d, x, wplanes, bias, aux, residual, out, pre, stream);
+        return rdo_conv2d_fwd_bf16x6(d, x, wplanes, bias, aux, residual, out, pre, workspace, workspace_floats, stream);
     FwdArgs a = make_args(d);
     a.x = x; a.w = w; a.bias = bias; a.aux = aux; a.residual = residual; a.out = out; a.pre = pre;
     const Choice c = choose(a, workspace ? workspace_floats : 0);

@@ -36,6 +36,8 @@ struct X6Args {
     int epilogue, square_input, add_residual;
     long wplane;          // elements per weight plane
     int ablate;           // diagnosis only: 1 skip B loads, 2 skip A split, 4 skip LDS stores, 8 skip MFMAs, 16 skip A loads
+    float* partial;       // split-K (v3): raw accumulators [ksplit][M][Cout]; nullptr -> final output
+    int ksplit;
 };
 
 // exact three-way split through the hardware RNE conversion (a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
@@ -498,10 +500,15 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int csteps = (a.Cin + KS - 1) / KS;
-    const int nsteps = a.KH * a.KW * csteps;
+    // split-K: this workgroup reduces stages [sbeg, sbeg + nsteps) of the KH*KW*csteps total
+    const int steps_total = a.KH * a.KW * csteps;
+    const int sbeg = (int)((long)steps_total * blockIdx.z / a.ksplit);
+    const int nsteps = (int)((long)steps_total * (blockIdx.z + 1) / a.ksplit) - sbeg;
 
-    // load cursor (wave-uniform): stage index, tap, channel offset; per-thread pixel offset of the cursor's tap
-    int lc = 0, ltap = 0, lkh = 0, lkw = 0;
+    // load cursor (wave-uniform): tap and channel offset of the stage being loaded; per-thread pixel offset of that tap
+    int ltap = sbeg / csteps;
+    int lc = (sbeg - ltap * csteps) * KS;
+    int lkh = ltap / a.KW, lkw = ltap - lkh * a.KW;
     int apix[2];
     bool apix_ok[2];
     auto retap = [&]() {
@@ -624,14 +631,28 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn0 + j * 32 + li;
         if (n >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[n] : 0.f;
+        const float bv = (a.bias && !a.partial) ? a.bias[n] : 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.M) finish(a, (long)m * a.Cout + n, acc[i][j][r] + bv);
+                if (m >= a.M) continue;
+                const long o = (long)m * a.Cout + n;
+                if (a.partial) a.partial[(long)blockIdx.z * a.M * a.Cout + o] = acc[i][j][r];
+                else finish(a, o, acc[i][j][r] + bv);
             }
+    }
+}
+
+// split-K second pass of the v3 kernel: sum the partial accumulators, bias, epilogue
+__global__ __launch_bounds__(256) void x6_splitk_epilogue_kernel(X6Args a) {
+    const long total = (long)a.M * a.Cout;
+    for (long o = (long)blockIdx.x * blockDim.x + threadIdx.x; o < total; o += (long)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < a.ksplit; ++z) v += a.partial[(long)z * total + o];
+        if (a.bias) v += a.bias[o % a.Cout];
+        finish(a, o, v);
     }
 }
 
@@ -657,8 +678,21 @@ extern "C" int rdo_split_bf16x3(const float* w, int64_t n, void* planes, void* s
         stream, "split_bf16x3", 0.0, 10.0 * n);
 }
 
+// split factor the v3 kernel wants for a shape: enough 128 x 192 x (K/ks) workgroups to fill the chip (>= 384), at least
+// 12 K stages (of 16 channels) per split, at most 8 splits; 0 = the shape is too small for this path
+extern "C" int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d) {
+    if (!d || d->Cin % 16 != 0 || d->Cout < 160) return 0;
+    const long M = (long)d->B * d->Ho * d->Wo;
+    const long tiles = rdo::ceil_div(M, 128) * rdo::ceil_div(d->Cout, 192);
+    const long stages = (long)d->KH * d->KW * (d->Cin / 16);
+    for (int ks = 1; ks <= 8; ++ks)
+        if (tiles * ks >= 384 && stages / ks >= 12) return ks;
+    return 0;
+}
+
 extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, const void* wplanes, const float* bias, const float* aux,
-                                     const float* residual, float* out, float* pre, void* stream) {
+                                     const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
+                                     void* stream) {
     RDO_REQUIRE(d && x && wplanes && out, "rdo_conv2d_fwd_bf16x6: null argument");
     RDO_REQUIRE(d->Cin % 16 == 0, "rdo_conv2d_fwd_bf16x6: Cin must be a multiple of 16");
     X6Args a{};
@@ -670,6 +704,11 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
     a.epilogue = d->epilogue; a.square_input = d->square_input; a.add_residual = d->add_residual;
     a.wplane = (long)d->Cout * d->KH * d->KW * d->Cin;
     a.ablate = getenv("RDO_X6_ABLATE") ? atoi(getenv("RDO_X6_ABLATE")) : 0;
+    int ks = rdo_conv2d_fwd_bf16x6_ksplit(d);
+    if (ks < 1) ks = 1;
+    if (ks > 1 && (!workspace || (long)ks * a.M * a.Cout > workspace_floats)) ks = 1;
+    a.ksplit = ks;
+    a.partial = ks > 1 ? workspace : nullptr;
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
     return rdo::dispatch(
         [a](hipStream_t s) {
@@ -696,9 +735,15 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
                         return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6v3) failed");
                     attr3 = true;
                 }
-                dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192));
+                dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
                 hipLaunchKernelGGL(conv_fwd_x6v3_kernel, grid, dim3(256), lds3, s, a);
-                return rdo::check_launch("conv_fwd_x6v3");
+                if (int rc = rdo::check_launch("conv_fwd_x6v3")) return rc;
+                if (a.ksplit > 1) {
+                    long g = rdo::ceil_div((long)a.M * a.Cout, 256);
+                    hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
+                    return rdo::check_launch("x6_splitk_epilogue");
+                }
+                return RDO_OK;
             }
             constexpr int BM = 64, BN = 192;
             constexpr size_t lds = (size_t)2 * 3 * (BM + BN) * 64;
