@@ -154,6 +154,13 @@ int rdo_gdn_bwd_dx(const float* g, const float* x, const float* norm, const floa
                    float* dx, void* stream);
 int rdo_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t H, int32_t W, int32_t inverse, float* out, void* stream);
 int rdo_iter_advance(int32_t* iter_ptr, void* stream);
+/* F.conv_transpose2d (quant_layer.py:30-37,123) = zero-insertion + padding of the input, then rdo_conv2d_fwd (stride 1, pad 0)
+ * with the weight re-laid out [co][K-1-kh][K-1-kw][ci]:  out[b][pt + h*s][pl + w*s][c] = x[b][h][w][c], zeros elsewhere */
+int rdo_zero_insert(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t pad_top, int32_t pad_left,
+                    int32_t Ho, int32_t Wo, float* out, void* stream);
+/* F.layer_norm over the last dimension (quant_layer.py:44-49,121): rows x C, biased variance, eps inside the sqrt */
+int rdo_layer_norm(const float* x, const float* weight, const float* bias, int64_t rows, int32_t C, float eps, float* out,
+                   void* stream);
 
 /* ---- K12: entropy-model likelihoods (eval rounding) and the rate / distortion sums -------------------------------------
  * Element-wise on [n] fp32 (NHWC: channel = i % C).  `params` = per channel 58 floats [33 softplus(matrix) | 13 bias |

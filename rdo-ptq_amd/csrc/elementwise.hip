@@ -140,6 +140,49 @@ __global__ __launch_bounds__(256) void nchw_nhwc_kernel(const float* x, int B, i
 
 __global__ void iter_advance_kernel(int32_t* it) { *it += 1; }
 
+// zero-insertion + padding for transposed convolution: out[b][pt + h*s][pl + w*s][c] = x[b][h][w][c], zeros elsewhere
+__global__ __launch_bounds__(256) void zero_insert_kernel(const float* x, int B, int H, int W, int C, int s, int pt, int pl,
+                                                          int Ho, int Wo, float* out) {
+    const long total = (long)B * Ho * Wo * C;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        long u = t;
+        const int c = (int)(u % C); u /= C;
+        const int wo = (int)(u % Wo); u /= Wo;
+        const int ho = (int)(u % Ho);
+        const int b = (int)(u / Ho);
+        const int hh = ho - pt, ww = wo - pl;
+        float v = 0.f;
+        if (hh >= 0 && ww >= 0 && hh % s == 0 && ww % s == 0) {
+            const int h = hh / s, w = ww / s;
+            if (h < H && w < W) v = x[(((long)b * H + h) * W + w) * C + c];
+        }
+        out[t] = v;
+    }
+}
+
+// LayerNorm over the last dimension (one wave per row): y = (x - mean) * rsqrt(var + eps) * w + b      F.layer_norm, quant_layer.py:121
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* x, const float* w, const float* b, long rows, int C,
+                                                         float eps, float* out) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + row * C;
+    float s1 = 0.f;
+    for (int c = lane; c < C; c += 64) s1 += xr[c];
+    for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+    const float mean = s1 / (float)C;
+    float s2 = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; s2 += d * d; }
+    for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+    const float rstd = rsqrtf(s2 / (float)C + eps);
+    for (int c = lane; c < C; c += 64) {
+        float v = (xr[c] - mean) * rstd;
+        if (w) v *= w[c];
+        if (b) v += b[c];
+        out[row * C + c] = v;
+    }
+}
+
 // ---- K6: per-channel dynamic activation quantisation (NHWC: channel = fastest dim)
 __device__ __forceinline__ unsigned f2ord(float f) {
     unsigned u = __float_as_uint(f);
@@ -290,6 +333,32 @@ int rdo_nchw_to_nhwc(const float* x, int32_t B, int32_t C, int32_t H, int32_t W,
         [=](hipStream_t s) {
             hipLaunchKernelGGL(nchw_nhwc_kernel, dim3(grid_for((long)B * C * H * W)), dim3(256), 0, s, x, B, C, H, W, inverse, out);
             return rdo::check_launch("nchw_to_nhwc");
+        },
+        stream);
+}
+
+int rdo_zero_insert(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t pad_top, int32_t pad_left,
+                    int32_t Ho, int32_t Wo, float* out, void* stream) {
+    RDO_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0 && pad_top >= 0 && pad_left >= 0 &&
+                    Ho >= pad_top + (H - 1) * stride + 1 && Wo >= pad_left + (W - 1) * stride + 1,
+                "rdo_zero_insert: bad geometry");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(zero_insert_kernel, dim3(grid_for((long)B * Ho * Wo * C)), dim3(256), 0, s, x, B, H, W, C, stride,
+                               pad_top, pad_left, Ho, Wo, out);
+            return rdo::check_launch("zero_insert");
+        },
+        stream);
+}
+
+int rdo_layer_norm(const float* x, const float* weight, const float* bias, int64_t rows, int32_t C, float eps, float* out,
+                   void* stream) {
+    RDO_REQUIRE(x && out && rows > 0 && C > 0, "rdo_layer_norm: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(layer_norm_kernel, dim3((unsigned)rdo::ceil_div(rows, 4)), dim3(256), 0, s, x, weight, bias, (long)rows,
+                               C, eps, out);
+            return rdo::check_launch("layer_norm");
         },
         stream);
 }

@@ -239,6 +239,34 @@ def nhwc_to_nchw(x, out=None):
     return out
 
 
+def zero_insert(x, stride, pad_top, pad_left, Ho, Wo, out=None):
+    """[B,H,W,C] -> [B,Ho,Wo,C] with x placed at (pad + h*stride, pad + w*stride) and zeros elsewhere."""
+    B, H, W, Cc = x.shape
+    out = torch.empty((B, Ho, Wo, Cc), device=x.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_zero_insert(_ptr(x), B, H, W, Cc, stride, pad_top, pad_left, Ho, Wo, _ptr(out), _stream()), "rdo_zero_insert")
+    return out
+
+
+def conv_transpose2d(x, w_iohw_rows, bias, stride, pad, output_padding, epilogue=L.EPI_NONE):
+    """x [B,H,W,Cin]; w_iohw_rows = to_rows(W, tconv=True) = [Cout,KH,KW,Cin] (un-flipped taps of the [Cin,Cout,KH,KW] weight)."""
+    Cout, KH, KW, Cin = w_iohw_rows.shape
+    B, H, W, _ = x.shape
+    q = KH - 1 - pad
+    if q < 0:
+        raise ValueError("conv_transpose2d: padding larger than kernel_size - 1 is not supported")
+    Hup, Wup = (H - 1) * stride + 1 + 2 * q + output_padding, (W - 1) * stride + 1 + 2 * q + output_padding
+    xu = zero_insert(x, stride, q, q, Hup, Wup)
+    return conv2d_fwd(xu, w_iohw_rows.flip(1, 2).contiguous(), bias, 1, 0, epilogue=epilogue)
+
+
+def layer_norm(x, weight, bias, eps=1e-5, out=None):
+    Cc = x.shape[-1]
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().rdo_layer_norm(_ptr(x), _ptr(weight), _ptr(bias), x.numel() // Cc, Cc, eps, _ptr(out), _stream()),
+            "rdo_layer_norm")
+    return out
+
+
 def iter_advance(iter_ptr):
     L.check(L.lib().rdo_iter_advance(_ptr(iter_ptr), _stream()), "rdo_iter_advance")
 

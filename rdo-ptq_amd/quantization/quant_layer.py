@@ -1,7 +1,6 @@
 """`QuantModule`: one fake-quantised layer (reference surface: quantization/quant_layer.py:11-138), forward on the
-HIP kernels.  Supported here: Conv2d (dilation 1, groups 1), Linear (as a 1x1 conv), GDN/IGDN (`f_gdn`, :142-154) and
-PixelShuffle; ConvTranspose2d / LayerNorm (Minnen2018 / Lu2022 paths) raise NotImplementedError until those rows of
-SURVEY 8(f) are built."""
+HIP kernels: Conv2d and ConvTranspose2d (dilation 1, groups 1; the transposed conv is zero-insertion + the forward conv
+kernel), Linear (as a 1x1 conv), LayerNorm over the last dimension, GDN/IGDN (`f_gdn`, :142-154) and PixelShuffle."""
 from typing import Union
 
 import torch
@@ -147,6 +146,20 @@ class QuantModule(nn.Module):
             y = ops.conv2d_fwd(x, gp, bp.contiguous(), 1, 0,
                                epilogue=L.EPI_IGDN if self.fwd_kwargs["inverse"] else L.EPI_GDN, aux=x, square_input=True)
             out = _nchw_view(y)
+        elif self.kind == "tconv":
+            kw = self.fwd_kwargs
+            if _sq(kw["dilation"]) != 1 or kw["groups"] != 1:
+                raise NotImplementedError("dilated / grouped transposed convolutions are not on the supported path")
+            y = ops.conv_transpose2d(_nhwc(input), to_rows(weight.detach(), tconv=True), bias, _sq(kw["stride"]),
+                                     _sq(kw["padding"]), _sq(kw["output_padding"]),
+                                     epilogue=L.EPI_LRELU if fuse else L.EPI_NONE)
+            out = _nchw_view(y)
+        elif self.kind == "layernorm":
+            ns = tuple(self.fwd_kwargs["normalized_shape"])
+            if len(ns) != 1 or ns[0] != input.shape[-1]:
+                raise NotImplementedError("LayerNorm over more than the last dimension is not on the supported path")
+            out = ops.layer_norm(input.contiguous(), None if weight is None else weight.detach().contiguous(), bias)
+            fuse = False
         elif self.kind == "linear":
             x = input.reshape(1, 1, -1, input.shape[-1]).contiguous()
             w = weight.detach().reshape(weight.shape[0], 1, 1, weight.shape[1]).contiguous()

@@ -300,3 +300,45 @@ def test_product_adaround_quantizer_matches_reference_goldens(golden_dir, tag, t
     np.testing.assert_allclose(ada(w).cpu().numpy(), qz[f"ada_{tag}_soft"], rtol=0, atol=tol)
     ada.soft_targets = False
     np.testing.assert_allclose(ada(w).cpu().numpy(), qz[f"ada_{tag}_hard"], rtol=0, atol=tol)
+
+
+@pytest.mark.parametrize("cfg", [(2, 9, 7, 12, 20, 5, 2, 2, 1), (1, 8, 8, 32, 16, 3, 2, 1, 1), (2, 6, 5, 8, 8, 4, 2, 1, 0),
+                                 (1, 7, 7, 16, 24, 3, 1, 1, 0)])
+def test_quantmodule_conv_transpose_matches_torch(cfg):
+    """QuantModule(nn.ConvTranspose2d) forward (zero-insertion + HIP conv) vs F.conv_transpose2d in fp64, FP and W8."""
+    from oracle import rdo_oracle as O
+    from quantization.quant_layer import QuantModule
+    B, H, W, Cin, Cout, K, s, p, op = cfg
+    torch.manual_seed(sum(cfg))
+    m = torch.nn.ConvTranspose2d(Cin, Cout, K, stride=s, padding=p, output_padding=op)
+    x = torch.randn(B, Cin, H, W)
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    w_cpu, b_cpu = m.weight.detach().clone(), m.bias.detach().clone()
+    qm = QuantModule(m, wq, dict(wq, leaf_param=False)).cuda()
+    ref = F.conv_transpose2d(x.double(), w_cpu.double(), b_cpu.double(), stride=s, padding=p, output_padding=op)
+    y = qm(x.cuda())
+    assert tuple(y.shape) == tuple(ref.shape)
+    assert _rel(y.cpu(), ref) < 5e-6
+    qm.set_quant_state(True, False)
+    yq = qm(x.cuda())
+    d, z = O.uaq_init(w_cpu, 8, True, "max", tconv=True)
+    wq_ref = O.uaq_fakequant(w_cpu, d, z, 256)
+    refq = F.conv_transpose2d(x.double(), wq_ref.double(), b_cpu.double(), stride=s, padding=p, output_padding=op)
+    assert _rel(yq.cpu(), refq) < 5e-6
+
+
+def test_quantmodule_layernorm_and_linear_match_torch():
+    from quantization.quant_layer import QuantModule
+    torch.manual_seed(5)
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    x = torch.randn(3, 50, 96)
+    ln = torch.nn.LayerNorm(96)
+    with torch.no_grad():
+        ln.weight.add_(0.3 * torch.randn(96)); ln.bias.add_(0.1 * torch.randn(96))
+    ref_ln = F.layer_norm(x, (96,), ln.weight.detach().clone(), ln.bias.detach().clone())
+    q = QuantModule(ln, wq, dict(wq, leaf_param=False)).cuda()
+    torch.testing.assert_close(q(x.cuda()).cpu(), ref_ln, rtol=2e-5, atol=2e-5)
+    lin = torch.nn.Linear(96, 40)
+    ref = F.linear(x.double(), lin.weight.detach().double(), lin.bias.detach().double())
+    q = QuantModule(lin, wq, dict(wq, leaf_param=False)).cuda()
+    assert _rel(q(x.cuda()).cpu(), ref) < 5e-6
