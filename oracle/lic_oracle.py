@@ -290,3 +290,39 @@ class Cheng2020Anchor(nn.Module):
         _, y_lik = self.gaussian_conditional(y, scales_hat, means=means_hat)
         x_hat = self.g_s(y_hat)
         return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
+
+
+# ----------------------------------------------------------------------------- Minnen2018 mean-scale hyperprior
+def conv(in_ch, out_ch, kernel_size=5, stride=2):
+    return nn.Conv2d(in_ch, out_ch, kernel_size=kernel_size, stride=stride, padding=kernel_size // 2)
+
+
+def deconv(in_ch, out_ch, kernel_size=5, stride=2):
+    return nn.ConvTranspose2d(in_ch, out_ch, kernel_size=kernel_size, stride=stride, output_padding=stride - 1,
+                              padding=kernel_size // 2)
+
+
+class MeanScaleHyperprior(nn.Module):
+    """Minnen et al. 2018 without the autoregressive context ('mbt2018-mean'), CompressAI topology and child order
+    (entropy_bottleneck, g_a, g_s, h_a, h_s, gaussian_conditional)  **[3P-unverified]**."""
+
+    def __init__(self, N=128, M=192):
+        super().__init__()
+        self.entropy_bottleneck = EntropyBottleneck(N)
+        self.g_a = nn.Sequential(conv(3, N), GDN(N), conv(N, N), GDN(N), conv(N, N), GDN(N), conv(N, M))
+        self.g_s = nn.Sequential(deconv(M, N), GDN(N, inverse=True), deconv(N, N), GDN(N, inverse=True), deconv(N, N),
+                                 GDN(N, inverse=True), deconv(N, 3))
+        self.h_a = nn.Sequential(conv(M, N, stride=1, kernel_size=3), nn.LeakyReLU(inplace=True), conv(N, N),
+                                 nn.LeakyReLU(inplace=True), conv(N, N))
+        self.h_s = nn.Sequential(deconv(N, M), nn.LeakyReLU(inplace=True), deconv(M, M * 3 // 2), nn.LeakyReLU(inplace=True),
+                                 conv(M * 3 // 2, M * 2, stride=1, kernel_size=3))
+        self.gaussian_conditional = GaussianConditional(None)
+        self.N, self.M = N, M
+
+    def forward(self, x):
+        y = self.g_a(x)
+        z = self.h_a(y)
+        z_hat, z_lik = self.entropy_bottleneck(z)
+        scales_hat, means_hat = self.h_s(z_hat).chunk(2, 1)
+        y_hat, y_lik = self.gaussian_conditional(y, scales_hat, means=means_hat)
+        return {"x_hat": self.g_s(y_hat), "likelihoods": {"y": y_lik, "z": z_lik}}

@@ -5,7 +5,8 @@ from .layers import (GDN, MaskedConv2d, NonNegativeParametrizer, ResidualBlock, 
                      ResidualBlockWithStride, conv1x1, conv3x3, subpel_conv3x3)
 from .entropy import EntropyBottleneck, GaussianConditional
 from .cheng2020 import Cheng2020Anchor
+from .minnen2018 import MeanScaleHyperprior
 
 __all__ = ["GDN", "MaskedConv2d", "NonNegativeParametrizer", "ResidualBlock", "ResidualBlockUpsample",
            "ResidualBlockWithStride", "conv1x1", "conv3x3", "subpel_conv3x3", "EntropyBottleneck", "GaussianConditional",
-           "Cheng2020Anchor"]
+           "Cheng2020Anchor", "MeanScaleHyperprior"]

@@ -38,7 +38,8 @@ class _Op:
     def __init__(self, name, qm: QuantModule, need_dgrad: bool):
         self.name, self.qm, self.need_dgrad = name, qm, need_dgrad
         self.is_gdn = qm.kind == "gdn"
-        if qm.kind not in ("conv", "gdn"):
+        self.tconv = None                     # (stride, padding, output_padding) of a ConvTranspose2d unit
+        if qm.kind not in ("conv", "gdn", "tconv"):
             raise NotImplementedError(f"calibration engine: QuantModule kind '{qm.kind}' is not supported yet")
         wq = qm.weight_quantizer
         if not wq.inited:
@@ -46,7 +47,12 @@ class _Op:
         if not wq.channel_wise:
             raise NotImplementedError("calibration engine: layer-wise (non channel-wise) scales are not built yet")
         w = qm.org_weight.detach()
-        self.w = to_rows(w)                    # OHWI or [C,C]
+        if qm.kind == "tconv":
+            # a transposed conv is the forward conv kernel (stride 1, pad 0) on the zero-inserted input with the taps
+            # flipped: keep every per-weight tensor of the engine in that flipped [co][kh'][kw'][ci] layout
+            self.w = to_rows(w, tconv=True).flip(1, 2).contiguous()
+        else:
+            self.w = to_rows(w)                # OHWI or [C,C]
         dev = self.w.device
         self.rows = self.w.shape[0]
         self.delta = wq.delta.reshape(-1).to(dev).contiguous()
@@ -61,7 +67,14 @@ class _Op:
             self.w4 = (self.rows, 1, 1, self.rows)
             self.bias = None
         else:
-            self.stride, self.pad = qm.conv_geometry()
+            if qm.kind == "tconv":
+                kw = qm.fwd_kwargs
+                if kw["groups"] != 1 or tuple(kw["dilation"]) != (1, 1):
+                    raise NotImplementedError("calibration engine: grouped / dilated transposed convolutions")
+                self.tconv = (int(kw["stride"][0]), int(kw["padding"][0]), int(kw["output_padding"][0]))
+                self.stride, self.pad = 1, 0
+            else:
+                self.stride, self.pad = qm.conv_geometry()
             self.K = self.w.shape[1]
             self.desc = ops.ada_desc(self.w, self.n_levels)
             self.w4 = tuple(self.w.shape)
@@ -194,7 +207,21 @@ class UnitEngine:
         o, t = self.ops, {}
         if self.kind == "layer":
             op = o["layer"]
-            Ho, Wo = self._out_hw(op, H, W)
+            if op.tconv is not None:
+                s_, p_, op_ = op.tconv
+                q_ = op.K - 1 - p_
+                if q_ < 0:
+                    raise NotImplementedError("calibration engine: transposed conv with padding > kernel_size - 1")
+                Hu, Wu = (H - 1) * s_ + 1 + 2 * q_ + op_, (W - 1) * s_ + 1 + 2 * q_ + op_
+                t["xu"] = self._buf(B, Hu, Wu, Cin)
+                self.tc_geom = (s_, q_, Hu, Wu)
+                Ho, Wo = Hu - op.K + 1, Wu - op.K + 1
+            elif op.is_gdn:
+                Ho, Wo = H, W
+                t["norm"] = self._buf(B, H, W, Cin)
+                t["t"] = self._buf(B, H, W, Cin)
+            else:
+                Ho, Wo = self._out_hw(op, H, W)
             t["y"] = self._buf(B, Ho, Wo, op.rows)
             t["dy"] = self._buf(B, Ho, Wo, op.rows)
             t["dpre"] = self._buf(B, Ho, Wo, op.rows)
@@ -260,8 +287,18 @@ class UnitEngine:
     def _forward_backward(self):
         o, t, x = self.ops, self.t, self.x_in
         ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x)
-        if self.kind == "layer":
+        if self.kind == "layer" and o["layer"].is_gdn:
+            # a GDN / IGDN that is its own unit (sequential Minnen2018-style coders): only gamma is trained, no dx needed
             op = o["layer"]
+            self._conv(op, x, t["y"], epilogue=L.EPI_IGDN if op.inverse else L.EPI_GDN, aux=x, pre=t["norm"], square=True)
+            self._loss(t["y"], t["dy"])
+            ops.gdn_bwd_t(t["dy"], x, t["norm"], op.inverse, t["t"])
+            self._wgrad(op, x, t["t"], square=True)
+        elif self.kind == "layer":
+            op = o["layer"]
+            if op.tconv is not None:
+                s_, q_, Hu, Wu = self.tc_geom
+                x = ops.zero_insert(x, s_, q_, q_, Hu, Wu, out=t["xu"])
             lrelu = self.include_act and op.qm.fused_lrelu()
             if lrelu:
                 self._conv(op, x, t["y"], epilogue=L.EPI_LRELU)
@@ -383,8 +420,10 @@ class UnitEngine:
         return rt + rd, rt, rd
 
     def alpha_of(self, name):
-        """Trained alpha in the logical weight shape (OIHW view of the OHWI storage)."""
+        """Trained alpha in the logical weight shape (OIHW view of the OHWI storage; [Cin,Cout,KH,KW] for transposed convs)."""
         op = self.ops[name]
+        if op.tconv is not None:
+            return op.alpha.flip(1, 2).permute(3, 0, 1, 2)
         return op.alpha.permute(0, 3, 1, 2) if op.alpha.dim() == 4 else op.alpha
 
     def finish(self):
@@ -392,8 +431,9 @@ class UnitEngine:
         (layer_opt.py:313-316 / block_opt.py:316-321)."""
         for name, op in self.ops.items():
             qm = op.qm
+            rows = op.alpha.flip(1, 2).contiguous() if op.tconv is not None else op.alpha
             ada = AdaRoundQuantizer(uaq=qm.weight_quantizer, round_mode="learned_hard_sigmoid",
-                                    weight_tensor=qm.org_weight.data, alpha_rows=op.alpha)
+                                    weight_tensor=qm.org_weight.data, alpha_rows=rows)
             ada.soft_targets = False
             qm.weight_quantizer = ada
             qm.act_quantizer.is_training = False

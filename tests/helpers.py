@@ -91,3 +91,44 @@ def product_unit(fx, tag, kind, dev="cuda"):
 
 def nhwc(a, dev="cuda"):
     return T(np.ascontiguousarray(a.transpose(0, 2, 3, 1))).to(dev)
+
+
+MINNEN_UNITS = ["g_a.0", "g_a.1", "g_s.0", "g_s.1", "h_s.0"]
+
+
+def minnen_oracle_op(fx, tag):
+    """QOp of one layer unit of the toy Minnen2018 golden (conv / tconv / gdn / igdn)."""
+    kind = str(fx[f"{tag}/kind"])
+    w, b = T(fx[f"{tag}/weight"]), T(fx[f"{tag}/bias"])
+    act = "lrelu" if int(fx[f"{tag}/act"]) else None
+    if kind == "gdn":
+        op = O.QOp("igdn" if int(fx[f"{tag}/inverse"]) else "gdn", w, b)
+    else:
+        s, p, opad = (int(v) for v in fx[f"{tag}/geom"])
+        op = O.QOp(kind, w, b, stride=s, padding=p, output_padding=opad, act=act)
+    op.delta, op.zp = T(fx[f"{tag}/delta"]), T(fx[f"{tag}/zp"])
+    return op
+
+
+def minnen_product_module(fx, tag, dev="cuda"):
+    """The product QuantModule for the same unit."""
+    import lic
+    from quantization.quant_layer import QuantModule
+    kind = str(fx[f"{tag}/kind"])
+    w, b = T(fx[f"{tag}/weight"]), T(fx[f"{tag}/bias"])
+    if kind == "gdn":
+        m = lic.GDN(w.shape[0], inverse=bool(int(fx[f"{tag}/inverse"])))
+        with torch.no_grad():
+            m.gamma.copy_(w); m.beta.copy_(b)
+    else:
+        s, p, opad = (int(v) for v in fx[f"{tag}/geom"])
+        if kind == "tconv":
+            m = nn.ConvTranspose2d(w.shape[0], w.shape[1], w.shape[2], stride=s, padding=p, output_padding=opad)
+        else:
+            m = nn.Conv2d(w.shape[1], w.shape[0], w.shape[2], stride=s, padding=p)
+        with torch.no_grad():
+            m.weight.copy_(w); m.bias.copy_(b)
+    qm = QuantModule(m.to(dev), WQ, AQ).to(dev)
+    if int(fx[f"{tag}/act"]):
+        qm.activation_function = nn.LeakyReLU(inplace=True)
+    return qm

@@ -98,3 +98,40 @@ def test_dp_split_sequence_equals_fused_step(recon, tag, kind):
     for n in res[0][0]:
         torch.testing.assert_close(res[0][0][n], res[1][0][n], rtol=0, atol=0)
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("tag", ["g_a.0", "g_a.1", "g_s.0", "g_s.1", "h_s.0"])
+def test_engine_minnen_layer_units_match_oracle(golden_dir, tag):
+    """Minnen2018-style sequential coders: 5x5 stride-2 conv, GDN / IGDN as their own units, transposed convs (one with a
+    fused LeakyReLU) -- HIP engine vs oracle on the reference's toy-model caches (tests/golden/recon_minnen.npz)."""
+    from helpers import minnen_oracle_op, minnen_product_module
+    from oracle import rdo_oracle as O
+    from quantization.engine import UnitEngine
+    fx = np.load(os.path.join(golden_dir, "recon_minnen.npz"))
+    B, iters = int(fx["meta"][3]), int(fx["meta"][4])
+    idx = fx[f"{tag}/idx"]
+    op_o = minnen_oracle_op(fx, tag)
+    log = O.reconstruct_unit("layer", {"layer": op_o}, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]),
+                             iters=iters, batch_size=B, idx_stream=idx,
+                             mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5))
+    qm = minnen_product_module(fx, tag)
+    eng = UnitEngine("layer", {"layer": qm}, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]),
+                     batch_size=B, iters=iters, seed=SEED, idx_table=torch.from_numpy(idx))
+    np.testing.assert_array_equal(eng.ops["layer"].delta.cpu().numpy(), fx[f"{tag}/delta"].reshape(-1))
+    eng.run()
+    torch.cuda.synchronize()
+    total, _, _ = eng.logs()
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=2e-4, atol=1e-7)
+    a_gpu = eng.alpha_of("layer").cpu()
+    assert a_gpu.shape == op_o.alpha.shape
+    np.testing.assert_allclose(a_gpu.numpy(), op_o.alpha.numpy(), rtol=0, atol=2e-3)
+    flips = int(((a_gpu >= 0) != (op_o.alpha >= 0)).sum())
+    assert flips <= 0.005 * a_gpu.numel()
+    eng.finish()
+    qm.trained = True
+    qm.set_quant_state(True, False)
+    with torch.no_grad():
+        y = qm(T(fx[f"{tag}/inp_q"][:2]).cuda())
+        y_ref = op_o(T(fx[f"{tag}/inp_q"][:2]))
+    err = float((y.cpu() - y_ref).abs().max() / (y_ref.abs().max() + 1e-12))
+    assert err < (5e-3 if flips else 2e-5), err

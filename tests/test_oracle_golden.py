@@ -197,3 +197,21 @@ def test_counter_rng_is_uniform_and_reproducible():
     assert abs(float(m1.float().mean()) - 0.5) < 0.03
     assert bool(O.qdrop_keep_mask_nhwc(1, 0, (1, 4, 4, 4), 1.0).all())
     assert not bool(O.qdrop_keep_mask_nhwc(1, 0, (1, 4, 4, 4), 0.0).any())
+
+
+@pytest.mark.parametrize("tag", ["g_a.0", "g_a.1", "g_s.0", "g_s.1", "h_s.0"])
+def test_reconstruction_loop_minnen_units(golden_dir, tag):
+    """5x5 stride-2 conv, GDN unit, transposed conv, IGDN unit, transposed conv + LeakyReLU: oracle replay of the reference's
+    layer_reconstruction runs on the toy Minnen2018 mean-scale model."""
+    from helpers import minnen_oracle_op
+    fx = np.load(os.path.join(golden_dir, "recon_minnen.npz"))
+    B, iters = int(fx["meta"][3]), int(fx["meta"][4])
+    op = minnen_oracle_op(fx, tag)
+    rand = T(fx[f"{tag}/rand"])
+    log = O.reconstruct_unit("layer", {"layer": op}, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]),
+                             iters=iters, batch_size=B, idx_stream=fx[f"{tag}/idx"], mask_fn=lambda i, shape: rand[i] < 0.5)
+    np.testing.assert_allclose(np.array(log.total), fx[f"{tag}/loss"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(op.alpha.numpy(), fx[f"{tag}/alpha_final"], rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        y = op(T(fx[f"{tag}/inp_q"])[:2])
+    np.testing.assert_allclose(y.numpy(), fx[f"{tag}/hard_out"], rtol=1e-5, atol=1e-6)

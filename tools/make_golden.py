@@ -406,6 +406,107 @@ def golden_recon(out_dir, iters=12):
     print("recon_toy.npz", len(fx), "arrays")
 
 
+def golden_recon_minnen(out_dir, iters=10):
+    """Verbatim layer_reconstruction runs of the reference on a toy Minnen2018 mean-scale model (N=8, M=12, 64x64 crops):
+    5x5 stride-2 conv, GDN as its own unit, transposed conv, IGDN, transposed conv with a fused LeakyReLU."""
+    import logging
+    from quantization import QuantModel, QuantModule, layer_reconstruction
+    import quantization.layer_opt as lo
+    import quantization.utils as qu
+    torch.manual_seed(2018)
+    N, M, n_img, B = 8, 12, 6, 2
+    model = L.MeanScaleHyperprior(N=N, M=M)
+    _randomise(model, torch.Generator().manual_seed(2018))
+    model.eval()
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq)
+    qnn.eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    cali = torch.rand(n_img, 3, 64, 64, generator=torch.Generator().manual_seed(78))
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Minnen2018")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True,
+                  b_range=(20, 2), warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    captured = {}
+    orig_save = qu.save_inp_oup_data
+
+    def save_spy(*a, **k):
+        r = orig_save(*a, **k)
+        captured["inp_q"], captured["inp_fp"], captured["out"] = r[0][0].clone(), r[0][1].clone(), r[1].clone()
+        return r
+    lo.save_inp_oup_data = save_spy
+    losses = []
+    orig_call = lo.LossFunction.__call__
+
+    def call(self, pred, tgt, quant_net_out=None, cali_data=None, grad=None):
+        r = orig_call(self, pred, tgt, quant_net_out, cali_data, grad)
+        losses.append(float(r))
+        return r
+    lo.LossFunction.__call__ = call
+    wanted = ["g_a.0", "g_a.1", "g_s.0", "g_s.1", "h_s.0"]
+    fx = {"cali": _np(cali), "meta": np.array([N, M, n_img, B, iters])}
+    for n_, m_ in qnn.model.named_modules():
+        if isinstance(m_, QuantModule) and m_.org_weight is not None:
+            fx["org/" + n_ + ".weight"] = _np(m_.org_weight)
+            if m_.org_bias is not None:
+                fx["org/" + n_ + ".bias"] = _np(m_.org_bias)
+    for k, v in model.entropy_bottleneck.state_dict().items():
+        fx["state/entropy_bottleneck." + k] = _np(v)
+    full_order = []
+    qnn.set_quant_state(True, False)
+    qnn.model.g_s[-1].set_quant_state(True, False)
+    logging.disable(logging.CRITICAL)
+    _stdout = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        for coder in ("g_a", "g_s", "h_a", "h_s"):
+            for name, m in getattr(qnn.model, coder).named_children():
+                if not isinstance(m, QuantModule):
+                    continue
+                full = f"{coder}.{name}"
+                full_order.append(full)
+                if full not in wanted:
+                    m.trained = True
+                    continue
+                idx_log, rand_log = [], []
+                del losses[:]
+                with _cuda_is_cpu(), _record_rng(idx_log, rand_log):
+                    layer_reconstruction(qnn, m, name, **kwargs)
+                fx[f"{full}/kind"] = np.array("tconv" if m.if_tconv else ("gdn" if m.fwd_func.__name__ == "f_gdn" else "conv"))
+                fx[f"{full}/act"] = np.array(int(isinstance(m.activation_function, nn.LeakyReLU)))
+                if m.fwd_func.__name__ == "f_gdn":
+                    fx[f"{full}/inverse"] = np.array(int(m.fwd_kwargs["inverse"]))
+                else:
+                    fx[f"{full}/geom"] = np.array([m.fwd_kwargs["stride"][0], m.fwd_kwargs["padding"][0],
+                                                   m.fwd_kwargs.get("output_padding", (0, 0))[0]])
+                fx[f"{full}/weight"] = _np(m.org_weight)
+                fx[f"{full}/bias"] = _np(m.org_bias)
+                fx[f"{full}/delta"] = _np(m.weight_quantizer.delta)
+                fx[f"{full}/zp"] = _np(m.weight_quantizer.zero_point)
+                fx[f"{full}/alpha_final"] = _np(m.weight_quantizer.alpha)
+                for k in ("inp_q", "inp_fp", "out"):
+                    fx[f"{full}/{k}"] = _np(captured[k])
+                fx[f"{full}/idx"] = np.stack([_np(t[:B]) for t in idx_log]).astype(np.int64)
+                fx[f"{full}/rand"] = np.stack([_np(t) for t in rand_log]).astype(np.float32)
+                fx[f"{full}/loss"] = np.array(losses, dtype=np.float64)
+                with torch.no_grad():
+                    m.set_quant_state(True, False)
+                    fx[f"{full}/hard_out"] = _np(m(captured["inp_q"][:2]))
+    finally:
+        sys.stdout = _stdout
+        logging.disable(logging.NOTSET)
+        lo.LossFunction.__call__ = orig_call
+        lo.save_inp_oup_data = orig_save
+    fx["full_order"] = np.array(full_order)
+    fx["order"] = np.array(wanted)
+    np.savez_compressed(os.path.join(out_dir, "recon_minnen.npz"), **fx)
+    print("recon_minnen.npz", len(fx), "arrays;", " ".join(f"{w}:{float(fx[w + '/loss'][0]):.4g}->{float(fx[w + '/loss'][-1]):.4g}" for w in wanted))
+
+
 def golden_blocks(out_dir):
     """Forward (and input/weight gradients) of the reference Cheng2020 quant blocks with nearest-rounded weights."""
     from quantization.quant_block import QuantRBWS, QuantRBU, QuantRB
@@ -477,6 +578,7 @@ def main():
     golden_model_surgery(a.out)
     golden_blocks(a.out)
     golden_recon(a.out)
+    golden_recon_minnen(a.out)
 
 
 if __name__ == "__main__":
