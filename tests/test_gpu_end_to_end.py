@@ -76,3 +76,46 @@ def test_main2_flow_on_toy_model():
         a = qnn(cali[:2])["x_hat"]
         b = qnn2(cali[:2])["x_hat"]
     torch.testing.assert_close(a, b, rtol=0, atol=0)
+
+
+def test_main2_flow_on_toy_minnen2018():
+    """Same driver flow on the Minnen2018 mean-scale family (5x5 stride-2 convs, transposed convs, GDN units): every
+    QuantModule is its own unit (no block wrappers), `qnn.model.g_s[-1]` keeps activation quantisation off (main2.py:262-263)."""
+    import lic
+    from quantization import QuantModel, QuantModule, layer_reconstruction
+    from test_datasets import evaluate_images
+    torch.manual_seed(2018)
+    model = lic.MeanScaleHyperprior(N=8, M=12).cuda().eval()
+    g = torch.Generator().manual_seed(8)
+    cali = torch.rand(8, 3, 64, 64, generator=g).cuda()
+    test_imgs = [torch.rand(1, 3, 96, 80, generator=g) for _ in range(2)]
+    psnr_fp, bpp_fp = evaluate_images(model, test_imgs, p=64)
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:4])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Minnen2018")
+    kwargs = dict(cali_data=cali, batch_size=4, iters=25, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
+                  warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    qnn.set_quant_state(True, False)
+    qnn.model.g_s[-1].set_quant_state(True, False)
+    n = 0
+    for coder in ("g_a", "g_s", "h_a", "h_s"):
+        for name, m in getattr(qnn.model, coder).named_children():
+            if isinstance(m, QuantModule):
+                layer_reconstruction(qnn, m, name, **kwargs)
+                n += 1
+    assert n == 20
+    assert all(m.trained for m in qnn.modules() if isinstance(m, QuantModule))
+    qnn.set_quant_state(True, False)
+    psnr_w8, bpp_w8 = evaluate_images(qnn.eval(), test_imgs, p=64)
+    qnn.set_quant_state(True, True)
+    qnn.model.g_s[-1].set_quant_state(True, False)
+    psnr_w8a8, bpp_w8a8 = evaluate_images(qnn.eval(), test_imgs, p=64)
+    for v in (psnr_fp, bpp_fp, psnr_w8, bpp_w8, psnr_w8a8, bpp_w8a8):
+        assert math.isfinite(v)
+    assert abs(psnr_w8 - psnr_fp) < 3.0
