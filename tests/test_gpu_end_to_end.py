@@ -119,3 +119,31 @@ def test_main2_flow_on_toy_minnen2018():
     for v in (psnr_fp, bpp_fp, psnr_w8, bpp_w8, psnr_w8a8, bpp_w8a8):
         assert math.isfinite(v)
     assert abs(psnr_w8 - psnr_fp) < 3.0
+
+
+def test_integer_export_reproduces_hard_rounded_weights():
+    import lic
+    from quantization import QuantModel, QuantModule, block_reconstruction, layer_reconstruction
+    from quantization.export import dequantize, integer_state
+    torch.manual_seed(3)
+    model = lic.Cheng2020Anchor(N=8).cuda().eval()
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    qnn = QuantModel(model, wq, dict(wq, leaf_param=False), is_cheng=True).cuda().eval()
+    cali = torch.rand(4, 3, 64, 64).cuda()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali)
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020")
+    kwargs = dict(cali_data=cali, batch_size=2, iters=10, weight=0.01, input_prob=0.5, asym=True, b_range=(20, 2), warmup=0.2,
+                  act_quant=False, opt_mode="mse", config=None, args=args)
+    block_reconstruction(qnn, qnn.model.g_a[0], "0", **kwargs)        # one trained block, the rest stays nearest-rounded
+    layer_reconstruction(qnn, qnn.model.h_a[0], "0", **kwargs)
+    st = integer_state(qnn)
+    assert len(st) == sum(1 for m in qnn.modules() if isinstance(m, QuantModule) and m.org_weight is not None)
+    mods = dict(qnn.named_modules())
+    for name, e in st.items():
+        assert e["levels"].dtype == torch.uint8
+        m = mods[name]
+        m.set_quant_state(True, False)
+        wq_used = m.weight_quantizer(m.weight).detach().cpu()
+        torch.testing.assert_close(dequantize(e).reshape(wq_used.shape), wq_used, rtol=0, atol=float(e["delta"].max()) * 1e-6)
