@@ -27,6 +27,10 @@ extern "C" {
 #define RDO_EHIP (-5)      /* a HIP runtime call failed */
 #define RDO_ENOMEM (-12)   /* workspace too small */
 
+/* Per-iteration loss logs are [iters][RDO_LOG_SLOTS] floats: kernels spread their atomicAdd partials over the slots of the
+ * current iteration (contended same-address float atomics serialise); the value of an iteration is the sum of its slots. */
+#define RDO_LOG_SLOTS 32
+
 /* epilogue / prologue selectors for the conv kernels */
 enum {
     RDO_EPI_NONE = 0,       /* out = acc + bias */
@@ -102,7 +106,7 @@ typedef struct rdo_sched_row {
 
 /* Fused: reduce `nsplit` wgrad slabs (+ optional pre-reduced grad) -> dL/dwq -> chain through the soft quantiser (and the
  * GDN re-parametrisation) -> + round-loss gradient -> Adam(beta1 .9, beta2 .999, eps 1e-8) on alpha -> next soft wq / wd.
- * Accumulates weight*sum(1-|2h-1|^b) of the CURRENT alpha (before the update) into *round_loss_out (atomicAdd).
+ * Accumulates weight*sum(1-|2h-1|^b) of the CURRENT alpha (before the update) into round_loss_out[*iter_ptr][slot] (atomicAdd).
  * `grad_scale` multiplies the data gradient (1/world_size after a sum all-reduce). */
 int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* slabs,
                       int nsplit, float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr,
@@ -136,7 +140,7 @@ int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t*
 
 /* ---- K8: lp_loss(pred, tgt[idx]) forward + gradient, p = 2: loss = sum((pred-tgt)^2)/(npix), sum over channels
  * grad = coef * 2 (pred - tgt) / npix ; `coef` = 2 reproduces rec_loss + (degenerate) task_loss of SURVEY 3.4.
- * Adds `coef * loss` into loss_out[*iter_ptr]  (atomicAdd).                          quantizer.py:71-79, layer_opt.py:133,150 */
+ * Adds `coef * loss` into loss_out[*iter_ptr][slot]  (atomicAdd, RDO_LOG_SLOTS slots per iteration).                          quantizer.py:71-79, layer_opt.py:133,150 */
 int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
                       int32_t B, int64_t per_image, int32_t C, float coef, float* grad, float* loss_out, void* stream);
 

@@ -166,7 +166,7 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const float t = red[0] + red[1] + red[2] + red[3];
-            if (t != 0.f) atomicAdd(a.round_loss_out + it, t);
+            if (t != 0.f) atomicAdd(a.round_loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), t);
         }
     }
 }

@@ -61,7 +61,10 @@ __global__ __launch_bounds__(256) void lp2_kernel(const float* pred, const float
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0 && loss_out) atomicAdd(loss_out + it, (red[0] + red[1] + red[2] + red[3]) * inv_npix * coef);
+    // 32 accumulation slots per iteration: same-address float atomics serialise at the memory side (~20 ns each), so a
+    // 2048-block launch would spend tens of microseconds on them; the reader sums the slots
+    if (threadIdx.x == 0 && loss_out)
+        atomicAdd(loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), (red[0] + red[1] + red[2] + red[3]) * inv_npix * coef);
 }
 
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* g, const float* y, long n4, float* out) {

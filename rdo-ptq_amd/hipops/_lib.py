@@ -9,6 +9,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librdoptq_hip.so")
 
 EPI_NONE, EPI_LRELU, EPI_LRELU_BWD, EPI_GDN, EPI_IGDN = range(5)
+LOG_SLOTS = 32            # RDO_LOG_SLOTS of include/rdo_ptq_hip.h
 
 
 class ConvDesc(C.Structure):

@@ -146,8 +146,8 @@ class UnitEngine:
         self.idx = idx_table.to(self.dev).contiguous()
         self.sched = ops.make_sched(self.iters, warmup, b_range, lr, self.dev)
         self.it = torch.zeros(1, dtype=torch.int32, device=self.dev)
-        self.loss_log = torch.zeros(self.iters, device=self.dev)
-        self.round_log = torch.zeros(self.iters, device=self.dev)
+        self.loss_log = torch.zeros(self.iters, L.LOG_SLOTS, device=self.dev)      # kernels spread atomics over the slots
+        self.round_log = torch.zeros(self.iters, L.LOG_SLOTS, device=self.dev)
         self.group = group
         self.world = 1
         if group is not None or (torch.distributed.is_available() and torch.distributed.is_initialized()):
@@ -411,12 +411,12 @@ class UnitEngine:
 
     def logs(self):
         """(total, rec+task, round) per iteration as CPU tensors (synchronises)."""
-        rt = self.loss_log.clone()
+        rt = self.loss_log.sum(1)
         if self.world > 1:
             torch.distributed.all_reduce(rt, group=self.group)
             rt /= self.world
         rt = rt.cpu()
-        rd = self.round_log.cpu()
+        rd = self.round_log.sum(1).cpu()
         return rt + rd, rt, rd
 
     def alpha_of(self, name):
