@@ -1,6 +1,7 @@
 // Forward / dgrad conv of the LARGE problems (rdo_conv2d_fwd_uses_bf16x6) with each fp32 operand split exactly into three
 // bf16 planes and the six significant cross products issued on v_mfma_f32_32x32x16_bf16 ("bf16x6").  v1/v2 kernels below are
-// kept for tuning (RDO_X6_VER); v3 (128 x 192 tile, K stage 16) is the one rdo_conv2d_fwd dispatches to.
+// kept for tuning (RDO_X6_VER = 1..4); v5 (128 x 192 tile, K stage 16, weight tile staged by LDS-DMA, fragment reads pipelined one
+// stage ahead) is the one rdo_conv2d_fwd dispatches to.
 //
 //   x = x1 + x2 + x3 exactly (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)), same for w;
 //   x*w ~= x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1          dropped terms <= 3 * 2^-24 |x w|  (fp32-rounding level)
@@ -441,6 +442,9 @@ __global__ __launch_bounds__(256, 3) void conv_fwd_x6v2_kernel(X6Args a) {
 // ---- v3: as v2 with a 128 x 192 workgroup tile (wave tile 64 x 96): half the weight-tile traffic and fragment reads per MFMA
 // LDS rows are 32 B per plane (2 chunks); chunk swizzle c ^= (row>>3)&1.
 
+// DMA = true stages the weight tile with global_load_lds (no VGPR round trip, no select / ds_write instructions): wave w issues
+// the 1 KiB pieces w, w+4, ... of the 18 KiB [plane][row][chunk] image, the chunk swizzle applied on the per-lane SOURCE address.
+template <bool DMA>
 __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
     constexpr int BM = 128, BN = 192, KS = 16;
     constexpr int TM = 2, TN = 3;                          // wave tile 64 x 96 (2x2 waves)
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE] + 4 KiB dummy target for masked chunk stores
     char* dummy = smem + 2 * STAGE;
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
     const int li = lane & 31, lh = lane >> 5;
     const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
@@ -489,6 +493,19 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         b_ok[j] = live && n < a.Cout;
         wbase[j] = (long)pl * a.wplane + (long)(n < a.Cout ? n : 0) * a.KH * a.KW * a.Cin + 8 * ch;
         b_lds[j] = live ? 3 * APLANE + pl * BPLANE + chunk_off16(row, ch) : -1;
+    }
+
+    // DMA pieces of this wave: piece k = wave + 4 j (k < 18); lane -> linear chunk 64 k + lane of the B image
+    int dma_src[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;   // waves 2,3 repeat pieces 16,17 (same bytes): no branch
+        const int e = k * 64 + lane;
+        const int pl = e / (BN * 2);
+        const int r = e - pl * (BN * 2);
+        const int row = r >> 1, ch = (r & 1) ^ ((row >> 3) & 1);
+        const int n = n0 + row < a.Cout ? n0 + row : 0;      // rows past Cout feed only columns that are never stored
+        dma_src[j] = (int)(pl * a.wplane) + n * a.KH * a.KW * a.Cin + 8 * ch;
     }
 
     f32x16 acc[TM][TN];
@@ -530,13 +547,24 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         }
     };
     retap();
+    int bcur = ltap * a.Cin + lc;      // DMA cursor (one stage ahead): element offset tap * Cin + channel of the stage being fetched
+    auto badvance = [&]() { bcur += KS; };   // Cin % 16 == 0: tap * Cin + c simply keeps counting along the OHWI row
+    auto dma_b = [&](auto jc, int buf) {
+        constexpr int j = decltype(jc)::value;
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        if (a.ablate & 1) return;
+        const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
+        char* dst = smem + buf * STAGE + 3 * APLANE + k * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void*)(a.wp + dma_src[j] + bcur), (lds_void*)dst, 16, 0, 0);
+    };
 
     f32x4 ra[2];
     bf16x8 rb[NB];
     bool ra_ok[2];
     auto load_a = [&](int t) {
         ra_ok[t] = apix_ok[t] && lc + 4 * aq < a.Cin;
-        ra[t] = *reinterpret_cast<const f32x4*>(a.x + (ra_ok[t] ? apix[t] + lc : 0));
+        if (!(a.ablate & 16)) ra[t] = *reinterpret_cast<const f32x4*>(a.x + (ra_ok[t] ? apix[t] + lc : 0));
     };
     auto load_b = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -547,11 +575,18 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         f32x4 v = ra_ok[t] ? ra[t] : f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.square_input) v = v * v;
         bf16x4 p0, p1, p2;
+        if (a.ablate & 4) { asm volatile("" ::"v"(v)); return; }
+        if (a.ablate & 2) {
+            p0 = __builtin_bit_cast(bf16x4, f32x4{v[0], v[1], 0.f, 0.f}.xy);
+            p1 = __builtin_bit_cast(bf16x4, f32x4{v[2], v[3], 0.f, 0.f}.xy);
+            p2 = p0;
+        } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            u16 h, m, l;
-            split3(v[e], h, m, l);
-            p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
+            for (int e = 0; e < 4; ++e) {
+                u16 h, m, l;
+                split3(v[e], h, m, l);
+                p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
+            }
         }
         char* st = smem + buf * STAGE + a_lds[t];
         *reinterpret_cast<bf16x4*>(st) = p0;
@@ -571,12 +606,13 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
 
     // prologue: stage 0 -> LDS buffer 0; stage 1 -> registers
     load_a(0); load_a(1);
-    all_b([&](auto jc) { load_b(jc); });
+    if constexpr (DMA) all_b([&](auto jc) { dma_b(jc, 0); });
+    else all_b([&](auto jc) { load_b(jc); });
     store_a(0, 0); store_a(1, 0);
-    all_b([&](auto jc) { store_b(jc, 0); });
-    if (nsteps > 1) advance();
+    if constexpr (!DMA) all_b([&](auto jc) { store_b(jc, 0); });
+    if (nsteps > 1) { advance(); badvance(); }
     load_a(0); load_a(1);
-    all_b([&](auto jc) { load_b(jc); });
+    if constexpr (!DMA) all_b([&](auto jc) { load_b(jc); });
     __syncthreads();
 
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
@@ -609,8 +645,20 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
                  for (int i = 0; i < TM; ++i)
 #pragma unroll
                      for (int j = 0; j < TN; ++j)
-                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[SL]][i], fb[PB[SL]][j], acc[i][j], 0, 0, 0);
-                 if constexpr (SL == 0) {
+                         if (!(a.ablate & 8) || (i == 0 && j == 0))
+                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[SL]][i], fb[PB[SL]][j], acc[i][j], 0, 0, 0);
+                 if constexpr (DMA) {
+                     // stage s+1's weight image goes straight to LDS (it must land before the barrier that ends this stage)
+                     // the register-staged A quads are written before any DMA is issued: hipcc waits vmcnt(0) at a use of
+                     // an ordinary load while a DMA is outstanding, and everything was drained at the last barrier anyway
+                     if constexpr (SL == 0) {
+                         store_a(0, buf ^ 1);
+                         store_a(1, buf ^ 1);
+                         load_a(0);
+                         load_a(1);
+                     }
+                     if constexpr (SL < NB) dma_b(std::integral_constant<int, SL>{}, buf ^ 1);
+                 } else if constexpr (SL == 0) {
                      store_a(0, buf ^ 1);
                      load_a(0);
                      store_a(1, buf ^ 1);
@@ -624,8 +672,234 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
              ...);
         }
         (std::make_integer_sequence<int, 6>{});
+        if (DMA && s + 2 < nsteps) badvance();
         __syncthreads();
     }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + li;
+        if (n >= a.Cout) continue;
+        const float bv = (a.bias && !a.partial) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                const long o = (long)m * a.Cout + n;
+                if (a.partial) a.partial[(long)blockIdx.z * a.M * a.Cout + o] = acc[i][j][r];
+                else finish(a, o, acc[i][j][r] + bv);
+            }
+    }
+}
+
+// ---- v5: the v3/DMA tile with the fragment reads software-pipelined one stage ahead ---------------------------------------------
+// Measured on v3: with loads and stores ablated the kernel still took 194 us against ~125 us of MFMA time -- every stage began with
+// 15 exposed ds_read_b128 behind the barrier.  Here stage t runs its MFMAs from registers while it (1) reads stage t+1's fragments
+// from LDS buffer (t+1)&1 as soon as a plane's registers die (plane 0 is double-buffered in registers, planes 1/2 are re-read in
+// place), (2) writes stage t+2's image into buffer t&1 (A: split + ds_write, B: LDS-DMA) and (3) loads stage t+3's A quads.
+// Slot order (A plane, B plane): (2,0) (0,2) (1,0) (1,1) (0,1) (0,0); fa2 is re-read after slot 0, fb2 after slot 1, fa1 after
+// slot 3, fb1 after slot 4, and next stage's fa0/fb0 go to the alternate register set at the top of the stage.
+__global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
+    constexpr int BM = 128, BN = 192, KS = 16;
+    constexpr int TM = 2, TN = 3;
+    constexpr int APLANE = BM * 32, BPLANE = BN * 32;
+    constexpr int STAGE = 3 * (APLANE + BPLANE);           // 24 KiB
+    constexpr int NB = 5;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
+    const int li = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+
+    const int aq = tid & 3;
+    int hi0[2], wi0[2], abase[2], a_lds[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int arow = (tid >> 2) + 64 * t;
+        const int m = m0 + arow;
+        const bool okr = m < a.M;
+        const int mm = okr ? m : 0;
+        const int b = mm / (a.Ho * a.Wo);
+        const int rem = mm - b * (a.Ho * a.Wo);
+        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+        hi0[t] = okr ? ho * a.stride - a.pad : -(1 << 28);
+        wi0[t] = wo * a.stride - a.pad;
+        abase[t] = b * a.H * a.W * a.Cin + 4 * aq;
+        a_lds[t] = chunk_off16(arow, aq >> 1) + (aq & 1) * 8;
+    }
+    int dma_src[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
+        const int e = k * 64 + lane;
+        const int pl = e / (BN * 2);
+        const int r = e - pl * (BN * 2);
+        const int row = r >> 1, ch = (r & 1) ^ ((row >> 3) & 1);
+        const int n = n0 + row < a.Cout ? n0 + row : 0;
+        dma_src[j] = (int)(pl * a.wplane) + n * a.KH * a.KW * a.Cin + 8 * ch;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int csteps = a.Cin / KS;
+    const int steps_total = a.KH * a.KW * csteps;
+    const int sbeg = (int)((long)steps_total * blockIdx.z / a.ksplit);
+    const int nsteps = (int)((long)steps_total * (blockIdx.z + 1) / a.ksplit) - sbeg;
+
+    int ltap = sbeg / csteps;
+    int lc = (sbeg - ltap * csteps) * KS;
+    int lkh = ltap / a.KW, lkw = ltap - lkh * a.KW;
+    int apix[2];
+    bool apix_ok[2];
+    auto retap = [&]() {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int hi = hi0[t] + lkh, wi = wi0[t] + lkw;
+            apix_ok[t] = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            apix[t] = abase[t] + (hi * a.W + wi) * a.Cin;
+        }
+    };
+    auto advance = [&]() {
+        lc += KS;
+        if (lc >= a.Cin) {
+            lc = 0;
+            ++lkw;
+            if (lkw == a.KW) { lkw = 0; ++lkh; }
+            retap();
+        }
+    };
+    retap();
+    const int bcur0 = sbeg * KS;       // Cin % 16 == 0: tap * Cin + c counts straight along the OHWI row
+
+    f32x4 ra[2];
+    bool ra_ok[2];
+    auto load_a = [&](int t) {
+        ra_ok[t] = apix_ok[t];
+        ra[t] = *reinterpret_cast<const f32x4*>(a.x + (ra_ok[t] ? apix[t] + lc : 0));
+    };
+    auto store_a = [&](int t, int buf) {
+        f32x4 v = ra_ok[t] ? ra[t] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.square_input) v = v * v;
+        bf16x4 p0, p1, p2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            u16 h, m, l;
+            split3(v[e], h, m, l);
+            p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
+        }
+        char* st = smem + buf * STAGE + a_lds[t];
+        *reinterpret_cast<bf16x4*>(st) = p0;
+        *reinterpret_cast<bf16x4*>(st + APLANE) = p1;
+        *reinterpret_cast<bf16x4*>(st + 2 * APLANE) = p2;
+    };
+    auto dma_b = [&](int j, int buf, int stage) {       // stage: index relative to sbeg, clamped by the caller
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
+        char* dst = smem + buf * STAGE + 3 * APLANE + k * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void*)(a.wp + dma_src[j] + bcur0 + stage * KS), (lds_void*)dst, 16, 0, 0);
+    };
+
+    int fa_off[3][TM], fb_off[3][TN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) fa_off[p][i] = p * APLANE + chunk_off16(wm0 + i * 32 + li, lh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb_off[p][j] = 3 * APLANE + p * BPLANE + chunk_off16(wn0 + j * 32 + li, lh);
+    }
+    // fragment registers: plane 0 double-buffered by stage parity, planes 1 and 2 single
+    bf16x8 fa0[2][TM], fb0[2][TN], fa12[2][TM], fb12[2][TN];
+    auto read_a = [&](bf16x8 (&dst)[TM], int p, int buf) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(smem + buf * STAGE + fa_off[p][i]);
+    };
+    auto read_b = [&](bf16x8 (&dst)[TN], int p, int buf) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(smem + buf * STAGE + fb_off[p][j]);
+    };
+    auto mma = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: images of stages 0 and 1 in LDS, A quads of stage 2 in flight, fragments of stage 0 in registers
+    load_a(0); load_a(1);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dma_b(j, 0, 0);
+    store_a(0, 0); store_a(1, 0);
+    if (nsteps > 1) advance();
+    load_a(0); load_a(1);
+    {
+        const int st1 = nsteps > 1 ? 1 : 0;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) dma_b(j, 1, st1);
+    }
+    store_a(0, 1); store_a(1, 1);
+    if (nsteps > 2) advance();
+    load_a(0); load_a(1);
+    __syncthreads();
+    read_a(fa0[0], 0, 0); read_b(fb0[0], 0, 0);
+    read_a(fa12[0], 1, 0); read_b(fb12[0], 1, 0);
+    read_a(fa12[1], 2, 0); read_b(fb12[1], 2, 0);
+    __syncthreads();      // every wave holds stage 0's fragments before buffer 0 is overwritten with stage 2
+
+    auto stage = [&](auto parc, int t) {
+        constexpr int PAR = decltype(parc)::value;          // t & 1: this stage's plane-0 register set; buffer t&1 is rewritten
+        constexpr int NXT = PAR ^ 1;                        // LDS buffer holding stage t+1
+        const int wst = t + 2 < nsteps ? t + 2 : nsteps - 1;
+        // top: next stage's plane-0 fragments into the alternate set
+        read_a(fa0[NXT], 0, NXT); read_b(fb0[NXT], 0, NXT);
+        if (t + 3 < nsteps) advance();
+        // slot 0: (A2, B0)
+        mma(fa12[1], fb0[PAR]);
+        read_a(fa12[1], 2, NXT);
+        store_a(0, PAR); store_a(1, PAR);
+        load_a(0); load_a(1);
+        dma_b(0, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 1: (A0, B2)
+        mma(fa0[PAR], fb12[1]);
+        read_b(fb12[1], 2, NXT);
+        dma_b(1, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 2: (A1, B0)
+        mma(fa12[0], fb0[PAR]);
+        dma_b(2, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 3: (A1, B1)
+        mma(fa12[0], fb12[0]);
+        read_a(fa12[0], 1, NXT);
+        dma_b(3, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 4: (A0, B1)
+        mma(fa0[PAR], fb12[0]);
+        read_b(fb12[0], 1, NXT);
+        dma_b(4, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        // slot 5: (A0, B0)
+        mma(fa0[PAR], fb0[PAR]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    int t = 0;
+    for (; t + 1 < nsteps; t += 2) {
+        stage(std::integral_constant<int, 0>{}, t);
+        stage(std::integral_constant<int, 1>{}, t + 1);
+    }
+    if (t < nsteps) stage(std::integral_constant<int, 0>{}, t);
 
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
@@ -712,7 +986,9 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
     return rdo::dispatch(
         [a](hipStream_t s) {
-            static const int ver = getenv("RDO_X6_VER") ? atoi(getenv("RDO_X6_VER")) : 3;
+            static const int ver_env = getenv("RDO_X6_VER") ? atoi(getenv("RDO_X6_VER")) : 5;
+            // the LDS-DMA loader addresses the weight planes with 32-bit element offsets
+            const int ver = (ver_env >= 4 && 3 * a.wplane >= (1L << 31)) ? 3 : ver_env;
             if (ver == 2) {
                 constexpr size_t lds2 = (size_t)2 * 3 * (64 + 192) * 32 + 4096;
                 static bool attr2 = false;
@@ -726,17 +1002,55 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
                 hipLaunchKernelGGL(conv_fwd_x6v2_kernel, grid, dim3(256), lds2, s, a);
                 return rdo::check_launch("conv_fwd_x6v2");
             }
+            if (ver == 5) {
+                constexpr size_t lds5 = (size_t)2 * 3 * (128 + 192) * 32;
+                static bool attr5 = false;
+                if (!attr5) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v5_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5) != hipSuccess)
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6v5) failed");
+                    attr5 = true;
+                }
+                dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
+                hipLaunchKernelGGL(conv_fwd_x6v5_kernel, grid, dim3(256), lds5, s, a);
+                if (int rc = rdo::check_launch("conv_fwd_x6v5")) return rc;
+                if (a.ksplit > 1) {
+                    long g = rdo::ceil_div((long)a.M * a.Cout, 256);
+                    hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
+                    return rdo::check_launch("x6_splitk_epilogue");
+                }
+                return RDO_OK;
+            }
+            if (ver == 4) {
+                constexpr size_t lds3 = (size_t)2 * 3 * (128 + 192) * 32 + 4096;
+                static bool attr4 = false;
+                if (!attr4) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<true>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6v3 dma) failed");
+                    attr4 = true;
+                }
+                dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
+                hipLaunchKernelGGL(conv_fwd_x6v3_kernel<true>, grid, dim3(256), lds3, s, a);
+                if (int rc = rdo::check_launch("conv_fwd_x6v3_dma")) return rc;
+                if (a.ksplit > 1) {
+                    long g = rdo::ceil_div((long)a.M * a.Cout, 256);
+                    hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
+                    return rdo::check_launch("x6_splitk_epilogue");
+                }
+                return RDO_OK;
+            }
             if (ver == 3) {
                 constexpr size_t lds3 = (size_t)2 * 3 * (128 + 192) * 32 + 4096;
                 static bool attr3 = false;
                 if (!attr3) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v3_kernel),
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<false>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
                         return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6v3) failed");
                     attr3 = true;
                 }
                 dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
-                hipLaunchKernelGGL(conv_fwd_x6v3_kernel, grid, dim3(256), lds3, s, a);
+                hipLaunchKernelGGL(conv_fwd_x6v3_kernel<false>, grid, dim3(256), lds3, s, a);
                 if (int rc = rdo::check_launch("conv_fwd_x6v3")) return rc;
                 if (a.ksplit > 1) {
                     long g = rdo::ceil_div((long)a.M * a.Cout, 256);
