@@ -37,7 +37,9 @@ enum {
     RDO_EPI_LRELU = 1,      /* out = leaky_relu(acc + bias, 0.01)                         quant_block.py:238,273,301,305 */
     RDO_EPI_LRELU_BWD = 2,  /* out = acc * (aux > 0 ? 1 : 0.01)        (dgrad through a LeakyReLU whose OUTPUT is aux)    */
     RDO_EPI_GDN = 3,        /* out = aux * rsqrt(acc + bias)                                      quant_layer.py:147-153 */
-    RDO_EPI_IGDN = 4        /* out = aux * sqrt(acc + bias)                                       quant_layer.py:147-153 */
+    RDO_EPI_IGDN = 4,       /* out = aux * sqrt(acc + bias)                                       quant_layer.py:147-153 */
+    RDO_EPI_RELU = 5,       /* out = max(acc + bias, 0): nn.ReLU fused into the QuantModule          quant_model.py:51-54 */
+    RDO_EPI_RELU_BWD = 6    /* out = aux > 0 ? acc : 0                    (dgrad through a ReLU whose OUTPUT is aux)        */
 };
 
 typedef struct rdo_conv_desc {
@@ -147,6 +149,8 @@ int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* 
 /* ---- K9: element-wise helpers on NHWC tensors */
 int rdo_lrelu_fwd(const float* x, int64_t n, float* out, void* stream);                         /* nn.LeakyReLU(0.01) */
 int rdo_lrelu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream);          /* out = g*(y>0?1:.01) */
+int rdo_relu_fwd(const float* x, int64_t n, float* out, void* stream);                          /* nn.ReLU             */
+int rdo_relu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream);          /* out = y>0 ? g : 0   */
 int rdo_pixel_shuffle(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t r, int32_t inverse, float* out,
                       void* stream);                                                     /* F.pixel_shuffle quant_layer.py:109 */
 int rdo_add(const float* a, const float* b, int64_t n, float* out, void* stream);

@@ -292,6 +292,53 @@ class Cheng2020Anchor(nn.Module):
         return {"x_hat": x_hat, "likelihoods": {"y": y_lik, "z": z_lik}}
 
 
+class AttentionBlock(nn.Module):
+    """Simplified (non-local-free) attention of Cheng et al. 2020, CompressAI layout **[3P-unverified]**:
+    out = x + conv_a(x) * sigmoid(conv_b(x)); conv_a = 3 residual units, conv_b = 3 residual units + conv1x1;
+    residual unit = conv1x1(N, N/2) - ReLU - conv3x3(N/2, N/2) - ReLU - conv1x1(N/2, N), identity add, ReLU."""
+
+    class ResidualUnit(nn.Module):
+        def __init__(self, N):
+            super().__init__()
+            self.conv = nn.Sequential(conv1x1(N, N // 2), nn.ReLU(inplace=True), conv3x3(N // 2, N // 2),
+                                      nn.ReLU(inplace=True), conv1x1(N // 2, N))
+            self.relu = nn.ReLU(inplace=True)
+
+        def forward(self, x):
+            out = self.conv(x)
+            out = out + x
+            return self.relu(out)
+
+    def __init__(self, N):
+        super().__init__()
+        RU = AttentionBlock.ResidualUnit
+        self.conv_a = nn.Sequential(RU(N), RU(N), RU(N))
+        self.conv_b = nn.Sequential(RU(N), RU(N), RU(N), conv1x1(N, N))
+
+    def forward(self, x):
+        a = self.conv_a(x)
+        b = self.conv_b(x)
+        return a * torch.sigmoid(b) + x
+
+
+class Cheng2020Attention(Cheng2020Anchor):
+    """Cheng2020Anchor with attention blocks after the 2nd and the last down-sampling stage (and mirrored in g_s),
+    CompressAI `cheng2020_attn` topology **[3P-unverified]**."""
+
+    def __init__(self, N=192):
+        super().__init__(N)
+        self.g_a = nn.Sequential(
+            ResidualBlockWithStride(3, N, stride=2), ResidualBlock(N, N),
+            ResidualBlockWithStride(N, N, stride=2), AttentionBlock(N), ResidualBlock(N, N),
+            ResidualBlockWithStride(N, N, stride=2), ResidualBlock(N, N),
+            conv3x3(N, N, stride=2), AttentionBlock(N))
+        self.g_s = nn.Sequential(
+            AttentionBlock(N), ResidualBlock(N, N), ResidualBlockUpsample(N, N, 2),
+            ResidualBlock(N, N), ResidualBlockUpsample(N, N, 2), AttentionBlock(N),
+            ResidualBlock(N, N), ResidualBlockUpsample(N, N, 2),
+            ResidualBlock(N, N), subpel_conv3x3(N, 3, 2))
+
+
 # ----------------------------------------------------------------------------- Minnen2018 mean-scale hyperprior
 def conv(in_ch, out_ch, kernel_size=5, stride=2):
     return nn.Conv2d(in_ch, out_ch, kernel_size=kernel_size, stride=stride, padding=kernel_size // 2)

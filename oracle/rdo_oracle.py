@@ -212,7 +212,7 @@ class QOp:
     n_bits: int = 8
     channel_wise: bool = True
     scale_method: str = "max"
-    act: Optional[str] = None            # fused activation: None | 'lrelu'
+    act: Optional[str] = None            # fused activation: None | 'lrelu' | 'relu' (quant_model.py:51-54 fuses either)
     mode: str = "fp"
     delta: Optional[torch.Tensor] = None
     zp: Optional[torch.Tensor] = None
@@ -259,6 +259,8 @@ class QOp:
             raise ValueError(self.kind)
         if self.act == "lrelu":
             y = F.leaky_relu(y, 0.01)
+        elif self.act == "relu":
+            y = F.relu(y)
         return y
 
 

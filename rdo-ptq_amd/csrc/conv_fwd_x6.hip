@@ -57,6 +57,8 @@ __device__ __forceinline__ void finish(const X6Args& a, long o, float v) {
     switch (a.epilogue) {
         case RDO_EPI_LRELU: v = v > 0.f ? v : 0.01f * v; break;
         case RDO_EPI_LRELU_BWD: v = a.aux[o] > 0.f ? v : 0.01f * v; break;
+        case RDO_EPI_RELU: v = v > 0.f ? v : 0.f; break;
+        case RDO_EPI_RELU_BWD: v = a.aux[o] > 0.f ? v : 0.f; break;
         case RDO_EPI_GDN: v = a.aux[o] * __frsqrt_rn(v); break;
         case RDO_EPI_IGDN: v = a.aux[o] * __fsqrt_rn(v); break;
         default: break;

@@ -67,22 +67,22 @@ __global__ __launch_bounds__(256) void lp2_kernel(const float* pred, const float
         atomicAdd(loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), (red[0] + red[1] + red[2] + red[3]) * inv_npix * coef);
 }
 
-__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* g, const float* y, long n4, float* out) {
+__global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* g, const float* y, long n4, float slope, float* out) {
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x) {
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[t], yv = reinterpret_cast<const f32x4*>(y)[t];
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = yv[e] > 0.f ? gv[e] : 0.01f * gv[e];
+        for (int e = 0; e < 4; ++e) o[e] = yv[e] > 0.f ? gv[e] : slope * gv[e];
         reinterpret_cast<f32x4*>(out)[t] = o;
     }
 }
 
-__global__ __launch_bounds__(256) void lrelu_fwd_kernel(const float* x, long n4, float* out) {
+__global__ __launch_bounds__(256) void lrelu_fwd_kernel(const float* x, long n4, float slope, float* out) {
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x) {
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[t];
         f32x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : 0.01f * v[e];
+        for (int e = 0; e < 4; ++e) o[e] = v[e] > 0.f ? v[e] : slope * v[e];
         reinterpret_cast<f32x4*>(out)[t] = o;
     }
 }
@@ -267,25 +267,30 @@ int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* 
         stream, "lp2_loss_grad", 0.0, 12.0 * B * per_image);
 }
 
-int rdo_lrelu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream) {
-    RDO_REQUIRE(g && y && out && n > 0 && n % 4 == 0, "rdo_lrelu_bwd: bad argument");
+static int act_bwd(const float* g, const float* y, int64_t n, float slope, float* out, void* stream, const char* tag) {
+    RDO_REQUIRE(g && y && out && n > 0 && n % 4 == 0, "%s: bad argument", tag);
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, g, y, (long)(n / 4), out);
-            return rdo::check_launch("lrelu_bwd");
+            hipLaunchKernelGGL(lrelu_bwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, g, y, (long)(n / 4), slope, out);
+            return rdo::check_launch(tag);
         },
         stream);
 }
 
-int rdo_lrelu_fwd(const float* x, int64_t n, float* out, void* stream) {
-    RDO_REQUIRE(x && out && n > 0 && n % 4 == 0, "rdo_lrelu_fwd: bad argument");
+static int act_fwd(const float* x, int64_t n, float slope, float* out, void* stream, const char* tag) {
+    RDO_REQUIRE(x && out && n > 0 && n % 4 == 0, "%s: bad argument", tag);
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, (long)(n / 4), out);
-            return rdo::check_launch("lrelu_fwd");
+            hipLaunchKernelGGL(lrelu_fwd_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, x, (long)(n / 4), slope, out);
+            return rdo::check_launch(tag);
         },
         stream);
 }
+
+int rdo_lrelu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream) { return act_bwd(g, y, n, 0.01f, out, stream, "rdo_lrelu_bwd"); }
+int rdo_lrelu_fwd(const float* x, int64_t n, float* out, void* stream) { return act_fwd(x, n, 0.01f, out, stream, "rdo_lrelu_fwd"); }
+int rdo_relu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream) { return act_bwd(g, y, n, 0.f, out, stream, "rdo_relu_bwd"); }
+int rdo_relu_fwd(const float* x, int64_t n, float* out, void* stream) { return act_fwd(x, n, 0.f, out, stream, "rdo_relu_fwd"); }
 
 int rdo_add(const float* a, const float* b, int64_t n, float* out, void* stream) {
     RDO_REQUIRE(a && b && out && n > 0 && n % 4 == 0, "rdo_add: bad argument");

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librdoptq_hip.so")
 
-EPI_NONE, EPI_LRELU, EPI_LRELU_BWD, EPI_GDN, EPI_IGDN = range(5)
+EPI_NONE, EPI_LRELU, EPI_LRELU_BWD, EPI_GDN, EPI_IGDN, EPI_RELU, EPI_RELU_BWD = range(7)
 LOG_SLOTS = 32            # RDO_LOG_SLOTS of include/rdo_ptq_hip.h
 
 
@@ -53,6 +53,8 @@ _SIGS = {
     "rdo_lp2_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, P, P, P]),
     "rdo_lrelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
     "rdo_lrelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
+    "rdo_relu_fwd": (C.c_int, [P, C.c_int64, P, P]),
+    "rdo_relu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_pixel_shuffle": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "rdo_add": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_gdn_bwd_t": (C.c_int, [P, P, P, C.c_int64, C.c_int32, P, P]),

@@ -188,6 +188,18 @@ def lrelu_bwd(g, y, out=None):
     return out
 
 
+def relu(x, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().rdo_relu_fwd(_ptr(x), x.numel(), _ptr(out), _stream()), "rdo_relu_fwd")
+    return out
+
+
+def relu_bwd(g, y, out=None):
+    out = torch.empty_like(g) if out is None else out
+    L.check(L.lib().rdo_relu_bwd(_ptr(g), _ptr(y), g.numel(), _ptr(out), _stream()), "rdo_relu_bwd")
+    return out
+
+
 def add(a, b, out=None):
     out = torch.empty_like(a) if out is None else out
     L.check(L.lib().rdo_add(_ptr(a), _ptr(b), a.numel(), _ptr(out), _stream()), "rdo_add")

@@ -6,7 +6,7 @@ import torch
 import torch.nn as nn
 
 from .entropy import EntropyBottleneck, GaussianConditional
-from .layers import (MaskedConv2d, ResidualBlock, ResidualBlockUpsample, ResidualBlockWithStride, conv3x3,
+from .layers import (AttentionBlock, MaskedConv2d, ResidualBlock, ResidualBlockUpsample, ResidualBlockWithStride, conv3x3,
                      subpel_conv3x3)
 
 
@@ -46,3 +46,16 @@ class Cheng2020Anchor(nn.Module):
         scales, means = self.entropy_parameters(torch.cat((hyper, ctx), dim=1)).chunk(2, 1)
         _, y_lik = self.gaussian_conditional(y, scales, means=means)
         return {"x_hat": self.g_s(y_hat), "likelihoods": {"y": y_lik, "z": z_lik}}
+
+
+class Cheng2020Attention(Cheng2020Anchor):
+    """`cheng2020_attn`: the anchor with attention blocks at 1/4 and 1/16 resolution in g_a, mirrored in g_s."""
+
+    def __init__(self, N=192):
+        super().__init__(N)
+        self.g_a = nn.Sequential(ResidualBlockWithStride(3, N), ResidualBlock(N, N), ResidualBlockWithStride(N, N),
+                                 AttentionBlock(N), ResidualBlock(N, N), ResidualBlockWithStride(N, N), ResidualBlock(N, N),
+                                 conv3x3(N, N, stride=2), AttentionBlock(N))
+        self.g_s = nn.Sequential(AttentionBlock(N), ResidualBlock(N, N), ResidualBlockUpsample(N, N), ResidualBlock(N, N),
+                                 ResidualBlockUpsample(N, N), AttentionBlock(N), ResidualBlock(N, N),
+                                 ResidualBlockUpsample(N, N), ResidualBlock(N, N), subpel_conv3x3(N, 3, 2))

@@ -115,6 +115,33 @@ class ResidualBlock(nn.Module):
         return y + (x if self.skip is None else self.skip(x))
 
 
+class _ResidualUnit(nn.Module):
+    """1x1 (N -> N/2) - ReLU - 3x3 - ReLU - 1x1 (N/2 -> N), identity add, ReLU: the unit the attention block stacks."""
+
+    def __init__(self, N):
+        super().__init__()
+        self.conv = nn.Sequential(conv1x1(N, N // 2), nn.ReLU(inplace=True), conv3x3(N // 2, N // 2), nn.ReLU(inplace=True),
+                                  conv1x1(N // 2, N))
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):
+        return self.relu(self.conv(x) + x)
+
+
+class AttentionBlock(nn.Module):
+    """x + trunk(x) * sigmoid(mask(x)) of Cheng2020-attn (CompressAI attribute names: conv_a = trunk, conv_b = mask)."""
+
+    ResidualUnit = _ResidualUnit
+
+    def __init__(self, N):
+        super().__init__()
+        self.conv_a = nn.Sequential(*[_ResidualUnit(N) for _ in range(3)])
+        self.conv_b = nn.Sequential(*[_ResidualUnit(N) for _ in range(3)], conv1x1(N, N))
+
+    def forward(self, x):
+        return x + self.conv_a(x) * torch.sigmoid(self.conv_b(x))
+
+
 class MaskedConv2d(nn.Conv2d):
     """Causal (type-A) masked convolution of the autoregressive context model."""
 

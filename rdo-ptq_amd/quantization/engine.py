@@ -299,15 +299,15 @@ class UnitEngine:
             if op.tconv is not None:
                 s_, q_, Hu, Wu = self.tc_geom
                 x = ops.zero_insert(x, s_, q_, q_, Hu, Wu, out=t["xu"])
-            lrelu = self.include_act and op.qm.fused_lrelu()
-            if lrelu:
-                self._conv(op, x, t["y"], epilogue=L.EPI_LRELU)
+            epi = op.qm.fused_epilogue() if self.include_act else None
+            if epi is not None:
+                self._conv(op, x, t["y"], epilogue=epi)
                 self._loss(t["y"], t["dy"])
-                ops.lrelu_bwd(t["dy"], t["y"], t["dpre"])
+                (ops.lrelu_bwd if epi == L.EPI_LRELU else ops.relu_bwd)(t["dy"], t["y"], t["dpre"])
                 self._wgrad(op, x, t["dpre"])
             else:
                 if self.include_act and type(op.qm.activation_function).__name__ != "StraightThrough":
-                    raise NotImplementedError("calibration engine: only LeakyReLU(0.01) may be fused into a layer unit")
+                    raise NotImplementedError("calibration engine: only LeakyReLU(0.01) or ReLU may be fused into a layer unit")
                 self._conv(op, x, t["y"])
                 self._loss(t["y"], t["dy"])
                 self._wgrad(op, x, t["dy"])

@@ -11,7 +11,7 @@ from .quantizer import AdaRoundQuantizer
 
 
 def integer_state(qnn) -> "OrderedDict[str, dict]":
-    """name -> {levels (uint8, logical weight shape), delta, zero_point, n_bits, bias, kind}."""
+    """name -> {levels (uint8, or int32 above 8 bits; logical weight shape), delta, zero_point, n_bits, bias, kind}."""
     out = OrderedDict()
     for name, m in qnn.named_modules():
         if not isinstance(m, QuantModule) or m.org_weight is None:
@@ -27,7 +27,7 @@ def integer_state(qnn) -> "OrderedDict[str, dict]":
         else:
             x_int = torch.round(w / d)
         levels = torch.clamp(x_int + z, 0, q.n_levels - 1)
-        out[name] = {"levels": levels.to(torch.uint8).cpu(), "delta": d.detach().cpu(), "zero_point": z.detach().cpu(),
+        out[name] = {"levels": levels.to(torch.uint8 if q.n_bits <= 8 else torch.int32).cpu(), "delta": d.detach().cpu(), "zero_point": z.detach().cpu(),
                      "n_bits": q.n_bits, "bias": None if m.org_bias is None else m.org_bias.detach().cpu(), "kind": m.kind}
     return out
 

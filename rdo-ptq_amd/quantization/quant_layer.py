@@ -106,6 +106,14 @@ class QuantModule(nn.Module):
     def fused_lrelu(self):
         return isinstance(self.activation_function, nn.LeakyReLU) and abs(self.activation_function.negative_slope - 0.01) < 1e-12
 
+    def fused_epilogue(self):
+        """Conv-kernel epilogue of the activation quant_model.py:51-54 fused into this module (None: not fusable)."""
+        if self.fused_lrelu():
+            return L.EPI_LRELU
+        if type(self.activation_function) is nn.ReLU:
+            return L.EPI_RELU
+        return None
+
     @staticmethod
     def _reparam(p, t):
         """NonNegativeParametrizer forward, max(t, bound)^2 - pedestal, with the constants taken as Python floats: the
@@ -132,11 +140,12 @@ class QuantModule(nn.Module):
             return _nchw_view(ops.lrelu(y) if isinstance(self.activation_function, nn.LeakyReLU) else y)
         weight, bias = self._weights()
         bias = None if bias is None else bias.detach().contiguous()
-        fuse = self.fused_lrelu() and self.se_module is None
+        epi = self.fused_epilogue() if self.se_module is None else None
+        fuse = epi is not None
+        epi = L.EPI_NONE if epi is None else epi
         if self.kind == "conv":
             stride, pad = self.conv_geometry()
-            y = ops.conv2d_fwd(_nhwc(input), to_rows(weight.detach()), bias, stride, pad,
-                               epilogue=L.EPI_LRELU if fuse else L.EPI_NONE)
+            y = ops.conv2d_fwd(_nhwc(input), to_rows(weight.detach()), bias, stride, pad, epilogue=epi)
             out = _nchw_view(y)
         elif self.kind == "gdn":
             c = input.shape[1]
@@ -151,8 +160,7 @@ class QuantModule(nn.Module):
             if _sq(kw["dilation"]) != 1 or kw["groups"] != 1:
                 raise NotImplementedError("dilated / grouped transposed convolutions are not on the supported path")
             y = ops.conv_transpose2d(_nhwc(input), to_rows(weight.detach(), tconv=True), bias, _sq(kw["stride"]),
-                                     _sq(kw["padding"]), _sq(kw["output_padding"]),
-                                     epilogue=L.EPI_LRELU if fuse else L.EPI_NONE)
+                                     _sq(kw["padding"]), _sq(kw["output_padding"]), epilogue=epi)
             out = _nchw_view(y)
         elif self.kind == "layernorm":
             ns = tuple(self.fwd_kwargs["normalized_shape"])
@@ -163,7 +171,7 @@ class QuantModule(nn.Module):
         elif self.kind == "linear":
             x = input.reshape(1, 1, -1, input.shape[-1]).contiguous()
             w = weight.detach().reshape(weight.shape[0], 1, 1, weight.shape[1]).contiguous()
-            y = ops.conv2d_fwd(x, w, bias, 1, 0, epilogue=L.EPI_LRELU if fuse else L.EPI_NONE)
+            y = ops.conv2d_fwd(x, w, bias, 1, 0, epilogue=epi)
             out = y.reshape(*input.shape[:-1], weight.shape[0])
         else:
             raise NotImplementedError(f"QuantModule({self.kind}) forward is not built yet (SURVEY 8f rows 3: Lu2022 / Minnen2018)")

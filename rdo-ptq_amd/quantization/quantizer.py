@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from hipops import ops
 
 GAMMA, ZETA = -0.1, 1.1
+MAX_BITS = 16
 
 
 class StraightThrough(nn.Module):
@@ -83,7 +84,9 @@ class UniformAffineQuantizer(nn.Module):
     def __init__(self, n_bits: int = 8, symmetric: bool = False, channel_wise: bool = False, scale_method: str = "max",
                  leaf_param: bool = False, tconv: bool = False, act: bool = False, prob: float = 1.0):
         super().__init__()
-        assert 2 <= n_bits <= 8, "bitwidth not supported"
+        # the reference stops at 8 bits (quantizer.py:139); BASELINE config 3 (W10A10) needs wider weight grids, which the
+        # kernels handle unchanged (levels are fp32-valued integers): accepted up to 16 bits as an extension
+        assert 2 <= n_bits <= MAX_BITS, "bitwidth not supported"
         self.sym = symmetric
         self.n_bits = n_bits
         self.n_levels = 2 ** n_bits
@@ -177,7 +180,7 @@ class UniformAffineQuantizer(nn.Module):
         return wq.reshape(x.shape)
 
     def bitwidth_refactor(self, refactored_bit: int):
-        assert 2 <= refactored_bit <= 8, "bitwidth not supported"
+        assert 2 <= refactored_bit <= MAX_BITS, "bitwidth not supported"
         self.n_bits = refactored_bit
         self.n_levels = 2 ** refactored_bit
 

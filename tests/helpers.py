@@ -93,6 +93,7 @@ def nhwc(a, dev="cuda"):
     return T(np.ascontiguousarray(a.transpose(0, 2, 3, 1))).to(dev)
 
 
+ATTN_UNITS = ["g_a.3.conv_a.0.conv.0", "g_a.3.conv_a.0.conv.2", "g_a.3.conv_a.0.conv.4", "g_a.3.conv_b.3"]
 MINNEN_UNITS = ["g_a.0", "g_a.1", "g_s.0", "g_s.1", "h_s.0"]
 
 
@@ -100,7 +101,7 @@ def minnen_oracle_op(fx, tag):
     """QOp of one layer unit of the toy Minnen2018 golden (conv / tconv / gdn / igdn)."""
     kind = str(fx[f"{tag}/kind"])
     w, b = T(fx[f"{tag}/weight"]), T(fx[f"{tag}/bias"])
-    act = "lrelu" if int(fx[f"{tag}/act"]) else None
+    act = {0: None, 1: "lrelu", 2: "relu"}[int(fx[f"{tag}/act"])]
     if kind == "gdn":
         op = O.QOp("igdn" if int(fx[f"{tag}/inverse"]) else "gdn", w, b)
     else:
@@ -130,5 +131,5 @@ def minnen_product_module(fx, tag, dev="cuda"):
             m.weight.copy_(w); m.bias.copy_(b)
     qm = QuantModule(m.to(dev), WQ, AQ).to(dev)
     if int(fx[f"{tag}/act"]):
-        qm.activation_function = nn.LeakyReLU(inplace=True)
+        qm.activation_function = nn.LeakyReLU(inplace=True) if int(fx[f"{tag}/act"]) == 1 else nn.ReLU(inplace=True)
     return qm

@@ -75,3 +75,79 @@ def test_save_inp_oup_data_matches_reference_caches(golden_dir):
             if isinstance(m, (QuantModule, BaseQuantBlock)):
                 m.trained = True
     assert checked == len(wanted) == 8
+
+
+def test_attention_model_caches_and_w8_forward_match_reference(golden_dir):
+    """Toy Cheng2020-attn (tests/golden/recon_attn.npz): the product QuantModel built from the reference's state reproduces
+    the reference's caches for four layer units inside the first attention block (ReLU-fused 1x1 / 3x3 convs, bare 1x1 convs,
+    sigmoid-gated residual around them), and -- with the reference's trained roundings installed -- its W8 forward
+    (x_hat, both likelihood tensors)."""
+    import lic
+    from quantization import BaseQuantBlock, QuantModel, QuantModule
+    from quantization.quantizer import AdaRoundQuantizer, to_rows
+    from quantization.utils import save_inp_oup_data
+    fx = np.load(os.path.join(golden_dir, "recon_attn.npz"))
+    N, n_img, B, iters = (int(v) for v in fx["meta"])
+    torch.manual_seed(0)
+    qnn = QuantModel(lic.Cheng2020Attention(N=N), WQ, AQ, is_cheng=True).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    with torch.no_grad():
+        for name, m in qnn.model.named_modules():
+            if isinstance(m, QuantModule) and m.org_weight is not None:
+                w = T(fx[f"org/{name}.weight"]).cuda()
+                m.weight.data.copy_(w); m.org_weight.copy_(w)
+                if m.org_bias is not None:
+                    b = T(fx[f"org/{name}.bias"]).cuda()
+                    m.bias.data.copy_(b); m.org_bias.copy_(b)
+        for k, v in qnn.model.entropy_bottleneck.state_dict().items():
+            v.copy_(T(fx[f"state/entropy_bottleneck.{k}"]).cuda())
+    cali = T(fx["cali"]).cuda()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    qnn.set_quant_state(True, False)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    wanted = [str(o) for o in fx["order"]]
+    # the unit schedule of the product surgery equals the reference's
+    order = []
+
+    def walk(mod, prefix=""):
+        for name, m in mod.named_children():
+            if isinstance(m, (QuantModule, BaseQuantBlock)):
+                order.append(prefix + name)
+            else:
+                walk(m, prefix + name + ".")
+    walk(qnn.model)
+    assert order == [str(s) for s in fx["full_order"]]
+    for full in order:
+        unit = _get(qnn.model, full)
+        if full in wanted:
+            assert type(unit.activation_function).__name__ == {0: "StraightThrough", 2: "ReLU"}[int(fx[f"{full}/act"])]
+            (inp_q, inp_fp), out = save_inp_oup_data(qnn, unit, cali, asym=True, act_quant=False, batch_size=2, input_prob=True)
+            for got, key in ((inp_q, "inp_q"), (inp_fp, "inp_fp"), (out, "out")):
+                ref = T(fx[f"{full}/{key}"])
+                assert tuple(got.shape) == tuple(ref.shape), (full, key)
+                err = float((got.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+                assert err < 3e-5, (full, key, err)
+            alpha = T(fx[f"{full}/alpha_final"]).cuda()
+            ada = AdaRoundQuantizer(uaq=unit.weight_quantizer, round_mode="learned_hard_sigmoid",
+                                    weight_tensor=unit.org_weight.data, alpha_rows=to_rows(alpha))
+            ada.soft_targets = False
+            unit.weight_quantizer = ada
+        for m in ([unit] if isinstance(unit, QuantModule) else unit.modules()):
+            if isinstance(m, (QuantModule, BaseQuantBlock)):
+                m.trained = True
+    # W8 forward, split at the rounding of the latents (one flipped round() would change x_hat everywhere): the analysis
+    # transform must reproduce the reference's continuous y, and the synthesis transform its x_hat from the reference's y_hat
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        y = qnn.model.g_a(cali[:2])
+        stages, h = [], T(fx["w8/y_hat"]).cuda()
+        for stage in qnn.model.g_s:
+            h = stage(h)
+            stages.append(h)
+    for got, key in [(y, "w8/y")] + [(h, f"w8/g_s.{k}") for k, h in enumerate(stages)] + [(stages[-1], "w8/x_hat")]:
+        ref = T(fx[key])
+        err = float((got.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
+        assert err < 1e-4, (key, err)

@@ -147,3 +147,53 @@ def test_integer_export_reproduces_hard_rounded_weights():
         m.set_quant_state(True, False)
         wq_used = m.weight_quantizer(m.weight).detach().cpu()
         torch.testing.assert_close(dequantize(e).reshape(wq_used.shape), wq_used, rtol=0, atol=float(e["delta"].max()) * 1e-6)
+
+
+def test_main2_flow_on_toy_cheng2020_attn_w10():
+    """BASELINE config 3 in miniature: Cheng2020-attn, 10-bit channel-wise weights (first / last layer 8-bit as main2.py:186
+    does), every unit calibrated -- residual blocks as block units, each conv inside the attention blocks as a layer unit."""
+    import lic
+    from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstruction, layer_reconstruction
+    from test_datasets import evaluate_images
+    torch.manual_seed(1005)
+    N, n_img, B, iters = 8, 8, 4, 12
+    model = lic.Cheng2020Attention(N=N).cuda().eval()
+    g = torch.Generator().manual_seed(9)
+    cali = torch.rand(n_img, 3, 64, 64, generator=g).cuda()
+    test_imgs = [torch.rand(1, 3, 64, 64, generator=g)]
+    psnr_fp, bpp_fp = evaluate_images(model, test_imgs, p=64)
+    wq = {"n_bits": 10, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
+                  warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    visited = []
+
+    def recon_model(m: nn.Module):
+        for name, module in m.named_children():
+            if isinstance(module, QuantModule):
+                visited.append(name)
+                layer_reconstruction(qnn, module, name, **kwargs)
+            elif isinstance(module, BaseQuantBlock):
+                visited.append(name)
+                block_reconstruction(qnn, module, name, **kwargs)
+            else:
+                recon_model(module)
+
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    recon_model(qnn)
+    # 13 residual blocks + 4 attention blocks x 19 convs + g_a conv + h_a 5 + h_s 5 (+2 pixel shuffles) + g_s tail 2 + 3 + 1
+    assert len(visited) == 13 + 4 * 19 + 1 + 5 + 7 + 2 + 3 + 1
+    mods = [m for m in qnn.modules() if isinstance(m, QuantModule) and m.org_weight is not None]
+    assert all(m.trained and hasattr(m.weight_quantizer, "alpha") for m in mods)
+    assert mods[0].weight_quantizer.n_bits == 8 and mods[1].weight_quantizer.n_bits == 10
+    qnn.set_quant_state(True, False)
+    psnr_w, bpp_w = evaluate_images(qnn.eval(), test_imgs, p=64)
+    assert math.isfinite(psnr_w) and math.isfinite(bpp_w)
+    assert abs(psnr_w - psnr_fp) < 3.0 and abs(bpp_w - bpp_fp) < 0.2 * bpp_fp + 0.05

@@ -135,3 +135,82 @@ def test_engine_minnen_layer_units_match_oracle(golden_dir, tag):
         y_ref = op_o(T(fx[f"{tag}/inp_q"][:2]))
     err = float((y.cpu() - y_ref).abs().max() / (y_ref.abs().max() + 1e-12))
     assert err < (5e-3 if flips else 2e-5), err
+
+
+@pytest.mark.parametrize("tag", ["g_a.3.conv_a.0.conv.0", "g_a.3.conv_a.0.conv.2", "g_a.3.conv_a.0.conv.4", "g_a.3.conv_b.3"])
+def test_engine_attention_layer_units_match_oracle(golden_dir, tag):
+    """Layer units inside a Cheng2020-attn attention block (ReLU fused into 1x1 / 3x3 convs, bare 1x1 convs): HIP engine vs
+    oracle on the reference's toy-model caches (tests/golden/recon_attn.npz)."""
+    from helpers import minnen_oracle_op, minnen_product_module
+    from oracle import rdo_oracle as O
+    from quantization.engine import UnitEngine
+    fx = np.load(os.path.join(golden_dir, "recon_attn.npz"))
+    B, iters = int(fx["meta"][2]), int(fx["meta"][3])
+    idx = fx[f"{tag}/idx"]
+    op_o = minnen_oracle_op(fx, tag)
+    log = O.reconstruct_unit("layer", {"layer": op_o}, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]),
+                             iters=iters, batch_size=B, idx_stream=idx,
+                             mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5))
+    qm = minnen_product_module(fx, tag)
+    eng = UnitEngine("layer", {"layer": qm}, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]),
+                     batch_size=B, iters=iters, seed=SEED, idx_table=torch.from_numpy(idx))
+    np.testing.assert_array_equal(eng.ops["layer"].delta.cpu().numpy(), fx[f"{tag}/delta"].reshape(-1))
+    eng.run()
+    torch.cuda.synchronize()
+    total, _, _ = eng.logs()
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=2e-4, atol=1e-7)
+    a_gpu = eng.alpha_of("layer").cpu()
+    np.testing.assert_allclose(a_gpu.numpy(), op_o.alpha.numpy(), rtol=0, atol=2e-3)
+    flips = int(((a_gpu >= 0) != (op_o.alpha >= 0)).sum())
+    assert flips <= 0.005 * a_gpu.numel()
+    eng.finish()
+    qm.trained = True
+    qm.set_quant_state(True, False)
+    with torch.no_grad():
+        y = qm(T(fx[f"{tag}/inp_q"][:2]).cuda())
+        y_ref = op_o(T(fx[f"{tag}/inp_q"][:2]))
+    err = float((y.cpu() - y_ref).abs().max() / (y_ref.abs().max() + 1e-12))
+    assert err < (5e-3 if flips else 2e-5), err
+
+
+def test_engine_ten_bit_weights_match_oracle(golden_dir):
+    """W10 (BASELINE config 3; an extension beyond the reference's 8-bit assert): 10-bit channel-wise grid, scale init,
+    AdaRound trajectory and hard-rounded forward of the HIP engine against the oracle at n_bits = 10."""
+    import torch.nn as nn
+    from oracle import rdo_oracle as O
+    from quantization.engine import UnitEngine
+    from quantization.quant_layer import QuantModule
+    from quantization.export import integer_state, dequantize
+    tag = "g_a.3.conv_a.0.conv.2"
+    fx = np.load(os.path.join(golden_dir, "recon_attn.npz"))
+    B, iters = int(fx["meta"][2]), int(fx["meta"][3])
+    idx = fx[f"{tag}/idx"]
+    w, b = T(fx[f"{tag}/weight"]), T(fx[f"{tag}/bias"])
+    op_o = O.QOp("conv", w, b, stride=1, padding=1, act="relu", n_bits=10)
+    log = O.reconstruct_unit("layer", {"layer": op_o}, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]),
+                             iters=iters, batch_size=B, idx_stream=idx,
+                             mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5))
+    conv = nn.Conv2d(w.shape[1], w.shape[0], 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(w); conv.bias.copy_(b)
+    wq10 = {"n_bits": 10, "channel_wise": True, "scale_method": "max"}
+    qm = QuantModule(conv.cuda(), wq10, {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}).cuda()
+    qm.activation_function = nn.ReLU(inplace=True)
+    eng = UnitEngine("layer", {"layer": qm}, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]),
+                     batch_size=B, iters=iters, seed=SEED, idx_table=torch.from_numpy(idx))
+    np.testing.assert_array_equal(eng.ops["layer"].delta.cpu().numpy(), op_o.delta.reshape(-1).numpy())
+    assert float(op_o.zp.max()) > 255            # the grid really is wider than 8 bits
+    eng.run()
+    torch.cuda.synchronize()
+    total, _, _ = eng.logs()
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=2e-4, atol=1e-7)
+    a_gpu = eng.alpha_of("layer").cpu()
+    np.testing.assert_allclose(a_gpu.numpy(), op_o.alpha.numpy(), rtol=0, atol=2e-3)
+    flips = int(((a_gpu >= 0) != (op_o.alpha >= 0)).sum())
+    assert flips <= 0.005 * a_gpu.numel()
+    eng.finish()
+    qm.trained = True
+    qm.set_quant_state(True, False)
+    ent = integer_state(qm)[""]
+    assert ent["levels"].dtype == torch.int32 and int(ent["levels"].max()) > 255 and int(ent["levels"].max()) <= 1023
+    torch.testing.assert_close(dequantize(ent).cuda(), qm.weight_quantizer(qm.weight).detach(), rtol=0, atol=1e-6)

@@ -215,3 +215,33 @@ def test_reconstruction_loop_minnen_units(golden_dir, tag):
     with torch.no_grad():
         y = op(T(fx[f"{tag}/inp_q"])[:2])
     np.testing.assert_allclose(y.numpy(), fx[f"{tag}/hard_out"], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag", ["g_a.3.conv_a.0.conv.0", "g_a.3.conv_a.0.conv.2", "g_a.3.conv_a.0.conv.4", "g_a.3.conv_b.3"])
+def test_reconstruction_loop_attention_units(golden_dir, tag):
+    """Layer units inside a Cheng2020-attn attention block (1x1 + ReLU, 3x3 + ReLU, bare 1x1, the mask branch's last 1x1):
+    oracle replay of the reference's layer_reconstruction runs (tests/golden/recon_attn.npz)."""
+    from helpers import minnen_oracle_op
+    fx = np.load(os.path.join(golden_dir, "recon_attn.npz"))
+    B, iters = int(fx["meta"][2]), int(fx["meta"][3])
+    op = minnen_oracle_op(fx, tag)
+    rand = T(fx[f"{tag}/rand"])
+    log = O.reconstruct_unit("layer", {"layer": op}, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]),
+                             iters=iters, batch_size=B, idx_stream=fx[f"{tag}/idx"], mask_fn=lambda i, shape: rand[i] < 0.5)
+    np.testing.assert_allclose(np.array(log.total), fx[f"{tag}/loss"], rtol=1e-6, atol=1e-9)
+    np.testing.assert_allclose(op.alpha.numpy(), fx[f"{tag}/alpha_final"], rtol=1e-6, atol=1e-7)
+    with torch.no_grad():
+        y = op(T(fx[f"{tag}/inp_q"])[:2])
+    np.testing.assert_allclose(y.numpy(), fx[f"{tag}/hard_out"], rtol=1e-5, atol=1e-6)
+
+
+def test_attention_unit_schedule(golden_dir):
+    """Unit order the reference's recon_model recursion (main2.py:227-253) produced on the toy Cheng2020-attn: residual blocks
+    are block units, every conv inside an AttentionBlock is its own layer unit (7 convs per branch pair -> 19 per block)."""
+    fx = np.load(os.path.join(golden_dir, "recon_attn.npz"))
+    order = [str(s) for s in fx["full_order"]]
+    assert order[:4] == ["g_a.0", "g_a.1", "g_a.2", "g_a.3.conv_a.0.conv.0"]
+    for blk in ("g_a.3", "g_a.8", "g_s.0", "g_s.5"):
+        inner = [o for o in order if o.startswith(blk + ".")]
+        assert len(inner) == 19 and inner[-1] == blk + ".conv_b.3", (blk, inner)
+    assert order.index("g_a.3.conv_b.3") < order.index("g_a.4")

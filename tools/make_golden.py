@@ -507,6 +507,127 @@ def golden_recon_minnen(out_dir, iters=10):
     print("recon_minnen.npz", len(fx), "arrays;", " ".join(f"{w}:{float(fx[w + '/loss'][0]):.4g}->{float(fx[w + '/loss'][-1]):.4g}" for w in wanted))
 
 
+def golden_recon_attn(out_dir, iters=10):
+    """Verbatim layer_reconstruction runs of the reference inside an attention block of a toy Cheng2020-attn (N=8, 64x64
+    crops): 1x1 conv + ReLU, 3x3 conv + ReLU, 1x1 conv without activation, and the mask branch's closing 1x1 conv.
+    recon_model (main2.py:227-253) reaches these by recursing through AttentionBlock -> Sequential -> ResidualUnit ->
+    Sequential and passes the LOCAL child name ('0', '2', '4', '3') as layer_name."""
+    import logging
+    from quantization import QuantModel, QuantModule, BaseQuantBlock, layer_reconstruction
+    import quantization.layer_opt as lo
+    import quantization.utils as qu
+    torch.manual_seed(2020)
+    N, n_img, B = 8, 6, 2
+    model = L.Cheng2020Attention(N=N)
+    _randomise(model, torch.Generator().manual_seed(2020))
+    model.eval()
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True)
+    qnn.eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    cali = torch.rand(n_img, 3, 64, 64, generator=torch.Generator().manual_seed(79))
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True,
+                  b_range=(20, 2), warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    captured = {}
+    orig_save = qu.save_inp_oup_data
+
+    def save_spy(*a, **k):
+        r = orig_save(*a, **k)
+        captured["inp_q"], captured["inp_fp"], captured["out"] = r[0][0].clone(), r[0][1].clone(), r[1].clone()
+        return r
+    lo.save_inp_oup_data = save_spy
+    losses = []
+    orig_call = lo.LossFunction.__call__
+
+    def call(self, pred, tgt, quant_net_out=None, cali_data=None, grad=None):
+        r = orig_call(self, pred, tgt, quant_net_out, cali_data, grad)
+        losses.append(float(r))
+        return r
+    lo.LossFunction.__call__ = call
+    wanted = ["g_a.3.conv_a.0.conv.0", "g_a.3.conv_a.0.conv.2", "g_a.3.conv_a.0.conv.4", "g_a.3.conv_b.3"]
+    fx = {"cali": _np(cali), "meta": np.array([N, n_img, B, iters])}
+    for k, v in model.state_dict().items():
+        fx["state/" + k.replace(".org_module", "")] = _np(v)
+    for n_, m_ in qnn.model.named_modules():
+        if isinstance(m_, QuantModule) and m_.org_weight is not None:
+            fx["org/" + n_ + ".weight"] = _np(m_.org_weight)
+            if m_.org_bias is not None:
+                fx["org/" + n_ + ".bias"] = _np(m_.org_bias)
+    full_order = []
+    qnn.set_quant_state(True, False)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    logging.disable(logging.CRITICAL)
+    _stdout = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+
+    def recon(mod, prefix=""):
+        for name, m in mod.named_children():
+            full = prefix + name
+            if isinstance(m, (QuantModule, BaseQuantBlock)):
+                full_order.append(full)
+                if full not in wanted:
+                    for mm in m.modules():
+                        if isinstance(mm, (QuantModule, BaseQuantBlock)):
+                            mm.trained = True
+                    continue
+                idx_log, rand_log = [], []
+                del losses[:]
+                with _cuda_is_cpu(), _record_rng(idx_log, rand_log):
+                    layer_reconstruction(qnn, m, name, **kwargs)
+                act = m.activation_function
+                fx[f"{full}/kind"] = np.array("conv")
+                fx[f"{full}/act"] = np.array(1 if isinstance(act, nn.LeakyReLU) else (2 if isinstance(act, nn.ReLU) else 0))
+                fx[f"{full}/geom"] = np.array([m.fwd_kwargs["stride"][0], m.fwd_kwargs["padding"][0], 0])
+                fx[f"{full}/weight"] = _np(m.org_weight)
+                fx[f"{full}/bias"] = _np(m.org_bias)
+                fx[f"{full}/delta"] = _np(m.weight_quantizer.delta)
+                fx[f"{full}/zp"] = _np(m.weight_quantizer.zero_point)
+                fx[f"{full}/alpha_final"] = _np(m.weight_quantizer.alpha)
+                for k in ("inp_q", "inp_fp", "out"):
+                    fx[f"{full}/{k}"] = _np(captured[k])
+                fx[f"{full}/idx"] = np.stack([_np(t[:B]) for t in idx_log]).astype(np.int64)
+                fx[f"{full}/rand"] = np.stack([_np(t) for t in rand_log]).astype(np.float32)
+                fx[f"{full}/loss"] = np.array(losses, dtype=np.float64)
+                with torch.no_grad():
+                    m.set_quant_state(True, False)
+                    fx[f"{full}/hard_out"] = _np(m(captured["inp_q"][:2]))
+            else:
+                recon(m, full + ".")
+    try:
+        recon(qnn.model)
+        # W8 forward of the whole model after these units are trained (the rest nearest-rounded): x_hat and likelihoods
+        qnn.set_quant_state(True, False)
+        qnn.eval()           # layer_reconstruction leaves the model in train mode; main2.py:269 evaluates `qnn.eval()`
+        with torch.no_grad():
+            out = qnn(cali[:2])
+            y = qnn.model.g_a(cali[:2])
+        fx["w8/x_hat"] = _np(out["x_hat"])
+        fx["w8/y"] = _np(y)                         # analysis latents (continuous: comparable at fp32 tolerance)
+        fx["w8/y_hat"] = _np(qnn.model.gaussian_conditional.quantize(y, "dequantize"))
+        fx["w8/lik_y"] = _np(out["likelihoods"]["y"])
+        fx["w8/lik_z"] = _np(out["likelihoods"]["z"])
+        with torch.no_grad():                        # synthesis transform stage by stage, from the rounded latents
+            h = torch.from_numpy(fx["w8/y_hat"])
+            for k, stage in enumerate(qnn.model.g_s):
+                h = stage(h)
+                fx[f"w8/g_s.{k}"] = _np(h)
+    finally:
+        sys.stdout = _stdout
+        logging.disable(logging.NOTSET)
+        lo.LossFunction.__call__ = orig_call
+        lo.save_inp_oup_data = orig_save
+    fx["full_order"] = np.array(full_order)
+    fx["order"] = np.array(wanted)
+    np.savez_compressed(os.path.join(out_dir, "recon_attn.npz"), **fx)
+    print("recon_attn.npz", len(fx), "arrays;", " ".join(f"{w.split('.', 2)[2]}:{float(fx[w + '/loss'][0]):.4g}->{float(fx[w + '/loss'][-1]):.4g}" for w in wanted))
+
+
 def golden_blocks(out_dir):
     """Forward (and input/weight gradients) of the reference Cheng2020 quant blocks with nearest-rounded weights."""
     from quantization.quant_block import QuantRBWS, QuantRBU, QuantRB
@@ -567,11 +688,15 @@ def golden_bd(out_dir):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--only", default=None, help="run a single generator, e.g. recon_attn")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     _install_shims()
     sys.path.insert(0, REF)
     torch.set_num_threads(4)
+    if a.only:
+        globals()["golden_" + a.only](a.out)
+        return
     golden_bd(a.out)
     golden_quantizers(a.out)
     golden_temp_decay(a.out)
@@ -579,6 +704,7 @@ def main():
     golden_blocks(a.out)
     golden_recon(a.out)
     golden_recon_minnen(a.out)
+    golden_recon_attn(a.out)
 
 
 if __name__ == "__main__":
