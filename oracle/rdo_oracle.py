@@ -255,6 +255,8 @@ class QOp:
             y = f_gdn(x, w, self.bias, inverse=(self.kind == "igdn"))
         elif self.kind == "linear":
             y = F.linear(x, w, self.bias)
+        elif self.kind == "layernorm":                       # quant_layer.py:44-49,121: F.layer_norm over the last dimension
+            y = F.layer_norm(x, (w.numel(),), weight=w, bias=self.bias)
         else:
             raise ValueError(self.kind)
         if self.act == "lrelu":
@@ -360,7 +362,7 @@ def reconstruct_unit(kind: str, ops: Dict[str, QOp], cached_q, cached_fp, cached
     `idx_stream[i]` replaces `torch.randperm(n)[:batch]` (:289) and `mask_fn(i, shape)` replaces
     `torch.rand_like(x) < input_prob` (:292) so runs are reproducible across implementations.
     `grad_hook(list_of_alpha_grads)` is called between backward and step (data-parallel all-reduce point)."""
-    fwd = UNIT_FORWARD[kind]
+    fwd = kind if callable(kind) else UNIT_FORWARD[kind]     # a callable (ops, x) -> y serves units outside the table (RSTB)
     for op in ops.values():
         op.to_adaround()
     alphas = [op.alpha for op in ops.values()]

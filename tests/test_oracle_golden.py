@@ -245,3 +245,97 @@ def test_attention_unit_schedule(golden_dir):
         inner = [o for o in order if o.startswith(blk + ".")]
         assert len(inner) == 19 and inner[-1] == blk + ".conv_b.3", (blk, inner)
     assert order.index("g_a.3.conv_b.3") < order.index("g_a.4")
+
+
+# ----------------------------------------------------------------------------- Lu2022 (NIC / RSTB): reference's own model code
+NIC_CFG = dict(height=64, width=64, in_chans=3, embed_dim=16, latent_dim=32, window_size=8)
+
+
+def _nic(golden_dir):
+    from oracle import swin_oracle as S
+    fx = np.load(os.path.join(golden_dir, "recon_nic.npz"))
+    state = {k[len("state/"):]: T(fx[k]) for k in fx.files if k.startswith("state/")}
+    return fx, S.NicOracle(state, NIC_CFG)
+
+
+def test_nic_fp_forward_matches_reference_model(golden_dir):
+    """Analysis + synthesis transforms of the functional restatement against models/nic_cvt.py:NIC.forward (FP32)."""
+    fx, nic = _nic(golden_dir)
+    x = T(fx["cali"])[:2]
+    with torch.no_grad():
+        y = nic.run(nic.coder("g_a"), x)
+        x_hat = nic.run(nic.coder("g_s"), torch.round(y))
+    np.testing.assert_allclose(y.numpy(), fx["fp/y"], rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(x_hat.numpy(), fx["fp/x_hat"], rtol=1e-4, atol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["g_a0", "g_a1", "g_a7", "h_a3", "h_s1", "g_s7"])
+def test_reconstruction_loop_nic_units(golden_dir, name):
+    """layer_/block_reconstruction of the reference on its toy NIC, replayed by the oracle: conv with a 7-stage FP tail,
+    shifted-window RSTB with a tail, RSTB at window == resolution (round_ste-only tail), single-token RSTB, transposed conv
+    with a tail, closing 5x5 transposed conv."""
+    from oracle import swin_oracle as S
+    fx, nic = _nic(golden_dir)
+    B, iters = int(fx["meta"][4]), int(fx["meta"][5])
+    unit = nic.stages[name]
+    rand = T(fx[f"{name}/rand"])
+    if isinstance(unit, S.RstbOracle):
+        ops, fwd = unit.ops, (lambda ops_, x: unit(x))
+    else:
+        ops, fwd = {"layer": unit}, "layer"
+    log = O.reconstruct_unit(fwd, ops, T(fx[f"{name}/inp_q"]), T(fx[f"{name}/inp_fp"]), T(fx[f"{name}/out"]), iters=iters,
+                             batch_size=B, idx_stream=fx[f"{name}/idx"], mask_fn=lambda i, shape: rand[i] < 0.5,
+                             tail=nic.tail_of(name))
+    np.testing.assert_allclose(np.array(log.total), fx[f"{name}/loss"], rtol=2e-5, atol=1e-7)
+    for k, op in ops.items():
+        pre = "" if k == "layer" else k + "."
+        np.testing.assert_allclose(op.delta.numpy().reshape(-1), fx[f"{name}/{pre}delta"].reshape(-1), rtol=0, atol=0)
+        np.testing.assert_allclose(op.alpha.numpy(), fx[f"{name}/{pre}alpha_final"], rtol=1e-5, atol=2e-6)
+    with torch.no_grad():
+        y = unit(T(fx[f"{name}/inp_q"])[:2])
+    np.testing.assert_allclose(y.numpy(), fx[f"{name}/hard_out"], rtol=1e-4, atol=1e-5)
+
+
+def _install_calibrated_state(fx, nic):
+    """Reference end state: the six calibrated units carry their trained hard rounding, every other unit nearest rounding."""
+    from oracle import swin_oracle as S
+    wanted = [str(o) for o in fx["order"]]
+    for name, st in nic.stages.items():
+        ops = st.ops if isinstance(st, S.RstbOracle) else {"layer": st}
+        for k, op in ops.items():
+            if name in wanted:
+                pre = "" if k == "layer" else k + "."
+                op.init_scale()
+                op.alpha, op.mode, op.soft = T(fx[f"{name}/{pre}alpha_final"]), "ada", False
+            else:
+                op.mode = "uaq"
+
+
+@pytest.mark.parametrize("tag", ["w8", "w8a8"])
+def test_nic_quantised_forward_stagewise(golden_dir, tag):
+    """Stage-by-stage W8 and W8A8 forwards (g_a, rounding, g_s) of the calibrated reference model.  W8A8 exercises every
+    activation-quantisation point of the Swin wrappers (QuantModule outputs, attention probabilities, attn @ v, block and
+    RSTB outputs; quant_block.py:343-346,410-416,545-546,635-636)."""
+    from oracle import swin_oracle as S
+    fx, nic = _nic(golden_dir)
+    _install_calibrated_state(fx, nic)
+    aq = tag == "w8a8"
+    h = T(fx["cali"])[:2]
+    with torch.no_grad():
+        for coder in ("g_a", "g_s"):
+            for name in nic.coder(coder):
+                st = nic.stages[name]
+                if isinstance(st, S.RstbOracle):
+                    st.aq = aq
+                    h = st(h)
+                else:
+                    h = st(h)
+                    if aq and name != "g_s7":
+                        h = O.act_quant(h)
+                ref = fx[f"{tag}/{name}"]
+                err = float(np.abs(h.numpy() - ref).max() / (np.abs(ref).max() + 1e-12))
+                # an activation landing on a rounding boundary may flip one 8-bit level: (1/255 of a channel range)
+                assert err < (1e-4 if not aq else 6e-3), (name, err)
+                h = T(ref)                                   # continue from the reference's tensor: no error build-up
+            if coder == "g_a":
+                h = T(fx[f"{tag}/y_hat"])

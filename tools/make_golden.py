@@ -628,6 +628,143 @@ def golden_recon_attn(out_dir, iters=10):
     print("recon_attn.npz", len(fx), "arrays;", " ".join(f"{w.split('.', 2)[2]}:{float(fx[w + '/loss'][0]):.4g}->{float(fx[w + '/loss'][-1]):.4g}" for w in wanted))
 
 
+def golden_recon_nic(out_dir, iters=6):
+    """Lu2022 path on the reference's OWN model code (models/nic_cvt.py: NIC, models/layers.py: RSTB...) at toy width
+    (embed 16, latent 32, 64x64 crops): verbatim layer_reconstruction / block_reconstruction runs for a 5x5 stride-2 conv
+    with a long FP tail, a shifted-window RSTB with a tail, an RSTB at window == resolution, a 1x1-token RSTB, a transposed
+    conv, and the closing 5x5 transposed conv; then stage-wise W8 and W8A8 forwards of the calibrated model."""
+    import logging
+    from models.nic_cvt import NIC
+    from quantization import QuantModel, QuantModule, BaseQuantBlock, layer_reconstruction, block_reconstruction
+    import quantization.layer_opt as lo
+    import quantization.block_opt as bo
+    import quantization.utils as qu
+    cfg = dict(height=64, width=64, in_chans=3, embed_dim=16, latent_dim=32, window_size=8, mlp_ratio=2.0, qkv_bias=True,
+               qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, use_checkpoint=False)
+    torch.manual_seed(2022)
+    model = NIC(cfg)
+    gen = torch.Generator().manual_seed(2022)
+    _randomise(model, gen)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if ".norm" in name and name.endswith("weight"):
+                p.copy_(1.0 + (torch.rand(p.shape, generator=gen) - 0.5) * 0.6)
+    model.eval()
+    n_img, B = 6, 2
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    fx = {"meta": np.array([cfg["embed_dim"], cfg["latent_dim"], cfg["window_size"], n_img, B, iters])}
+    for k, v in model.state_dict().items():
+        fx["state/" + k] = _np(v)
+    cali = torch.rand(n_img, 3, 64, 64, generator=torch.Generator().manual_seed(80))
+    fx["cali"] = _np(cali)
+    with torch.no_grad():
+        out_fp = model(cali[:2])
+        fx["fp/y"] = _np(model.g_a(cali[:2]))
+        fx["fp/x_hat"] = _np(out_fp["x_hat"])
+        fx["fp/lik_y"] = _np(out_fp["likelihoods"]["y"])
+        fx["fp/lik_z"] = _np(out_fp["likelihoods"]["z"])
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq)
+    qnn.eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Lu2022")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True,
+                  b_range=(20, 2), warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    captured = {}
+    orig_save = qu.save_inp_oup_data
+
+    def save_spy(*a, **k):
+        r = orig_save(*a, **k)
+        captured["inp_q"], captured["inp_fp"], captured["out"] = r[0][0].clone(), r[0][1].clone(), r[1].clone()
+        return r
+    lo.save_inp_oup_data = save_spy
+    bo.save_inp_oup_data = save_spy
+    losses = []
+    originals = {}
+    for mod_ in (lo, bo):
+        cls = mod_.LossFunction
+        originals[mod_] = cls.__call__
+
+        def make(orig_call):
+            def call(self, pred, tgt, quant_net_out=None, cali_data=None, grad=None):
+                r = orig_call(self, pred, tgt, quant_net_out, cali_data, grad)
+                losses.append(float(r))
+                return r
+            return call
+        cls.__call__ = make(cls.__call__)
+    wanted = ["g_a0", "g_a1", "g_a7", "h_a3", "h_s1", "g_s7"]
+    full_order = []
+    qnn.set_quant_state(True, False)
+    qnn.model.g_s7.set_quant_state(True, False)
+    logging.disable(logging.CRITICAL)
+    _stdout = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        for name, m in qnn.model.named_children():
+            if not isinstance(m, (QuantModule, BaseQuantBlock)):
+                continue
+            full_order.append(name)
+            if name not in wanted:
+                for mm in m.modules():
+                    if isinstance(mm, (QuantModule, BaseQuantBlock)):
+                        mm.trained = True
+                continue
+            idx_log, rand_log = [], []
+            del losses[:]
+            with _cuda_is_cpu(), _record_rng(idx_log, rand_log):
+                (layer_reconstruction if isinstance(m, QuantModule) else block_reconstruction)(qnn, m, name, **kwargs)
+            for k in ("inp_q", "inp_fp", "out"):
+                fx[f"{name}/{k}"] = _np(captured[k])
+            fx[f"{name}/idx"] = np.stack([_np(t[:B]) for t in idx_log]).astype(np.int64)
+            fx[f"{name}/rand"] = np.stack([_np(t) for t in rand_log]).astype(np.float32)
+            fx[f"{name}/loss"] = np.array(losses, dtype=np.float64)
+            inner = [("", m)] if isinstance(m, QuantModule) else \
+                [(n_ + ".", mm) for n_, mm in m.named_modules() if isinstance(mm, QuantModule)]
+            for n_, mm in inner:
+                fx[f"{name}/{n_}delta"] = _np(mm.weight_quantizer.delta)
+                fx[f"{name}/{n_}zp"] = _np(mm.weight_quantizer.zero_point)
+                fx[f"{name}/{n_}alpha_final"] = _np(mm.weight_quantizer.alpha)
+            with torch.no_grad():
+                m.set_quant_state(True, False)
+                xin = captured["inp_q"][:2]
+                fx[f"{name}/hard_out"] = _np(m(xin) if isinstance(m, QuantModule) else m(xin, tuple(xin.shape[2:4])))
+        qnn.eval()
+
+        def stagewise(tag):
+            with torch.no_grad():
+                h = cali[:2]
+                for nm in [n for n in full_order if n.startswith("g_a")]:
+                    mod = getattr(qnn.model, nm)
+                    h = mod(h) if isinstance(mod, QuantModule) else mod(h, tuple(h.shape[2:4]))
+                    fx[f"{tag}/{nm}"] = _np(h)
+                h = torch.round(h)
+                fx[f"{tag}/y_hat"] = _np(h)
+                for nm in [n for n in full_order if n.startswith("g_s")]:
+                    mod = getattr(qnn.model, nm)
+                    h = mod(h) if isinstance(mod, QuantModule) else mod(h, tuple(h.shape[2:4]))
+                    fx[f"{tag}/{nm}"] = _np(h)
+        qnn.set_quant_state(True, False)
+        stagewise("w8")
+        qnn.set_quant_state(True, True)
+        qnn.model.g_s7.set_quant_state(True, False)
+        stagewise("w8a8")
+    finally:
+        sys.stdout = _stdout
+        logging.disable(logging.NOTSET)
+        for mod_, c in originals.items():
+            mod_.LossFunction.__call__ = c
+        lo.save_inp_oup_data = orig_save
+        bo.save_inp_oup_data = orig_save
+    fx["full_order"] = np.array(full_order)
+    fx["order"] = np.array(wanted)
+    np.savez_compressed(os.path.join(out_dir, "recon_nic.npz"), **fx)
+    print("recon_nic.npz", len(fx), "arrays;", " ".join(f"{w}:{float(fx[w + '/loss'][0]):.4g}->{float(fx[w + '/loss'][-1]):.4g}" for w in wanted))
+
+
 def golden_blocks(out_dir):
     """Forward (and input/weight gradients) of the reference Cheng2020 quant blocks with nearest-rounded weights."""
     from quantization.quant_block import QuantRBWS, QuantRBU, QuantRB
@@ -705,6 +842,7 @@ def main():
     golden_recon(a.out)
     golden_recon_minnen(a.out)
     golden_recon_attn(a.out)
+    golden_recon_nic(a.out)
 
 
 if __name__ == "__main__":
