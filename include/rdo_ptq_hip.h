@@ -170,6 +170,33 @@ int rdo_zero_insert(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, 
 int rdo_layer_norm(const float* x, const float* weight, const float* bias, int64_t rows, int32_t C, float eps, float* out,
                    void* stream);
 
+/* ---- Lu2022 transformer path: window attention core, LayerNorm backward, GELU ------------------------------
+ * Replaces the tensor ops of WindowAttention / SwinTransformerBlock (models/layers.py:138-170, 260-303) and of their Quant*
+ * wrappers (quantization/quant_block.py:384-417, 497-547).  Tensors are [B, H, W, *] fp32 in natural pixel order; the cyclic
+ * shift and the window partition are address arithmetic inside the kernels.  qkv channels: which*C + head*(C/heads) + d. */
+typedef struct rdo_attn_desc {
+    int32_t B, H, W, C;          /* tokens B*H*W, model width C */
+    int32_t heads;               /* C % heads == 0 */
+    int32_t window;              /* window side; H % window == W % window == 0; window*window <= 64 */
+    int32_t shift;               /* cyclic shift (0 or window/2): also switches the -100 region mask on (layers.py:236-257) */
+    float scale;                 /* q multiplier, head_dim^-0.5 unless overridden (layers.py:107) */
+} rdo_attn_desc;
+/* bias: [heads][N][N] = relative_position_bias_table[relative_position_index] (layers.py:152-155), N = window^2.
+ * out [B,H,W,C] = softmax(scale*q k^T + bias + mask) v.  probs (nullable): the probabilities as [windows][N][N][heads] for the
+ * activation-quantised evaluation path (quant_block.py:410-411); out == NULL stops after writing probs. */
+int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const float* bias, float* out, float* probs, void* stream);
+/* out = probs @ v for probabilities produced (and possibly fake-quantised) outside */
+int rdo_window_attention_pv(const rdo_attn_desc* d, const float* qkv, const float* probs, float* out, void* stream);
+/* dqkv [B,H,W,3C] from dout [B,H,W,C]; probabilities are recomputed */
+int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const float* bias, const float* dout, float* dqkv, void* stream);
+/* LayerNorm backward over the last dimension (C <= 512).  dx (nullable) and, when dgamma_slabs != NULL, nslabs partial sums
+ * [nslabs][C] of dy * xhat (consumed by rdo_adaround_step like the wgrad slabs).  gamma == NULL means weight 1. */
+int rdo_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t C, float eps, float* dx,
+                       float* dgamma_slabs, int32_t nslabs, void* stream);
+int rdo_gelu_fwd(const float* x, int64_t n, float* out, void* stream);                      /* nn.GELU(): exact erf form */
+int rdo_gelu_bwd(const float* dy, const float* x, int64_t n, float* dx, void* stream);
+int rdo_round(const float* x, int64_t n, float* out, void* stream);                         /* torch.round (half to even): round_ste forward */
+
 /* ---- K12: entropy-model likelihoods (eval rounding) and the rate / distortion sums -------------------------------------
  * Element-wise on [n] fp32 (NHWC: channel = i % C).  `params` = per channel 58 floats [33 softplus(matrix) | 13 bias |
  * 12 tanh(factor)] of CompressAI's EntropyBottleneck(filters=(3,3,3,3)); medians[C].       models/nic_cvt.py:297,300-308;

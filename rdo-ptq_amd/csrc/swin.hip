@@ -1,0 +1,413 @@
+// Lu2022 transformer path (reference: models/layers.py:87-305, quantization/quant_block.py:330-547): window attention core with
+// the cyclic shift / window partition folded into the addressing, LayerNorm backward, GELU.  These are small HBM/latency-bound
+// VALU kernels (windows of <= 64 tokens, head dims 12..48): one wavefront owns one (window, head) pair, K/V/Q tiles live in LDS,
+// the N x N score row of a query stays in registers.  The linears around them run on the conv kernels as 1x1 convolutions.
+//
+// Token order: qkv / out are [B, H, W, *] in NATURAL pixel order.  Window (b, wh, ww), token (ih, iw) reads the pixel
+// ((wh*ws + ih + shift) % H, (ww*ws + iw + shift) % W): torch.roll(x, -shift) followed by window_partition (layers.py:271-279),
+// and writes its output to the same pixel (window_reverse + roll(+shift), :288-294).
+// qkv channel layout is that of nn.Linear(dim, 3*dim) reshaped (3, heads, hd) (layers.py:147): c = which*C + head*hd + d.
+#include "rdo_common.h"
+
+namespace {
+
+constexpr int NMAX = 64;
+
+struct AttnGeom {
+    int B, H, W, C, heads, ws, shift, N, hd, hs;   // hs: LDS row stride (odd)
+    float scale;
+};
+
+__device__ __forceinline__ int token_pixel(const AttnGeom& g, int win, int tok) {
+    const int nww = g.W / g.ws, nwh = g.H / g.ws;
+    const int b = win / (nwh * nww);
+    const int r = win - b * (nwh * nww);
+    const int wh = r / nww, ww = r - wh * nww;
+    const int ih = tok / g.ws, iw = tok - ih * g.ws;
+    int h = wh * g.ws + ih + g.shift, w = ww * g.ws + iw + g.shift;
+    if (h >= g.H) h -= g.H;
+    if (w >= g.W) w -= g.W;
+    return (b * g.H + h) * g.W + w;
+}
+
+// region id of a token in the SHIFTED image (layers.py:239-250): 3 bands per axis
+__device__ __forceinline__ int token_region(const AttnGeom& g, int win, int tok) {
+    const int nww = g.W / g.ws, nwh = g.H / g.ws;
+    const int r = win % (nwh * nww);
+    const int wh = r / nww, ww = r - wh * nww;
+    const int ih = tok / g.ws, iw = tok - ih * g.ws;
+    const int sh = wh * g.ws + ih, sw = ww * g.ws + iw;
+    const int rh = sh < g.H - g.ws ? 0 : (sh < g.H - g.shift ? 1 : 2);
+    const int rw = sw < g.W - g.ws ? 0 : (sw < g.W - g.shift ? 1 : 2);
+    return rh * 3 + rw;
+}
+
+// cooperative load of one of q/k/v (or a gradient w.r.t. the output) of this (window, head) into LDS rows of stride hs
+__device__ __forceinline__ void load_tile(const AttnGeom& g, const float* src, int row_stride, int ch0, int win, float* dst, float mul) {
+    for (int e = threadIdx.x; e < g.N * g.hd; e += 64) {
+        const int tok = e / g.hd, d = e - tok * g.hd;
+        dst[tok * g.hs + d] = mul * src[(long)token_pixel(g, win, tok) * row_stride + ch0 + d];
+    }
+}
+
+// softmax row of query `i` from Q (pre-scaled), K in LDS: S[j] for j < N
+__device__ __forceinline__ void score_row(const AttnGeom& g, const float* Q, const float* K, const float* bias, int win, int head, int i,
+                                          float (&S)[NMAX]) {
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) S[j] = 0.f;
+    for (int d = 0; d < g.hd; ++d) {
+        const float qd = Q[i * g.hs + d];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < g.N) S[j] += qd * K[j * g.hs + d];
+    }
+    const float* br = bias + ((long)head * g.N + i) * g.N;
+    const int ri = g.shift > 0 ? token_region(g, win, i) : 0;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+        if (j < g.N) {
+            float s = S[j] + br[j];
+            if (g.shift > 0 && token_region(g, win, j) != ri) s += -100.0f;
+            S[j] = s;
+            mx = fmaxf(mx, s);
+        }
+    float sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+        if (j < g.N) {
+            S[j] = expf(S[j] - mx);
+            sum += S[j];
+        }
+    const float inv = 1.0f / sum;
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j)
+        if (j < g.N) S[j] *= inv;
+}
+
+// grid (windows, heads), block 64.  probs (nullable): [windows][N][N][heads] -- channel-last so the per-head activation
+// quantiser (quant_block.py:410-411) can run on it as a [pixels, heads] matrix.  no_pv: stop after writing probs.
+__global__ __launch_bounds__(64) void win_attn_fwd_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
+                                                          int no_pv) {
+    extern __shared__ float lds[];
+    float* Q = lds;
+    float* K = Q + g.N * g.hs;
+    float* V = K + g.N * g.hs;
+    const int win = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
+    load_tile(g, qkv, 3 * g.C, head * g.hd, win, Q, g.scale);
+    load_tile(g, qkv, 3 * g.C, g.C + head * g.hd, win, K, 1.f);
+    load_tile(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
+    __syncthreads();
+    if (i >= g.N) return;
+    float S[NMAX];
+    score_row(g, Q, K, bias, win, head, i, S);
+    if (probs) {
+        float* pr = probs + (((long)win * g.N + i) * g.N) * g.heads + head;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < g.N) pr[(long)j * g.heads] = S[j];
+    }
+    if (no_pv) return;
+    float* o = out + (long)token_pixel(g, win, i) * g.C + head * g.hd;
+    for (int d = 0; d < g.hd; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < g.N) acc += S[j] * V[j * g.hs + d];
+        o[d] = acc;
+    }
+}
+
+// out = probs @ v with probs given (after activation quantisation): the second half of the split evaluation path
+__global__ __launch_bounds__(64) void win_attn_pv_kernel(const float* qkv, const float* probs, AttnGeom g, float* out) {
+    extern __shared__ float lds[];
+    float* V = lds;
+    const int win = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
+    load_tile(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
+    __syncthreads();
+    if (i >= g.N) return;
+    const float* pr = probs + (((long)win * g.N + i) * g.N) * g.heads + head;
+    float S[NMAX];
+#pragma unroll
+    for (int j = 0; j < NMAX; ++j) S[j] = j < g.N ? pr[(long)j * g.heads] : 0.f;
+    float* o = out + (long)token_pixel(g, win, i) * g.C + head * g.hd;
+    for (int d = 0; d < g.hd; ++d) {
+        float acc = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < g.N) acc += S[j] * V[j * g.hs + d];
+        o[d] = acc;
+    }
+}
+
+// backward of the fused core (probabilities recomputed): dqkv [B,H,W,3C] from dout [B,H,W,C]
+//   dP = dO V^T;  D_i = sum_j P_ij dP_ij;  dS = P o (dP - D);  dQ = scale * dS K;  dK = scale * dS^T Q;  dV = P^T dO
+__global__ __launch_bounds__(64) void win_attn_bwd_kernel(const float* qkv, const float* bias, const float* dout, AttnGeom g, float* dqkv) {
+    extern __shared__ float lds[];
+    const int NS = g.N + 1;
+    float* Q = lds;                       // pre-scaled
+    float* K = Q + g.N * g.hs;
+    float* V = K + g.N * g.hs;
+    float* dO = V + g.N * g.hs;
+    float* P = dO + g.N * g.hs;           // [N][N+1]
+    float* dS = P + g.N * NS;
+    const int win = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
+    load_tile(g, qkv, 3 * g.C, head * g.hd, win, Q, g.scale);
+    load_tile(g, qkv, 3 * g.C, g.C + head * g.hd, win, K, 1.f);
+    load_tile(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
+    load_tile(g, dout, g.C, head * g.hd, win, dO, 1.f);
+    __syncthreads();
+    const long pix = i < g.N ? token_pixel(g, win, i) : 0;
+    if (i < g.N) {
+        float S[NMAX], dP[NMAX];
+        score_row(g, Q, K, bias, win, head, i, S);
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j) dP[j] = 0.f;
+        for (int d = 0; d < g.hd; ++d) {
+            const float od = dO[i * g.hs + d];
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j)
+                if (j < g.N) dP[j] += od * V[j * g.hs + d];
+        }
+        float D = 0.f;
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < g.N) D += S[j] * dP[j];
+#pragma unroll
+        for (int j = 0; j < NMAX; ++j)
+            if (j < g.N) {
+                const float ds = S[j] * (dP[j] - D);
+                P[i * NS + j] = S[j];
+                dS[i * NS + j] = ds;
+                dP[j] = ds;
+            }
+        // dQ_i = scale * sum_j dS_ij K_j   (q entered the scores as scale * q)
+        float* dq = dqkv + pix * 3 * g.C + head * g.hd;
+        for (int d = 0; d < g.hd; ++d) {
+            float acc = 0.f;
+#pragma unroll
+            for (int j = 0; j < NMAX; ++j)
+                if (j < g.N) acc += dP[j] * K[j * g.hs + d];
+            dq[d] = g.scale * acc;
+        }
+    }
+    __syncthreads();
+    if (i < g.N) {
+        // lane = key j: dK_j = sum_i dS_ij Qs_i (Qs already carries the scale), dV_j = sum_i P_ij dO_i
+        float* dk = dqkv + pix * 3 * g.C + g.C + head * g.hd;
+        float* dv = dqkv + pix * 3 * g.C + 2 * g.C + head * g.hd;
+        for (int d = 0; d < g.hd; ++d) {
+            float ak = 0.f, av = 0.f;
+            for (int r = 0; r < g.N; ++r) {
+                ak += dS[r * NS + i] * Q[r * g.hs + d];
+                av += P[r * NS + i] * dO[r * g.hs + d];
+            }
+            dk[d] = ak;
+            dv[d] = av;
+        }
+    }
+}
+
+// ---- LayerNorm backward: one wave per row, a block's 4 waves walk rows with stride; dgamma partials per block (slab layout
+// [blocks][C], summed by the AdaRound step like the wgrad slabs).  dx = rstd * (g - mean(g) - xhat * mean(g * xhat)), g = dy * gamma
+constexpr int LN_CPL = 8;   // channels per lane: C <= 512
+__global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* x, const float* gamma, const float* dy, long rows, int C, float eps,
+                                                             float* dx, float* dgamma_slabs) {
+    __shared__ float part[4][512];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dg[LN_CPL];
+#pragma unroll
+    for (int k = 0; k < LN_CPL; ++k) dg[k] = 0.f;
+    for (long row = (long)blockIdx.x * 4 + wave; row < rows; row += (long)gridDim.x * 4) {
+        const float* xr = x + row * C;
+        const float* gr = dy + row * C;
+        float s1 = 0.f;
+        for (int c = lane; c < C; c += 64) s1 += xr[c];
+        for (int o = 32; o > 0; o >>= 1) s1 += __shfl_xor(s1, o, 64);
+        const float mean = s1 / (float)C;
+        float s2 = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; s2 += d * d; }
+        for (int o = 32; o > 0; o >>= 1) s2 += __shfl_xor(s2, o, 64);
+        const float rstd = rsqrtf(s2 / (float)C + eps);
+        float a = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < LN_CPL; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                const float xh = (xr[c] - mean) * rstd;
+                const float g = gr[c] * (gamma ? gamma[c] : 1.f);
+                a += g;
+                b += g * xh;
+                dg[k] += gr[c] * xh;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o, 64); b += __shfl_xor(b, o, 64); }
+        a /= (float)C;
+        b /= (float)C;
+        if (dx) {
+#pragma unroll
+            for (int k = 0; k < LN_CPL; ++k) {
+                const int c = lane + 64 * k;
+                if (c < C) {
+                    const float xh = (xr[c] - mean) * rstd;
+                    const float g = gr[c] * (gamma ? gamma[c] : 1.f);
+                    dx[row * C + c] = rstd * (g - a - xh * b);
+                }
+            }
+        }
+    }
+    if (!dgamma_slabs) return;
+#pragma unroll
+    for (int k = 0; k < LN_CPL; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) part[wave][c] = dg[k];
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256)
+        dgamma_slabs[(long)blockIdx.x * C + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+}
+
+// exact (erf) GELU, nn.GELU() default (layers.py:37,40)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* x, long n, float* out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const float v = x[t];
+        out[t] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    }
+}
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dy, const float* x, long n, float* dx) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
+        const float v = x[t];
+        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+        const float pdf = 0.39894228040143268f * expf(-0.5f * v * v);
+        dx[t] = dy[t] * (cdf + v * pdf);
+    }
+}
+__global__ __launch_bounds__(256) void round_kernel(const float* x, long n, float* out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) out[t] = rintf(x[t]);
+}
+
+unsigned grid1d(long n) {
+    long g = rdo::ceil_div(n, 256);
+    return (unsigned)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+int make_geom(const rdo_attn_desc* d, AttnGeom* g, const char* who) {
+    RDO_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    RDO_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->heads > 0 && d->window > 0, "%s: bad geometry", who);
+    RDO_REQUIRE(d->C % d->heads == 0, "%s: C=%d not divisible by heads=%d", who, d->C, d->heads);
+    RDO_REQUIRE(d->H % d->window == 0 && d->W % d->window == 0, "%s: %dx%d not divisible by window %d", who, d->H, d->W, d->window);
+    RDO_REQUIRE(d->window * d->window <= NMAX, "%s: windows of more than %d tokens are not supported", who, NMAX);
+    RDO_REQUIRE(d->shift >= 0 && d->shift < d->window, "%s: shift must be in [0, window)", who);
+    g->B = d->B; g->H = d->H; g->W = d->W; g->C = d->C; g->heads = d->heads; g->ws = d->window; g->shift = d->shift;
+    g->N = d->window * d->window;
+    g->hd = d->C / d->heads;
+    g->hs = g->hd | 1;
+    g->scale = d->scale;
+    return RDO_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const float* bias, float* out, float* probs, void* stream) {
+    AttnGeom g;
+    if (int rc = make_geom(d, &g, "rdo_window_attention_fwd")) return rc;
+    RDO_REQUIRE(qkv && bias && (out || probs), "rdo_window_attention_fwd: null argument");
+    const int windows = g.B * (g.H / g.ws) * (g.W / g.ws);
+    const size_t lds = (size_t)3 * g.N * g.hs * sizeof(float);
+    const int no_pv = out == nullptr;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(windows, g.heads), dim3(64), lds, s, qkv, bias, g, out, probs, no_pv);
+            return rdo::check_launch("window_attention_fwd");
+        },
+        stream, "window_attention_fwd", 4.0 * windows * g.heads * (double)g.N * g.N * g.hd,
+        4.0 * ((double)g.B * g.H * g.W * g.C * 4));
+}
+
+int rdo_window_attention_pv(const rdo_attn_desc* d, const float* qkv, const float* probs, float* out, void* stream) {
+    AttnGeom g;
+    if (int rc = make_geom(d, &g, "rdo_window_attention_pv")) return rc;
+    RDO_REQUIRE(qkv && probs && out, "rdo_window_attention_pv: null argument");
+    const int windows = g.B * (g.H / g.ws) * (g.W / g.ws);
+    const size_t lds = (size_t)g.N * g.hs * sizeof(float);
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(win_attn_pv_kernel, dim3(windows, g.heads), dim3(64), lds, s, qkv, probs, g, out);
+            return rdo::check_launch("window_attention_pv");
+        },
+        stream, "window_attention_pv");
+}
+
+int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const float* bias, const float* dout, float* dqkv, void* stream) {
+    AttnGeom g;
+    if (int rc = make_geom(d, &g, "rdo_window_attention_bwd")) return rc;
+    RDO_REQUIRE(qkv && bias && dout && dqkv, "rdo_window_attention_bwd: null argument");
+    const int windows = g.B * (g.H / g.ws) * (g.W / g.ws);
+    const size_t lds = ((size_t)4 * g.N * g.hs + (size_t)2 * g.N * (g.N + 1)) * sizeof(float);
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            static bool attr = false;
+            if (!attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        96 * 1024) != hipSuccess)
+                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_bwd) failed");
+                attr = true;
+            }
+            if (lds > 96 * 1024) return rdo::set_error(RDO_EINVAL, "rdo_window_attention_bwd: head dim too large for the LDS tile");
+            hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(windows, g.heads), dim3(64), lds, s, qkv, bias, dout, g, dqkv);
+            return rdo::check_launch("window_attention_bwd");
+        },
+        stream, "window_attention_bwd", 10.0 * windows * g.heads * (double)g.N * g.N * g.hd,
+        4.0 * ((double)g.B * g.H * g.W * g.C * 8));
+}
+
+int rdo_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t C, float eps, float* dx,
+                       float* dgamma_slabs, int32_t nslabs, void* stream) {
+    RDO_REQUIRE(x && dy && rows > 0 && C > 0 && C <= 512, "rdo_layer_norm_bwd: bad argument (C <= 512)");
+    RDO_REQUIRE(dx || dgamma_slabs, "rdo_layer_norm_bwd: nothing to compute");
+    RDO_REQUIRE(!dgamma_slabs || nslabs > 0, "rdo_layer_norm_bwd: nslabs must be positive");
+    long blocks = rdo::ceil_div(rows, 4);
+    if (dgamma_slabs) blocks = nslabs;       // every slab is written (rows are strided over the blocks)
+    else if (blocks > 2048) blocks = 2048;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(layer_norm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, gamma, dy, (long)rows, C, eps, dx,
+                               dgamma_slabs);
+            return rdo::check_launch("layer_norm_bwd");
+        },
+        stream, "layer_norm_bwd", 0.0, 12.0 * rows * C);
+}
+
+int rdo_gelu_fwd(const float* x, int64_t n, float* out, void* stream) {
+    RDO_REQUIRE(x && out && n > 0, "rdo_gelu_fwd: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, x, (long)n, out);
+            return rdo::check_launch("gelu_fwd");
+        },
+        stream, "gelu_fwd", 0.0, 8.0 * n);
+}
+
+int rdo_gelu_bwd(const float* dy, const float* x, int64_t n, float* dx, void* stream) {
+    RDO_REQUIRE(dy && x && dx && n > 0, "rdo_gelu_bwd: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid1d(n)), dim3(256), 0, s, dy, x, (long)n, dx);
+            return rdo::check_launch("gelu_bwd");
+        },
+        stream, "gelu_bwd", 0.0, 12.0 * n);
+}
+
+int rdo_round(const float* x, int64_t n, float* out, void* stream) {
+    RDO_REQUIRE(x && out && n > 0, "rdo_round: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(round_kernel, dim3(grid1d(n)), dim3(256), 0, s, x, (long)n, out);
+            return rdo::check_launch("round");
+        },
+        stream, "round", 0.0, 8.0 * n);
+}
+
+}  // extern "C"

@@ -23,6 +23,10 @@ class AdaDesc(C.Structure):
                 ("Cin", C.c_int32)]
 
 
+class AttnDesc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "heads", "window", "shift")] + [("scale", C.c_float)]
+
+
 class SchedRow(C.Structure):
     _fields_ = [("b", C.c_float), ("round_on", C.c_float), ("step_size", C.c_float), ("bc2_sqrt", C.c_float)]
 
@@ -54,6 +58,13 @@ _SIGS = {
     "rdo_lrelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
     "rdo_lrelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_relu_fwd": (C.c_int, [P, C.c_int64, P, P]),
+    "rdo_window_attention_fwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P]),
+    "rdo_window_attention_pv": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),
+    "rdo_window_attention_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P]),
+    "rdo_layer_norm_bwd": (C.c_int, [P, P, P, C.c_int64, C.c_int32, C.c_float, P, P, C.c_int32, P]),
+    "rdo_gelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
+    "rdo_gelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
+    "rdo_round": (C.c_int, [P, C.c_int64, P, P]),
     "rdo_relu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_pixel_shuffle": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "rdo_add": (C.c_int, [P, P, C.c_int64, P, P]),

@@ -279,6 +279,59 @@ def layer_norm(x, weight, bias, eps=1e-5, out=None):
     return out
 
 
+def layer_norm_bwd(x, weight, dy, eps=1e-5, dx=None, dgamma_slabs=None):
+    """dx (returned) and, when `dgamma_slabs` [nslabs, C] is given, the partial sums of dy * xhat."""
+    Cc = x.shape[-1]
+    ns = 0 if dgamma_slabs is None else dgamma_slabs.shape[0]
+    L.check(L.lib().rdo_layer_norm_bwd(_ptr(x), _ptr(weight), _ptr(dy), x.numel() // Cc, Cc, eps, _ptr(dx), _ptr(dgamma_slabs), ns,
+                                       _stream()), "rdo_layer_norm_bwd")
+    return dx
+
+
+def attn_desc(B, H, W, Cc, heads, window, shift, scale=None):
+    return L.AttnDesc(B, H, W, Cc, heads, window, shift, float((Cc // heads) ** -0.5 if scale is None else scale))
+
+
+def window_attention(d, qkv, bias, out=None, probs=None, compute_out=True):
+    """Fused (S)W-MSA core on [B, H, W, 3C] -> [B, H, W, C]; `probs` [windows, N, N, heads] is filled when given."""
+    if compute_out and out is None:
+        out = torch.empty((d.B, d.H, d.W, d.C), device=qkv.device, dtype=torch.float32)
+    L.check(L.lib().rdo_window_attention_fwd(C.byref(d), _ptr(qkv), _ptr(bias), _ptr(out) if compute_out else None, _ptr(probs),
+                                             _stream()), "rdo_window_attention_fwd")
+    return out
+
+
+def window_attention_pv(d, qkv, probs, out=None):
+    out = torch.empty((d.B, d.H, d.W, d.C), device=qkv.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_window_attention_pv(C.byref(d), _ptr(qkv), _ptr(probs), _ptr(out), _stream()), "rdo_window_attention_pv")
+    return out
+
+
+def window_attention_bwd(d, qkv, bias, dout, dqkv=None):
+    dqkv = torch.empty_like(qkv) if dqkv is None else dqkv
+    L.check(L.lib().rdo_window_attention_bwd(C.byref(d), _ptr(qkv), _ptr(bias), _ptr(dout), _ptr(dqkv), _stream()),
+            "rdo_window_attention_bwd")
+    return dqkv
+
+
+def gelu(x, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().rdo_gelu_fwd(_ptr(x), x.numel(), _ptr(out), _stream()), "rdo_gelu_fwd")
+    return out
+
+
+def gelu_bwd(dy, x, dx=None):
+    dx = torch.empty_like(x) if dx is None else dx
+    L.check(L.lib().rdo_gelu_bwd(_ptr(dy), _ptr(x), x.numel(), _ptr(dx), _stream()), "rdo_gelu_bwd")
+    return dx
+
+
+def round_(x, out=None):
+    out = torch.empty_like(x) if out is None else out
+    L.check(L.lib().rdo_round(_ptr(x), x.numel(), _ptr(out), _stream()), "rdo_round")
+    return out
+
+
 def iter_advance(iter_ptr):
     L.check(L.lib().rdo_iter_advance(_ptr(iter_ptr), _stream()), "rdo_iter_advance")
 
