@@ -29,7 +29,7 @@ from hipops.plan import Plan
 from .quant_layer import QuantModule
 from .quantizer import AdaRoundQuantizer, to_rows
 
-UNIT_KINDS = ("layer", "rb", "rbws", "rbu")
+UNIT_KINDS = ("layer", "rb", "rbws", "rbu", "rstb")
 
 
 class _Op:
@@ -39,7 +39,8 @@ class _Op:
         self.name, self.qm, self.need_dgrad = name, qm, need_dgrad
         self.is_gdn = qm.kind == "gdn"
         self.tconv = None                     # (stride, padding, output_padding) of a ConvTranspose2d unit
-        if qm.kind not in ("conv", "gdn", "tconv"):
+        self.is_ln = qm.kind == "layernorm"
+        if qm.kind not in ("conv", "gdn", "tconv", "linear", "layernorm"):
             raise NotImplementedError(f"calibration engine: QuantModule kind '{qm.kind}' is not supported yet")
         wq = qm.weight_quantizer
         if not wq.inited:
@@ -47,7 +48,11 @@ class _Op:
         if not wq.channel_wise:
             raise NotImplementedError("calibration engine: layer-wise (non channel-wise) scales are not built yet")
         w = qm.org_weight.detach()
-        if qm.kind == "tconv":
+        if qm.kind == "linear":
+            self.w = w.reshape(w.shape[0], 1, 1, w.shape[1]).contiguous()      # a Linear is a 1x1 conv over the token matrix
+        elif qm.kind == "layernorm":
+            self.w = w.reshape(1, -1).contiguous()                              # gamma: one quantisation "channel" (per tensor)
+        elif qm.kind == "tconv":
             # a transposed conv is the forward conv kernel (stride 1, pad 0) on the zero-inserted input with the taps
             # flipped: keep every per-weight tensor of the engine in that flipped [co][kh'][kw'][ci] layout
             self.w = to_rows(w, tconv=True).flip(1, 2).contiguous()
@@ -58,7 +63,17 @@ class _Op:
         self.delta = wq.delta.reshape(-1).to(dev).contiguous()
         self.zp = wq.zero_point.reshape(-1).to(dev).contiguous()
         self.n_levels = wq.n_levels
-        if self.is_gdn:
+        if self.is_ln:
+            self.desc = ops.ada_desc(self.w, self.n_levels, conv_layout=False)
+            self.stride, self.pad, self.K = 1, 0, 1
+            self.w4 = tuple(self.w.shape)
+            self.bias = None if qm.bias is None else qm.bias.detach().contiguous()
+        elif qm.kind == "linear":
+            self.stride, self.pad, self.K = 1, 0, 1
+            self.desc = ops.ada_desc(self.w, self.n_levels)
+            self.w4 = tuple(self.w.shape)
+            self.bias = None if qm.bias is None else qm.bias.detach().contiguous()
+        elif self.is_gdn:
             self.inverse = bool(qm.fwd_kwargs["inverse"])
             self.beta, reparam = qm.gdn_constants()
             self.beta = self.beta.to(dev).contiguous()
@@ -424,6 +439,8 @@ class UnitEngine:
         op = self.ops[name]
         if op.tconv is not None:
             return op.alpha.flip(1, 2).permute(3, 0, 1, 2)
+        if op.qm.kind in ("linear", "layernorm"):
+            return op.alpha.reshape(op.qm.org_weight.shape)
         return op.alpha.permute(0, 3, 1, 2) if op.alpha.dim() == 4 else op.alpha
 
     def finish(self):
@@ -432,6 +449,8 @@ class UnitEngine:
         for name, op in self.ops.items():
             qm = op.qm
             rows = op.alpha.flip(1, 2).contiguous() if op.tconv is not None else op.alpha
+            if qm.kind == "linear":
+                rows = op.alpha.reshape(op.alpha.shape[0], -1)
             ada = AdaRoundQuantizer(uaq=qm.weight_quantizer, round_mode="learned_hard_sigmoid",
                                     weight_tensor=qm.org_weight.data, alpha_rows=rows)
             ada.soft_targets = False

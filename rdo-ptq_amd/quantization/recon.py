@@ -7,8 +7,10 @@ import time
 import torch
 
 from . import dp
+from hipops import ops
 from .engine import UnitEngine
-from .quant_block import BaseQuantBlock
+from .quant_block import BaseQuantBlock, QuantRSTB
+from .swin_engine import TapeEngine
 from .quant_layer import QuantModule, _nhwc
 from .utils import LinearTempDecay, save_inp_oup_data, set_mode
 
@@ -31,6 +33,21 @@ def find_unquantized_module(model, _name_="g_a", module_list=None, name_list=Non
         else:
             find_unquantized_module(module, _name_, module_list, name_list)
     return module_list[1:], name_list[1:]
+
+
+def fp_out(module_list, x, round_after, batch=8):
+    """`fp_out` of the reference (layer_opt.py:45-75) over a whole cache: the remaining stages of the sub-coder in full
+    precision (their quant state was switched off by find_unquantized_module), then round for analysis-transform units."""
+    outs = []
+    with torch.no_grad():
+        for i in range(0, x.shape[0], batch):
+            h = x[i:i + batch]
+            for m in module_list:
+                h = m(h) if isinstance(m, QuantModule) else m(h, (h.shape[2], h.shape[3]))
+            if round_after:
+                h = ops.round_(_nhwc(h)).permute(0, 3, 1, 2)
+            outs.append(h)
+    return torch.cat(outs)
 
 
 class LossFunction:
@@ -59,6 +76,8 @@ def _unit_modules(unit):
     if kind == "rbu":
         return kind, {"subpel_conv": unit.subpel_conv[0], "conv": unit.conv, "igdn": unit.igdn,
                       "upsample": unit.upsample[0], "upscale": unit.subpel_conv[1].upscale_factor}
+    if kind == "rstb":
+        return kind, {"rstb": unit}
     raise NotImplementedError(f"reconstruction of {type(unit).__name__} is not built yet")
 
 
@@ -81,9 +100,13 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     logging.info("Cached init time: {}".format(time.time() - t0))
     module_list, name_list = find_unquantized_module(model, unit_name, [], [])
     logging.info(name_list)
-    if module_list:
-        raise NotImplementedError("task loss through the rest of the sub-coder (Lu2022 naming) is not built yet")
+    # Lu2022 naming (g_a0 ... g_s7): the task term runs through the untrained rest of the sub-coder, and through round_ste for
+    # analysis-transform units (layer_opt.py:45-75); its target is the same function of the cached FP outputs (:262-263)
+    tail_round = "g_a" in unit_name
+    task_cache = None
     model.set_quant_state(False, False)
+    if module_list or tail_round:
+        task_cache = _nhwc(fp_out(module_list, out_fp, tail_round))
     set_mode(model, act_quant)
     if not is_block and ("g_s7" in unit_name or "7" in unit_name):
         logging.info("=======last layer, close activation quantization=======")
@@ -94,9 +117,13 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
         return None                                   # PixelShuffle units carry nothing to train (layer_opt.py:245-246)
     kind, mods = _unit_modules(unit)
     # the CLI --lr is ignored by the reference (Adam default 1e-3, layer_opt.py:253-254); kept that way.
-    eng = UnitEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), batch_size=batch_size, iters=iters,
-                     weight=weight, b_range=b_range, warmup=warmup, input_prob=input_prob, lr=1e-3,
-                     seed=torch.initial_seed() ^ (hash(unit_name) & 0xFFFF), include_act_func=include_act_func)
+    common = dict(batch_size=batch_size, iters=iters, weight=weight, b_range=b_range, warmup=warmup, input_prob=input_prob,
+                  lr=1e-3, seed=torch.initial_seed() ^ (hash(unit_name) & 0xFFFF), include_act_func=include_act_func)
+    if kind == "rstb" or task_cache is not None:
+        eng = TapeEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), tail=module_list, tail_round=tail_round,
+                         task_cache=task_cache, **common)
+    else:
+        eng = UnitEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), **common)
     eng.run()
     if logging.getLogger().isEnabledFor(logging.INFO) and iters >= 500:
         total, rt, rd = eng.logs()

@@ -1,0 +1,392 @@
+"""Calibration engine for the Lu2022 path: RSTB block units and the task loss through the FP rest of the sub-coder.
+
+The reference trains a Lu2022 unit against two terms (block_opt.py:299-308, layer_opt.py:296-303):
+
+    rec  = lp_loss(unit(x_q),               cached FP output of the unit)
+    task = lp_loss(fp_out(unit(x_q)),       fp_out(cached FP output))       fp_out = remaining untrained stages of g_a / h_a /
+                                                                            h_s / g_s in full precision, + round_ste for g_a
+
+so every iteration runs forward AND backward through the rest of the sub-coder (up to 14 Swin blocks and 3 resamplers for
+g_a0).  `TapeEngine` records that as one static HIP op list per iteration, exactly like `UnitEngine` does for the Cheng2020
+units: the forward pass of the trainable unit and of the frozen tail is issued stage by stage, each stage pushing a closure
+that issues its backward kernels; the closures run in reverse after the two loss kernels.  Gradients are plain buffers keyed by
+the tensor they belong to; a second contribution to the same tensor goes through a temporary and `rdo_add`.
+
+Tokens stay in natural pixel order ([B, H, W, C] == [B, L, C]); Linears run on the conv kernels as 1x1 convolutions (bf16x6
+split-precision path for the large ones), the attention core / LayerNorm / GELU on csrc/swin.hip."""
+from collections import OrderedDict
+
+import torch
+
+from hipops import _lib as L
+from hipops import ops
+
+from .engine import UnitEngine, _Op
+from .quant_layer import QuantModule
+from .quantizer import to_rows
+
+
+class _FpOp:
+    """Frozen full-precision parameters of one conv / transposed conv / linear of the tail, in the kernels' layouts.
+    Quacks like `_Op` for UnitEngine._conv / ._dgrad (wq4, wd4, bias, stride, pad, K, plane buffers)."""
+    is_gdn = False
+    slabs = None
+
+    def __init__(self, qm: QuantModule):
+        self.qm, self.kind = qm, qm.kind
+        w = qm.org_weight.detach()
+        self.bias = None if qm.org_bias is None else qm.org_bias.detach().contiguous()
+        self.tconv = None
+        if qm.kind == "linear":
+            self.w = w.reshape(w.shape[0], 1, 1, w.shape[1]).contiguous()
+            self.stride, self.pad = 1, 0
+        elif qm.kind == "conv":
+            self.w = to_rows(w)
+            self.stride, self.pad = qm.conv_geometry()
+        elif qm.kind == "tconv":
+            kw = qm.fwd_kwargs
+            self.tconv = (int(kw["stride"][0]), int(kw["padding"][0]), int(kw["output_padding"][0]))
+            self.w = to_rows(w, tconv=True).flip(1, 2).contiguous()      # forward = stride-1 conv on the zero-inserted input
+            self.stride, self.pad = 1, 0
+            self.w_bwd = w.permute(0, 2, 3, 1).contiguous()              # dgrad = strided conv of dy with [Cin_t][kh][kw][Cout_t]
+        else:
+            raise NotImplementedError(f"tail stage of kind '{qm.kind}'")
+        self.K = self.w.shape[1]
+        self.w4 = tuple(self.w.shape)
+        self.same = self.tconv is None and self.stride == 1 and 2 * self.pad == self.K - 1
+        if self.same:
+            self.wd = self.w.flip(1, 2).permute(3, 1, 2, 0).contiguous()         # [ci][kh'][kw'][co], taps flipped
+        elif self.tconv is None:
+            # dgrad of a strided conv = transposed conv of dy: stride-1 conv of the zero-inserted dy with this layout
+            self.w_bwd = self.w.permute(3, 1, 2, 0).flip(1, 2).contiguous()       # [ci][kh'][kw'][co]
+        self.wq_planes = self.wd_planes = None
+
+    def wq4(self):
+        return self.w
+
+    def wd4(self):
+        return self.wd
+
+    def enable_planes(self, fwd, dgrad):
+        """Called while the plan is being recorded: allocate only; `fill_planes` runs eagerly afterwards (weights are frozen)."""
+        if fwd and self.wq_planes is None:
+            self.wq_planes = torch.empty((3,) + tuple(self.w.shape), device=self.w.device, dtype=torch.int16)
+        if dgrad and self.wd_planes is None and getattr(self, "wd", None) is not None:
+            self.wd_planes = torch.empty((3,) + tuple(self.wd.shape), device=self.wd.device, dtype=torch.int16)
+
+    def fill_planes(self):
+        if self.wq_planes is not None:
+            ops.split_bf16x3(self.w, self.wq_planes)
+        if self.wd_planes is not None:
+            ops.split_bf16x3(self.wd, self.wd_planes)
+
+    def refresh_planes(self):
+        pass
+
+
+class _Ln:
+    """LayerNorm parameters: trainable (gamma = soft-rounded AdaRound weight of `op`) or frozen."""
+
+    def __init__(self, qm: QuantModule, op=None):
+        self.op = op
+        self.gamma = op.wq.view(-1) if op is not None else qm.org_weight.detach().contiguous()
+        self.beta = (op.bias if op is not None else (None if qm.org_bias is None else qm.org_bias.detach().contiguous()))
+
+
+class TapeEngine(UnitEngine):
+    """UnitEngine for kind 'rstb' and for any unit that carries a tail (`tail`: list of untrained QuantModule / QuantRSTB stages
+    run in full precision; `tail_round`: round_ste after them, i.e. the unit sits in g_a; `task_cache`: fp_out of the cached FP
+    outputs, [n, H', W', C'] NHWC)."""
+
+    def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, tail=(), tail_round=False, task_cache=None, **kw):
+        self.tail, self.tail_round, self.task_cache = list(tail), bool(tail_round), task_cache
+        if (self.tail or self.tail_round) and task_cache is None:
+            raise ValueError("TapeEngine: a tail needs the task target cache")
+        self._keep, self._fp = [], []
+        super().__init__(kind, modules, cache_q, cache_fp, cache_out, **kw)
+        for p in self._fp:
+            p.fill_planes()             # frozen tail weights: exact bf16 splits made once, outside the recorded plan
+
+    # ------------------------------------------------------------------------------------------------------------------ ops
+    def _build_ops(self):
+        if self.kind != "rstb":
+            return super()._build_ops()
+        o = OrderedDict()
+        rstb = self.mods["rstb"]
+        for i, blk in enumerate(rstb.residual_group.blocks):
+            pre = f"residual_group.blocks.{i}."
+            o[pre + "norm1"] = _Op(pre + "norm1", blk.norm1, False)
+            o[pre + "attn.qkv"] = _Op(pre + "attn.qkv", blk.attn.qkv, True)
+            o[pre + "attn.proj"] = _Op(pre + "attn.proj", blk.attn.proj, True)
+            o[pre + "norm2"] = _Op(pre + "norm2", blk.norm2, False)
+            o[pre + "mlp.fc1"] = _Op(pre + "mlp.fc1", blk.mlp.fc1, True)
+            o[pre + "mlp.fc2"] = _Op(pre + "mlp.fc2", blk.mlp.fc2, True)
+        self.ops = o
+        if self.split:
+            total = sum(op.numel() for op in o.values())
+            self.bucket = torch.zeros(total, device=self.dev)
+            off = 0
+            for op in o.values():
+                op.dalpha = self.bucket[off:off + op.numel()]
+                off += op.numel()
+
+    def _alloc(self):
+        if self.kind != "rstb":
+            return super()._alloc()
+        _, H, W, Cin = self.cq.shape
+        self.x_in = self._buf(self.B, H, W, Cin)
+        self.t = {}
+
+    def _buf(self, *shape):
+        t = super()._buf(*shape)
+        self._keep.append(t)
+        return t
+
+    # ------------------------------------------------------------------------------------------------------------------ tape
+    def _grad_slot(self, t):
+        """(buffer to write the next gradient contribution of `t` into, True if it is the first one)."""
+        g = self.G.get(id(t))
+        if g is None:
+            g = self._buf(*t.shape)
+            self.G[id(t)] = g
+            return g, True
+        return self._buf(*t.shape), False
+
+    def _grad_commit(self, t, buf, first):
+        if first:
+            return
+        g = self.G[id(t)]
+        if id(g) in self._aliased:
+            # g also serves as the gradient of another tensor (both inputs of a residual add share their output's gradient):
+            # accumulate into a private buffer instead of in place
+            acc = self._buf(*t.shape)
+            ops.add(g, buf, out=acc)
+            self.G[id(t)] = acc
+        else:
+            ops.add(g, buf, out=g)
+
+    # -- linear over the token matrix ------------------------------------------------------------------------------------
+    def _linear(self, x, p, need_dx=True):
+        rows, cin = x.numel() // x.shape[-1], x.shape[-1]
+        cout = p.w4[0]
+        y = self._buf(*x.shape[:-1], cout)
+        x4, y4 = x.view(1, 1, rows, cin), y.view(1, 1, rows, cout)
+        self._conv(p, x4, y4)
+
+        def bwd():
+            dy4 = self.G[id(y)].view(1, 1, rows, cout)
+            if isinstance(p, _Op):
+                self._wgrad(p, x4, dy4)
+            if need_dx:
+                dx, first = self._grad_slot(x)
+                self._dgrad(p, dy4, dx.view(1, 1, rows, cin))
+                self._grad_commit(x, dx, first)
+        self.tape.append(bwd)
+        return y
+
+    def _layer_norm(self, x, ln: _Ln, need_dx=True):
+        y = self._buf(*x.shape)
+        ops.layer_norm(x, ln.gamma, ln.beta, out=y)
+
+        def bwd():
+            dy = self.G[id(y)]
+            slabs = None
+            if ln.op is not None:
+                rows = x.numel() // x.shape[-1]
+                if ln.op.slabs is None:
+                    ln.op.slabs = self._buf(max(1, min(64, (rows + 3) // 4)), x.shape[-1])
+                slabs = ln.op.slabs
+            dx, first = self._grad_slot(x) if need_dx else (None, True)
+            ops.layer_norm_bwd(x, ln.gamma, dy, dx=dx, dgamma_slabs=slabs)
+            if need_dx:
+                self._grad_commit(x, dx, first)
+        self.tape.append(bwd)
+        return y
+
+    def _attention(self, qkv, desc, bias):
+        out = self._buf(desc.B, desc.H, desc.W, desc.C)
+        ops.window_attention(desc, qkv, bias, out=out)
+
+        def bwd():
+            dq, first = self._grad_slot(qkv)
+            ops.window_attention_bwd(desc, qkv, bias, self.G[id(out)], dq)
+            self._grad_commit(qkv, dq, first)
+        self.tape.append(bwd)
+        return out
+
+    def _gelu(self, x):
+        y = self._buf(*x.shape)
+        ops.gelu(x, out=y)
+
+        def bwd():
+            dx, first = self._grad_slot(x)
+            ops.gelu_bwd(self.G[id(y)], x, dx)
+            self._grad_commit(x, dx, first)
+        self.tape.append(bwd)
+        return y
+
+    def _add(self, a, b, grad_a=True):
+        y = self._buf(*a.shape)
+        ops.add(a, b, out=y)
+
+        def bwd():
+            dy = self.G[id(y)]
+            if grad_a:
+                self._aliased.add(id(dy))
+            for t in ((a, b) if grad_a else (b,)):
+                if id(t) not in self.G:
+                    self.G[id(t)] = dy                     # first contribution: share the buffer (never written in place again)
+                else:
+                    g = self.G[id(t)]
+                    if g is dy:
+                        continue
+                    # the stored gradient may itself be a shared buffer: accumulate into a private copy
+                    acc = self._buf(*t.shape)
+                    ops.add(g, dy, out=acc)
+                    self.G[id(t)] = acc
+        self.tape.append(bwd)
+        return y
+
+    # -- one RSTB (trainable: AdaRound ops of this engine; frozen: the stage's FP parameters) -----------------------------------
+    def _rstb(self, x, rstb, ops_of=None, need_dx=True):
+        B, H, W, C = x.shape
+        t = x
+        for i, blk in enumerate(rstb.residual_group.blocks):
+            pre = f"residual_group.blocks.{i}."
+            if ops_of is not None:
+                p = {k: ops_of[pre + k] for k in ("attn.qkv", "attn.proj", "mlp.fc1", "mlp.fc2")}
+                ln1, ln2 = _Ln(blk.norm1, ops_of[pre + "norm1"]), _Ln(blk.norm2, ops_of[pre + "norm2"])
+            else:
+                p = {"attn.qkv": _FpOp(blk.attn.qkv), "attn.proj": _FpOp(blk.attn.proj), "mlp.fc1": _FpOp(blk.mlp.fc1),
+                     "mlp.fc2": _FpOp(blk.mlp.fc2)}
+                ln1, ln2 = _Ln(blk.norm1), _Ln(blk.norm2)
+                self._keep.extend(p.values())
+                self._fp.extend(p.values())
+            first_block_input = t is x
+            want_dt = need_dx or not first_block_input
+            n1 = self._layer_norm(t, ln1, need_dx=want_dt)
+            qkv = self._linear(n1, p["attn.qkv"])
+            desc = ops.attn_desc(B, H, W, C, blk.num_heads, blk.window_size, blk.shift_size, blk.attn.scale)
+            bias = blk.attn.position_bias()
+            self._keep.append(bias)
+            a = self._attention(qkv, desc, bias)
+            pr = self._linear(a, p["attn.proj"])
+            t1 = self._add(t, pr, grad_a=want_dt)
+            n2 = self._layer_norm(t1, ln2)
+            f1 = self._linear(n2, p["mlp.fc1"])
+            g = self._gelu(f1)
+            f2 = self._linear(g, p["mlp.fc2"])
+            t = self._add(t1, f2)
+        return self._add(t, x, grad_a=True) if need_dx else self._add_in(t, x)
+
+    def _add_in(self, t, x):
+        """t + x where x needs no gradient (the cached unit input)."""
+        y = self._buf(*t.shape)
+        ops.add(t, x, out=y)
+
+        def bwd():
+            self.G[id(t)] = self.G[id(y)]
+        self.tape.append(bwd)
+        return y
+
+    # -- frozen conv / transposed conv stage of the tail -----------------------------------------------------------------------
+    def _fp_conv(self, x, qm):
+        p = _FpOp(qm)
+        self._keep.append(p)
+        self._fp.append(p)
+        B, H, W, _ = x.shape
+        if p.tconv is None:
+            Ho, Wo = (H + 2 * p.pad - p.K) // p.stride + 1, (W + 2 * p.pad - p.K) // p.stride + 1
+            y = self._buf(B, Ho, Wo, p.w4[0])
+            self._conv(p, x, y)
+
+            def bwd():
+                dy = self.G[id(y)]
+                dx, first = self._grad_slot(x)
+                if p.same:
+                    self._dgrad(p, dy, dx)
+                else:
+                    q = p.K - 1 - p.pad
+                    opad = H - ((Ho - 1) * p.stride - 2 * p.pad + p.K)
+                    Hu, Wu = (Ho - 1) * p.stride + 1 + 2 * q + opad, (Wo - 1) * p.stride + 1 + 2 * q + opad
+                    du = self._buf(B, Hu, Wu, p.w4[0])
+                    ops.zero_insert(dy, p.stride, q, q, Hu, Wu, out=du)
+                    ops.conv2d_fwd(du, p.w_bwd, None, 1, 0, out=dx)
+                self._grad_commit(x, dx, first)
+            self.tape.append(bwd)
+            return y
+        s_, p_, op_ = p.tconv
+        q = p.K - 1 - p_
+        Hu, Wu = (H - 1) * s_ + 1 + 2 * q + op_, (W - 1) * s_ + 1 + 2 * q + op_
+        xu = self._buf(B, Hu, Wu, x.shape[-1])
+        ops.zero_insert(x, s_, q, q, Hu, Wu, out=xu)
+        y = self._buf(B, Hu - p.K + 1, Wu - p.K + 1, p.w4[0])
+        self._conv(p, xu, y)
+
+        def bwd():
+            dx, first = self._grad_slot(x)
+            ops.conv2d_fwd(self.G[id(y)], p.w_bwd, None, s_, p_, out=dx)
+            self._grad_commit(x, dx, first)
+        self.tape.append(bwd)
+        return y
+
+    # ------------------------------------------------------------------------------------------------------------------
+    def _unit_forward(self, x):
+        """Trainable unit -> (output tensor, closure list already on the tape)."""
+        if self.kind == "rstb":
+            return self._rstb(x, self.mods["rstb"], ops_of=self.ops, need_dx=False)
+        op = self.ops["layer"]
+        if op.is_gdn:
+            raise NotImplementedError("TapeEngine: GDN units do not occur in Lu2022 coders")
+        t = self.t
+        xin = x
+        if op.tconv is not None:
+            s_, q_, Hu, Wu = self.tc_geom
+            xin = ops.zero_insert(x, s_, q_, q_, Hu, Wu, out=t["xu"])
+        epi = op.qm.fused_epilogue() if self.include_act else None
+        y = t["y"]
+        self._conv(op, xin, y, epilogue=L.EPI_NONE if epi is None else epi)
+
+        def bwd():
+            dy = self.G[id(y)]
+            if epi is not None:
+                (ops.lrelu_bwd if epi == L.EPI_LRELU else ops.relu_bwd)(dy, y, t["dpre"])
+                dy = t["dpre"]
+            self._wgrad(op, xin, dy)
+        self.tape.append(bwd)
+        return y
+
+    def _forward_backward(self):
+        if self.kind != "rstb" and not self.tail and not self.tail_round:
+            return super()._forward_backward()
+        from .quant_block import QuantRSTB
+        self.tape, self.G, self._aliased = [], {}, set()
+        x = self.x_in
+        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x)
+        y = self._unit_forward(x)
+        n_unit = len(self.tape)
+        plain = not self.tail and not self.tail_round                 # fp_out is the identity: task == rec (coef 2)
+        dy = self._buf(*y.shape)
+        ops.lp2_loss_grad(y, self.co, self.idx, self.it, 2.0 if plain else 1.0, dy, self.loss_log)
+        if not plain:
+            z = y
+            for st in self.tail:
+                z = self._rstb(z, st, ops_of=None, need_dx=True) if isinstance(st, QuantRSTB) else self._fp_conv(z, st)
+            zr = z
+            if self.tail_round:
+                zr = self._buf(*z.shape)
+                ops.round_(z, out=zr)                                  # round_ste: identity gradient
+            dz = self._buf(*z.shape)
+            ops.lp2_loss_grad(zr, self.task_cache, self.idx, self.it, 1.0, dz, self.loss_log)
+            if z is y:                                                 # round-only tail: both terms meet at the unit output
+                ops.add(dz, dy, out=dy)
+            else:
+                self.G[id(z)] = dz
+                for bw in reversed(self.tape[n_unit:]):
+                    bw()
+                ops.add(self.G[id(y)], dy, out=dy)
+        self.G[id(y)] = dy
+        for bw in reversed(self.tape[:n_unit]):
+            bw()
+        self.G.clear()
+        self.tape = []

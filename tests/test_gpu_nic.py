@@ -113,3 +113,90 @@ def test_nic_caches_and_quantised_forwards_match_reference(golden_dir):
                     h = ref.cuda()
                 if coder == "g_a":
                     h = T(fx[f"{tag}/y_hat"]).cuda()
+
+
+@pytest.mark.parametrize("name", ["g_a0", "g_a1", "g_a7", "h_a3", "h_s1", "g_s7"])
+def test_tape_engine_nic_units_match_oracle(golden_dir, name):
+    """Hot loop of the Lu2022 units on the HIP tape engine vs the oracle (pinned to the reference's block_/layer_reconstruction
+    on the same caches): conv with a 7-stage FP tail, shifted-window RSTB with a 6-stage tail, RSTB with a round-only tail,
+    single-token RSTB (plain rec == task), transposed conv with a tail, last transposed conv.  Same mini-batch indices and
+    counter-RNG QDrop masks on both sides; tolerances as in test_gpu_engine.py."""
+    import sys
+    sys.path.insert(0, os.path.dirname(__file__))
+    import test_oracle_golden as TG
+    from oracle import rdo_oracle as O, swin_oracle as S
+    from quantization import BaseQuantBlock, QuantModel, QuantModule
+    from quantization.recon import fp_out, _unit_modules
+    from quantization.quant_layer import _nhwc
+    from quantization.swin_engine import TapeEngine
+    from helpers import nhwc
+    SEED = 1005
+    fx, model = build(golden_dir)
+    B, iters = int(fx["meta"][4]), int(fx["meta"][5])
+    idx = fx[f"{name}/idx"]
+    # --- oracle
+    _, nic = TG._nic(golden_dir)
+    unit_o = nic.stages[name]
+    if isinstance(unit_o, S.RstbOracle):
+        ops_o, fwd = unit_o.ops, (lambda ops_, x: unit_o(x))
+    else:
+        ops_o, fwd = {"layer": unit_o}, "layer"
+    log = O.reconstruct_unit(fwd, ops_o, T(fx[f"{name}/inp_q"]), T(fx[f"{name}/inp_fp"]), T(fx[f"{name}/out"]), iters=iters,
+                             batch_size=B, idx_stream=idx, mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5),
+                             tail=nic.tail_of(name))
+    # --- product
+    qnn = QuantModel(model=model, weight_quant_params=WQ, act_quant_params=AQ).cuda().eval()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(T(fx["cali"])[:B].cuda())                       # scale init
+    qnn.set_quant_state(False, False)
+    order = [n for n, m in qnn.model.named_children() if isinstance(m, (QuantModule, BaseQuantBlock))]
+    coder = [n for n in order if n.startswith(name[:3])]
+    tail = [getattr(qnn.model, n) for n in coder[coder.index(name) + 1:]]
+    tail_round = name.startswith("g_a")
+    unit = getattr(qnn.model, name)
+    kind, mods = _unit_modules(unit)
+    out_c = T(fx[f"{name}/out"]).cuda()
+    task_cache = _nhwc(fp_out(tail, out_c, tail_round)) if (tail or tail_round) else None
+    eng = TapeEngine(kind, mods, nhwc(fx[f"{name}/inp_q"]), nhwc(fx[f"{name}/inp_fp"]), nhwc(fx[f"{name}/out"]),
+                     tail=tail, tail_round=tail_round, task_cache=task_cache, batch_size=B, iters=iters, seed=SEED,
+                     idx_table=torch.from_numpy(idx))
+    eng.run()
+    torch.cuda.synchronize()
+    total, _, _ = eng.logs()
+    # analysis-transform units end in round_ste: a latent within fp32 noise of x.5 rounds the other way on the GPU and moves
+    # the task term by up to (2|d|+1)/(B*H*W) -- allow three such events; everything else is compared at 3e-4 relative
+    atol = 3.0 * 3.0 / (task_cache.shape[0] and (B * task_cache.shape[1] * task_cache.shape[2])) if tail_round else 1e-7
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=3e-4, atol=atol)
+    flips = tot = 0
+    for k, op in ops_o.items():
+        a_gpu = eng.alpha_of(k).cpu()
+        assert a_gpu.shape == op.alpha.shape, (k, a_gpu.shape, op.alpha.shape)
+        np.testing.assert_allclose(a_gpu.numpy(), op.alpha.numpy(), rtol=0, atol=2e-3, err_msg=k)
+        flips += int(((a_gpu >= 0) != (op.alpha >= 0)).sum())
+        tot += a_gpu.numel()
+    assert flips <= 0.005 * tot, f"{flips}/{tot} rounding decisions differ"
+    eng.finish()
+    for m in unit.modules():
+        if isinstance(m, (QuantModule, BaseQuantBlock)):
+            m.trained = True
+    unit.set_quant_state(True, False)
+    with torch.no_grad():
+        xin = T(fx[f"{name}/inp_q"])[:2]
+        y = unit(xin.cuda()) if isinstance(unit, QuantModule) else unit(xin.cuda(), tuple(xin.shape[2:4]))
+        y_ref = unit_o(xin)
+    err = _rel(y.cpu(), y_ref)
+    assert err < (5e-3 if flips else 5e-5), err
+
+
+@pytest.mark.parametrize("name", ["g_a0", "g_a1", "h_s1", "g_a7"])
+def test_tape_engine_first_iteration_gradient(golden_dir, name):
+    """d(rec + task)/d alpha of the first iteration (rounding regulariser still off): tape engine (data-parallel op sequence,
+    plan A only) against torch autograd through the oracle's unit + FP tail.  1e-4 of the largest gradient entry."""
+    import subprocess, sys
+    env = dict(os.environ, GRAFT_REPO_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, os.path.join(env["GRAFT_REPO_ROOT"], "tools", "dbg_nic_grad.py"), name], env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    rels = [float(l.split("rel")[1]) for l in out.stdout.splitlines() if " rel " in l]
+    assert rels and max(rels) < 1e-4, out.stdout

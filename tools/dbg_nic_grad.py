@@ -1,0 +1,54 @@
+"""First-iteration alpha gradients of the tape engine vs the oracle for the NIC golden units (debug helper)."""
+import sys, os, numpy as np, torch
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, R); sys.path.insert(0, R + '/tests'); sys.path.insert(0, R + '/rdo-ptq_amd')
+import test_gpu_nic as G
+import test_oracle_golden as TG
+from oracle import swin_oracle as S, rdo_oracle as O
+from quantization import BaseQuantBlock, QuantModel, QuantModule
+from quantization.recon import fp_out, _unit_modules
+from quantization.quant_layer import _nhwc
+from quantization.swin_engine import TapeEngine
+from helpers import WQ, AQ, T, nhwc
+gd = R + '/tests/golden'
+SEED = 1005
+for name in sys.argv[1:] or ["g_a0", "g_a1", "g_a7", "h_a3", "h_s1", "g_s7"]:
+    fx, model = G.build(gd)
+    B = int(fx["meta"][4])
+    idx = fx[f"{name}/idx"]
+    _, nic = TG._nic(gd)
+    unit_o = nic.stages[name]
+    ops_o, fwd = (unit_o.ops, (lambda ops_, x: unit_o(x))) if isinstance(unit_o, S.RstbOracle) else ({"layer": unit_o}, "layer")
+    grads = []
+    O.reconstruct_unit(fwd, ops_o, T(fx[f"{name}/inp_q"]), T(fx[f"{name}/inp_fp"]), T(fx[f"{name}/out"]), iters=6, batch_size=B,
+                       idx_stream=idx, mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5), tail=nic.tail_of(name),
+                       grad_hook=lambda gs: (grads.extend(g.clone() for g in gs) if not grads else None))
+    qnn = QuantModel(model=model, weight_quant_params=WQ, act_quant_params=AQ).cuda().eval()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(T(fx["cali"])[:B].cuda())
+    qnn.set_quant_state(False, False)
+    order = [n for n, m in qnn.model.named_children() if isinstance(m, (QuantModule, BaseQuantBlock))]
+    coder = [n for n in order if n.startswith(name[:3])]
+    tail = [getattr(qnn.model, n) for n in coder[coder.index(name) + 1:]]
+    tail_round = name.startswith("g_a")
+    unit = getattr(qnn.model, name)
+    kind, mods = _unit_modules(unit)
+    out_c = T(fx[f"{name}/out"]).cuda()
+    task_cache = _nhwc(fp_out(tail, out_c, tail_round)) if (tail or tail_round) else None
+    eng = TapeEngine(kind, mods, nhwc(fx[f"{name}/inp_q"]), nhwc(fx[f"{name}/inp_fp"]), nhwc(fx[f"{name}/out"]), tail=tail,
+                     tail_round=tail_round, task_cache=task_cache, batch_size=B, iters=6, seed=SEED, idx_table=torch.from_numpy(idx),
+                     force_dp_split=True)
+    eng.plan_a.run(1, graph=False)
+    torch.cuda.synchronize()
+    print(name)
+    for (k, op), g_o in zip(eng.ops.items(), grads):
+        g = op.dalpha.reshape(op.alpha.shape)
+        if op.qm.kind in ("linear", "layernorm"):
+            g = g.reshape(op.qm.org_weight.shape)
+        elif op.tconv is not None:
+            g = g.flip(1, 2).permute(3, 0, 1, 2)
+        else:
+            g = g.permute(0, 3, 1, 2)
+        d = (g.cpu() - g_o).abs()
+        print(f"   {k:44s} max|g| {float(g_o.abs().max()):.3e}  max|d| {float(d.max()):.3e}  rel {float(d.max() / (g_o.abs().max() + 1e-30)):.2e}")
