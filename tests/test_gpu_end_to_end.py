@@ -197,3 +197,71 @@ def test_main2_flow_on_toy_cheng2020_attn_w10():
     psnr_w, bpp_w = evaluate_images(qnn.eval(), test_imgs, p=64)
     assert math.isfinite(psnr_w) and math.isfinite(bpp_w)
     assert abs(psnr_w - psnr_fp) < 3.0 and abs(bpp_w - bpp_fp) < 0.2 * bpp_fp + 0.05
+
+
+def test_main2_flow_on_toy_lu2022():
+    """BASELINE config 4 in miniature: the Lu2022 transformer coder (lic.NIC at embed 16 / latent 32) through the drop-in
+    package only -- QuantModel surgery (RSTB -> QuantRSTB), recon_model over all 24 g_a/h_a/h_s/g_s units plus the entropy
+    parameter / context convs with the sub-coder task loss, W8 and W8A8 evaluation, pickle round trip."""
+    import lic
+    from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstruction, layer_reconstruction
+    from test_datasets import evaluate_images
+    torch.manual_seed(1005)
+    cfg = dict(height=64, width=64, in_chans=3, embed_dim=16, latent_dim=32, window_size=8, mlp_ratio=2.0, qkv_bias=True,
+               qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, use_checkpoint=False)
+    model = lic.NIC(cfg)
+    g = torch.Generator().manual_seed(11)
+    with torch.no_grad():
+        for n_, p_ in model.named_parameters():
+            if p_.dim() >= 2 and "entropy_bottleneck" not in n_:
+                p_.copy_((torch.rand(p_.shape, generator=g) - 0.5) * 2 * (3.0 / p_[0].numel()) ** 0.5)
+    model = model.cuda().eval()
+    n_img, B, iters = 8, 4, 8
+    cali = torch.rand(n_img, 3, 64, 64, generator=g).cuda()
+    test_imgs = [torch.rand(1, 3, 64, 64, generator=g)]
+    psnr_fp, bpp_fp = evaluate_images(model, test_imgs, p=64)
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Lu2022")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
+                  warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    visited = []
+
+    def recon_model(m: nn.Module):
+        for name, module in m.named_children():
+            if isinstance(module, QuantModule):
+                visited.append(name)
+                layer_reconstruction(qnn, module, name, **kwargs)
+            elif isinstance(module, BaseQuantBlock):
+                visited.append(name)
+                block_reconstruction(qnn, module, name, **kwargs)
+            else:
+                recon_model(module)
+
+    qnn.model.g_s7.set_quant_state(True, False)
+    recon_model(qnn)
+    assert visited[:3] == ["g_a0", "g_a1", "g_a2"] and len(visited) == 24 + 1 + 3
+    mods = [m for m in qnn.modules() if isinstance(m, QuantModule) and m.org_weight is not None]
+    assert all(m.trained and hasattr(m.weight_quantizer, "alpha") and not m.weight_quantizer.soft_targets for m in mods)
+    qnn.set_quant_state(True, False)
+    psnr_w8, bpp_w8 = evaluate_images(qnn.eval(), test_imgs, p=64)
+    qnn.set_quant_state(True, True)
+    qnn.model.g_s7.set_quant_state(True, False)
+    psnr_w8a8, bpp_w8a8 = evaluate_images(qnn.eval(), test_imgs, p=64)
+    for v in (psnr_fp, bpp_fp, psnr_w8, bpp_w8, psnr_w8a8, bpp_w8a8):
+        assert math.isfinite(v)
+    assert abs(psnr_w8 - psnr_fp) < 3.0 and abs(bpp_w8 - bpp_fp) < 0.2 * bpp_fp + 0.05
+    buf = io.BytesIO()
+    torch.save(qnn, buf)
+    buf.seek(0)
+    qnn2 = torch.load(buf, weights_only=False)
+    qnn.set_quant_state(True, False)
+    qnn2.set_quant_state(True, False)
+    with torch.no_grad():
+        torch.testing.assert_close(qnn(cali[:2])["x_hat"], qnn2(cali[:2])["x_hat"], rtol=0, atol=0)
