@@ -1,7 +1,7 @@
 // Lu2022 transformer path (reference: models/layers.py:87-305, quantization/quant_block.py:330-547): window attention core with
-// the cyclic shift / window partition folded into the addressing, LayerNorm backward, GELU.  These are small HBM/latency-bound
-// VALU kernels (windows of <= 64 tokens, head dims 12..48): one wavefront owns one (window, head) pair, K/V/Q tiles live in LDS,
-// the N x N score row of a query stays in registers.  The linears around them run on the conv kernels as 1x1 convolutions.
+// the cyclic shift / window partition folded into the addressing, LayerNorm backward, GELU.  Windows have <= 64 tokens and head
+// dims 12..48: one workgroup owns one (window, head) pair with its Q/K/V tiles in LDS.  The linears around them run on the conv
+// kernels as 1x1 convolutions.
 //
 // Token order: qkv / out are [B, H, W, *] in NATURAL pixel order.  Window (b, wh, ww), token (ih, iw) reads the pixel
 // ((wh*ws + ih + shift) % H, (ww*ws + iw + shift) % W): torch.roll(x, -shift) followed by window_partition (layers.py:271-279),
@@ -50,74 +50,6 @@ __device__ __forceinline__ void load_tile(const AttnGeom& g, const float* src, i
     }
 }
 
-// softmax row of query `i` from Q (pre-scaled), K in LDS: S[j] for j < N
-__device__ __forceinline__ void score_row(const AttnGeom& g, const float* Q, const float* K, const float* bias, int win, int head, int i,
-                                          float (&S)[NMAX]) {
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j) S[j] = 0.f;
-    for (int d = 0; d < g.hd; ++d) {
-        const float qd = Q[i * g.hs + d];
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j)
-            if (j < g.N) S[j] += qd * K[j * g.hs + d];
-    }
-    const float* br = bias + ((long)head * g.N + i) * g.N;
-    const int ri = g.shift > 0 ? token_region(g, win, i) : 0;
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j)
-        if (j < g.N) {
-            float s = S[j] + br[j];
-            if (g.shift > 0 && token_region(g, win, j) != ri) s += -100.0f;
-            S[j] = s;
-            mx = fmaxf(mx, s);
-        }
-    float sum = 0.f;
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j)
-        if (j < g.N) {
-            S[j] = expf(S[j] - mx);
-            sum += S[j];
-        }
-    const float inv = 1.0f / sum;
-#pragma unroll
-    for (int j = 0; j < NMAX; ++j)
-        if (j < g.N) S[j] *= inv;
-}
-
-// grid (windows, heads), block 64.  probs (nullable): [windows][N][N][heads] -- channel-last so the per-head activation
-// quantiser (quant_block.py:410-411) can run on it as a [pixels, heads] matrix.  no_pv: stop after writing probs.
-__global__ __launch_bounds__(64) void win_attn_fwd_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
-                                                          int no_pv) {
-    extern __shared__ float lds[];
-    float* Q = lds;
-    float* K = Q + g.N * g.hs;
-    float* V = K + g.N * g.hs;
-    const int win = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
-    load_tile(g, qkv, 3 * g.C, head * g.hd, win, Q, g.scale);
-    load_tile(g, qkv, 3 * g.C, g.C + head * g.hd, win, K, 1.f);
-    load_tile(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
-    __syncthreads();
-    if (i >= g.N) return;
-    float S[NMAX];
-    score_row(g, Q, K, bias, win, head, i, S);
-    if (probs) {
-        float* pr = probs + (((long)win * g.N + i) * g.N) * g.heads + head;
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j)
-            if (j < g.N) pr[(long)j * g.heads] = S[j];
-    }
-    if (no_pv) return;
-    float* o = out + (long)token_pixel(g, win, i) * g.C + head * g.hd;
-    for (int d = 0; d < g.hd; ++d) {
-        float acc = 0.f;
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j)
-            if (j < g.N) acc += S[j] * V[j * g.hs + d];
-        o[d] = acc;
-    }
-}
-
 // out = probs @ v with probs given (after activation quantisation): the second half of the split evaluation path
 __global__ __launch_bounds__(64) void win_attn_pv_kernel(const float* qkv, const float* probs, AttnGeom g, float* out) {
     extern __shared__ float lds[];
@@ -140,71 +72,164 @@ __global__ __launch_bounds__(64) void win_attn_pv_kernel(const float* qkv, const
     }
 }
 
-// backward of the fused core (probabilities recomputed): dqkv [B,H,W,3C] from dout [B,H,W,C]
-//   dP = dO V^T;  D_i = sum_j P_ij dP_ij;  dS = P o (dP - D);  dQ = scale * dS K;  dK = scale * dS^T Q;  dV = P^T dO
-__global__ __launch_bounds__(64) void win_attn_bwd_kernel(const float* qkv, const float* bias, const float* dout, AttnGeom g, float* dqkv) {
+// ---- fused core: one 4-wave workgroup per (window, head); the small GEMMs (Q K^T, P V and, backward, dO V^T, dS K, dS^T Q,
+// P^T dO) run on v_mfma_f32_32x32x2_f32 (exact fp32 products) straight from fp32 LDS images, wave w owning the 32 x 32 tile
+// (w>>1, w&1) of every 64 x 64 / 64 x hd product; softmax rows are handled by one thread each between the GEMM phases.
+// Matrices are zero-padded to 64 rows; [64][hs] operands use an odd row stride hs >= hd + 2, score matrices [64][65].
+//   backward: dP = dO V^T;  D_i = sum_j P_ij dP_ij;  dS = P o (dP - D);  dQ = scale * dS K;  dK = dS^T (scale Q);  dV = P^T dO
+// (a first VALU version -- one wave per pair, score row in registers -- took 0.4 / 1.9 ms per launch on the 128^2 maps of the
+// full-size model, 71 % of a Lu2022 iteration; see profiles/r01_lu2022.md)
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int SS = 65;
+
+// C[i][j] += sum_k A(i,k) * B(k,j) for the wave's tile; TA: A stored [k][i]; TB: B stored [j][k] (else [k][j]).
+// bcols: valid columns of B when B is [k][j] (reads past it are replaced by 0 so the tile may overhang the matrix)
+template <bool TA, bool TB>
+__device__ __forceinline__ f32x16 tile_gemm(const float* A, int lda, const float* B, int ldb, int ti, int tj, int K, int bcols) {
+    const int l = threadIdx.x & 63, lr = l & 31, lk = l >> 5;
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ai = 32 * ti + lr, bj = 32 * tj + lr;
+    for (int s = 0; s < K; s += 2) {
+        const int k = s + lk;
+        const float a = TA ? A[k * lda + ai] : A[ai * lda + k];
+        float b;
+        if (TB) b = B[bj * ldb + k];
+        else b = bj < bcols ? B[k * ldb + bj] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__device__ __forceinline__ void tile_to_lds(const f32x16& acc, float* D, int ldd, int ti, int tj) {
+    const int l = threadIdx.x & 63, lr = l & 31, lk = l >> 5;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) D[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk) * ldd + 32 * tj + lr] = acc[r];
+}
+
+// rows of this tile that are tokens (< N), columns < hd  ->  global [pixel][ch0 + d]
+__device__ __forceinline__ void tile_to_global(const AttnGeom& g, const f32x16& acc, float* dst, int row_stride, int ch0, int win, int ti,
+                                               int tj, float mul) {
+    const int l = threadIdx.x & 63, lr = l & 31, lk = l >> 5;
+    const int d = 32 * tj + lr;
+    if (d >= g.hd) return;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk;
+        if (i < g.N) dst[(long)token_pixel(g, win, i) * row_stride + ch0 + d] = mul * acc[r];
+    }
+}
+
+__device__ __forceinline__ void zero_lds(float* p, int n) {
+    for (int e = threadIdx.x; e < n; e += 256) p[e] = 0.f;
+}
+
+__device__ __forceinline__ void load_tile256(const AttnGeom& g, const float* src, int row_stride, int ch0, int win, float* dst, float mul) {
+    for (int e = threadIdx.x; e < g.N * g.hd; e += 256) {
+        const int tok = e / g.hd, d = e - tok * g.hd;
+        dst[tok * g.hs + d] = mul * src[(long)token_pixel(g, win, tok) * row_stride + ch0 + d];
+    }
+}
+
+// softmax of row i of S (+ bias, + shift mask) in place; returns nothing, P[i][j >= N] = 0
+__device__ __forceinline__ void softmax_row(const AttnGeom& g, float* S, const float* bias, int win, int head, int i) {
+    float* row = S + i * SS;
+    const float* br = bias + ((long)head * g.N + i) * g.N;
+    const int ri = g.shift > 0 ? token_region(g, win, i) : 0;
+    float mx = -3.0e38f;
+    for (int j = 0; j < g.N; ++j) {
+        float s = row[j] + br[j];
+        if (g.shift > 0 && token_region(g, win, j) != ri) s += -100.0f;
+        row[j] = s;
+        mx = fmaxf(mx, s);
+    }
+    float sum = 0.f;
+    for (int j = 0; j < g.N; ++j) {
+        const float e = expf(row[j] - mx);
+        row[j] = e;
+        sum += e;
+    }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < g.N; ++j) row[j] *= inv;
+    for (int j = g.N; j < 64; ++j) row[j] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
+                                                                int no_pv) {
     extern __shared__ float lds[];
-    const int NS = g.N + 1;
-    float* Q = lds;                       // pre-scaled
-    float* K = Q + g.N * g.hs;
-    float* V = K + g.N * g.hs;
-    float* dO = V + g.N * g.hs;
-    float* P = dO + g.N * g.hs;           // [N][N+1]
-    float* dS = P + g.N * NS;
-    const int win = blockIdx.x, head = blockIdx.y, i = threadIdx.x;
-    load_tile(g, qkv, 3 * g.C, head * g.hd, win, Q, g.scale);
-    load_tile(g, qkv, 3 * g.C, g.C + head * g.hd, win, K, 1.f);
-    load_tile(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
-    load_tile(g, dout, g.C, head * g.hd, win, dO, 1.f);
+    float* Q = lds;
+    float* K = Q + 64 * g.hs;
+    float* V = K + 64 * g.hs;
+    float* S = V + 64 * g.hs;
+    const int win = blockIdx.x, head = blockIdx.y;
+    const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
+    zero_lds(lds, 3 * 64 * g.hs);
     __syncthreads();
-    const long pix = i < g.N ? token_pixel(g, win, i) : 0;
-    if (i < g.N) {
-        float S[NMAX], dP[NMAX];
-        score_row(g, Q, K, bias, win, head, i, S);
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j) dP[j] = 0.f;
-        for (int d = 0; d < g.hd; ++d) {
-            const float od = dO[i * g.hs + d];
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j)
-                if (j < g.N) dP[j] += od * V[j * g.hs + d];
+    load_tile256(g, qkv, 3 * g.C, head * g.hd, win, Q, g.scale);
+    load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, win, K, 1.f);
+    load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
+    __syncthreads();
+    const int hk = (g.hd + 1) & ~1;
+    tile_to_lds(tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0), S, SS, ti, tj);
+    __syncthreads();
+    if (threadIdx.x < g.N) {
+        const int i = threadIdx.x;
+        softmax_row(g, S, bias, win, head, i);
+        if (probs) {
+            float* pr = probs + (((long)win * g.N + i) * g.N) * g.heads + head;
+            for (int j = 0; j < g.N; ++j) pr[(long)j * g.heads] = S[i * SS + j];
         }
-        float D = 0.f;
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j)
-            if (j < g.N) D += S[j] * dP[j];
-#pragma unroll
-        for (int j = 0; j < NMAX; ++j)
-            if (j < g.N) {
-                const float ds = S[j] * (dP[j] - D);
-                P[i * NS + j] = S[j];
-                dS[i * NS + j] = ds;
-                dP[j] = ds;
-            }
-        // dQ_i = scale * sum_j dS_ij K_j   (q entered the scores as scale * q)
-        float* dq = dqkv + pix * 3 * g.C + head * g.hd;
-        for (int d = 0; d < g.hd; ++d) {
-            float acc = 0.f;
-#pragma unroll
-            for (int j = 0; j < NMAX; ++j)
-                if (j < g.N) acc += dP[j] * K[j * g.hs + d];
-            dq[d] = g.scale * acc;
+    }
+    if (no_pv) return;
+    __syncthreads();
+    if (32 * tj < g.hd) {
+        const int nk = (g.N + 1) & ~1;
+        const f32x16 o = tile_gemm<false, false>(S, SS, V, g.hs, ti, tj, nk, g.hd);
+        tile_to_global(g, o, out, g.C, head * g.hd, win, ti, tj, 1.f);
+    }
+}
+
+__global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv, const float* bias, const float* dout, AttnGeom g,
+                                                                float* dqkv) {
+    extern __shared__ float lds[];
+    float* Q = lds;                       // pre-scaled
+    float* K = Q + 64 * g.hs;
+    float* V = K + 64 * g.hs;
+    float* dO = V + 64 * g.hs;
+    float* P = dO + 64 * g.hs;            // [64][65]: scores, then probabilities
+    float* dS = P + 64 * SS;              // [64][65]: dP, then dS
+    const int win = blockIdx.x, head = blockIdx.y;
+    const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
+    zero_lds(lds, 4 * 64 * g.hs);
+    __syncthreads();
+    load_tile256(g, qkv, 3 * g.C, head * g.hd, win, Q, g.scale);
+    load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, win, K, 1.f);
+    load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
+    load_tile256(g, dout, g.C, head * g.hd, win, dO, 1.f);
+    __syncthreads();
+    const int hk = (g.hd + 1) & ~1, nk = (g.N + 1) & ~1;
+    tile_to_lds(tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0), P, SS, ti, tj);
+    tile_to_lds(tile_gemm<false, true>(dO, g.hs, V, g.hs, ti, tj, hk, 0), dS, SS, ti, tj);      // dP = dO V^T
+    __syncthreads();
+    if (threadIdx.x < 64) {
+        const int i = threadIdx.x;
+        if (i < g.N) {
+            softmax_row(g, P, bias, win, head, i);
+            float D = 0.f;
+            for (int j = 0; j < g.N; ++j) D += P[i * SS + j] * dS[i * SS + j];
+            for (int j = 0; j < g.N; ++j) dS[i * SS + j] = P[i * SS + j] * (dS[i * SS + j] - D);
+            for (int j = g.N; j < 64; ++j) dS[i * SS + j] = 0.f;
+        } else {
+            for (int j = 0; j < 64; ++j) { P[i * SS + j] = 0.f; dS[i * SS + j] = 0.f; }
         }
     }
     __syncthreads();
-    if (i < g.N) {
-        // lane = key j: dK_j = sum_i dS_ij Qs_i (Qs already carries the scale), dV_j = sum_i P_ij dO_i
-        float* dk = dqkv + pix * 3 * g.C + g.C + head * g.hd;
-        float* dv = dqkv + pix * 3 * g.C + 2 * g.C + head * g.hd;
-        for (int d = 0; d < g.hd; ++d) {
-            float ak = 0.f, av = 0.f;
-            for (int r = 0; r < g.N; ++r) {
-                ak += dS[r * NS + i] * Q[r * g.hs + d];
-                av += P[r * NS + i] * dO[r * g.hs + d];
-            }
-            dk[d] = ak;
-            dv[d] = av;
-        }
+    if (32 * tj < g.hd) {
+        // dQ = scale * dS K ; dK = dS^T Qs (Qs carries the scale) ; dV = P^T dO
+        tile_to_global(g, tile_gemm<false, false>(dS, SS, K, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, head * g.hd, win, ti, tj, g.scale);
+        tile_to_global(g, tile_gemm<true, false>(dS, SS, Q, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, g.C + head * g.hd, win, ti, tj, 1.f);
+        tile_to_global(g, tile_gemm<true, false>(P, SS, dO, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, 2 * g.C + head * g.hd, win, ti, tj, 1.f);
     }
 }
 
@@ -301,7 +326,8 @@ int make_geom(const rdo_attn_desc* d, AttnGeom* g, const char* who) {
     g->B = d->B; g->H = d->H; g->W = d->W; g->C = d->C; g->heads = d->heads; g->ws = d->window; g->shift = d->shift;
     g->N = d->window * d->window;
     g->hd = d->C / d->heads;
-    g->hs = g->hd | 1;
+    g->hs = (g->hd + 2) | 1;                 // odd row stride with room for the zero column an odd head dim needs
+    RDO_REQUIRE(g->hd <= 64, "%s: head dims above 64 are not supported", who);
     g->scale = d->scale;
     return RDO_OK;
 }
@@ -315,11 +341,18 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
     if (int rc = make_geom(d, &g, "rdo_window_attention_fwd")) return rc;
     RDO_REQUIRE(qkv && bias && (out || probs), "rdo_window_attention_fwd: null argument");
     const int windows = g.B * (g.H / g.ws) * (g.W / g.ws);
-    const size_t lds = (size_t)3 * g.N * g.hs * sizeof(float);
+    const size_t lds = ((size_t)3 * 64 * g.hs + (size_t)64 * SS) * sizeof(float);
     const int no_pv = out == nullptr;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(win_attn_fwd_kernel, dim3(windows, g.heads), dim3(64), lds, s, qkv, bias, g, out, probs, no_pv);
+            static bool attr = false;
+            if (!attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_fwd_mfma_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_fwd_mfma) failed");
+                attr = true;
+            }
+            hipLaunchKernelGGL(win_attn_fwd_mfma_kernel, dim3(windows, g.heads), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv);
             return rdo::check_launch("window_attention_fwd");
         },
         stream, "window_attention_fwd", 4.0 * windows * g.heads * (double)g.N * g.N * g.hd,
@@ -345,18 +378,17 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
     if (int rc = make_geom(d, &g, "rdo_window_attention_bwd")) return rc;
     RDO_REQUIRE(qkv && bias && dout && dqkv, "rdo_window_attention_bwd: null argument");
     const int windows = g.B * (g.H / g.ws) * (g.W / g.ws);
-    const size_t lds = ((size_t)4 * g.N * g.hs + (size_t)2 * g.N * (g.N + 1)) * sizeof(float);
+    const size_t lds = ((size_t)4 * 64 * g.hs + (size_t)2 * 64 * SS) * sizeof(float);
     return rdo::dispatch(
         [=](hipStream_t s) {
             static bool attr = false;
             if (!attr) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        96 * 1024) != hipSuccess)
-                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_bwd) failed");
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_bwd_mfma_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess)
+                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_bwd_mfma) failed");
                 attr = true;
             }
-            if (lds > 96 * 1024) return rdo::set_error(RDO_EINVAL, "rdo_window_attention_bwd: head dim too large for the LDS tile");
-            hipLaunchKernelGGL(win_attn_bwd_kernel, dim3(windows, g.heads), dim3(64), lds, s, qkv, bias, dout, g, dqkv);
+            hipLaunchKernelGGL(win_attn_bwd_mfma_kernel, dim3(windows, g.heads), dim3(256), lds, s, qkv, bias, dout, g, dqkv);
             return rdo::check_launch("window_attention_bwd");
         },
         stream, "window_attention_bwd", 10.0 * windows * g.heads * (double)g.N * g.N * g.hd,
