@@ -194,7 +194,7 @@ class TapeEngine(UnitEngine):
             if ln.op is not None:
                 rows = x.numel() // x.shape[-1]
                 if ln.op.slabs is None:
-                    ln.op.slabs = self._buf(max(1, min(64, (rows + 3) // 4)), x.shape[-1])
+                    ln.op.slabs = self._buf(max(1, min(1024, (rows + 15) // 16)), x.shape[-1])     # one block of 4 waves per slab
                 slabs = ln.op.slabs
             dx, first = self._grad_slot(x) if need_dx else (None, True)
             ops.layer_norm_bwd(x, ln.gamma, dy, dx=dx, dgamma_slabs=slabs)
