@@ -192,12 +192,20 @@ class TapeEngine(UnitEngine):
             dy = self.G[id(y)]
             slabs = None
             if ln.op is not None:
-                rows = x.numel() // x.shape[-1]
+                # dgamma partial sums: one 4-wave block per slab.  Many slabs keep the 65k-row maps parallel; they are folded
+                # 32 -> 1 by rdo_reduce_slabs so that the AdaRound step (one thread per weight) sums at most 32 of them
+                rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
                 if ln.op.slabs is None:
-                    ln.op.slabs = self._buf(max(1, min(1024, (rows + 15) // 16)), x.shape[-1])     # one block of 4 waves per slab
-                slabs = ln.op.slabs
+                    n1 = max(1, min(32, (rows + 15) // 16))
+                    n2 = 32 if rows >= 16 * 32 * 4 else 1
+                    ln.op.slabs = self._buf(n1, Cc)
+                    ln.op.slabs_wide = self._buf(n2 * n1, Cc) if n2 > 1 else ln.op.slabs
+                slabs = ln.op.slabs_wide
             dx, first = self._grad_slot(x) if need_dx else (None, True)
             ops.layer_norm_bwd(x, ln.gamma, dy, dx=dx, dgamma_slabs=slabs)
+            if ln.op is not None and ln.op.slabs_wide is not ln.op.slabs:
+                n1 = ln.op.slabs.shape[0]
+                ops.reduce_slabs(slabs.view(slabs.shape[0] // n1, n1 * x.shape[-1]), out=ln.op.slabs.view(-1))
             if need_dx:
                 self._grad_commit(x, dx, first)
         self.tape.append(bwd)
