@@ -227,6 +227,14 @@ int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream);
 int rdo_plan_op_info(const rdo_plan* p, int i, const char** tag, double* flops, double* bytes);
 int rdo_plan_profile(rdo_plan* p, float* ms, void* stream);
 
+/* ---- MS-SSIM pieces of the evaluation path (pytorch_msssim.ms_ssim as used by test_datasets.py:25-27, losses/losses.py:27,54).
+ * Planes [planes][H][W] fp32 (planes = B*C of an NCHW image).  rdo_ssim_level: spatial means of the SSIM and contrast-structure
+ * maps of one scale (11-tap separable window `window11`: HOST pointer to 11 floats; valid padding) -> ssim_mean[planes],
+ * cs_mean[planes].  rdo_avg_pool2: F.avg_pool2d(x, 2, padding=(H%2, W%2)) -> [planes][(H+2(H%2)-2)/2+1][...]. */
+int rdo_ssim_level(const float* x, const float* y, int32_t planes, int32_t H, int32_t W, const float* window11, float c1, float c2,
+                   float* ssim_mean, float* cs_mean, void* stream);
+int rdo_avg_pool2(const float* x, int32_t planes, int32_t H, int32_t W, float* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

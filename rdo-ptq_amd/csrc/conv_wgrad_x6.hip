@@ -41,14 +41,19 @@ __device__ __forceinline__ void split3(float v, short& a, short& b, short& c) {
     a = (short)bf16_bits(h); b = (short)bf16_bits(m); c = (short)bf16_bits(l);
 }
 
-// byte offset of 16-byte chunk c (0..3) of `row` inside one plane of a [rows][32 bf16] tile
-__device__ __forceinline__ int chunk_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
+// byte offset of 16-byte chunk c (0..3) of `row` inside one plane of a [rows][32 bf16] tile.  Every group of four rows is
+// followed by a 16-byte pad: rows r and r+4 then start 4 banks apart, which keeps the fragment ds_read_b128 conflict-free (8
+// consecutive rows hit 8 different 16-byte bank slots) AND spreads the loader's 8-byte transpose stores -- lanes of one store
+// differ in the channel quad, i.e. in row/4 -- over 16 slots instead of the 4 an XOR swizzle of the chunk index leaves them
+// (rocprofv3 SQ_LDS_BANK_CONFLICT was 21 % of the kernel's cycles with the XOR layout).
+constexpr int ROWB = 64, GROUPB = 4 * ROWB + 16;     // bytes per row / per padded group of four rows
+__device__ __forceinline__ int chunk_off(int row, int c) { return (row >> 2) * GROUPB + (row & 3) * ROWB + (c << 4); }
 
 template <int TCO, int TCI>
 __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
     constexpr int WCO = TCO / 2, WCI = TCI / 2;
     constexpr int TM = WCO / 32, TN = WCI / 32;
-    constexpr int YPLANE = TCO * 64, XPLANE = TCI * 64;       // bytes per plane per stage
+    constexpr int YPLANE = TCO / 4 * GROUPB, XPLANE = TCI / 4 * GROUPB;       // bytes per plane per stage
     constexpr int STAGE = 3 * (YPLANE + XPLANE);
     constexpr int QY = TCO / 4, QX = TCI / 4;                 // channel quads per pixel
     constexpr int NBLK = (QY + QX) * 8 / 256;                 // 4-pixel x 4-channel blocks per thread per step
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
             split3(v, h, m, l);
             p0[p] = h; p1[p] = m; p2[p] = l;
         }
-        // row + cc: rows of one aligned group of four share (row >> 2), so the swizzle term is unchanged: + cc * 64 bytes
+        // row + cc: rows of one aligned group of four are 64 bytes apart
         char* st = smem + buf * STAGE + blk_lds[j] + cc * 64;
         const int plane = blk_x[j] ? XPLANE : YPLANE;
         *reinterpret_cast<bf16x4*>(st) = p0;
@@ -243,7 +248,7 @@ int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy,
     a.nsplit = nsplit; a.mchunk = mchunk; a.square_input = d->square_input;
     a.tiles_co = (int)rdo::ceil_div(a.Cout, T);
     a.tiles_ci = (int)rdo::ceil_div(a.Cin, T);
-    constexpr size_t lds = (size_t)2 * 3 * (T + T) * 64;
+    constexpr size_t lds = (size_t)2 * 3 * (T + T) / 4 * (4 * 64 + 16);
     auto kern = conv_wgrad_x6_kernel<T, T>;
     static bool attr_set = false;
     if (!attr_set) {

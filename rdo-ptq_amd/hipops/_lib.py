@@ -65,6 +65,8 @@ _SIGS = {
     "rdo_gelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
     "rdo_gelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_round": (C.c_int, [P, C.c_int64, P, P]),
+    "rdo_ssim_level": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_float), C.c_float, C.c_float, P, P, P]),
+    "rdo_avg_pool2": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "rdo_relu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_pixel_shuffle": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "rdo_add": (C.c_int, [P, P, C.c_int64, P, P]),

@@ -332,6 +332,24 @@ def round_(x, out=None):
     return out
 
 
+def ssim_level(x, y, window, c1, c2):
+    """x, y: [planes, H, W]; window: 11 Python floats -> (ssim_mean[planes], cs_mean[planes])."""
+    planes, H, W = x.shape
+    ssim = torch.empty(planes, device=x.device, dtype=torch.float32)
+    cs = torch.empty(planes, device=x.device, dtype=torch.float32)
+    win = (C.c_float * 11)(*[float(v) for v in window])
+    L.check(L.lib().rdo_ssim_level(_ptr(x), _ptr(y), planes, H, W, win, c1, c2, _ptr(ssim), _ptr(cs), _stream()), "rdo_ssim_level")
+    return ssim, cs
+
+
+def avg_pool2(x):
+    planes, H, W = x.shape
+    ph, pw = H % 2, W % 2
+    out = torch.empty((planes, (H + 2 * ph - 2) // 2 + 1, (W + 2 * pw - 2) // 2 + 1), device=x.device, dtype=torch.float32)
+    L.check(L.lib().rdo_avg_pool2(_ptr(x), planes, H, W, _ptr(out), _stream()), "rdo_avg_pool2")
+    return out
+
+
 def iter_advance(iter_ptr):
     L.check(L.lib().rdo_iter_advance(_ptr(iter_ptr), _stream()), "rdo_iter_advance")
 

@@ -2,8 +2,9 @@
 
     bpp = sum_over_likelihood_tensors( -log2(p) ) / (N*H*W),   loss = lambda * 255^2 * MSE + bpp      (metric 'mse')
 
-MS-SSIM (pytorch_msssim in the reference) is not built yet: the 'ms-ssim' metric raises, and `ms_ssim_loss` is reported
-as NaN for the 'mse' metric (the reference computes it there for logging only, losses.py:24-28)."""
+MS-SSIM (`pytorch_msssim.ms_ssim` in the reference, requirements.txt:6) runs on `rdo_ssim_level` / `rdo_avg_pool2`: five scales,
+11-tap Gaussian window (sigma 1.5), weights (0.0448, 0.2856, 0.3001, 0.2363, 0.1333) -- restated from the package's published
+algorithm [3P-unverified]."""
 import math
 
 import torch
@@ -29,6 +30,33 @@ def mse_of(a, b, clamp01=False) -> torch.Tensor:
     return ops.sq_diff_sum(a.reshape(-1), b.reshape(-1), 1.0 / a.numel(), clamp01).reshape(())
 
 
+_MS_WEIGHTS = (0.0448, 0.2856, 0.3001, 0.2363, 0.1333)
+_MS_WINDOW = [math.exp(-((k - 5) ** 2) / (2 * 1.5 ** 2)) for k in range(11)]
+_MS_WINDOW = [v / sum(_MS_WINDOW) for v in _MS_WINDOW]
+
+
+def ms_ssim(x, y, data_range=1.0, size_average=True):
+    """MS-SSIM of NCHW image batches in [0, data_range]; sides must exceed 160 pixels (five scales of an 11-tap window)."""
+    if x.shape != y.shape or x.dim() != 4:
+        raise ValueError("ms_ssim expects two NCHW tensors of the same shape")
+    if min(x.shape[-2:]) <= (11 - 1) * 2 ** 4:
+        raise ValueError("image side must exceed 160 for the 5-scale MS-SSIM")
+    B, Cc, H, W = x.shape
+    a = x.detach().contiguous().reshape(B * Cc, H, W)
+    b = y.detach().contiguous().reshape(B * Cc, H, W)
+    c1, c2 = (0.01 * data_range) ** 2, (0.03 * data_range) ** 2
+    terms = []
+    for s in range(5):
+        ssim, cs = ops.ssim_level(a, b, _MS_WINDOW, c1, c2)
+        if s < 4:
+            terms.append(torch.relu(cs))
+            a, b = ops.avg_pool2(a), ops.avg_pool2(b)
+    terms.append(torch.relu(ssim))
+    w = torch.tensor(_MS_WEIGHTS, device=x.device).view(-1, 1)
+    val = torch.prod(torch.stack(terms) ** w, dim=0).view(B, Cc)          # 5 x (B*C) scalars: host-side glue
+    return val.mean() if size_average else val.mean(1)
+
+
 class RateDistortionLoss(nn.Module):
     def __init__(self, lmbda=1e-2, metric="mse"):
         super().__init__()
@@ -37,11 +65,14 @@ class RateDistortionLoss(nn.Module):
     def forward(self, output, target):
         N, _, H, W = target.size()
         out = {"bpp_loss": bpp_of(output["likelihoods"], N * H * W), "mse_loss": mse_of(output["x_hat"], target)}
+        big = min(target.shape[-2:]) > 160
         if self.metric == "mse":
-            out["ms_ssim_loss"] = torch.tensor(float("nan"), device=target.device)
+            out["ms_ssim_loss"] = 1 - ms_ssim(output["x_hat"], target, data_range=1.0) if big else \
+                torch.tensor(float("nan"), device=target.device)
             out["loss"] = self.lmbda * 255 ** 2 * out["mse_loss"] + out["bpp_loss"]
         elif self.metric == "ms-ssim":
-            raise NotImplementedError("MS-SSIM is not built yet (SURVEY 8f row 2)")
+            out["ms_ssim_loss"] = 1 - ms_ssim(output["x_hat"], target, data_range=1.0)
+            out["loss"] = self.lmbda * out["ms_ssim_loss"] + out["bpp_loss"]
         else:
             raise ValueError(self.metric)
         return out
@@ -57,12 +88,22 @@ class Metrics(nn.Module):
     def forward(self, output, target):
         N, _, H, W = target.size()
         bpp = bpp_of(output["likelihoods"], N * H * W)
-        return bpp, self.PSNR(output["x_hat"], target), torch.tensor(float("nan"), device=target.device)
+        return bpp, self.PSNR(output["x_hat"], target), self.MS_SSIM(output["x_hat"], target)
+
+    def MS_SSIM(self, x, y):
+        if min(x.shape[-2:]) <= 160:           # pytorch_msssim asserts here; report "not available" for small crops instead
+            return torch.tensor(float("nan"), device=x.device)
+        return torch.mean(ms_ssim(x, y, data_range=1.0, size_average=True))
 
 
 def compute_psnr(a, b):
     """test_datasets.py:21-23"""
     return -10 * math.log10(float(mse_of(a, b)))
+
+
+def compute_msssim(a, b):
+    """test_datasets.py:25-27: MS-SSIM in dB."""
+    return -10 * math.log10(1 - float(ms_ssim(a, b, data_range=1.0)))
 
 
 def compute_bpp(out_net):

@@ -1,5 +1,5 @@
 """Evaluation harness `Test_kodak` (reference surface: test_datasets.py:76-117): pad to a multiple of 256, full-model
-forward, crop, clamp, PSNR / bpp.  MS-SSIM is reported as NaN until that metric is built."""
+forward, crop, clamp, PSNR / MS-SSIM / bpp."""
 import logging
 import math
 import os
@@ -8,7 +8,7 @@ import numpy as np
 import torch
 import torch.nn.functional as F
 
-from losses.losses import compute_bpp, compute_psnr
+from losses.losses import compute_bpp, compute_msssim, compute_psnr
 
 
 def pad(x, p=2 ** 6):
@@ -25,10 +25,10 @@ def crop(x, size):
     return F.pad(x, (-left, -(W - w - left), -top, -(H - h - top)), mode="constant", value=0)
 
 
-def evaluate_images(model, images, p=256):
-    """images: iterable of [1,3,h,w] tensors in [0,1] -> (mean PSNR dB, mean bpp)."""
+def evaluate_images(model, images, p=256, with_msssim=False):
+    """images: iterable of [1,3,h,w] tensors in [0,1] -> (mean PSNR dB, mean bpp[, mean MS-SSIM dB])."""
     device = next(model.parameters()).device
-    psnr = bpp = 0.0
+    psnr = bpp = msssim = 0.0
     n = 0
     for x in images:
         x = x.to(device)
@@ -38,8 +38,10 @@ def evaluate_images(model, images, p=256):
         rec = crop(out["x_hat"], (h, w)).clamp(0, 1)
         psnr += compute_psnr(x, rec)
         bpp += compute_bpp(out)
+        if with_msssim:
+            msssim += compute_msssim(x, rec)
         n += 1
-    return psnr / n, bpp / n
+    return (psnr / n, bpp / n, msssim / n) if with_msssim else (psnr / n, bpp / n)
 
 
 def Test_kodak(model=None, testset_path="./datasets/kodak24"):
@@ -50,9 +52,9 @@ def Test_kodak(model=None, testset_path="./datasets/kodak24"):
         for f in files:
             img = np.asarray(Image.open(os.path.join(testset_path, f)).convert("RGB"), dtype=np.float32) / 255.0
             yield torch.from_numpy(img).permute(2, 0, 1).unsqueeze(0)
-    psnr, bpp = evaluate_images(model, load())
+    psnr, bpp, msssim = evaluate_images(model, load(), with_msssim=True)
     logging.info("Test Data: Kodak24 with 512x768 ")
     logging.info(f"AVG PSNR: {psnr:.2f}dB")
-    logging.info(f"AVG MS-SSIM: {float('nan'):.2f}dB")
+    logging.info(f"AVG MS-SSIM: {msssim:.2f}dB")
     logging.info(f"AVG Bit-rate: {bpp:.4f} bpp")
     return psnr, bpp

@@ -100,8 +100,16 @@ def test_rd_loss_and_metrics_match_reference_formulas():
     b2, psnr, _ = Metrics()(out, x.cuda())
     per_img = torch.mean((xh - x) ** 2, dim=[1, 2, 3])
     assert abs(float(psnr) - float(torch.mean(10 * torch.log10(1. / per_img)))) < 1e-4
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(ValueError):                      # 64 x 48 is too small for the five MS-SSIM scales
         RateDistortionLoss(metric="ms-ssim")(out, x.cuda())
+    # the 'ms-ssim' objective on a large enough image: lambda * (1 - MS-SSIM) + bpp (losses.py:30-33)
+    from oracle import msssim_oracle as MO
+    xb = torch.rand(1, 3, 192, 192, generator=g)
+    xbh = (xb + 0.05 * torch.randn(1, 3, 192, 192, generator=g)).clamp(0, 1)
+    outb = {"x_hat": xbh.cuda(), "likelihoods": {"y": ly[:1].cuda()}}
+    rb = RateDistortionLoss(lmbda=4.58, metric="ms-ssim")(outb, xb.cuda())
+    want = 4.58 * (1 - float(MO.ms_ssim(xbh, xb))) + float((-torch.log2(ly[:1])).sum() / (192 * 192))
+    assert abs(float(rb["loss"]) - want) < 1e-4 * want
 
 
 @pytest.mark.parametrize("quant", [False, True])
@@ -155,3 +163,20 @@ def test_full_model_forward_matches_oracle(quant):
         assert float(bad) < 5e-3, (k, float(bad))
     psnr, bpp = evaluate_images(qnn, [x[i:i + 1] for i in range(2)], p=64)
     assert math.isfinite(psnr) and bpp > 0
+
+
+@pytest.mark.parametrize("shape", [(1, 3, 192, 176), (2, 3, 256, 256), (1, 3, 337, 263)])
+def test_ms_ssim_matches_oracle(shape):
+    """MS-SSIM (rdo_ssim_level + rdo_avg_pool2, five scales) against the oracle's restatement of pytorch_msssim.ms_ssim, incl.
+    odd sizes (padded 2x2 pooling).  fp32 separable filtering in a different summation order: 2e-5 absolute."""
+    from oracle import msssim_oracle as MO
+    from losses.losses import compute_msssim, ms_ssim
+    g = torch.Generator().manual_seed(shape[2])
+    x = torch.rand(shape, generator=g)
+    y = (x + 0.08 * torch.randn(shape, generator=g)).clamp(0, 1)
+    ref = MO.ms_ssim(x, y, data_range=1.0, size_average=False)
+    got = ms_ssim(x.cuda(), y.cuda(), data_range=1.0, size_average=False).cpu()
+    torch.testing.assert_close(got, ref, rtol=0, atol=2e-5)
+    assert abs(compute_msssim(x[:1].cuda(), y[:1].cuda()) - (-10 * math.log10(1 - float(MO.ms_ssim(x[:1], y[:1]))))) < 1e-3
+    with pytest.raises(ValueError):
+        ms_ssim(x[..., :160, :160].cuda(), y[..., :160, :160].cuda())
