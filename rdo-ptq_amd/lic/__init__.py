@@ -5,9 +5,9 @@ from .layers import (AttentionBlock, GDN, MaskedConv2d, NonNegativeParametrizer,
                      ResidualBlockWithStride, conv1x1, conv3x3, subpel_conv3x3)
 from .entropy import EntropyBottleneck, GaussianConditional
 from .cheng2020 import Cheng2020Anchor, Cheng2020Attention
-from .minnen2018 import MeanScaleHyperprior
+from .minnen2018 import JointAutoregressiveHierarchicalPriors, MeanScaleHyperprior
 from .nic import NIC, RSTB
 
 __all__ = ["AttentionBlock", "Cheng2020Attention", "GDN", "MaskedConv2d", "NonNegativeParametrizer", "ResidualBlock", "ResidualBlockUpsample",
            "ResidualBlockWithStride", "conv1x1", "conv3x3", "subpel_conv3x3", "EntropyBottleneck", "GaussianConditional",
-           "Cheng2020Anchor", "MeanScaleHyperprior", "NIC", "RSTB"]
+           "Cheng2020Anchor", "JointAutoregressiveHierarchicalPriors", "MeanScaleHyperprior", "NIC", "RSTB"]

@@ -265,3 +265,41 @@ def test_main2_flow_on_toy_lu2022():
     qnn2.set_quant_state(True, False)
     with torch.no_grad():
         torch.testing.assert_close(qnn(cali[:2])["x_hat"], qnn2(cali[:2])["x_hat"], rtol=0, atol=0)
+
+
+def test_mbt2018_context_model_w8a8_eval_at_kodak_size():
+    """BASELINE config 5 in miniature: Minnen2018 with the autoregressive context model (lic.JointAutoregressiveHierarchicalPriors,
+    narrow widths), nearest-rounded W8 weights + dynamic A8 activations, one 768x512 image through `evaluate_images` (pad, forward,
+    crop, PSNR / bpp / MS-SSIM), once locally and once through the image-parallel path on a 1-rank process group."""
+    import os
+    import lic
+    from quantization import QuantModel, QuantModule, BaseQuantBlock
+    from test_datasets import evaluate_images
+    torch.manual_seed(5)
+    model = lic.JointAutoregressiveHierarchicalPriors(N=16, M=24).cuda().eval()
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    g = torch.Generator().manual_seed(6)
+    imgs = [torch.rand(1, 3, 512, 768, generator=g), torch.rand(1, 3, 512, 768, generator=g)]
+    psnr_fp, bpp_fp, ms_fp = evaluate_images(model, imgs, p=64, with_msssim=True, distributed=False)
+    for m in qnn.modules():
+        if isinstance(m, (QuantModule, BaseQuantBlock)):
+            m.trained = True
+    qnn.set_quant_state(True, True)
+    qnn.model.g_s[-1].set_quant_state(True, False)
+    local = evaluate_images(qnn, imgs, p=64, with_msssim=True, distributed=False)
+    assert all(math.isfinite(v) for v in local + (psnr_fp, bpp_fp, ms_fp))
+    assert abs(local[0] - psnr_fp) < 3.0
+    if not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        sharded = evaluate_images(qnn, imgs, p=64, with_msssim=True)
+    finally:
+        torch.distributed.destroy_process_group()
+    for a, b in zip(local, sharded):
+        assert abs(a - b) < 1e-5 * max(1.0, abs(a))       # reduction kernels accumulate with float atomics: order varies
