@@ -1,15 +1,14 @@
 // Forward / dgrad conv of the LARGE problems (rdo_conv2d_fwd_uses_bf16x6) with each fp32 operand split exactly into three
-// bf16 planes and the six significant cross products issued on v_mfma_f32_32x32x16_bf16 ("bf16x6").  v1/v2 kernels below are
-// kept for tuning (RDO_X6_VER = 1..4); v5 (128 x 192 tile, K stage 16, weight tile staged by LDS-DMA, fragment reads pipelined one
-// stage ahead) is the one rdo_conv2d_fwd dispatches to.
+// bf16 planes and the six significant cross products issued on v_mfma_f32_32x32x16_bf16 ("bf16x6").
+// v5 (128 x 192 tile, K stage 16, weight tile staged by LDS-DMA, fragment reads pipelined one stage ahead) is the one
+// rdo_conv2d_fwd dispatches to; v3 (register-staged) remains as the fallback for weight tensors beyond 2^31 plane elements.
 //
 //   x = x1 + x2 + x3 exactly (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)), same for w;
 //   x*w ~= x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1          dropped terms <= 3 * 2^-24 |x w|  (fp32-rounding level)
 //
 // Each bf16 product is exact in fp32 and the MFMA accumulates in fp32, so the result has fp32-level accuracy at 16/6 the
 // fp32-MFMA rate.  Weights arrive pre-split ([3][Cout][KH][KW][Cin] bf16, rdo_split_bf16x3); activations are split in the
-// loader.  Tile 64 x 192, K stage 32 (two 16-deep MFMA steps), LDS rows of 64 B per plane with a 16-byte chunk swizzle
-// chunk ^= (row>>2)&3 (conflict-free ds_read_b128), same slot pipeline as conv_fwd.hip.
+// loader.
 #include <utility>
 
 #include "rdo_common.h"
@@ -36,7 +35,6 @@ struct X6Args {
     int M, csteps;
     int epilogue, square_input, add_residual;
     long wplane;          // elements per weight plane
-    int ablate;           // diagnosis only: 1 skip B loads, 2 skip A split, 4 skip LDS stores, 8 skip MFMAs, 16 skip A loads
     float* partial;       // split-K (v3): raw accumulators [ksplit][M][Cout]; nullptr -> final output
     int ksplit;
 };
@@ -67,379 +65,8 @@ __device__ __forceinline__ void finish(const X6Args& a, long o, float v) {
     a.out[o] = v;
 }
 
-// byte offset of 16-byte chunk c (0..3) of `row` inside one plane of a [rows][32 bf16] tile
-__device__ __forceinline__ int chunk_off(int row, int c) { return row * 64 + ((c ^ ((row >> 2) & 3)) << 4); }
-
-template <int BM, int BN>
-__global__ __launch_bounds__(256) void conv_fwd_x6_kernel(X6Args a) {
-    constexpr int WM = BM / 2, WN = BN / 2;           // 2x2 waves
-    constexpr int TM = WM / 32, TN = WN / 32;
-    constexpr int AQ = BM / 32;                        // fp32 quads of A per thread per stage
-    constexpr int BC = (BN * 4 * 3 + 255) / 256;       // 16-byte chunks of B (3 planes) per thread per stage
-    constexpr int NQ = AQ + BC;
-    constexpr int APLANE = BM * 64, BPLANE = BN * 64;  // bytes per plane per stage
-    constexpr int STAGE = 3 * (APLANE + BPLANE);
-    static_assert(NQ <= 12, "one staging item per MFMA group");
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
-    const int li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-    const int q = tid & 7, r0 = tid >> 3;
-
-    int hi0[AQ], wi0[AQ], abase[AQ];
-#pragma unroll
-    for (int j = 0; j < AQ; ++j) {
-        int m = m0 + r0 + 32 * j;
-        const bool okr = m < a.M;
-        int mm = okr ? m : 0;
-        int b = mm / (a.Ho * a.Wo);
-        int rem = mm - b * (a.Ho * a.Wo);
-        int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        hi0[j] = okr ? ho * a.stride - a.pad : -(1 << 28);
-        wi0[j] = wo * a.stride - a.pad;
-        abase[j] = b * a.H * a.W * a.Cin;
-    }
-    // B chunks: item e = tid + 256*j over [plane][row][chunk]; (plane, row, chunk) are fixed per (thread, j)
-    int brow[BC], bchunk[BC], bplane[BC];
-#pragma unroll
-    for (int j = 0; j < BC; ++j) {
-        int e = tid + 256 * j;
-        bplane[j] = e / (BN * 4);
-        int r = e - bplane[j] * (BN * 4);
-        brow[j] = r >> 2;
-        bchunk[j] = r & 3;
-    }
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    f32x4 ra[AQ];
-    bf16x8 rb[BC];
-    unsigned okmask = 0;
-    const int nsteps = a.KH * a.KW * a.csteps;
-
-    auto load_item = [&](auto jc, int s) {
-        constexpr int j = decltype(jc)::value;
-        const int tap = s / a.csteps;
-        const int cbase = (s - tap * a.csteps) * BK;
-        const int kh = tap / a.KW, kw = tap - kh * a.KW;
-        bool ok;
-        if constexpr (j < AQ) {
-            const int c0 = cbase + 4 * q;
-            const int hi = hi0[j] + kh, wi = wi0[j] + kw;
-            ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W && c0 < a.Cin;
-            const int off = abase[j] + (hi * a.W + wi) * a.Cin + c0;
-            ra[j] = *reinterpret_cast<const f32x4*>(a.x + (ok ? off : 0));
-        } else {
-            constexpr int jb = j - AQ;
-            const int n = n0 + brow[jb];
-            const int c0 = cbase + 8 * bchunk[jb];
-            ok = bplane[jb] >= 0 && n < a.Cout && c0 < a.Cin;
-            const long off = (long)bplane[jb] * a.wplane + ((long)n * a.KH * a.KW + (kh * a.KW + kw)) * a.Cin + c0;
-            rb[jb] = *reinterpret_cast<const bf16x8*>(a.wp + (ok ? off : 0));
-        }
-        okmask = ok ? (okmask | (1u << j)) : (okmask & ~(1u << j));
-    };
-    auto store_item = [&](auto jc, int buf) {
-        constexpr int j = decltype(jc)::value;
-        char* st = smem + buf * STAGE;
-        const bool ok = (okmask >> j) & 1u;
-        if constexpr (j < AQ) {
-            f32x4 v = ok ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a.square_input) v = v * v;
-            bf16x4 p0, p1, p2;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u16 h, m, l;
-                split3(v[e], h, m, l);
-                p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
-            }
-            const int row = r0 + 32 * j;
-            const int off = chunk_off(row, q >> 1) + (q & 1) * 8;
-            *reinterpret_cast<bf16x4*>(st + 0 * APLANE + off) = p0;
-            *reinterpret_cast<bf16x4*>(st + 1 * APLANE + off) = p1;
-            *reinterpret_cast<bf16x4*>(st + 2 * APLANE + off) = p2;
-        } else {
-            constexpr int jb = j - AQ;
-            static_assert((BN * 12) % 256 == 0, "B chunks must divide evenly over the 256 threads");
-            bf16x8 v = ok ? rb[jb] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            *reinterpret_cast<bf16x8*>(st + 3 * APLANE + bplane[jb] * BPLANE + chunk_off(brow[jb], bchunk[jb])) = v;
-        }
-    };
-    auto for_each_item = [&](auto&& f) {
-        [&]<int... J>(std::integer_sequence<int, J...>) { (f(std::integral_constant<int, J>{}), ...); }
-        (std::make_integer_sequence<int, NQ>{});
-    };
-
-    for_each_item([&](auto jc) { load_item(jc, 0); });
-    for_each_item([&](auto jc) { store_item(jc, 0); });
-    for_each_item([&](auto jc) { load_item(jc, nsteps > 1 ? 1 : 0); });
-    __syncthreads();
-
-    // products in increasing magnitude: (a3,b1) (a2,b2) (a1,b3) (a2,b1) (a1,b2) (a1,b1)
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        const int s2 = s + 2 < nsteps ? s + 2 : nsteps - 1;
-        const char* st = smem + buf * STAGE;
-        bf16x8 fa[2][3][TM], fb[2][3][TN];
-        auto read_frags = [&](int kb, int set) {
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int row = wm0 + i * 32 + li;
-                    fa[set][p][i] = *reinterpret_cast<const bf16x8*>(st + p * APLANE + chunk_off(row, 2 * kb + lh));
-                }
-#pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int row = wn0 + j * 32 + li;
-                    fb[set][p][j] = *reinterpret_cast<const bf16x8*>(st + 3 * APLANE + p * BPLANE + chunk_off(row, 2 * kb + lh));
-                }
-            }
-        };
-        read_frags(0, 0);
-        [&]<int... SL>(std::integer_sequence<int, SL...>) {
-            (([&] {
-                 constexpr int kb = SL / 6, pr = SL % 6;
-                 if constexpr (SL == 1) read_frags(1, 1);
-#pragma unroll
-                 for (int i = 0; i < TM; ++i)
-#pragma unroll
-                     for (int j = 0; j < TN; ++j)
-                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kb][PA[pr]][i], fb[kb][PB[pr]][j], acc[i][j], 0, 0, 0);
-                 if constexpr (SL < NQ) {
-                     store_item(std::integral_constant<int, SL>{}, buf ^ 1);
-                     load_item(std::integral_constant<int, SL>{}, s2);
-                 }
-                 __builtin_amdgcn_sched_barrier(0);
-             }()),
-             ...);
-        }
-        (std::make_integer_sequence<int, 12>{});
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + j * 32 + li;
-        if (n >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (m < a.M) finish(a, (long)m * a.Cout + n, acc[i][j][r] + bv);
-            }
-    }
-}
-
-// ---- v2: K stage of 16 (one MFMA k-step), 48 KiB LDS -> 3 workgroups per CU, lean incremental addressing --------------
-// LDS rows are 32 B per plane (2 chunks); chunk swizzle c ^= (row>>3)&1.
+// LDS rows are 32 B per plane (2 chunks of 8 bf16); chunk swizzle c ^= (row>>3)&1 keeps ds_read_b128 conflict-free.
 __device__ __forceinline__ int chunk_off16(int row, int c) { return row * 32 + ((c ^ ((row >> 3) & 1)) << 4); }
-
-__global__ __launch_bounds__(256, 3) void conv_fwd_x6v2_kernel(X6Args a) {
-    constexpr int BM = 64, BN = 192, KS = 16;
-    constexpr int TN = 3;                                  // wave tile 32 x 96 (2x2 waves)
-    constexpr int APLANE = BM * 32, BPLANE = BN * 32;      // bytes per plane per stage
-    constexpr int STAGE = 3 * (APLANE + BPLANE);           // 24 KiB
-    constexpr int NB = 5;                                  // B chunks per thread (the 5th only for tid < 128)
-
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE] + 4 KiB dummy target for masked chunk stores
-    char* dummy = smem + 2 * STAGE;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 96;
-    const int li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
-
-    // A: one fp32 quad per thread per stage: row = tid>>2, k-quad = tid&3
-    const int arow = tid >> 2, aq = tid & 3;
-    int hi0, wi0, abase;
-    {
-        const int m = m0 + arow;
-        const bool okr = m < a.M;
-        const int mm = okr ? m : 0;
-        const int b = mm / (a.Ho * a.Wo);
-        const int rem = mm - b * (a.Ho * a.Wo);
-        const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-        hi0 = okr ? ho * a.stride - a.pad : -(1 << 28);
-        wi0 = wo * a.stride - a.pad;
-        abase = b * a.H * a.W * a.Cin + 4 * aq;
-    }
-    const int a_lds = chunk_off16(arow, aq >> 1) + (aq & 1) * 8;
-    // B: chunk e = tid + 256 j over [plane][row][chunk(2)]
-    long wbase[NB];
-    int b_lds[NB];
-    bool b_ok[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int e = tid + 256 * j;
-        const bool live = e < 3 * BN * 2;
-        const int ee = live ? e : 0;
-        const int pl = ee / (BN * 2);
-        const int r = ee - pl * (BN * 2);
-        const int row = r >> 1, ch = r & 1;
-        const int n = n0 + row;
-        b_ok[j] = live && n < a.Cout;
-        wbase[j] = (long)pl * a.wplane + (long)(n < a.Cout ? n : 0) * a.KH * a.KW * a.Cin + 8 * ch;
-        b_lds[j] = live ? 3 * APLANE + pl * BPLANE + chunk_off16(row, ch) : -1;
-    }
-
-    f32x16 acc[TN];
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
-
-    const int csteps = (a.Cin + KS - 1) / KS;
-    const int nsteps = a.KH * a.KW * csteps;
-
-    // load cursor (wave-uniform): stage index, tap, channel offset; per-thread pixel offset of the cursor's tap
-    int lc = 0, ltap = 0, lkh = 0, lkw = 0;
-    int apix;
-    bool apix_ok;
-    auto retap = [&]() {
-        const int hi = hi0 + lkh, wi = wi0 + lkw;
-        apix_ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        apix = abase + (hi * a.W + wi) * a.Cin;
-    };
-    auto advance = [&]() {      // move the cursor one stage forward (clamped at the last stage by the caller)
-        lc += KS;
-        if (lc >= a.Cin) {
-            lc = 0;
-            ++ltap;
-            ++lkw;
-            if (lkw == a.KW) { lkw = 0; ++lkh; }
-            retap();
-        }
-    };
-    retap();
-
-    f32x4 ra;
-    bf16x8 rb[NB];
-    bool ra_ok;
-    auto load_a = [&]() {
-        ra_ok = apix_ok && lc + 4 * aq < a.Cin;
-        if (!(a.ablate & 16)) ra = *reinterpret_cast<const f32x4*>(a.x + (ra_ok ? apix + lc : 0));
-    };
-    auto load_b = [&](auto jc) {
-        constexpr int j = decltype(jc)::value;
-        const long off = wbase[j] + (long)ltap * a.Cin + lc;
-        if (!(a.ablate & 1)) rb[j] = *reinterpret_cast<const bf16x8*>(a.wp + (b_ok[j] ? off : 0));
-    };
-    auto store_a = [&](int buf) {
-        f32x4 v = ra_ok ? ra : f32x4{0.f, 0.f, 0.f, 0.f};
-        if (a.square_input) v = v * v;
-        bf16x4 p0, p1, p2;
-        if (a.ablate & 2) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { p0[e] = (short)(__float_as_uint(v[e]) >> 16); p1[e] = 0; p2[e] = 0; }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u16 h, m, l;
-                split3(v[e], h, m, l);
-                p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
-            }
-        }
-        if (a.ablate & 4) { asm volatile("" ::"v"(p0), "v"(p1), "v"(p2)); return; }
-        char* st = smem + buf * STAGE + a_lds;
-        *reinterpret_cast<bf16x4*>(st) = p0;
-        *reinterpret_cast<bf16x4*>(st + APLANE) = p1;
-        *reinterpret_cast<bf16x4*>(st + 2 * APLANE) = p2;
-    };
-    auto store_b = [&](auto jc, int buf) {
-        constexpr int j = decltype(jc)::value;
-        const bf16x8 v = b_ok[j] ? rb[j] : bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        if (a.ablate & 4) { asm volatile("" ::"v"(v)); return; }
-        char* dst = b_lds[j] >= 0 ? smem + buf * STAGE + b_lds[j] : dummy + tid * 16;
-        *reinterpret_cast<bf16x8*>(dst) = v;
-    };
-    auto all_b = [&](auto&& f) {
-        [&]<int... J>(std::integer_sequence<int, J...>) { (f(std::integral_constant<int, J>{}), ...); }
-        (std::make_integer_sequence<int, NB>{});
-    };
-
-    // prologue: stage 0 -> LDS buffer 0; stage 1 -> registers
-    load_a();
-    all_b([&](auto jc) { load_b(jc); });
-    store_a(0);
-    all_b([&](auto jc) { store_b(jc, 0); });
-    if (nsteps > 1) advance();
-    load_a();
-    all_b([&](auto jc) { load_b(jc); });
-    __syncthreads();
-
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
-    // fragment addresses are loop-invariant up to the buffer offset
-    int fa_off[3], fb_off[3][TN];
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-        fa_off[p] = p * APLANE + chunk_off16(wm0 + li, lh);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) fb_off[p][j] = 3 * APLANE + p * BPLANE + chunk_off16(wn0 + j * 32 + li, lh);
-    }
-
-    for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        const char* st = smem + buf * STAGE;
-        bf16x8 fa[3], fb[3][TN];
-#pragma unroll
-        for (int p = 0; p < 3; ++p) {
-            fa[p] = *reinterpret_cast<const bf16x8*>(st + fa_off[p]);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(st + fb_off[p][j]);
-        }
-        if (s + 2 < nsteps) advance();     // cursor -> stage s+2 (uniform branch; tail stages re-load the last stage)
-        [&]<int... SL>(std::integer_sequence<int, SL...>) {
-            (([&] {
-                 if (!(a.ablate & 8)) {
-#pragma unroll
-                     for (int j = 0; j < TN; ++j)
-                         acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[SL]], fb[PB[SL]][j], acc[j], 0, 0, 0);
-                 } else {
-                     asm volatile("" ::"v"(fa[PA[SL]]), "v"(fb[PB[SL]][0]), "v"(fb[PB[SL]][1]), "v"(fb[PB[SL]][2]));
-                 }
-                 if constexpr (SL == 0) {
-                     store_a(buf ^ 1);
-                     load_a();
-                 } else {
-                     store_b(std::integral_constant<int, SL - 1>{}, buf ^ 1);
-                     load_b(std::integral_constant<int, SL - 1>{});
-                 }
-                 __builtin_amdgcn_sched_barrier(0);
-             }()),
-             ...);
-        }
-        (std::make_integer_sequence<int, 6>{});
-        __syncthreads();
-    }
-
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn0 + j * 32 + li;
-        if (n >= a.Cout) continue;
-        const float bv = a.bias ? a.bias[n] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-            if (m < a.M) finish(a, (long)m * a.Cout + n, acc[j][r] + bv);
-        }
-    }
-}
 
 // ---- v3: as v2 with a 128 x 192 workgroup tile (wave tile 64 x 96): half the weight-tile traffic and fragment reads per MFMA
 // LDS rows are 32 B per plane (2 chunks); chunk swizzle c ^= (row>>3)&1.
@@ -555,7 +182,6 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         constexpr int j = decltype(jc)::value;
         typedef __attribute__((address_space(3))) void lds_void;
         typedef const __attribute__((address_space(1))) void glb_void;
-        if (a.ablate & 1) return;
         const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
         char* dst = smem + buf * STAGE + 3 * APLANE + k * 1024;
         __builtin_amdgcn_global_load_lds((glb_void*)(a.wp + dma_src[j] + bcur), (lds_void*)dst, 16, 0, 0);
@@ -566,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
     bool ra_ok[2];
     auto load_a = [&](int t) {
         ra_ok[t] = apix_ok[t] && lc + 4 * aq < a.Cin;
-        if (!(a.ablate & 16)) ra[t] = *reinterpret_cast<const f32x4*>(a.x + (ra_ok[t] ? apix[t] + lc : 0));
+        ra[t] = *reinterpret_cast<const f32x4*>(a.x + (ra_ok[t] ? apix[t] + lc : 0));
     };
     auto load_b = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
@@ -577,18 +203,11 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         f32x4 v = ra_ok[t] ? ra[t] : f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.square_input) v = v * v;
         bf16x4 p0, p1, p2;
-        if (a.ablate & 4) { asm volatile("" ::"v"(v)); return; }
-        if (a.ablate & 2) {
-            p0 = __builtin_bit_cast(bf16x4, f32x4{v[0], v[1], 0.f, 0.f}.xy);
-            p1 = __builtin_bit_cast(bf16x4, f32x4{v[2], v[3], 0.f, 0.f}.xy);
-            p2 = p0;
-        } else {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                u16 h, m, l;
-                split3(v[e], h, m, l);
-                p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
-            }
+        for (int e = 0; e < 4; ++e) {
+            u16 h, m, l;
+            split3(v[e], h, m, l);
+            p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
         }
         char* st = smem + buf * STAGE + a_lds[t];
         *reinterpret_cast<bf16x4*>(st) = p0;
@@ -647,8 +266,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
                  for (int i = 0; i < TM; ++i)
 #pragma unroll
                      for (int j = 0; j < TN; ++j)
-                         if (!(a.ablate & 8) || (i == 0 && j == 0))
-                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[SL]][i], fb[PB[SL]][j], acc[i][j], 0, 0, 0);
+                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[SL]][i], fb[PB[SL]][j], acc[i][j], 0, 0, 0);
                  if constexpr (DMA) {
                      // stage s+1's weight image goes straight to LDS (it must land before the barrier that ends this stage)
                      // the register-staged A quads are written before any DMA is issued: hipcc waits vmcnt(0) at a use of
@@ -979,7 +597,6 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
     a.csteps = (d->Cin + BK - 1) / BK;
     a.epilogue = d->epilogue; a.square_input = d->square_input; a.add_residual = d->add_residual;
     a.wplane = (long)d->Cout * d->KH * d->KW * d->Cin;
-    a.ablate = getenv("RDO_X6_ABLATE") ? atoi(getenv("RDO_X6_ABLATE")) : 0;
     int ks = rdo_conv2d_fwd_bf16x6_ksplit(d);
     if (ks < 1) ks = 1;
     if (ks > 1 && (!workspace || (long)ks * a.M * a.Cout > workspace_floats)) ks = 1;
@@ -988,92 +605,31 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
     return rdo::dispatch(
         [a](hipStream_t s) {
+            // RDO_X6_VER=3 / 4 select the earlier register-staged / LDS-DMA variants of the same tile (kept for A/B measurements);
+            // the LDS-DMA loaders address the weight planes with 32-bit element offsets
             static const int ver_env = getenv("RDO_X6_VER") ? atoi(getenv("RDO_X6_VER")) : 5;
-            // the LDS-DMA loader addresses the weight planes with 32-bit element offsets
-            const int ver = (ver_env >= 4 && 3 * a.wplane >= (1L << 31)) ? 3 : ver_env;
-            if (ver == 2) {
-                constexpr size_t lds2 = (size_t)2 * 3 * (64 + 192) * 32 + 4096;
-                static bool attr2 = false;
-                if (!attr2) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v2_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2) != hipSuccess)
-                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6v2) failed");
-                    attr2 = true;
-                }
-                dim3 grid((unsigned)rdo::ceil_div(a.M, 64), (unsigned)rdo::ceil_div(a.Cout, 192));
-                hipLaunchKernelGGL(conv_fwd_x6v2_kernel, grid, dim3(256), lds2, s, a);
-                return rdo::check_launch("conv_fwd_x6v2");
+            const int ver = (ver_env != 3 && 3 * a.wplane >= (1L << 31)) ? 3 : ver_env;
+            const void* kern = ver == 3 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<false>)
+                             : ver == 4 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<true>)
+                                        : reinterpret_cast<const void*>(conv_fwd_x6v5_kernel);
+            const size_t lds = (size_t)2 * 3 * (128 + 192) * 32 + (ver == 5 ? 0 : 4096);
+            static bool attr[3] = {false, false, false};
+            if (!attr[ver - 3]) {
+                if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6 v%d) failed", ver);
+                attr[ver - 3] = true;
             }
-            if (ver == 5) {
-                constexpr size_t lds5 = (size_t)2 * 3 * (128 + 192) * 32;
-                static bool attr5 = false;
-                if (!attr5) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v5_kernel),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds5) != hipSuccess)
-                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6v5) failed");
-                    attr5 = true;
-                }
-                dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
-                hipLaunchKernelGGL(conv_fwd_x6v5_kernel, grid, dim3(256), lds5, s, a);
-                if (int rc = rdo::check_launch("conv_fwd_x6v5")) return rc;
-                if (a.ksplit > 1) {
-                    long g = rdo::ceil_div((long)a.M * a.Cout, 256);
-                    hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
-                    return rdo::check_launch("x6_splitk_epilogue");
-                }
-                return RDO_OK;
+            dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
+            if (ver == 3) hipLaunchKernelGGL(conv_fwd_x6v3_kernel<false>, grid, dim3(256), lds, s, a);
+            else if (ver == 4) hipLaunchKernelGGL(conv_fwd_x6v3_kernel<true>, grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL(conv_fwd_x6v5_kernel, grid, dim3(256), lds, s, a);
+            if (int rc = rdo::check_launch("conv_fwd_x6")) return rc;
+            if (a.ksplit > 1) {
+                long g = rdo::ceil_div((long)a.M * a.Cout, 256);
+                hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
+                return rdo::check_launch("x6_splitk_epilogue");
             }
-            if (ver == 4) {
-                constexpr size_t lds3 = (size_t)2 * 3 * (128 + 192) * 32 + 4096;
-                static bool attr4 = false;
-                if (!attr4) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<true>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
-                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6v3 dma) failed");
-                    attr4 = true;
-                }
-                dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
-                hipLaunchKernelGGL(conv_fwd_x6v3_kernel<true>, grid, dim3(256), lds3, s, a);
-                if (int rc = rdo::check_launch("conv_fwd_x6v3_dma")) return rc;
-                if (a.ksplit > 1) {
-                    long g = rdo::ceil_div((long)a.M * a.Cout, 256);
-                    hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
-                    return rdo::check_launch("x6_splitk_epilogue");
-                }
-                return RDO_OK;
-            }
-            if (ver == 3) {
-                constexpr size_t lds3 = (size_t)2 * 3 * (128 + 192) * 32 + 4096;
-                static bool attr3 = false;
-                if (!attr3) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<false>),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3) != hipSuccess)
-                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6v3) failed");
-                    attr3 = true;
-                }
-                dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
-                hipLaunchKernelGGL(conv_fwd_x6v3_kernel<false>, grid, dim3(256), lds3, s, a);
-                if (int rc = rdo::check_launch("conv_fwd_x6v3")) return rc;
-                if (a.ksplit > 1) {
-                    long g = rdo::ceil_div((long)a.M * a.Cout, 256);
-                    hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
-                    return rdo::check_launch("x6_splitk_epilogue");
-                }
-                return RDO_OK;
-            }
-            constexpr int BM = 64, BN = 192;
-            constexpr size_t lds = (size_t)2 * 3 * (BM + BN) * 64;
-            auto kern = conv_fwd_x6_kernel<BM, BN>;
-            static bool attr_set = false;
-            if (!attr_set) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-                    hipSuccess)
-                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6) failed");
-                attr_set = true;
-            }
-            dim3 grid((unsigned)rdo::ceil_div(a.M, BM), (unsigned)rdo::ceil_div(a.Cout, BN));
-            hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
-            return rdo::check_launch("conv_fwd_x6");
+            return RDO_OK;
         },
         stream, "conv_fwd_x6_128x192", flops,
         4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout) + 6.0 * a.wplane);
