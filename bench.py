@@ -162,7 +162,8 @@ def gpu_leg(a, rank, world, device):
     t_cache = time.time() - t0
     log(f"caches built in {t_cache:.1f}s; recording engines")
     force_dp = bool(os.environ.get("RDO_BENCH_FORCE_DP"))    # exercise the grad -> RCCL all-reduce -> apply sequence on 1 rank
-    iters = a.warmup + a.steps + 1                     # +1: the event-profiled iteration after the timed region
+    unit_wall = bool(os.environ.get("RDO_BENCH_UNIT_WALL"))   # diagnostic: per-unit wall time of graph replays after the timed region
+    iters = a.warmup + a.steps + 1 + (a.steps if unit_wall else 0)   # +1: the event-profiled iteration after the timed region
     gi = torch.Generator().manual_seed(77 + rank)
     engines = []
     for name, u in units:
@@ -195,6 +196,13 @@ def gpu_leg(a, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     log(f"timed region done: {dt:.3f}s for {a.steps} steps")
+    if unit_wall:
+        for uname, e in engines:
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            e.run(a.steps)
+            torch.cuda.synchronize()
+            log(f"  unit {uname:24s} wall {(time.perf_counter() - t1) / a.steps * 1e3:7.3f} ms/iteration ({e.plan_a.num_ops} ops)")
     # ---- roofline probe: one more iteration of every unit, each op bracketed by hipEvents on the launch stream
     per_tag = {}
     for uname, e in engines:

@@ -372,6 +372,9 @@ extern "C" int64_t rdo_conv2d_fwd_workspace(const rdo_conv_desc* d) {
     return need;
 }
 
+bool rdo_conv_is_thin(const rdo_conv_desc* d, bool forward);                                                            // conv_thin.hip
+int rdo_launch_thin_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, float* out, hipStream_t s);
+
 extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
                               const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
                               const void* wplanes, void* stream) {
@@ -389,6 +392,12 @@ extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const floa
     RDO_REQUIRE(epi == RDO_EPI_NONE || epi == RDO_EPI_LRELU || epi == RDO_EPI_RELU || aux != nullptr,
                 "rdo_conv2d_fwd: epilogue %d needs aux", epi);
     RDO_REQUIRE(!d->add_residual || residual != nullptr, "rdo_conv2d_fwd: add_residual without residual");
+    if (rdo_conv_is_thin(d, true) && pre == nullptr) {
+        const rdo_conv_desc dd = *d;
+        const double M = (double)d->B * d->Ho * d->Wo;
+        return rdo::dispatch([=](hipStream_t s) { return rdo_launch_thin_fwd(&dd, x, w, bias, out, s); }, stream, "conv_thin_fwd",
+                             2.0 * M * d->Cout * d->Cin * d->KH * d->KW, 4.0 * ((double)d->B * d->H * d->W * d->Cin + M * d->Cout));
+    }
     if (wplanes && rdo_conv2d_fwd_uses_bf16x6(d))
         return rdo_conv2d_fwd_bf16x6(d, x, wplanes, bias, aux, residual, out, pre, workspace, workspace_floats, stream);
     FwdArgs a = make_args(d);

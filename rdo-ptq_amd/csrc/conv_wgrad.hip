@@ -230,6 +230,8 @@ inline int tiles_total(const rdo_conv_desc* d) {
 }  // namespace
 
 int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, int mchunk, hipStream_t s);
+bool rdo_conv_is_thin(const rdo_conv_desc* d, bool forward);                                                            // conv_thin.hip
+int rdo_launch_thin_wgrad(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, hipStream_t s);
 
 // 1 when rdo_conv2d_wgrad runs this shape on the split-bf16 MFMA path (conv_wgrad_x6.hip): big-tile problems whose output
 // rows are a multiple of 4 pixels wide and whose channel counts allow 16-byte quads.  RDO_CONV_X6=0 disables it.
@@ -276,6 +278,12 @@ extern "C" int rdo_conv2d_wgrad(const rdo_conv_desc* d, const float* x, const fl
     const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) % 16 == 0);
     const bool big = big_tiles(d);
+    if (rdo_conv_is_thin(d, false)) {
+        const rdo_conv_desc dd = *d;
+        return rdo::dispatch([=](hipStream_t s) { return rdo_launch_thin_wgrad(&dd, x, dy, slabs, nsplit, s); }, stream,
+                             "conv_thin_wgrad", 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW,
+                             4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout + (double)nsplit * a.Cout * a.KH * a.KW * a.Cin));
+    }
     if (vec && rdo_conv2d_wgrad_uses_bf16x6(d)) {
         const rdo_conv_desc dd = *d;
         const int mchunk = a.mchunk;

@@ -32,6 +32,10 @@ CONV_CASES = [
     (2, 16, 16, 192, 192, 1, 2, 0),   # skip 1x1 s2
     (1, 8, 8, 192, 768, 3, 1, 1),     # subpel conv
     (3, 5, 7, 36, 20, 5, 2, 2),       # everything ragged
+    (2, 32, 32, 3, 192, 1, 2, 0),     # RGB stems (thin-conv kernels): 1x1 s2 skip of g_a.0
+    (2, 20, 28, 3, 100, 5, 2, 2),     #   5x5 s2 first layer of Minnen2018 / Lu2022, ragged Cout
+    (1, 9, 11, 3, 300, 3, 1, 1),      #   more than 256 output channels
+    (4, 64, 64, 3, 192, 3, 2, 1),     #   enough pixels for several chunks per slab
 ]
 
 
@@ -50,6 +54,11 @@ def test_conv_fwd_matches_fp64(ops, case):
     got = out.cpu().permute(0, 3, 1, 2)
     assert got.shape == ref.shape
     assert _rel(got, ref) < 5e-6   # ~sqrt(K)*2^-24 for K up to 4800 (fp32 fmaf chain)
+    if Cin == 3:                   # fused activations of the thin-conv path
+        from hipops import _lib as L
+        for epi, fn in ((L.EPI_LRELU, lambda t: F.leaky_relu(t, 0.01)), (L.EPI_RELU, F.relu)):
+            y = ops.conv2d_fwd(xd, wd, b.cuda(), stride=s, pad=p, epilogue=epi).cpu().permute(0, 3, 1, 2)
+            assert _rel(y, fn(ref)) < 5e-6
 
 
 def test_conv_fwd_epilogues(ops):
