@@ -238,7 +238,9 @@ int rdo_launch_thin_wgrad(const rdo_conv_desc* d, const float* x, const float* d
 extern "C" int rdo_conv2d_wgrad_uses_bf16x6(const rdo_conv_desc* d) {
     static const bool enabled = !(getenv("RDO_CONV_X6") && atoi(getenv("RDO_CONV_X6")) == 0);
     if (!d || !enabled || g_force_big == 0) return 0;
-    return big_tiles(d) && d->Wo % 4 == 0 && d->Cin % 4 == 0 && d->Cout % 4 == 0;
+    // the x6 loader addresses both tensors with 32-bit byte offsets (buffer loads)
+    const bool fits = (double)d->B * d->H * d->W * d->Cin * 4.0 < 4.0e9 && (double)d->B * d->Ho * d->Wo * d->Cout * 4.0 < 4.0e9;
+    return big_tiles(d) && fits && d->Wo % 4 == 0 && d->Wo >= 16 && d->Cin % 4 == 0 && d->Cout % 4 == 0;
 }
 
 extern "C" void rdo_debug_force_wgrad_choice(int big, int nsplit) {

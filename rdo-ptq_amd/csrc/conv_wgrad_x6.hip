@@ -29,16 +29,29 @@ struct WgX6Args {
     int M, mchunk, nsplit;
     int tiles_co, tiles_ci;
     int square_input;
+    unsigned x_bytes, dy_bytes;
 };
 
-__device__ __forceinline__ u16 bf16_bits(__bf16 h) { return __builtin_bit_cast(u16, h); }
-__device__ __forceinline__ void split3(float v, short& a, short& b, short& c) {
-    const __bf16 h = (__bf16)v;
-    const float r1 = v - (float)h;
-    const __bf16 m = (__bf16)r1;
-    const float r2 = r1 - (float)m;
-    const __bf16 l = (__bf16)r2;
-    a = (short)bf16_bits(h); b = (short)bf16_bits(m); c = (short)bf16_bits(l);
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+// two RNE conversions in one v_cvt_pk_bf16_f32; the packed pair is already the LDS image of two consecutive k
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16v2));
+}
+__device__ __forceinline__ float lo_f(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float hi_f(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+// exact three-way split of four values (four consecutive pixels of one channel) -> three 8-byte runs
+__device__ __forceinline__ void split3_x4(float v0, float v1, float v2, float v3, bf16x4& p0, bf16x4& p1, bf16x4& p2) {
+    const unsigned h01 = cvt_pk(v0, v1), h23 = cvt_pk(v2, v3);
+    const float r0 = v0 - lo_f(h01), r1 = v1 - hi_f(h01), r2 = v2 - lo_f(h23), r3 = v3 - hi_f(h23);
+    const unsigned m01 = cvt_pk(r0, r1), m23 = cvt_pk(r2, r3);
+    const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m23), s3 = r3 - hi_f(m23);
+    const unsigned l01 = cvt_pk(s0, s1), l23 = cvt_pk(s2, s3);
+    p0 = __builtin_bit_cast(bf16x4, u32x2{h01, h23});
+    p1 = __builtin_bit_cast(bf16x4, u32x2{m01, m23});
+    p2 = __builtin_bit_cast(bf16x4, u32x2{l01, l23});
 }
 
 // byte offset of 16-byte chunk c (0..3) of `row` inside one plane of a [rows][32 bf16] tile.  Every group of four rows is
@@ -49,7 +62,7 @@ __device__ __forceinline__ void split3(float v, short& a, short& b, short& c) {
 constexpr int ROWB = 64, GROUPB = 4 * ROWB + 16;     // bytes per row / per padded group of four rows
 __device__ __forceinline__ int chunk_off(int row, int c) { return (row >> 2) * GROUPB + (row & 3) * ROWB + (c << 4); }
 
-template <int TCO, int TCI>
+template <int TCO, int TCI, bool SQ>
 __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
     constexpr int WCO = TCO / 2, WCI = TCI / 2;
     constexpr int TM = WCO / 32, TN = WCI / 32;
@@ -103,38 +116,86 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 rq[NBLK][4];
-    unsigned okmask = 0;   // bit 4*j + p: pixel p of block j holds real data
+    // Loads go through buffer descriptors: an invalid pixel (halo, ragged tail, channel past the tensor) is requested at an
+    // out-of-range offset and the hardware returns zeros -- no per-value select, no validity mask to carry to the store phase
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
 
-    // issue the four pixel loads of block j for reduction step s (4 consecutive output pixels never straddle an image row:
-    // the host guarantees Wo % 4 == 0 and chunk starts that are multiples of 32)
-    auto load_block = [&](auto jc, int s) {
-        constexpr int j = decltype(jc)::value;
-        const int m = mbeg + s * PK + 4 * blk_pg[j];
-        const bool inrange = m < mend;
-        if (!blk_x[j]) {
-            const int c = co0 + blk_c[j];
-            const bool okc = inrange && c < a.Cout;
+    // Running position of every block: the loads of consecutive reduction steps are 32 output pixels apart, so the pixel
+    // decomposition (image, row, column) and the element offsets advance with a few adds / compares instead of the divisions and
+    // 64-bit multiplies a from-scratch decode costs every step (they were a third of the kernel's vector instructions).
+    int st_step[NBLK], st_m[NBLK], st_off[NBLK], st_wo[NBLK], st_ho[NBLK], st_hi[NBLK], st_wi0[NBLK];
 #pragma unroll
-            for (int p = 0; p < 4; ++p) {
-                const bool ok = okc && m + p < mend;
-                rq[j][p] = *reinterpret_cast<const f32x4*>(a.dy + (ok ? (m + p) * a.Cout + c : 0));
-                okmask = ok ? (okmask | (1u << (4 * j + p))) : (okmask & ~(1u << (4 * j + p)));
-            }
+    for (int j = 0; j < NBLK; ++j) {
+        st_step[j] = 0;
+        const int m = mbeg + 4 * blk_pg[j];
+        st_m[j] = m;
+        if (!blk_x[j]) {
+            st_off[j] = m * a.Cout + co0 + blk_c[j];
+            st_wo[j] = st_ho[j] = st_hi[j] = st_wi0[j] = 0;
         } else {
-            const int c = ci0 + blk_c[j];
-            const int mm = inrange ? m : 0;
+            const int mm = m < a.M ? m : 0;
             const int b = mm / HoWo;
             const int rem = mm - b * HoWo;
             const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
-            const int hi = ho * a.stride - a.pad + kh, wi0 = wo * a.stride - a.pad + kw;
-            const bool okr = inrange && c < a.Cin && (unsigned)hi < (unsigned)a.H;
-            const int base = ((b * a.H + hi) * a.W + wi0) * a.Cin + c;
+            st_wo[j] = wo; st_ho[j] = ho;
+            st_hi[j] = ho * a.stride - a.pad + kh;
+            st_wi0[j] = wo * a.stride - a.pad + kw;
+            st_off[j] = ((b * a.H + st_hi[j]) * a.W + st_wi0[j]) * a.Cin + ci0 + blk_c[j];
+        }
+    }
+    const int x_step = PK * a.stride * a.Cin;                                  // 32 output pixels further along the row
+    const int x_row = (a.stride * a.W - a.Wo * a.stride) * a.Cin;              // wrap to the next output row
+    const int x_img = (a.H * a.W - a.Ho * a.stride * a.W) * a.Cin;             // wrap to the next image
+    auto advance = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        st_m[j] += PK;
+        if (!blk_x[j]) {
+            st_off[j] += PK * a.Cout;
+            return;
+        }
+        st_wo[j] += PK;
+        st_off[j] += x_step;
+        st_wi0[j] += PK * a.stride;
+        while (st_wo[j] >= a.Wo) {
+            st_wo[j] -= a.Wo;
+            st_wi0[j] -= a.Wo * a.stride;
+            st_off[j] += x_row;
+            st_hi[j] += a.stride;
+            if (++st_ho[j] >= a.Ho) {
+                st_ho[j] = 0;
+                st_hi[j] -= a.Ho * a.stride;
+                st_off[j] += x_img;
+            }
+        }
+    };
+    // issue the four pixel loads of block j for reduction step s (4 consecutive output pixels never straddle an image row:
+    // the host guarantees Wo % 4 == 0 and chunk starts that are multiples of 32); steps are requested in non-decreasing order
+    auto load_block = [&](auto jc, int s) {
+        constexpr int j = decltype(jc)::value;
+        if (s > st_step[j]) {
+            advance(jc);
+            st_step[j] = s;
+        }
+        const int m = st_m[j];
+        const bool inrange = m < mend;
+        if (!blk_x[j]) {
+            const bool okc = inrange && co0 + blk_c[j] < a.Cout;
 #pragma unroll
             for (int p = 0; p < 4; ++p) {
-                const int wi = wi0 + p * a.stride;
+                const bool ok = okc && m + p < mend;
+                rq[j][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rsrc_y, ok ? (unsigned)(st_off[j] + p * a.Cout) * 4u : OOB, 0, 0));
+            }
+        } else {
+            const bool okr = inrange && ci0 + blk_c[j] < a.Cin && (unsigned)st_hi[j] < (unsigned)a.H;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int wi = st_wi0[j] + p * a.stride;
                 const bool ok = okr && m + p < mend && (unsigned)wi < (unsigned)a.W;
-                rq[j][p] = *reinterpret_cast<const f32x4*>(a.x + (ok ? base + p * a.stride * a.Cin : 0));
-                okmask = ok ? (okmask | (1u << (4 * j + p))) : (okmask & ~(1u << (4 * j + p)));
+                rq[j][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rsrc_x, ok ? (unsigned)(st_off[j] + p * a.stride * a.Cin) * 4u : OOB, 0, 0));
             }
         }
     };
@@ -143,14 +204,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
         constexpr int j = decltype(jc)::value;
         constexpr int cc = decltype(ccc)::value;
         bf16x4 p0, p1, p2;
-#pragma unroll
-        for (int p = 0; p < 4; ++p) {
-            float v = ((okmask >> (4 * j + p)) & 1u) ? rq[j][p][cc] : 0.f;
-            if (blk_x[j] && a.square_input) v = v * v;
-            short h, m, l;
-            split3(v, h, m, l);
-            p0[p] = h; p1[p] = m; p2[p] = l;
+        float v0 = rq[j][0][cc], v1 = rq[j][1][cc], v2 = rq[j][2][cc], v3 = rq[j][3][cc];
+        if constexpr (SQ) {
+            const bool q = blk_x[j];
+            v0 = q ? v0 * v0 : v0; v1 = q ? v1 * v1 : v1; v2 = q ? v2 * v2 : v2; v3 = q ? v3 * v3 : v3;
         }
+        split3_x4(v0, v1, v2, v3, p0, p1, p2);
         // row + cc: rows of one aligned group of four are 64 bytes apart
         char* st = smem + buf * STAGE + blk_lds[j] + cc * 64;
         const int plane = blk_x[j] ? XPLANE : YPLANE;
@@ -179,42 +238,67 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
     constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
     constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 
+    // One workgroup (one wave per SIMD) per CU: nothing else hides this wave's LDS latency, so the fragment reads are pipelined
+    // half a step ahead into a second register set, and a step needs a single barrier, in its middle:
+    //   first half : MFMAs of k-group 0 from set A | all 12 transpose-stores of step s+1 into the other buffer | set B <- (s, k-group 1)
+    //   barrier    : step s+1's image is complete, and nobody reads this step's buffer any more (its fragments are in registers)
+    //   second half: MFMAs of k-group 1 from set B | global loads of step s+2 | set A <- (s+1, k-group 0) from the other buffer
+    bf16x8 fa[2][3][TM], fb[2][3][TN];
+    auto read_frag = [&](auto setc, const char* st, int kb, int idx) {       // idx 0..17: plane-major A then B fragments
+        constexpr int S = decltype(setc)::value;
+        const int p = idx / (TM + TN), r = idx - p * (TM + TN);
+        if (r < TM)
+            fa[S][p][r] = *reinterpret_cast<const bf16x8*>(st + p * YPLANE + chunk_off(wco0 + r * 32 + li, 2 * kb + lh));
+        else
+            fb[S][p][r - TM] = *reinterpret_cast<const bf16x8*>(st + 3 * YPLANE + p * XPLANE +
+                                                                 chunk_off(wci0 + (r - TM) * 32 + li, 2 * kb + lh));
+    };
+    static_assert(3 * (TM + TN) == 18 && NBLK == 3, "slot schedule below is written for the 192 x 192 tile");
+    if (nsteps > 0) {
+        [&]<int... I>(std::integer_sequence<int, I...>) {
+            (read_frag(std::integral_constant<int, 0>{}, smem, 0, I), ...);
+        }(std::make_integer_sequence<int, 18>{});
+    }
+
     for (int s = 0; s < nsteps; ++s) {
         const int buf = s & 1;
         const int s2 = s + 2 < nsteps ? s + 2 : nsteps - 1;
         const char* st = smem + buf * STAGE;
+        const char* stn = smem + (buf ^ 1) * STAGE;
         [&]<int... SL>(std::integer_sequence<int, SL...>) {
-            bf16x8 fa[3][TM], fb[3][TN];
             (([&] {
-                 constexpr int kb = SL / 6, pr = SL % 6;
-                 if constexpr (pr == 0) {
-#pragma unroll
-                     for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                         for (int i = 0; i < TM; ++i)
-                             fa[p][i] = *reinterpret_cast<const bf16x8*>(st + p * YPLANE + chunk_off(wco0 + i * 32 + li, 2 * kb + lh));
-#pragma unroll
-                         for (int j = 0; j < TN; ++j)
-                             fb[p][j] = *reinterpret_cast<const bf16x8*>(st + 3 * YPLANE + p * XPLANE +
-                                                                          chunk_off(wci0 + j * 32 + li, 2 * kb + lh));
-                     }
-                 }
 #pragma unroll
                  for (int i = 0; i < TM; ++i)
 #pragma unroll
                      for (int j = 0; j < TN; ++j)
-                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[pr]][i], fb[PB[pr]][j], acc[i][j], 0, 0, 0);
-                 if constexpr (SL < 4 * NBLK) {
-                     constexpr int jb = SL / 4, cc = SL % 4;
-                     store_part(std::integral_constant<int, jb>{}, std::integral_constant<int, cc>{}, buf ^ 1);
-                     if constexpr (cc == 3) load_block(std::integral_constant<int, jb>{}, s2);
-                 }
+                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[0][PA[SL]][i], fb[0][PB[SL]][j], acc[i][j], 0, 0, 0);
+                 store_part(std::integral_constant<int, (2 * SL) / 4>{}, std::integral_constant<int, (2 * SL) % 4>{}, buf ^ 1);
+                 store_part(std::integral_constant<int, (2 * SL + 1) / 4>{}, std::integral_constant<int, (2 * SL + 1) % 4>{}, buf ^ 1);
+                 read_frag(std::integral_constant<int, 1>{}, st, 1, 3 * SL);
+                 read_frag(std::integral_constant<int, 1>{}, st, 1, 3 * SL + 1);
+                 read_frag(std::integral_constant<int, 1>{}, st, 1, 3 * SL + 2);
                  __builtin_amdgcn_sched_barrier(0);
              }()),
              ...);
         }
-        (std::make_integer_sequence<int, 12>{});
+        (std::make_integer_sequence<int, 6>{});
         __syncthreads();
+        [&]<int... SL>(std::integer_sequence<int, SL...>) {
+            (([&] {
+#pragma unroll
+                 for (int i = 0; i < TM; ++i)
+#pragma unroll
+                     for (int j = 0; j < TN; ++j)
+                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[1][PA[SL]][i], fb[1][PB[SL]][j], acc[i][j], 0, 0, 0);
+                 if constexpr (SL < NBLK) load_block(std::integral_constant<int, SL>{}, s2);
+                 read_frag(std::integral_constant<int, 0>{}, stn, 0, 3 * SL);
+                 read_frag(std::integral_constant<int, 0>{}, stn, 0, 3 * SL + 1);
+                 read_frag(std::integral_constant<int, 0>{}, stn, 0, 3 * SL + 2);
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
+        }
+        (std::make_integer_sequence<int, 6>{});
     }
 
     const long wsize = (long)a.Cout * a.KH * a.KW * a.Cin;
@@ -248,15 +332,20 @@ int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy,
     a.nsplit = nsplit; a.mchunk = mchunk; a.square_input = d->square_input;
     a.tiles_co = (int)rdo::ceil_div(a.Cout, T);
     a.tiles_ci = (int)rdo::ceil_div(a.Cin, T);
+    a.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * sizeof(float));     // < 2^32: checked by uses_bf16x6
+    a.dy_bytes = (unsigned)((size_t)a.M * d->Cout * sizeof(float));
     constexpr size_t lds = (size_t)2 * 3 * (T + T) / 4 * (4 * 64 + 16);
-    auto kern = conv_wgrad_x6_kernel<T, T>;
     static bool attr_set = false;
     if (!attr_set) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<T, T, false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<T, T, true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6, %zu B LDS) failed", lds);
         attr_set = true;
     }
     dim3 grid((unsigned)nsplit, (unsigned)(a.KH * a.KW * a.tiles_co * a.tiles_ci));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
+    if (a.square_input) hipLaunchKernelGGL((conv_wgrad_x6_kernel<T, T, true>), grid, dim3(256), lds, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_x6_kernel<T, T, false>), grid, dim3(256), lds, s, a);
     return rdo::check_launch("conv_wgrad_x6");
 }
