@@ -50,6 +50,27 @@ __device__ __forceinline__ void split3(float v, u16& a, u16& b, u16& c) {
     a = bf16_bits(h); b = bf16_bits(m); c = bf16_bits(l);
 }
 
+typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// two RNE conversions in one v_cvt_pk_bf16_f32; the packed pair is already the LDS image of two consecutive k
+__device__ __forceinline__ unsigned cvt_pk(float a, float b) {
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16v2));
+}
+__device__ __forceinline__ float lo_f(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
+__device__ __forceinline__ float hi_f(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+// exact three-way split of a quad of consecutive channels -> three 8-byte runs (22 vector instructions for 4 values)
+__device__ __forceinline__ void split3_x4(const f32x4& v, bf16x4& p0, bf16x4& p1, bf16x4& p2) {
+    const unsigned h01 = cvt_pk(v[0], v[1]), h23 = cvt_pk(v[2], v[3]);
+    const float r0 = v[0] - lo_f(h01), r1 = v[1] - hi_f(h01), r2 = v[2] - lo_f(h23), r3 = v[3] - hi_f(h23);
+    const unsigned m01 = cvt_pk(r0, r1), m23 = cvt_pk(r2, r3);
+    const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m23), s3 = r3 - hi_f(m23);
+    const unsigned l01 = cvt_pk(s0, s1), l23 = cvt_pk(s2, s3);
+    p0 = __builtin_bit_cast(bf16x4, u32x2{h01, h23});
+    p1 = __builtin_bit_cast(bf16x4, u32x2{m01, m23});
+    p2 = __builtin_bit_cast(bf16x4, u32x2{l01, l23});
+}
+
 __device__ __forceinline__ void finish(const X6Args& a, long o, float v) {
     if (a.pre) a.pre[o] = v;
     switch (a.epilogue) {
@@ -203,12 +224,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         f32x4 v = ra_ok[t] ? ra[t] : f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.square_input) v = v * v;
         bf16x4 p0, p1, p2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            u16 h, m, l;
-            split3(v[e], h, m, l);
-            p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
-        }
+        split3_x4(v, p0, p1, p2);
         char* st = smem + buf * STAGE + a_lds[t];
         *reinterpret_cast<bf16x4*>(st) = p0;
         *reinterpret_cast<bf16x4*>(st + APLANE) = p1;
@@ -411,12 +427,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
         f32x4 v = ra_ok[t] ? ra[t] : f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.square_input) v = v * v;
         bf16x4 p0, p1, p2;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            u16 h, m, l;
-            split3(v[e], h, m, l);
-            p0[e] = (short)h; p1[e] = (short)m; p2[e] = (short)l;
-        }
+        split3_x4(v, p0, p1, p2);
         char* st = smem + buf * STAGE + a_lds[t];
         *reinterpret_cast<bf16x4*>(st) = p0;
         *reinterpret_cast<bf16x4*>(st + APLANE) = p1;
