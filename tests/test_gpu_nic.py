@@ -200,3 +200,39 @@ def test_tape_engine_first_iteration_gradient(golden_dir, name):
     assert out.returncode == 0, out.stderr[-2000:]
     rels = [float(l.split("rel")[1]) for l in out.stdout.splitlines() if " rel " in l]
     assert rels and max(rels) < 1e-4, out.stdout
+
+
+@pytest.mark.parametrize("name", ["g_a1", "h_s1"])
+def test_tape_engine_dp_split_equals_fused(golden_dir, name):
+    """The data-parallel op sequence of the tape engine (plan A: forward/backward + rdo_adaround_grad into the flat bucket; plan B:
+    rdo_adaround_apply) on one rank reproduces the fused rdo_adaround_step run bit for bit -- for an RSTB with a tail and a
+    transposed-conv layer unit with a tail."""
+    from quantization import BaseQuantBlock, QuantModel, QuantModule
+    from quantization.recon import fp_out, _unit_modules
+    from quantization.quant_layer import _nhwc
+    from quantization.swin_engine import TapeEngine
+    from helpers import nhwc
+    res = []
+    for split in (False, True):
+        fx, model = build(golden_dir)
+        B, iters = int(fx["meta"][4]), int(fx["meta"][5])
+        qnn = QuantModel(model=model, weight_quant_params=WQ, act_quant_params=AQ).cuda().eval()
+        qnn.set_quant_state(True, False)
+        with torch.no_grad():
+            qnn(T(fx["cali"])[:B].cuda())
+        qnn.set_quant_state(False, False)
+        order = [n for n, m in qnn.model.named_children() if isinstance(m, (QuantModule, BaseQuantBlock))]
+        coder = [n for n in order if n.startswith(name[:3])]
+        tail = [getattr(qnn.model, n) for n in coder[coder.index(name) + 1:]]
+        tail_round = name.startswith("g_a")
+        kind, mods = _unit_modules(getattr(qnn.model, name))
+        task_cache = _nhwc(fp_out(tail, T(fx[f"{name}/out"]).cuda(), tail_round))
+        eng = TapeEngine(kind, mods, nhwc(fx[f"{name}/inp_q"]), nhwc(fx[f"{name}/inp_fp"]), nhwc(fx[f"{name}/out"]), tail=tail,
+                         tail_round=tail_round, task_cache=task_cache, batch_size=B, iters=iters, seed=7,
+                         idx_table=torch.from_numpy(fx[f"{name}/idx"]), force_dp_split=split)
+        eng.run()
+        torch.cuda.synchronize()
+        res.append(({n: eng.alpha_of(n).clone() for n in eng.ops}, eng.logs()[0]))
+    for n in res[0][0]:
+        torch.testing.assert_close(res[0][0][n], res[1][0][n], rtol=0, atol=0)
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=0)
