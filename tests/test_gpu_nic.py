@@ -106,7 +106,7 @@ def test_nic_caches_and_quantised_forwards_match_reference(golden_dir):
                         # W8A8: each Swin block re-quantises its activations at seven points with dynamic 8-bit grids.  A value
                         # on a rounding boundary may land one level off (1/255 of the channel range); window attention then
                         # spreads that to the window's tokens and later quantisers flip more.  From identical inputs every
-                        # single stage is exact or flips < 0.3 % of its elements (tools/dbg_nic_gpu.py); over a whole RSTB the
+                        # single stage is exact or flips < 0.3 % of its elements (tools/nic_w8a8_stage_check.py); over a whole RSTB the
                         # deviation must stay well below one quantisation level on average
                         mean_dev = float((h.cpu() - ref).abs().mean() / ref.abs().max())
                         assert err < 3e-2 and mean_dev < 2e-3, (tag, name, err, mean_dev)
@@ -195,7 +195,7 @@ def test_tape_engine_first_iteration_gradient(golden_dir, name):
     plan A only) against torch autograd through the oracle's unit + FP tail.  1e-4 of the largest gradient entry."""
     import subprocess, sys
     env = dict(os.environ, GRAFT_REPO_ROOT=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-    out = subprocess.run([sys.executable, os.path.join(env["GRAFT_REPO_ROOT"], "tools", "dbg_nic_grad.py"), name], env=env,
+    out = subprocess.run([sys.executable, os.path.join(env["GRAFT_REPO_ROOT"], "tools", "nic_grad_check.py"), name], env=env,
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     rels = [float(l.split("rel")[1]) for l in out.stdout.splitlines() if " rel " in l]

@@ -1,4 +1,4 @@
-"""First-iteration alpha gradients of the tape engine vs the oracle for the NIC golden units (debug helper)."""
+"""First-iteration alpha gradients of the tape engine vs the oracle for the NIC golden units (used by tests/test_gpu_nic.py)."""
 import sys, os, numpy as np, torch
 R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0, R); sys.path.insert(0, R + '/tests'); sys.path.insert(0, R + '/rdo-ptq_amd')

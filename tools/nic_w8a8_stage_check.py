@@ -1,3 +1,5 @@
+"""Stage-by-stage W8A8 comparison of one Swin block of the toy NIC (product on the GPU vs oracle on the CPU) from identical inputs:
+shows which activation-quantisation points are exact and how many elements flip by one 8-bit level (see tests/test_gpu_nic.py)."""
 import sys, os, numpy as np, torch
 R=os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 sys.path.insert(0,R); sys.path.insert(0,R+'/tests'); sys.path.insert(0,R+'/rdo-ptq_amd')
