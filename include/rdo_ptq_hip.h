@@ -113,7 +113,9 @@ typedef struct rdo_sched_row {
 int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* slabs,
                       int nsplit, float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr,
                       float* alpha, float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out,
-                      void* stream);
+                      void* wq_planes, void* wd_planes, void* stream);
+/* wq_planes / wd_planes (nullable): [3][numel] bf16 -- the exact three-way split of the new wq / wd (what rdo_split_bf16x3 would
+ * produce), written in the same pass so that the split-precision conv path needs no separate refresh launch. */
 
 /* only the data-gradient half (slab reduce + chain rule -> dalpha_data), for the all-reduce bucket of the DP path */
 int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,
@@ -122,7 +124,7 @@ int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha,
 int rdo_adaround_apply(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* dalpha,
                        float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr,
                        float* alpha, float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out,
-                       void* stream);
+                       void* wq_planes, void* wd_planes, void* stream);
 
 /* ---- K5: nearest fake-quant of a weight (UniformAffineQuantizer.forward)                  quantizer.py:175-177 */
 int rdo_uaq_fakequant(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, float* wq, float* wd,

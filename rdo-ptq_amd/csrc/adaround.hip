@@ -39,7 +39,20 @@ struct AdaArgs {
     float* wd;
     float* round_loss_out;
     int mode;               // 0 fused step, 1 grad only, 2 apply
+    unsigned short* wq_planes;   // optional: exact bf16 three-way split of the new wq, [3][numel] (conv_fwd_x6.hip operand)
+    unsigned short* wd_planes;   // optional: the same for the dgrad layout wd
 };
+
+// exact three-way bf16 split (hardware RNE conversions), as rdo_split_bf16x3
+__device__ __forceinline__ void split3_store(float v, unsigned short* planes, long n, long i) {
+    const __bf16 h = (__bf16)v;
+    const float r1 = v - (float)h;
+    const __bf16 m = (__bf16)r1;
+    const __bf16 l = (__bf16)(r1 - (float)m);
+    planes[i] = __builtin_bit_cast(unsigned short, h);
+    planes[n + i] = __builtin_bit_cast(unsigned short, m);
+    planes[2 * n + i] = __builtin_bit_cast(unsigned short, l);
+}
 
 __device__ __forceinline__ long wd_index(const rdo_ada_desc& d, long e) {
     // e = ((co*KH + kh)*KW + kw)*Cin + ci  ->  ((ci*KH + KH-1-kh)*KW + KW-1-kw)*Cout + co
@@ -156,6 +169,28 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
             *reinterpret_cast<vec_t*>(a.v + e0) = v4;
             *reinterpret_cast<vec_t*>(a.alpha + e0) = al4;
             *reinterpret_cast<vec_t*>(a.wq + e0) = o4;
+            if (a.wq_planes) {
+                if constexpr (W == 4) {                        // one 8-byte store per plane
+                    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+                    u16x4 ph, pm, pl;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const __bf16 h = (__bf16)o4[k];
+                        const float r1 = o4[k] - (float)h;
+                        const __bf16 m = (__bf16)r1;
+                        const __bf16 l = (__bf16)(r1 - (float)m);
+                        ph[k] = __builtin_bit_cast(unsigned short, h);
+                        pm[k] = __builtin_bit_cast(unsigned short, m);
+                        pl[k] = __builtin_bit_cast(unsigned short, l);
+                    }
+                    *reinterpret_cast<u16x4*>(a.wq_planes + e0) = ph;
+                    *reinterpret_cast<u16x4*>(a.wq_planes + d.numel + e0) = pm;
+                    *reinterpret_cast<u16x4*>(a.wq_planes + 2 * d.numel + e0) = pl;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < W; ++k) split3_store(o4[k], a.wq_planes, d.numel, e0 + k);
+                }
+            }
         }
     }
     if (a.mode != 1 && a.round_loss_out && round_on != 0.f) {
@@ -172,7 +207,7 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
 }
 
 // wd[ci][KH-1-kh][KW-1-kw][co] = wq[co][kh][kw][ci]: 32x32 tiles through LDS, 128-byte segments on both sides
-__global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const float* wq, float* wd) {
+__global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const float* wq, float* wd, unsigned short* wd_planes) {
     const int taps = d.KH * d.KW, cdim = d.Cin;
     const int ctiles = (cdim + 31) / 32;
     int bid = blockIdx.x;
@@ -192,7 +227,11 @@ __global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int ci = ct * 32 + ty + 8 * k, co = rt * 32 + tx;
-        if (ci < cdim && co < d.rows) wd[((long)ci * taps + tapf) * d.rows + co] = tile[tx][ty + 8 * k];
+        if (ci < cdim && co < d.rows) {
+            const long o = ((long)ci * taps + tapf) * d.rows + co;
+            wd[o] = tile[tx][ty + 8 * k];
+            if (wd_planes) split3_store(tile[tx][ty + 8 * k], wd_planes, d.numel, o);
+        }
     }
 }
 
@@ -293,7 +332,7 @@ int run_step(AdaArgs a, void* stream) {
                 hipLaunchKernelGGL(ada_step_kernel<1>, dim3(grid_for(a.d.numel)), dim3(256), 0, s, a);
             if (a.mode != 1 && a.wd && a.d.Cin > 0) {
                 const long blocks = rdo::ceil_div(a.d.rows, 32) * a.d.KH * a.d.KW * rdo::ceil_div(a.d.Cin, 32);
-                hipLaunchKernelGGL(wd_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.d, (const float*)a.wq, a.wd);
+                hipLaunchKernelGGL(wd_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.d, (const float*)a.wq, a.wd, a.wd_planes);
             }
             return rdo::check_launch("ada_step");
         },
@@ -366,7 +405,8 @@ int rdo_reduce_slabs(const float* slabs, int nsplit, int64_t numel, float* out, 
 
 int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* slabs, int nsplit,
                       float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr, float* alpha,
-                      float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out, void* stream) {
+                      float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out, void* wq_planes, void* wd_planes,
+                      void* stream) {
     if (int rc = check_desc(d, "rdo_adaround_step")) return rc;
     RDO_REQUIRE(w && delta && zp && slabs && nsplit >= 1 && sched && iter_ptr && alpha && adam_m && adam_v && wq,
                 "rdo_adaround_step: null pointer");
@@ -374,6 +414,8 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
     a.d = *d; a.w = w; a.delta = delta; a.zp = zp; a.slabs = slabs; a.nsplit = nsplit; a.grad_scale = grad_scale;
     a.round_weight = round_weight; a.sched = sched; a.iter_ptr = iter_ptr; a.alpha = alpha; a.m = adam_m; a.v = adam_v;
     a.wq = wq; a.wd = wd; a.round_loss_out = round_loss_out; a.mode = 0;
+    a.wq_planes = static_cast<unsigned short*>(wq_planes);
+    a.wd_planes = wd ? static_cast<unsigned short*>(wd_planes) : nullptr;
     return run_step(a, stream);
 }
 
@@ -389,7 +431,8 @@ int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha,
 
 int rdo_adaround_apply(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* dalpha,
                        float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr, float* alpha,
-                       float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out, void* stream) {
+                       float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out, void* wq_planes, void* wd_planes,
+                       void* stream) {
     if (int rc = check_desc(d, "rdo_adaround_apply")) return rc;
     RDO_REQUIRE(w && delta && zp && dalpha && sched && iter_ptr && alpha && adam_m && adam_v && wq,
                 "rdo_adaround_apply: null pointer");
@@ -397,6 +440,8 @@ int rdo_adaround_apply(const rdo_ada_desc* d, const float* w, const float* delta
     a.d = *d; a.w = w; a.delta = delta; a.zp = zp; a.dalpha_in = dalpha; a.grad_scale = grad_scale;
     a.round_weight = round_weight; a.sched = sched; a.iter_ptr = iter_ptr; a.alpha = alpha; a.m = adam_m; a.v = adam_v;
     a.wq = wq; a.wd = wd; a.round_loss_out = round_loss_out; a.mode = 2;
+    a.wq_planes = static_cast<unsigned short*>(wq_planes);
+    a.wd_planes = wd ? static_cast<unsigned short*>(wd_planes) : nullptr;
     return run_step(a, stream);
 }
 

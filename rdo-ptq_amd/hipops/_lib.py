@@ -47,9 +47,9 @@ _SIGS = {
     "rdo_reduce_slabs": (C.c_int, [P, C.c_int, C.c_int64, P, P]),
     "rdo_adaround_init_alpha": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P]),
     "rdo_adaround_fwd": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, P, P, P]),
-    "rdo_adaround_step": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P]),
+    "rdo_adaround_step": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rdo_adaround_grad": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, C.c_int, P, P]),
-    "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P]),
+    "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rdo_uaq_fakequant": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, P]),
     "rdo_uaq_init_minmax": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, P, P, P]),
     "rdo_actquant_perchannel": (C.c_int, [P, C.c_int64, C.c_int32, P, P, P]),

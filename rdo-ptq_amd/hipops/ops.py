@@ -134,10 +134,12 @@ def uaq_init_minmax(w, n_levels):
     return delta, zp
 
 
-def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_ptr, alpha, m, v, wq, wd, round_log):
+def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_ptr, alpha, m, v, wq, wd, round_log,
+                  wq_planes=None, wd_planes=None):
+    """`wq_planes` / `wd_planes`: optional int16 [3, numel] tensors that receive the bf16 three-way split of the new weights."""
     L.check(L.lib().rdo_adaround_step(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(slabs), slabs.shape[0], grad_scale,
                                       round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(alpha), _ptr(m), _ptr(v), _ptr(wq),
-                                      _ptr(wd), _ptr(round_log), _stream()), "rdo_adaround_step")
+                                      _ptr(wd), _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _stream()), "rdo_adaround_step")
 
 
 def adaround_grad(d, w, alpha, delta, zp, slabs, dalpha):
@@ -145,10 +147,11 @@ def adaround_grad(d, w, alpha, delta, zp, slabs, dalpha):
                                       _ptr(dalpha), _stream()), "rdo_adaround_grad")
 
 
-def adaround_apply(d, w, delta, zp, dalpha, grad_scale, round_weight, sched, iter_ptr, alpha, m, v, wq, wd, round_log):
+def adaround_apply(d, w, delta, zp, dalpha, grad_scale, round_weight, sched, iter_ptr, alpha, m, v, wq, wd, round_log,
+                   wq_planes=None, wd_planes=None):
     L.check(L.lib().rdo_adaround_apply(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(dalpha), grad_scale, round_weight,
                                        _ptr(sched), _ptr(iter_ptr), _ptr(alpha), _ptr(m), _ptr(v), _ptr(wq), _ptr(wd),
-                                       _ptr(round_log), _stream()), "rdo_adaround_apply")
+                                       _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _stream()), "rdo_adaround_apply")
 
 
 def actquant_perchannel(x, out=None, ws=None):

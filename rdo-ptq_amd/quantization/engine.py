@@ -390,9 +390,9 @@ class UnitEngine:
             self._forward_backward()
             if not self.split:
                 for op in self.ops.values():
+                    # the bf16 planes of the new weights (split-precision conv path) are written by the same launch
                     ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
-                                      op.alpha, op.m, op.v, op.wq, op.wd, self.round_log)
-                    op.refresh_planes()
+                                      op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
                 ops.iter_advance(self.it)
             else:
                 for op in self.ops.values():
@@ -402,8 +402,7 @@ class UnitEngine:
             with self.plan_b.record():
                 for op in self.ops.values():
                     ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, 1.0 / self.world, self.weight, self.sched,
-                                       self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log)
-                    op.refresh_planes()
+                                       self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
                 ops.iter_advance(self.it)
 
     # ------------------------------------------------------------------------------------------------------------------
