@@ -109,6 +109,29 @@ __global__ __launch_bounds__(256) void pixel_shuffle_kernel(const float* x, int 
     }
 }
 
+// r == 2: one thread per (small pixel, channel c): the four sub-pixels of c are one aligned float4 of the small tensor, and each
+// of them lands in its own output pixel with lanes running over c -- 16-byte accesses on the small side, 256-byte runs on the large
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float* x, long npix_small, int H, int W, int C, int inverse,
+                                                             float* out) {
+    const long total = npix_small * C;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(t % C);
+        const long p = t / C;                              // small pixel (b, h, w)
+        const int w = (int)(p % W);
+        const long bh = p / W;                             // b * H + h
+        const long big0 = ((bh * 2) * (2L * W) + 2 * w) * C + c;      // large pixel (b, 2h, 2w)
+        const long row = 2L * W * C;
+        if (inverse) {
+            f32x4 v;
+            v[0] = x[big0]; v[1] = x[big0 + C]; v[2] = x[big0 + row]; v[3] = x[big0 + row + C];
+            reinterpret_cast<f32x4*>(out)[t] = v;
+        } else {
+            const f32x4 v = reinterpret_cast<const f32x4*>(x)[t];
+            out[big0] = v[0]; out[big0 + C] = v[1]; out[big0 + row] = v[2]; out[big0 + row + C] = v[3];
+        }
+    }
+}
+
 __global__ __launch_bounds__(256) void gdn_bwd_t_kernel(const float* g, const float* x, const float* nrm, long n, int inverse,
                                                         float* t) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
@@ -307,8 +330,12 @@ int rdo_pixel_shuffle(const float* x, int32_t B, int32_t H, int32_t W, int32_t C
     RDO_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && r > 0, "rdo_pixel_shuffle: bad argument");
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for((long)B * H * W * C * r * r)), dim3(256), 0, s, x, B, H, W, C, r,
-                               inverse, out);
+            if (r == 2 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) % 16 == 0)
+                hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for((long)B * H * W * C)), dim3(256), 0, s, x, (long)B * H * W, H, W,
+                                   C, inverse, out);
+            else
+                hipLaunchKernelGGL(pixel_shuffle_kernel, dim3(grid_for((long)B * H * W * C * r * r)), dim3(256), 0, s, x, B, H, W, C, r,
+                                   inverse, out);
             return rdo::check_launch("pixel_shuffle");
         },
         stream);
