@@ -220,7 +220,7 @@ inline bool big_tiles(const rdo_conv_desc* d) {
     // is one more slab for the AdaRound step to read back -- use the small tile (9x more tiles, 9x fewer splits) instead
     const long big_tiles_total = (long)d->KH * d->KW * rdo::ceil_div(d->Cout, 192) * rdo::ceil_div(d->Cin, 192);
     // many tiles (the 768 / 1152-channel sub-pixel convs): few pixel splits fill the chip, so short reductions still pay off
-    const long min_m = big_tiles_total >= 32 ? 1024 : 8192;
+    const long min_m = big_tiles_total >= 32 ? 1024 : 4096;
     return d->Cout >= 160 && d->Cin >= 160 && M >= min_m && big_tiles_total >= 4;
 }
 
