@@ -303,3 +303,64 @@ def test_mbt2018_context_model_w8a8_eval_at_kodak_size():
         torch.distributed.destroy_process_group()
     for a, b in zip(local, sharded):
         assert abs(a - b) < 1e-5 * max(1.0, abs(a))       # reduction kernels accumulate with float atomics: order varies
+
+
+def test_main2_flow_with_activation_quantised_calibration():
+    """`main2.py --act_quant`: the caches of every unit are built with the already calibrated prefix running W8A8 (dynamic 8-bit
+    activations, batch 1 as in the reference), the unit itself trains without activation quantisation (its `trained` flag is still
+    off).  Checks the choreography on a toy Cheng2020: the cached quantised input of a later unit equals a manual W8A8 forward of
+    the calibrated prefix, every unit ends trained, and the W8A8 model evaluates."""
+    import lic
+    from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstruction, layer_reconstruction
+    from quantization.utils import save_inp_oup_data
+    from test_datasets import evaluate_images
+    torch.manual_seed(1005)
+    N, n_img, B, iters = 8, 4, 2, 6
+    model = lic.Cheng2020Anchor(N=N).cuda().eval()
+    g = torch.Generator().manual_seed(13)
+    cali = torch.rand(n_img, 3, 64, 64, generator=g).cuda()
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
+                  warmup=0.2, act_quant=True, opt_mode="mse", config=None, args=args)
+    qnn.set_quant_state(True, True)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    units = list(qnn.model.g_a.named_children())
+    for name, u in units[:2]:
+        block_reconstruction(qnn, u, name, **kwargs)
+    # the third unit's quantised input = W8A8 forward of the two calibrated blocks (batch 1: the activation grids are dynamic)
+    (inp_q, inp_fp), out_fp = save_inp_oup_data(qnn, units[2][1], cali, asym=True, act_quant=True, batch_size=1, input_prob=True)
+    # utils.set_mode (utils.py:28-35) re-enables only the QuantModules of trained units: the block-level quantisers (after the
+    # element-wise joins) stay off in the cache passes -- reproduce exactly that state by hand
+    for _, u in units[:2]:
+        u.set_quant_state(True, True)
+        u.use_act_quant = False
+    with torch.no_grad():
+        manual = torch.cat([units[1][1](units[0][1](cali[i:i + 1])) for i in range(n_img)])
+    torch.testing.assert_close(inp_q, manual, rtol=0, atol=0)
+    assert float((inp_q - inp_fp).abs().max()) > 0                      # the quantised prefix really differs from the FP one
+
+    def recon_rest(m: nn.Module, skip):
+        for name, module in m.named_children():
+            if module in skip:
+                continue
+            if isinstance(module, QuantModule):
+                layer_reconstruction(qnn, module, name, **kwargs)
+            elif isinstance(module, BaseQuantBlock):
+                block_reconstruction(qnn, module, name, **kwargs)
+            else:
+                recon_rest(module, skip)
+    recon_rest(qnn, {units[0][1], units[1][1]})
+    mods = [m for m in qnn.modules() if isinstance(m, QuantModule) and m.org_weight is not None]
+    assert all(m.trained and hasattr(m.weight_quantizer, "alpha") for m in mods)
+    qnn.set_quant_state(True, True)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    psnr, bpp = evaluate_images(qnn.eval(), [torch.rand(1, 3, 64, 64, generator=g)], p=64)
+    assert math.isfinite(psnr) and math.isfinite(bpp)
