@@ -151,3 +151,55 @@ def test_attention_model_caches_and_w8_forward_match_reference(golden_dir):
         ref = T(fx[key])
         err = float((got.cpu() - ref).abs().max()) / (float(ref.abs().max()) + 1e-12)
         assert err < 1e-4, (key, err)
+
+
+def test_activation_quantised_cache_building_matches_reference(golden_dir):
+    """`--act_quant` cache pass (tests/golden/recon_toy_aq.npz): with the reference's trained roundings of g_a.0 / g_a.1
+    installed, the product's save_inp_oup_data(act_quant=True, batch 1) reproduces the reference's quantised input, FP input and
+    FP target of g_a.2.  The W8A8 prefix goes through five dynamic 8-bit activation quantisers: a value on a rounding boundary
+    may land one level off on the GPU, so the quantised input is compared on its mean deviation."""
+    import lic
+    from quantization import BaseQuantBlock, QuantModel, QuantModule
+    from quantization.quantizer import AdaRoundQuantizer, to_rows
+    from quantization.utils import save_inp_oup_data
+    fx = np.load(os.path.join(golden_dir, "recon_toy_aq.npz"))
+    N, n_img, B, iters = (int(v) for v in fx["meta"])
+    torch.manual_seed(0)
+    qnn = QuantModel(lic.Cheng2020Anchor(N=N), WQ, AQ, is_cheng=True).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    with torch.no_grad():
+        for name, m in qnn.model.named_modules():
+            if isinstance(m, QuantModule) and m.org_weight is not None:
+                w = T(fx[f"org/{name}.weight"]).cuda()
+                m.weight.data.copy_(w); m.org_weight.copy_(w)
+                if m.org_bias is not None:
+                    b = T(fx[f"org/{name}.bias"]).cuda()
+                    m.bias.data.copy_(b); m.org_bias.copy_(b)
+    cali = T(fx["cali"]).cuda()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    qnn.set_quant_state(True, True)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    units = list(qnn.model.g_a.named_children())
+    for name, u in units[:2]:
+        for n_, m in u.named_modules():
+            if isinstance(m, QuantModule) and m.org_weight is not None:
+                alpha = T(fx[f"g_a.{name}/{n_}.alpha_final"]).cuda()
+                ada = AdaRoundQuantizer(uaq=m.weight_quantizer, round_mode="learned_hard_sigmoid",
+                                        weight_tensor=m.org_weight.data, alpha_rows=to_rows(alpha))
+                ada.soft_targets = False
+                m.weight_quantizer = ada
+        for m in u.modules():
+            if isinstance(m, (QuantModule, BaseQuantBlock)):
+                m.trained = True
+    (inp_q, inp_fp), out = save_inp_oup_data(qnn, units[2][1], cali, asym=True, act_quant=True, batch_size=1, input_prob=True)
+    for got, key, tol in ((inp_fp, "inp_fp", 3e-5), (out, "out", 3e-5)):
+        ref = T(fx[f"g_a.2/{key}"])
+        assert float((got.cpu() - ref).abs().max()) / float(ref.abs().max()) < tol, key
+    ref = T(fx["g_a.2/inp_q"])
+    dev = (inp_q.cpu() - ref).abs()
+    assert float(dev.max()) / float(ref.abs().max()) < 2e-2 and float(dev.mean()) / float(ref.abs().max()) < 1e-3
+    # and it is the quantised path that was compared: the quantised input is measurably away from the FP input
+    assert float((ref - T(fx["g_a.2/inp_fp"])).abs().max()) > 5e-3

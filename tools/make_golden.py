@@ -765,6 +765,55 @@ def golden_recon_nic(out_dir, iters=6):
     print("recon_nic.npz", len(fx), "arrays;", " ".join(f"{w}:{float(fx[w + '/loss'][0]):.4g}->{float(fx[w + '/loss'][-1]):.4g}" for w in wanted))
 
 
+def golden_recon_toy_aq(out_dir, iters=6):
+    """`main2.py --act_quant` on the toy Cheng2020 (N=8): the reference calibrates g_a.0 and g_a.1 with act_quant=True (their
+    caches are built from the W8A8 prefix, batch 1), then builds the caches of g_a.2.  Records the trained alphas of the two
+    blocks and the three cache tensors of g_a.2 -- the activation-quantised cache-building pass (utils.py:195-258, set_mode :28-35)."""
+    import logging
+    from quantization import QuantModule, BaseQuantBlock, block_reconstruction
+    import quantization.block_opt as bo
+    import quantization.utils as qu
+    N, n_img, B = 8, 4, 2
+    model, qnn = _toy_qnn(N, 1005)
+    cali = torch.rand(n_img, 3, 64, 64, generator=torch.Generator().manual_seed(81))
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True,
+                  b_range=(20, 2), warmup=0.2, act_quant=True, opt_mode="mse", config=None, args=args)
+    fx = {"cali": _np(cali), "meta": np.array([N, n_img, B, iters])}
+    for n_, m_ in qnn.model.named_modules():
+        if isinstance(m_, QuantModule) and m_.org_weight is not None:
+            fx["org/" + n_ + ".weight"] = _np(m_.org_weight)
+            if m_.org_bias is not None:
+                fx["org/" + n_ + ".bias"] = _np(m_.org_bias)
+    for k, v in model.entropy_bottleneck.state_dict().items():
+        fx["state/entropy_bottleneck." + k] = _np(v)
+    qnn.set_quant_state(True, True)
+    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    logging.disable(logging.CRITICAL)
+    _stdout = sys.stdout
+    sys.stdout = open(os.devnull, "w")
+    try:
+        units = list(qnn.model.g_a.named_children())
+        for name, u in units[:2]:
+            with _cuda_is_cpu():
+                block_reconstruction(qnn, u, name, **kwargs)
+            for n_, mm in u.named_modules():
+                if isinstance(mm, QuantModule) and mm.org_weight is not None:
+                    fx[f"g_a.{name}/{n_}.alpha_final"] = _np(mm.weight_quantizer.alpha)
+        with _cuda_is_cpu():
+            (inp_q, inp_fp), out = qu.save_inp_oup_data(qnn, units[2][1], cali, True, True, batch_size=1, input_prob=True)
+        fx["g_a.2/inp_q"], fx["g_a.2/inp_fp"], fx["g_a.2/out"] = _np(inp_q), _np(inp_fp), _np(out)
+    finally:
+        sys.stdout = _stdout
+        logging.disable(logging.NOTSET)
+    np.savez_compressed(os.path.join(out_dir, "recon_toy_aq.npz"), **fx)
+    d = float(np.abs(fx["g_a.2/inp_q"] - fx["g_a.2/inp_fp"]).max())
+    print("recon_toy_aq.npz", len(fx), "arrays; max |inp_q - inp_fp| =", d)
+
+
 def golden_blocks(out_dir):
     """Forward (and input/weight gradients) of the reference Cheng2020 quant blocks with nearest-rounded weights."""
     from quantization.quant_block import QuantRBWS, QuantRBU, QuantRB
@@ -843,6 +892,7 @@ def main():
     golden_recon_minnen(a.out)
     golden_recon_attn(a.out)
     golden_recon_nic(a.out)
+    golden_recon_toy_aq(a.out)
 
 
 if __name__ == "__main__":
