@@ -35,6 +35,7 @@ struct X6Args {
     int M, csteps;
     int epilogue, square_input, add_residual;
     long wplane;          // elements per weight plane
+    int xcd_mode;         // 1: XCD-aware tile numbering
     float* partial;       // split-K (v3): raw accumulators [ksplit][M][Cout]; nullptr -> final output
     int ksplit;
 };
@@ -69,6 +70,25 @@ __device__ __forceinline__ void split3_x4(const f32x4& v, bf16x4& p0, bf16x4& p1
     p0 = __builtin_bit_cast(bf16x4, u32x2{h01, h23});
     p1 = __builtin_bit_cast(bf16x4, u32x2{m01, m23});
     p2 = __builtin_bit_cast(bf16x4, u32x2{l01, l23});
+}
+
+// XCD-aware tile id: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs (each with its own L2).  Re-number
+// so that every XCD works on a CONTIGUOUS range of logical tile ids: neighbouring M tiles read overlapping input rows (3x3 halo)
+// and the same weight tile, so they should share an L2.  Bijective for any grid size (q, r split of the tail).
+struct TileId { int m, n, z; };
+__device__ __forceinline__ TileId xcd_tile_id(int mode) {
+    if (mode == 0) return TileId{(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+    const int nwg = gridDim.x * gridDim.y * gridDim.z;
+    const int lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    const int xcd = lin & 7, slot = lin >> 3;
+    const int q = nwg >> 3, r = nwg & 7;
+    const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    TileId t;
+    t.m = id % gridDim.x;
+    const int rest = id / gridDim.x;
+    t.n = rest % gridDim.y;
+    t.z = rest / gridDim.y;
+    return t;
 }
 
 __device__ __forceinline__ void finish(const X6Args& a, long o, float v) {
@@ -108,7 +128,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
     const int li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const TileId tile = xcd_tile_id(a.xcd_mode);
+    const int m0 = tile.m * BM, n0 = tile.n * BN;
 
     // A: two fp32 quads per thread per stage: rows tid>>2 and 64 + tid>>2, k-quad = tid&3
     const int aq = tid & 3;
@@ -169,8 +190,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
     const int csteps = (a.Cin + KS - 1) / KS;
     // split-K: this workgroup reduces stages [sbeg, sbeg + nsteps) of the KH*KW*csteps total
     const int steps_total = a.KH * a.KW * csteps;
-    const int sbeg = (int)((long)steps_total * blockIdx.z / a.ksplit);
-    const int nsteps = (int)((long)steps_total * (blockIdx.z + 1) / a.ksplit) - sbeg;
+    const int sbeg = (int)((long)steps_total * tile.z / a.ksplit);
+    const int nsteps = (int)((long)steps_total * (tile.z + 1) / a.ksplit) - sbeg;
 
     // load cursor (wave-uniform): tap and channel offset of the stage being loaded; per-thread pixel offset of that tap
     int ltap = sbeg / csteps;
@@ -324,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= a.M) continue;
                 const long o = (long)m * a.Cout + n;
-                if (a.partial) a.partial[(long)blockIdx.z * a.M * a.Cout + o] = acc[i][j][r];
+                if (a.partial) a.partial[(long)tile.z * a.M * a.Cout + o] = acc[i][j][r];
                 else finish(a, o, acc[i][j][r] + bv);
             }
     }
@@ -349,7 +370,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
     const int li = lane & 31, lh = lane >> 5;
-    const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+    const TileId tile = xcd_tile_id(a.xcd_mode);
+    const int m0 = tile.m * BM, n0 = tile.n * BN;
 
     const int aq = tid & 3;
     int hi0[2], wi0[2], abase[2], a_lds[2];
@@ -389,15 +411,21 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
 
     const int csteps = a.Cin / KS;
     const int steps_total = a.KH * a.KW * csteps;
-    const int sbeg = (int)((long)steps_total * blockIdx.z / a.ksplit);
-    const int nsteps = (int)((long)steps_total * (blockIdx.z + 1) / a.ksplit) - sbeg;
+    const int sbeg = (int)((long)steps_total * tile.z / a.ksplit);
+    const int nsteps = (int)((long)steps_total * (tile.z + 1) / a.ksplit) - sbeg;
 
-    int ltap = sbeg / csteps;
-    int lc = (sbeg - ltap * csteps) * KS;
-    int lkh = ltap / a.KW, lkw = ltap - lkh * a.KW;
+    // Stage order: channel slice OUTER, the KH*KW taps INNER.  The nine taps of one 16-channel slice read three input rows that
+    // overlap almost completely, so their activations stay in L1/L2 between uses; with taps outer every tap re-fetched its rows
+    // through the fabric (rocprofv3 FETCH_SIZE: 444 MiB per launch for a 50 MB input = no reuse at all across the 9 taps).
+    const int taps = a.KH * a.KW;
+    int ls = sbeg;                       // absolute stage index of the load cursor
+    int lc = 0;
     int apix[2];
     bool apix_ok[2];
-    auto retap = [&]() {
+    auto retap = [&]() {                 // cursor -> (tap, channel slice) of stage ls
+        const int cs = ls / taps, tap = ls - cs * taps;
+        const int lkh = tap / a.KW, lkw = tap - lkh * a.KW;
+        lc = cs * KS;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             const int hi = hi0[t] + lkh, wi = wi0[t] + lkw;
@@ -406,16 +434,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
         }
     };
     auto advance = [&]() {
-        lc += KS;
-        if (lc >= a.Cin) {
-            lc = 0;
-            ++lkw;
-            if (lkw == a.KW) { lkw = 0; ++lkh; }
-            retap();
-        }
+        ++ls;
+        retap();
     };
     retap();
-    const int bcur0 = sbeg * KS;       // Cin % 16 == 0: tap * Cin + c counts straight along the OHWI row
+    // element offset of stage s (relative to sbeg) along the OHWI weight row: tap * Cin + channel slice * 16
+    auto boff = [&](int s) {
+        const int g = sbeg + s;
+        const int cs = g / taps, tap = g - cs * taps;
+        return tap * a.Cin + cs * KS;
+    };
 
     f32x4 ra[2];
     bool ra_ok[2];
@@ -438,7 +466,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
         typedef const __attribute__((address_space(1))) void glb_void;
         const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
         char* dst = smem + buf * STAGE + 3 * APLANE + k * 1024;
-        __builtin_amdgcn_global_load_lds((glb_void*)(a.wp + dma_src[j] + bcur0 + stage * KS), (lds_void*)dst, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((glb_void*)(a.wp + dma_src[j] + boff(stage)), (lds_void*)dst, 16, 0, 0);
     };
 
     int fa_off[3][TM], fb_off[3][TN];
@@ -544,7 +572,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
                 const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (m >= a.M) continue;
                 const long o = (long)m * a.Cout + n;
-                if (a.partial) a.partial[(long)blockIdx.z * a.M * a.Cout + o] = acc[i][j][r];
+                if (a.partial) a.partial[(long)tile.z * a.M * a.Cout + o] = acc[i][j][r];
                 else finish(a, o, acc[i][j][r] + bv);
             }
     }
@@ -613,6 +641,7 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
     a.csteps = (d->Cin + BK - 1) / BK;
     a.epilogue = d->epilogue; a.square_input = d->square_input; a.add_residual = d->add_residual;
     a.wplane = (long)d->Cout * d->KH * d->KW * d->Cin;
+    a.xcd_mode = getenv("RDO_XCD") ? atoi(getenv("RDO_XCD")) : 1;
     int ks = rdo_conv2d_fwd_bf16x6_ksplit(d);
     if (ks < 1) ks = 1;
     if (ks > 1 && (!workspace || (long)ks * a.M * a.Cout > workspace_floats)) ks = 1;

@@ -79,8 +79,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
     const int li = lane & 31, lh = lane >> 5;
     const int wco0 = (wave >> 1) * WCO, wci0 = (wave & 1) * WCI;
 
-    const int chunk = blockIdx.x;
-    int t = blockIdx.y;
+    // XCD-aware numbering: the dispatcher deals consecutive workgroup ids round-robin over the 8 XCDs.  Give every XCD a
+    // contiguous range of logical ids with the TAP fastest: the nine tap-workgroups of one pixel chunk read the same dY and
+    // (shifted) X pixels at the same time and should share an L2 instead of fetching them eight times through the fabric.
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int chunk = lid / gridDim.y;
+    int t = lid - chunk * gridDim.y;
     const int tci = t % a.tiles_ci; t /= a.tiles_ci;
     const int tco = t % a.tiles_co; t /= a.tiles_co;
     const int tap = t;
