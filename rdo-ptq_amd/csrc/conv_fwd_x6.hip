@@ -83,11 +83,12 @@ __device__ __forceinline__ TileId xcd_tile_id(int mode) {
     const int xcd = lin & 7, slot = lin >> 3;
     const int q = nwg >> 3, r = nwg & 7;
     const int id = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + slot;
+    // N fastest: the N tiles of one M tile read the same activations; then M; split-K slices last
     TileId t;
-    t.m = id % gridDim.x;
-    const int rest = id / gridDim.x;
-    t.n = rest % gridDim.y;
-    t.z = rest / gridDim.y;
+    t.n = id % gridDim.y;
+    const int rest = id / gridDim.y;
+    t.m = rest % gridDim.x;
+    t.z = rest / gridDim.x;
     return t;
 }
 
