@@ -131,7 +131,8 @@ def test_full_size_rb_unit_step_matches_torch_autograd():
 
 
 @pytest.mark.parametrize("H,Cin,Cout,K,s,p", [(128, N, N, 3, 1, 1), (64, N, 4 * N, 3, 1, 1), (128, N, N, 1, 1, 0),
-                                              (64, N, N, 3, 1, 1), (128, N, N, 3, 2, 1), (32, N, 4 * N, 3, 1, 1)])
+                                              (64, N, N, 3, 1, 1), (128, N, N, 3, 2, 1), (32, N, 4 * N, 3, 1, 1),
+                                              (64, 32, N, 5, 1, 2), (128, N, 320, 5, 2, 2), (32, N, N, 3, 1, 1)])
 def test_split_bf16_conv_path_has_fp32_accuracy(ops, H, Cin, Cout, K, s, p):
     """The bf16x6 path rdo_conv2d_fwd takes for large problems: error vs an fp64 reference no larger than the fp32-MFMA
     kernel's, and the three bf16 planes re-sum to the fp32 weights exactly."""
