@@ -1,7 +1,9 @@
 // Forward / dgrad conv of the LARGE problems (rdo_conv2d_fwd_uses_bf16x6) with each fp32 operand split exactly into three
 // bf16 planes and the six significant cross products issued on v_mfma_f32_32x32x16_bf16 ("bf16x6").
-// v5 (128 x 192 tile, K stage 16, weight tile staged by LDS-DMA, fragment reads pipelined one stage ahead) is the one
-// rdo_conv2d_fwd dispatches to; v3 (register-staged) remains as the fallback for weight tensors beyond 2^31 plane elements.
+// rdo_conv2d_fwd dispatches to v6 (stride-1 3-wide kernels: the three kw taps share one activation image in LDS) or v5 (everything
+// else): 128 x 192 tile, K stage 16, weight tile staged by LDS-DMA, fragment reads pipelined one stage ahead, channel-slice-outer /
+// taps-inner stage order, XCD-aware tile numbering.  v3 (register-staged) remains as the fallback for weight tensors beyond 2^31
+// plane elements.
 //
 //   x = x1 + x2 + x3 exactly (x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)), same for w;
 //   x*w ~= x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1          dropped terms <= 3 * 2^-24 |x w|  (fp32-rounding level)
@@ -579,6 +581,229 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
     }
 }
 
+// ---- v6: v5 for stride-1 convs with KW == 3: the three kw taps of a (channel slice, kh) pair share ONE activation image -------------
+// The A tile of tap kw is the tile of tap kw-1 shifted by one pixel, so instead of loading and splitting 128 rows per stage the
+// workgroup keeps the halo rows of its output pixels -- R image rows of Wt + 2 pixels, R * Wt = 128 -- in LDS per GROUP of three
+// stages and the fragment reads of tap kw start kw rows further down: a third of the activation loads, splits and LDS writes.
+// Stage order (channel slice, kh, kw); K is split at group boundaries.  Requirements (host-checked): stride 1, KW == 3, pad == 1,
+// Cin % 16 == 0, M % 128 == 0 and W either a multiple of 128 or a divisor of it with H * W % 128 == 0.
+__global__ __launch_bounds__(256, 2) void conv_fwd_x6v6_kernel(X6Args a) {
+    constexpr int BM = 128, BN = 192, KS = 16;
+    constexpr int TM = 2, TN = 3;
+    constexpr int AROWS = 144;                               // halo rows per image: 8 x 18 (W = 16) is the largest case
+    constexpr int APLANE = AROWS * 32, BPLANE = BN * 32;
+    constexpr int ABUF = 3 * APLANE, BBUF = 3 * BPLANE;
+    constexpr int NB = 5, NA = 3;                            // DMA pieces / activation quads per thread
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][ABUF] [2][BBUF]
+    char* const sA = smem;
+    char* const sB = smem + 2 * ABUF;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
+    const int li = lane & 31, lh = lane >> 5;
+    const TileId tile = xcd_tile_id(a.xcd_mode);
+    const int m0 = tile.m * BM, n0 = tile.n * BN;
+
+    // tile geometry: 128 consecutive output pixels = R rows of Wt pixels of one image
+    const int Wt = a.W < 128 ? a.W : 128, Wh = Wt + 2, R = 128 / Wt, NQ = R * Wh;
+    const int b0 = m0 / (a.H * a.W);
+    const int rem0 = m0 - b0 * (a.H * a.W);
+    const int ho0 = rem0 / a.W, wo0 = rem0 - ho0 * a.W;
+
+    // activation quads of this thread: e = tid + 256 j over [halo row q][quad of 4 channels]
+    int a_off[NA], a_hi[NA], a_lds[NA];
+    bool a_live[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int e = tid + 256 * j;
+        const int q = e >> 2, aq = e & 3;
+        const int r = q / Wh, wq = q - r * Wh;
+        const int wi = wo0 + wq - 1;
+        a_live[j] = q < NQ && (unsigned)wi < (unsigned)a.W;
+        a_hi[j] = ho0 + r - a.pad;                           // + kh
+        a_off[j] = ((b0 * a.H + a_hi[j]) * a.W + wi) * a.Cin + 4 * aq;      // + kh * W * Cin + channel slice
+        a_lds[j] = q < AROWS ? chunk_off16(q, aq >> 1) + (aq & 1) * 8 : -1;
+    }
+    int dma_src[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
+        const int e = k * 64 + lane;
+        const int pl = e / (BN * 2);
+        const int r = e - pl * (BN * 2);
+        const int row = r >> 1, ch = (r & 1) ^ ((row >> 3) & 1);
+        const int n = n0 + row < a.Cout ? n0 + row : 0;
+        dma_src[j] = (int)(pl * a.wplane) + n * a.KH * a.KW * a.Cin + 8 * ch;
+    }
+    // halo row of this lane's output pixels (tap kw reads row hb + kw)
+    int hb[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int ml = wm0 + i * 32 + li;
+        const int r = ml / Wt;
+        hb[i] = r * Wh + (ml - r * Wt);
+    }
+    int fb_off[3][TN];
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb_off[p][j] = p * BPLANE + chunk_off16(wn0 + j * 32 + li, lh);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int csteps = a.Cin / KS;
+    const int groups_total = csteps * a.KH;                  // group = (channel slice, kh); three stages (kw) each
+    const int gbeg = (int)((long)groups_total * tile.z / a.ksplit);
+    const int ngroups = (int)((long)groups_total * (tile.z + 1) / a.ksplit) - gbeg;
+    const int nsteps = 3 * ngroups;
+
+    f32x4 ra[NA];
+    bool ra_ok[NA];
+    auto load_a = [&](int j, int g) {                         // quad j of group gbeg + g (clamped by the caller)
+        const int G = gbeg + g;
+        const int cs = G / a.KH, kh = G - cs * a.KH;
+        ra_ok[j] = a_live[j] && (unsigned)(a_hi[j] + kh) < (unsigned)a.H;
+        ra[j] = *reinterpret_cast<const f32x4*>(a.x + (ra_ok[j] ? a_off[j] + kh * a.W * a.Cin + cs * KS : 0));
+    };
+    auto store_a = [&](int j, int abuf) {
+        if (a_lds[j] < 0) return;
+        f32x4 v = ra_ok[j] ? ra[j] : f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.square_input) v = v * v;
+        bf16x4 p0, p1, p2;
+        split3_x4(v, p0, p1, p2);
+        char* st = sA + abuf * ABUF + a_lds[j];
+        *reinterpret_cast<bf16x4*>(st) = p0;
+        *reinterpret_cast<bf16x4*>(st + APLANE) = p1;
+        *reinterpret_cast<bf16x4*>(st + 2 * APLANE) = p2;
+    };
+    // weight row offset of stage t (relative to the first stage of this workgroup): (kh * 3 + kw) * Cin + channel slice * 16
+    auto boff = [&](int t) {
+        const int G = gbeg + t / 3, kw = t - (t / 3) * 3;
+        const int cs = G / a.KH, kh = G - cs * a.KH;
+        return (kh * 3 + kw) * a.Cin + cs * KS;
+    };
+    auto dma_b = [&](int j, int buf, int t) {
+        typedef __attribute__((address_space(3))) void lds_void;
+        typedef const __attribute__((address_space(1))) void glb_void;
+        const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
+        char* dst = sB + buf * BBUF + k * 1024;
+        __builtin_amdgcn_global_load_lds((glb_void*)(a.wp + dma_src[j] + boff(t)), (lds_void*)dst, 16, 0, 0);
+    };
+
+    bf16x8 fa0[2][TM], fb0[2][TN], fa12[2][TM], fb12[2][TN];
+    auto read_a = [&](bf16x8 (&dst)[TM], int p, int abuf, int kw) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+            dst[i] = *reinterpret_cast<const bf16x8*>(sA + abuf * ABUF + p * APLANE + chunk_off16(hb[i] + kw, lh));
+    };
+    auto read_b = [&](bf16x8 (&dst)[TN], int p, int buf) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(sB + buf * BBUF + fb_off[p][j]);
+    };
+    auto mma = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fb)[TN]) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    };
+
+    // prologue: activation image of group 0 in A buffer 0, quads of group 1 in registers, weight images of stages 0 and 1
+#pragma unroll
+    for (int j = 0; j < NA; ++j) load_a(j, 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dma_b(j, 0, 0);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) store_a(j, 0);
+#pragma unroll
+    for (int j = 0; j < NA; ++j) load_a(j, ngroups > 1 ? 1 : 0);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) dma_b(j, 1, 1);
+    __syncthreads();
+    read_a(fa0[0], 0, 0, 0); read_b(fb0[0], 0, 0);
+    read_a(fa12[0], 1, 0, 0); read_b(fb12[0], 1, 0);
+    read_a(fa12[1], 2, 0, 0); read_b(fb12[1], 2, 0);
+    __syncthreads();
+
+    // one stage: MFMAs of stage t from registers | fragments of stage t+1 | weight image of stage t+2 | the group's share of the
+    // activation work (kw 0: two quads of the next group's image, kw 1: the third; kw 2: loads of the group after next)
+    auto stage = [&](auto parc, auto kwc, int t, int g) {
+        constexpr int PAR = decltype(parc)::value, NXT = PAR ^ 1, KW = decltype(kwc)::value;
+        const int ab = g & 1;                                        // A buffer of this stage's group
+        const int an = KW == 2 ? ab ^ 1 : ab, kn = KW == 2 ? 0 : KW + 1;   // buffer / tap of stage t+1
+        const int wst = t + 2 < nsteps ? t + 2 : nsteps - 1;
+        read_a(fa0[NXT], 0, an, kn); read_b(fb0[NXT], 0, NXT);
+        // slot 0: (A2, B0)
+        mma(fa12[1], fb0[PAR]);
+        read_a(fa12[1], 2, an, kn);
+        if constexpr (KW == 0) { store_a(0, ab ^ 1); store_a(1, ab ^ 1); }
+        if constexpr (KW == 1) store_a(2, ab ^ 1);
+        if constexpr (KW == 2) {
+            const int g2 = g + 2 < ngroups ? g + 2 : ngroups - 1;
+#pragma unroll
+            for (int j = 0; j < NA; ++j) load_a(j, g2);
+        }
+        dma_b(0, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0[PAR], fb12[1]);
+        read_b(fb12[1], 2, NXT);
+        dma_b(1, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa12[0], fb0[PAR]);
+        dma_b(2, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa12[0], fb12[0]);
+        read_a(fa12[0], 1, an, kn);
+        dma_b(3, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0[PAR], fb12[0]);
+        read_b(fb12[0], 1, NXT);
+        dma_b(4, PAR, wst);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0[PAR], fb0[PAR]);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    // two groups (six stages) per trip: the stage parity -- which plane-0 register set and weight buffer a stage uses -- is back
+    // where it started, so no control-flow join mixes the two register assignments
+    int g = 0;
+    for (; g + 1 < ngroups; g += 2) {
+        const int t = 3 * g;
+        stage(I0{}, I0{}, t, g); stage(I1{}, I1{}, t + 1, g); stage(I0{}, I2{}, t + 2, g);
+        stage(I1{}, I0{}, t + 3, g + 1); stage(I0{}, I1{}, t + 4, g + 1); stage(I1{}, I2{}, t + 5, g + 1);
+    }
+    if (g < ngroups) {
+        const int t = 3 * g;
+        stage(I0{}, I0{}, t, g); stage(I1{}, I1{}, t + 1, g); stage(I0{}, I2{}, t + 2, g);
+    }
+
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn0 + j * 32 + li;
+        if (n >= a.Cout) continue;
+        const float bv = (a.bias && !a.partial) ? a.bias[n] : 0.f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (m >= a.M) continue;
+                const long o = (long)m * a.Cout + n;
+                if (a.partial) a.partial[(long)tile.z * a.M * a.Cout + o] = acc[i][j][r];
+                else finish(a, o, acc[i][j][r] + bv);
+            }
+    }
+}
+
 // split-K second pass of the v3 kernel: sum the partial accumulators, bias, epilogue
 __global__ __launch_bounds__(256) void x6_splitk_epilogue_kernel(X6Args a) {
     const long total = (long)a.M * a.Cout;
@@ -651,10 +876,34 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
     return rdo::dispatch(
         [a](hipStream_t s) {
-            // RDO_X6_VER=3 / 4 select the earlier register-staged / LDS-DMA variants of the same tile (kept for A/B measurements);
+            // default: v6 where its geometry applies, else v5.  RDO_X6_VER=5 forces v5; 3 / 4 select the earlier register-staged /
+            // LDS-DMA variants of the same tile (kept for A/B measurements);
             // the LDS-DMA loaders address the weight planes with 32-bit element offsets
-            static const int ver_env = getenv("RDO_X6_VER") ? atoi(getenv("RDO_X6_VER")) : 5;
-            const int ver = (ver_env != 3 && 3 * a.wplane >= (1L << 31)) ? 3 : ver_env;
+            static const int ver_env = getenv("RDO_X6_VER") ? atoi(getenv("RDO_X6_VER")) : 6;
+            const int ver = (ver_env != 3 && 3 * a.wplane >= (1L << 31)) ? 3 : (ver_env >= 5 ? 5 : ver_env);
+            // v6 (the three kw taps share one activation image) takes the stride-1 3-wide kernels whose tiles are whole image rows
+            const bool v6_ok = a.stride == 1 && a.KW == 3 && a.pad == 1 && a.Cin % 16 == 0 && a.M % 128 == 0 && a.W >= 16 &&
+                               (a.W % 128 == 0 || (128 % a.W == 0 && (a.H * a.W) % 128 == 0)) &&
+                               a.ksplit <= (a.Cin / 16) * a.KH;
+            if (ver_env >= 6 && v6_ok && 3 * a.wplane < (1L << 31)) {
+                constexpr size_t lds6 = (size_t)2 * 3 * 144 * 32 + (size_t)2 * 3 * 192 * 32;
+                static bool attr6 = false;
+                if (!attr6) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v6_kernel),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6) != hipSuccess)
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6 v6) failed");
+                    attr6 = true;
+                }
+                dim3 grid6((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
+                hipLaunchKernelGGL(conv_fwd_x6v6_kernel, grid6, dim3(256), lds6, s, a);
+                if (int rc = rdo::check_launch("conv_fwd_x6v6")) return rc;
+                if (a.ksplit > 1) {
+                    long g = rdo::ceil_div((long)a.M * a.Cout, 256);
+                    hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
+                    return rdo::check_launch("x6_splitk_epilogue");
+                }
+                return RDO_OK;
+            }
             const void* kern = ver == 3 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<false>)
                              : ver == 4 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<true>)
                                         : reinterpret_cast<const void*>(conv_fwd_x6v5_kernel);
