@@ -143,7 +143,9 @@ ThinArgs make(const rdo_conv_desc* d) {
 // shapes the thin kernels take over: few input channels, no squared input; forward additionally: plain / (leaky-)ReLU epilogue
 bool rdo_conv_is_thin(const rdo_conv_desc* d, bool forward) {
     if (!(d->Cin <= 4 && d->KH * d->KW * d->Cin <= PMAX && !d->square_input)) return false;
-    if (!forward) return true;
+    // wgrad keeps one accumulator per patch value in registers: 3x3x3 and 1x1x3 only (the 75-value 5x5 stem spilled: 3.4 ms
+    // against 0.35 ms on the MFMA kernel)
+    if (!forward) return d->KH * d->KW * d->Cin <= 32;
     return !d->add_residual && (d->epilogue == RDO_EPI_NONE || d->epilogue == RDO_EPI_LRELU || d->epilogue == RDO_EPI_RELU);
 }
 
@@ -169,7 +171,6 @@ int rdo_launch_thin_wgrad(const rdo_conv_desc* d, const float* x, const float* d
     a.mchunk = (int)(rdo::ceil_div(rdo::ceil_div(a.M, nsplit), PB) * PB);
     dim3 grid((unsigned)nsplit, (unsigned)rdo::ceil_div(a.Cout, 64));
     if (a.patch <= 4) hipLaunchKernelGGL((thin_wgrad_kernel<4, 8>), grid, dim3(512), 0, s, a);
-    else if (a.patch <= 32) hipLaunchKernelGGL((thin_wgrad_kernel<32, 8>), grid, dim3(512), 0, s, a);
-    else hipLaunchKernelGGL((thin_wgrad_kernel<PMAX, 2>), grid, dim3(128), 0, s, a);
+    else hipLaunchKernelGGL((thin_wgrad_kernel<32, 8>), grid, dim3(512), 0, s, a);
     return rdo::check_launch("conv_thin_wgrad");
 }
