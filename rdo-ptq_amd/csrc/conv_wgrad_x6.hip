@@ -284,6 +284,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
                  read_frag(std::integral_constant<int, 1>{}, st, 1, 3 * SL);
                  read_frag(std::integral_constant<int, 1>{}, st, 1, 3 * SL + 1);
                  read_frag(std::integral_constant<int, 1>{}, st, 1, 3 * SL + 2);
+                 // one wave per SIMD: the split arithmetic of the two store parts must sit BETWEEN the nine MFMAs (each leaves
+                 // ~24 issue cycles), not in front of them; the LDS writes / reads follow
+#pragma unroll
+                 for (int g = 0; g < TM * TN; ++g) {
+                     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // 1 MFMA
+                     __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);     // 6 VALU
+                 }
+                 __builtin_amdgcn_sched_group_barrier(0x300, 9, 0);         // 6 ds_write_b64 + 3 ds_read_b128
                  __builtin_amdgcn_sched_barrier(0);
              }()),
              ...);
