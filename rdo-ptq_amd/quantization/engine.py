@@ -9,7 +9,9 @@ This replaces the Python/autograd loop body of the reference (`for i in range(it
 Forward, the hand-derived backward, the loss and the optimiser are enqueued as one native plan per iteration
 (hipops.plan.Plan -> rdo_plan_run, hipGraph replay), with every per-iteration scalar (temperature b, Adam bias corrections,
 mini-batch indices) read on the device from tables indexed by a device-side iteration counter: zero host work or syncs
-inside the loop.  Units: a bare conv `QuantModule` ('layer') and the Cheng2020 blocks QuantRB / QuantRBWS / QuantRBU.
+inside the loop.  Units: a single `QuantModule` ('layer': conv, transposed conv, GDN / IGDN, with a fused LeakyReLU / ReLU) and the
+Cheng2020 blocks QuantRB / QuantRBWS / QuantRBU; the Lu2022 RSTB blocks and every unit whose task loss runs through the rest of
+its sub-coder are handled by `swin_engine.TapeEngine`, a subclass that reuses the ops, buffers and plans defined here.
 
 Loss = round + rec + task exactly as the reference computes it for Sequential-indexed CompressAI models, where the task
 term degenerates to a second copy of the reconstruction term: `coef = 2`.
