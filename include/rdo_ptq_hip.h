@@ -148,6 +148,13 @@ int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t*
 int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
                       int32_t B, int64_t per_image, int32_t C, float coef, float* grad, float* loss_out, void* stream);
 
+/* general task exponent (main2.py:52 --task_loss -> LossFunction.metric, layer_opt.py:150,274): adds
+ *   coef2 * sum d^2 / npix + coefp * sum |d|^p / npix   to the loss slot and writes its gradient; p >= 1.
+ * (coef2, coefp) = (1, 1) is rec_loss + task_loss on the same tensors, (0, 1) the task term alone.                           */
+int rdo_lp_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
+                     int32_t B, int64_t per_image, int32_t C, float coef2, float coefp, float p, float* grad,
+                     float* loss_out, void* stream);
+
 /* ---- K9: element-wise helpers on NHWC tensors */
 int rdo_lrelu_fwd(const float* x, int64_t n, float* out, void* stream);                         /* nn.LeakyReLU(0.01) */
 int rdo_lrelu_bwd(const float* g, const float* y, int64_t n, float* out, void* stream);          /* out = g*(y>0?1:.01) */

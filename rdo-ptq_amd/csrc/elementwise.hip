@@ -67,6 +67,39 @@ __global__ __launch_bounds__(256) void lp2_kernel(const float* pred, const float
         atomicAdd(loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), (red[0] + red[1] + red[2] + red[3]) * inv_npix * coef);
 }
 
+// general exponent: loss = coef2 * sum d^2 + coefp * sum |d|^p, both over the same (pred, tgt) pair -- rec_loss (p = 2) and the
+// task term with main2.py's --task_loss exponent (layer_opt.py:133,150) in one pass
+__global__ __launch_bounds__(256) void lp_kernel(const float* pred, const float* tgt, const int32_t* idx_table,
+                                                 const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef2,
+                                                 float coefp, float pw, float* grad, float* loss_out) {
+    const int it = *iter_ptr;
+    const long quads = per_image / 4;
+    const long total = (long)B * quads;
+    float acc = 0.f;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(t / quads);
+        const long off = (t - (long)b * quads) * 4;
+        const f32x4 p = *reinterpret_cast<const f32x4*>(pred + (long)b * per_image + off);
+        const f32x4 y = *reinterpret_cast<const f32x4*>(tgt + (long)idx_table[(long)it * B + b] * per_image + off);
+        f32x4 g;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float d = p[e] - y[e], a = fabsf(d);
+            const float am1 = powf(a, pw - 1.f);                 // |d|^(p-1); pow(0, 0) = 1 and the sign factor below is 0
+            acc += coef2 * d * d + coefp * am1 * a;
+            const float sg = (float)((d > 0.f) - (d < 0.f));
+            g[e] = (coef2 * 2.f * d + coefp * pw * am1 * sg) * inv_npix;
+        }
+        *reinterpret_cast<f32x4*>(grad + (long)b * per_image + off) = g;
+    }
+    __shared__ float red[4];
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0 && loss_out)
+        atomicAdd(loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), (red[0] + red[1] + red[2] + red[3]) * inv_npix);
+}
+
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* g, const float* y, long n4, float slope, float* out) {
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x) {
         const f32x4 gv = reinterpret_cast<const f32x4*>(g)[t], yv = reinterpret_cast<const f32x4*>(y)[t];
@@ -288,6 +321,21 @@ int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* 
             return rdo::check_launch("lp2_loss_grad");
         },
         stream, "lp2_loss_grad", 0.0, 12.0 * B * per_image);
+}
+
+int rdo_lp_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
+                     int64_t per_image, int32_t C, float coef2, float coefp, float p, float* grad, float* loss_out, void* stream) {
+    RDO_REQUIRE(pred && tgt_cache && idx_table && iter_ptr && grad, "rdo_lp_loss_grad: null pointer");
+    RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_lp_loss_grad: bad shape");
+    RDO_REQUIRE(p >= 1.f, "rdo_lp_loss_grad: exponent %g < 1 has no finite gradient at zero", (double)p);
+    const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(lp_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, pred, tgt_cache, idx_table,
+                               iter_ptr, B, (long)per_image, inv_npix, coef2, coefp, p, grad, loss_out);
+            return rdo::check_launch("lp_loss_grad");
+        },
+        stream, "lp_loss_grad", 0.0, 12.0 * B * per_image);
 }
 
 static int act_bwd(const float* g, const float* y, int64_t n, float slope, float* out, void* stream, const char* tag) {

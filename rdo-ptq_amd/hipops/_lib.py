@@ -55,6 +55,7 @@ _SIGS = {
     "rdo_actquant_perchannel": (C.c_int, [P, C.c_int64, C.c_int32, P, P, P]),
     "rdo_gather_qdrop": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_float, C.c_uint32, P, P]),
     "rdo_lp2_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, P, P, P]),
+    "rdo_lp_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, P, P, P]),
     "rdo_lrelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
     "rdo_lrelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_relu_fwd": (C.c_int, [P, C.c_int64, P, P]),

@@ -179,6 +179,15 @@ def lp2_loss_grad(pred, tgt_cache, idx_table, iter_ptr, coef, grad, loss_log):
     return grad
 
 
+def lp_loss_grad(pred, tgt_cache, idx_table, iter_ptr, coef2, coefp, p, grad, loss_log):
+    """coef2 * lp_loss(., p=2) + coefp * lp_loss(., p=p) of the same (pred, tgt) pair, and its gradient."""
+    B = pred.shape[0]
+    per_image = pred[0].numel()
+    L.check(L.lib().rdo_lp_loss_grad(_ptr(pred), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
+                                     pred.shape[-1], coef2, coefp, p, _ptr(grad), _ptr(loss_log), _stream()), "rdo_lp_loss_grad")
+    return grad
+
+
 def lrelu(x, out=None):
     out = torch.empty_like(x) if out is None else out
     L.check(L.lib().rdo_lrelu_fwd(_ptr(x), x.numel(), _ptr(out), _stream()), "rdo_lrelu_fwd")

@@ -29,7 +29,7 @@ from hipops import ops
 from hipops.plan import Plan
 
 from .quant_layer import QuantModule
-from .quantizer import AdaRoundQuantizer, to_rows
+from .quantizer import AdaRoundQuantizer, from_rows, to_rows
 
 UNIT_KINDS = ("layer", "rb", "rbws", "rbu", "rstb")
 
@@ -47,8 +47,6 @@ class _Op:
         wq = qm.weight_quantizer
         if not wq.inited:
             wq(qm.weight)                      # lazy scale init, as the reference's first forward would do
-        if not wq.channel_wise:
-            raise NotImplementedError("calibration engine: layer-wise (non channel-wise) scales are not built yet")
         w = qm.org_weight.detach()
         if qm.kind == "linear":
             self.w = w.reshape(w.shape[0], 1, 1, w.shape[1]).contiguous()      # a Linear is a 1x1 conv over the token matrix
@@ -62,8 +60,10 @@ class _Op:
             self.w = to_rows(w)                # OHWI or [C,C]
         dev = self.w.device
         self.rows = self.w.shape[0]
-        self.delta = wq.delta.reshape(-1).to(dev).contiguous()
-        self.zp = wq.zero_point.reshape(-1).to(dev).contiguous()
+        # layer-wise scales (main2.py without --channel_wise): one (delta, zero_point) repeated over the rows
+        self.channel_wise = bool(wq.channel_wise)
+        self.delta = wq.delta.reshape(-1).to(dev).expand(self.rows).contiguous()
+        self.zp = wq.zero_point.reshape(-1).to(dev).expand(self.rows).contiguous()
         self.n_levels = wq.n_levels
         if self.is_ln:
             self.desc = ops.ada_desc(self.w, self.n_levels, conv_layout=False)
@@ -138,7 +138,7 @@ class _Op:
 class UnitEngine:
     def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
                  warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
-                 use_graph=True, force_dp_split=False):
+                 use_graph=True, force_dp_split=False, task_p=2.0):
         if kind not in UNIT_KINDS:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
@@ -147,6 +147,7 @@ class UnitEngine:
         self.kind, self.mods = kind, modules
         self.cq, self.cf, self.co = cache_q, cache_fp, cache_out
         self.B, self.iters = int(batch_size), int(iters)
+        self.task_p = float(task_p)            # exponent of the task term (main2.py --task_loss); rec_loss is always p = 2
         self.weight, self.input_prob, self.seed = float(weight), float(input_prob), int(seed) & 0xFFFFFFFF
         self.include_act = include_act_func
         self.use_graph = use_graph
@@ -299,7 +300,11 @@ class UnitEngine:
                               wplanes=op.wd_planes)
 
     def _loss(self, pred, grad):
-        ops.lp2_loss_grad(pred, self.co, self.idx, self.it, 2.0, grad, self.loss_log)
+        # rec_loss + task_loss on the same tensors (fp_out is the identity for these coders)
+        if self.task_p == 2.0:
+            ops.lp2_loss_grad(pred, self.co, self.idx, self.it, 2.0, grad, self.loss_log)
+        else:
+            ops.lp_loss_grad(pred, self.co, self.idx, self.it, 1.0, 1.0, self.task_p, grad, self.loss_log)
 
     def _forward_backward(self):
         o, t, x = self.ops, self.t, self.x_in
@@ -452,6 +457,9 @@ class UnitEngine:
             rows = op.alpha.flip(1, 2).contiguous() if op.tconv is not None else op.alpha
             if qm.kind == "linear":
                 rows = op.alpha.reshape(op.alpha.shape[0], -1)
+            if not op.channel_wise and not op.is_ln:
+                # the per-tensor quantiser keeps alpha in the logical (OIHW) element order, flattened to one row
+                rows = from_rows(rows, qm.org_weight.data, op.tconv is not None).contiguous().reshape(1, -1)
             ada = AdaRoundQuantizer(uaq=qm.weight_quantizer, round_mode="learned_hard_sigmoid",
                                     weight_tensor=qm.org_weight.data, alpha_rows=rows)
             ada.soft_targets = False

@@ -87,8 +87,10 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     if opt_mode != "mse":
         raise NotImplementedError("only opt_mode='mse' (the mode main2.py uses) is built")
     task_p = getattr(args, "task_loss", 2.0) if args is not None else 2.0
-    if float(p) != 2.0 or float(task_p) != 2.0:
-        raise NotImplementedError("the HIP loss kernel implements p = task_loss = 2 (main2.py defaults)")
+    if float(p) != 2.0:
+        raise NotImplementedError("rec_loss is built for p = 2 (the value main2.py passes); --task_loss may be any exponent >= 1")
+    if float(task_p) < 1.0:
+        raise ValueError("--task_loss < 1 has no finite gradient at zero error")
     rank, world_size = dp.world()
     if world_size > 1:                      # data parallel: this rank calibrates on its shard with its share of the batch
         cali_data = dp.shard(cali_data)
@@ -118,7 +120,8 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     kind, mods = _unit_modules(unit)
     # the CLI --lr is ignored by the reference (Adam default 1e-3, layer_opt.py:253-254); kept that way.
     common = dict(batch_size=batch_size, iters=iters, weight=weight, b_range=b_range, warmup=warmup, input_prob=input_prob,
-                  lr=1e-3, seed=torch.initial_seed() ^ (hash(unit_name) & 0xFFFF), include_act_func=include_act_func)
+                  lr=1e-3, seed=torch.initial_seed() ^ (hash(unit_name) & 0xFFFF), include_act_func=include_act_func,
+                  task_p=float(task_p))
     if kind == "rstb" or task_cache is not None:
         eng = TapeEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), tail=module_list, tail_round=tail_round,
                          task_cache=task_cache, **common)

@@ -375,7 +375,10 @@ class TapeEngine(UnitEngine):
         n_unit = len(self.tape)
         plain = not self.tail and not self.tail_round                 # fp_out is the identity: task == rec (coef 2)
         dy = self._buf(*y.shape)
-        ops.lp2_loss_grad(y, self.co, self.idx, self.it, 2.0 if plain else 1.0, dy, self.loss_log)
+        if plain:
+            self._loss(y, dy)
+        else:
+            ops.lp2_loss_grad(y, self.co, self.idx, self.it, 1.0, dy, self.loss_log)
         if not plain:
             z = y
             for st in self.tail:
@@ -385,7 +388,10 @@ class TapeEngine(UnitEngine):
                 zr = self._buf(*z.shape)
                 ops.round_(z, out=zr)                                  # round_ste: identity gradient
             dz = self._buf(*z.shape)
-            ops.lp2_loss_grad(zr, self.task_cache, self.idx, self.it, 1.0, dz, self.loss_log)
+            if self.task_p == 2.0:
+                ops.lp2_loss_grad(zr, self.task_cache, self.idx, self.it, 1.0, dz, self.loss_log)
+            else:
+                ops.lp_loss_grad(zr, self.task_cache, self.idx, self.it, 0.0, 1.0, self.task_p, dz, self.loss_log)
             if z is y:                                                 # round-only tail: both terms meet at the unit output
                 ops.add(dz, dy, out=dy)
             else:

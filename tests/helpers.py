@@ -47,13 +47,14 @@ def _conv(w, b, stride, pad, dev):
     return c.to(dev)
 
 
-def product_unit(fx, tag, kind, dev="cuda"):
+def product_unit(fx, tag, kind, dev="cuda", wq=None):
     """-> (unit module of the product `quantization` package, engine kind, engine module dict) from fixture tensors."""
     import lic
     from quantization.quant_block import QuantRB, QuantRBU, QuantRBWS
     from quantization.quant_layer import QuantModule
     from quantization.recon import _unit_modules
     g = lambda n: T(fx[f"{tag}/{n}"]) if f"{tag}/{n}" in fx else None
+    WQ = wq or globals()["WQ"]
     if kind == "layer":
         s, p = LAYER_GEOM[tag]
         qm = QuantModule(_conv(g("layer.weight"), g("layer.bias"), s, p, dev), WQ, AQ)

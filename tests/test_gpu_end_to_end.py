@@ -78,7 +78,8 @@ def test_main2_flow_on_toy_model():
     torch.testing.assert_close(a, b, rtol=0, atol=0)
 
 
-def test_main2_flow_on_toy_minnen2018():
+@pytest.mark.parametrize("channel_wise", [True, False])
+def test_main2_flow_on_toy_minnen2018(channel_wise):
     """Same driver flow on the Minnen2018 mean-scale family (5x5 stride-2 convs, transposed convs, GDN units): every
     QuantModule is its own unit (no block wrappers), `qnn.model.g_s[-1]` keeps activation quantisation off (main2.py:262-263)."""
     import lic
@@ -90,8 +91,9 @@ def test_main2_flow_on_toy_minnen2018():
     cali = torch.rand(8, 3, 64, 64, generator=g).cuda()
     test_imgs = [torch.rand(1, 3, 96, 80, generator=g) for _ in range(2)]
     psnr_fp, bpp_fp = evaluate_images(model, test_imgs, p=64)
-    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
-    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    # channel_wise=False is main2.py run without --channel_wise (main2.py:42,175-176): per-tensor weight scales
+    wq = {"n_bits": 8, "channel_wise": channel_wise, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": channel_wise, "scale_method": "max", "leaf_param": False}
     qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq).cuda().eval()
     qnn.set_first_last_layer_to_8bit()
     qnn.disable_network_output_quantization()
@@ -119,6 +121,13 @@ def test_main2_flow_on_toy_minnen2018():
     for v in (psnr_fp, bpp_fp, psnr_w8, bpp_w8, psnr_w8a8, bpp_w8a8):
         assert math.isfinite(v)
     assert abs(psnr_w8 - psnr_fp) < 3.0
+    if not channel_wise:
+        from quantization.export import dequantize, integer_state
+        qnn.set_quant_state(True, False)
+        for name, entry in integer_state(qnn).items():
+            m = dict(qnn.named_modules())[name]
+            assert entry["delta"].numel() == 1
+            torch.testing.assert_close(dequantize(entry), m.weight_quantizer(m.org_weight).cpu(), rtol=0, atol=1e-7)
 
 
 def test_integer_export_reproduces_hard_rounded_weights():

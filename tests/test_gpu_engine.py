@@ -73,6 +73,102 @@ def test_engine_matches_oracle(recon, tag, kind, graph):
     assert float(err) < (5e-3 if flips else 2e-5), float(err)
 
 
+@pytest.mark.parametrize("tag,kind", [("g_a.0", "rbws"), ("g_s.1", "rbu"), ("g_a.6", "layer")])
+def test_engine_layer_wise_scales(recon, tag, kind):
+    """main2.py without --channel_wise (main2.py:42,175): one (delta, zero_point) per weight tensor.  Engine vs oracle with
+    the oracle's own per-tensor scale init (pinned by the quantiser goldens), then the hand-back through the per-tensor
+    AdaRoundQuantizer, whose alpha lives in the logical OIHW order."""
+    from oracle import rdo_oracle as O
+    from quantization.engine import UnitEngine
+    fx = recon
+    _, _, B, iters = (int(v) for v in fx["meta"])
+    idx = fx[f"{tag}/idx"]
+    ops_o = oracle_ops(fx, tag, kind)
+    for op in ops_o.values():
+        op.delta = op.zp = None
+        op.channel_wise = False
+    log = O.reconstruct_unit(kind, ops_o, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]), iters=iters,
+                             batch_size=B, idx_stream=idx,
+                             mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5), input_prob=0.5)
+    unit, k, mods = product_unit(fx, tag, kind, wq={"n_bits": 8, "channel_wise": False, "scale_method": "max"})
+    eng = UnitEngine(k, mods, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]), batch_size=B,
+                     iters=iters, input_prob=0.5, seed=SEED, idx_table=torch.from_numpy(idx))
+    for n, op in eng.ops.items():
+        assert float(op.delta.min()) == float(op.delta.max()) == float(ops_o[n].delta)
+        assert float(op.zp.min()) == float(op.zp.max()) == float(ops_o[n].zp)
+    eng.run()
+    torch.cuda.synchronize()
+    total, _, rd = eng.logs()
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(rd.numpy(), np.array(log.round), rtol=2e-4, atol=1e-7)
+    flips = tot = 0
+    for n, op in ops_o.items():
+        a_gpu = eng.alpha_of(n).cpu()
+        np.testing.assert_allclose(a_gpu.numpy(), op.alpha.numpy(), rtol=0, atol=2e-3)
+        flips += int(((a_gpu >= 0) != (op.alpha >= 0)).sum())
+        tot += a_gpu.numel()
+    assert flips <= 0.005 * tot
+    eng.finish()
+    for m in unit.modules():
+        if hasattr(m, "trained"):
+            m.trained = True
+    unit.set_quant_state(True, False)
+    with torch.no_grad():
+        y = unit(T(fx[f"{tag}/inp_q"][:2]).cuda())
+        y_ref = O.UNIT_FORWARD[kind](ops_o, T(fx[f"{tag}/inp_q"][:2]))
+    err = (y.cpu() - y_ref).abs().max() / (y_ref.abs().max() + 1e-12)
+    assert float(err) < (5e-3 if flips else 2e-5), float(err)
+
+
+@pytest.mark.parametrize("tag,kind", [("g_a.0", "rbws"), ("g_a.6", "layer")])
+@pytest.mark.parametrize("task_p", [1.0, 2.4])
+def test_engine_task_loss_exponent(recon, tag, kind, task_p):
+    """main2.py --task_loss is the exponent of the task term (layer_opt.py:150,274): rec_loss keeps p = 2."""
+    from oracle import rdo_oracle as O
+    from quantization.engine import UnitEngine
+    fx = recon
+    _, _, B, iters = (int(v) for v in fx["meta"])
+    idx = fx[f"{tag}/idx"]
+    ops_o = oracle_ops(fx, tag, kind)
+    log = O.reconstruct_unit(kind, ops_o, T(fx[f"{tag}/inp_q"]), T(fx[f"{tag}/inp_fp"]), T(fx[f"{tag}/out"]), iters=iters,
+                             batch_size=B, idx_stream=idx, task_p=task_p,
+                             mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5), input_prob=0.5)
+    unit, k, mods = product_unit(fx, tag, kind)
+    eng = UnitEngine(k, mods, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]), batch_size=B,
+                     iters=iters, input_prob=0.5, seed=SEED, idx_table=torch.from_numpy(idx), task_p=task_p)
+    eng.run()
+    torch.cuda.synchronize()
+    total = eng.logs()[0]
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=2e-4, atol=1e-7)
+    flips = tot = 0
+    for n, op in ops_o.items():
+        a_gpu = eng.alpha_of(n).cpu()
+        # p = 1: the gradient is sign(d), so an error that is ~0 in one implementation may flip sign in the other
+        np.testing.assert_allclose(a_gpu.numpy(), op.alpha.numpy(), rtol=0, atol=2e-3 if task_p != 1.0 else 2.5e-2)
+        flips += int(((a_gpu >= 0) != (op.alpha >= 0)).sum())
+        tot += a_gpu.numel()
+    assert flips <= 0.005 * tot
+
+
+def test_lp_loss_kernel_matches_autograd():
+    from hipops import ops
+    g = torch.Generator().manual_seed(3)
+    B, H, W, C, n = 3, 4, 8, 12, 5
+    tgt = torch.randn(n, H, W, C, generator=g)
+    pred = torch.randn(B, H, W, C, generator=g)
+    idx = torch.tensor([[4, 0, 2]], dtype=torch.int32)
+    for c2, cp, p in ((1.0, 1.0, 1.5), (0.0, 1.0, 3.0), (1.0, 1.0, 1.0)):
+        pr = pred.clone().requires_grad_(True)
+        d = pr - tgt[idx[0].long()]
+        loss = c2 * d.pow(2).sum(-1).mean() + cp * d.abs().pow(p).sum(-1).mean()
+        loss.backward()
+        grad = torch.empty_like(pred).cuda()
+        log = torch.zeros(1, 32, device="cuda")
+        ops.lp_loss_grad(pred.cuda(), tgt.cuda(), idx.cuda(), torch.zeros(1, dtype=torch.int32, device="cuda"), c2, cp, p, grad, log)
+        torch.testing.assert_close(grad.cpu(), pr.grad, rtol=2e-5, atol=1e-7)
+        torch.testing.assert_close(log.sum().cpu(), loss.detach(), rtol=1e-5, atol=0)
+
+
 def test_engine_rejects_cpu_tensors(recon):
     from quantization.engine import UnitEngine
     fx = recon
