@@ -101,7 +101,24 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
         if (a.mode == 2) {
             g4 = *reinterpret_cast<const vec_t*>(a.dalpha_in + e0);
         } else {
-            for (int s = 0; s < a.nsplit; ++s) g4 += *reinterpret_cast<const vec_t*>(a.slabs + (long)s * d.numel + e0);
+            // eight slab loads in flight per thread: with ~5 waves per CU at these sizes a serial chain of nsplit dependent
+            // loads (one L2 / fabric round trip each) was the whole kernel time
+            const float* sp = a.slabs + e0;
+            int s = 0;
+            for (; s + 8 <= a.nsplit; s += 8) {
+                vec_t t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const vec_t*>(sp + (long)(s + u) * d.numel);
+                g4 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
+            if (s + 4 <= a.nsplit) {
+                vec_t t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const vec_t*>(sp + (long)(s + u) * d.numel);
+                g4 += (t[0] + t[1]) + (t[2] + t[3]);
+                s += 4;
+            }
+            for (; s < a.nsplit; ++s) g4 += *reinterpret_cast<const vec_t*>(sp + (long)s * d.numel);
         }
         vec_t m4 = wv4 * 0.f, v4 = m4, o4 = m4;
         if (a.mode != 1) {
