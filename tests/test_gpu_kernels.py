@@ -351,3 +351,24 @@ def test_quantmodule_layernorm_and_linear_match_torch():
     ref = F.linear(x.double(), lin.weight.detach().double(), lin.bias.detach().double())
     q = QuantModule(lin, wq, dict(wq, leaf_param=False)).cuda()
     assert _rel(q(x.cuda()).cpu(), ref) < 5e-6
+
+
+def test_integration_md_ctypes_stub_runs_as_written():
+    """The ctypes binding shown in INTEGRATION.md section B (what a reference maintainer would add) is executed verbatim
+    against the built library and compared with the oracle's conv (torch CPU fp32)."""
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    code = re.search(r"```python\n(# quantization/_hip\.py.*?)```", text, re.S).group(1)
+    code = code.replace('C.CDLL("librdoptq_hip.so")', f'C.CDLL("{os.path.join(root, "rdo-ptq_amd", "lib", "librdoptq_hip.so")}")')
+    ns = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(2, 12, 10, 8, generator=g)
+    w = torch.randn(16, 3, 3, 8, generator=g) * 0.2
+    b = torch.randn(16, generator=g)
+    y = ns["conv2d_nhwc"](x.cuda(), w.cuda(), b.cuda(), 2, 1, lrelu=True)
+    torch.cuda.synchronize()
+    ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=2, padding=1), 0.01).permute(0, 2, 3, 1)
+    torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-5)
