@@ -59,12 +59,18 @@ const char* rdo_last_error(void);
  * epilogue (needed by the GDN backward).  dgrad of a stride-1 conv is this same entry point run on dY with `wd`. */
 int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
                    const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
-                   const void* wplanes /* nullable: [3][Cout*KH*KW*Cin] bf16 from rdo_split_bf16x3(w) */, void* stream);
+                   const void* wplanes /* nullable: 3 x Cout*KH*KW*Cin bf16 from rdo_split_bf16x3_conv(w) */, void* stream);
 /* Large problems can run on the bf16 MFMA at fp32-level accuracy: every fp32 operand is split EXACTLY into three bf16
  * planes (x = x1 + x2 + x3) and the six significant cross products are accumulated in fp32 (dropped terms <= 3*2^-24 |x w|).
  * Activations are split in the kernel's loader; the caller supplies the weight planes.  rdo_conv2d_fwd takes this path when
  * `wplanes` is given and rdo_conv2d_fwd_uses_bf16x6(d) is 1; rdo_conv2d_fwd_bf16x6 forces it (Cin % 16 == 0). */
 int rdo_conv2d_fwd_uses_bf16x6(const rdo_conv_desc* d);
+/* Weight planes of the split-precision path, "fragment order": plane p holds element (co, kh, kw, ci) of w [Cout][KH][KW][Cin] at
+ *   p * numel + ((((ci / 16) * KH + kh) * KW + kw) * Cout + co) * 16 + ci % 16        (Cin % 16 == 0; otherwise element order)
+ * so that the Cout x 16 weight tile of one K stage is one contiguous run for the kernels' LDS-DMA (whole cache lines).
+ * rdo_split_bf16x3 keeps the element order (generic helper, not a conv operand). */
+int rdo_split_bf16x3_conv(const float* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, void* planes /* 3*numel bf16 */,
+                          void* stream);
 int rdo_split_bf16x3(const float* w, int64_t n, void* planes /* 3*n bf16 */, void* stream);
 int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, const void* wplanes, const float* bias, const float* aux,
                           const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats, void* stream);
@@ -114,8 +120,9 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
                       int nsplit, float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr,
                       float* alpha, float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out,
                       void* wq_planes, void* wd_planes, void* stream);
-/* wq_planes / wd_planes (nullable): [3][numel] bf16 -- the exact three-way split of the new wq / wd (what rdo_split_bf16x3 would
- * produce), written in the same pass so that the split-precision conv path needs no separate refresh launch. */
+/* wq_planes / wd_planes (nullable): 3 x numel bf16 -- the exact three-way split of the new wq / wd in fragment order (what
+ * rdo_split_bf16x3_conv would produce for wq [rows][KH][KW][Cin] and for wd [Cin][KH][KW][rows]), written in the same pass so that
+ * the split-precision conv path needs no separate refresh launch. */
 
 /* only the data-gradient half (slab reduce + chain rule -> dalpha_data), for the all-reduce bucket of the DP path */
 int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,

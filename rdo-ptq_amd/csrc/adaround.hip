@@ -200,12 +200,15 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
                         pm[k] = __builtin_bit_cast(unsigned short, m);
                         pl[k] = __builtin_bit_cast(unsigned short, l);
                     }
-                    *reinterpret_cast<u16x4*>(a.wq_planes + e0) = ph;
-                    *reinterpret_cast<u16x4*>(a.wq_planes + d.numel + e0) = pm;
-                    *reinterpret_cast<u16x4*>(a.wq_planes + 2 * d.numel + e0) = pl;
+                    // fragment order (rdo::frag_index): four consecutive channels stay consecutive (Cin % 16 == 0, e0 % 4 == 0)
+                    const long f0 = d.Cin > 0 ? rdo::frag_index(e0, d.rows, d.KH, d.KW, d.Cin) : e0;
+                    *reinterpret_cast<u16x4*>(a.wq_planes + f0) = ph;
+                    *reinterpret_cast<u16x4*>(a.wq_planes + d.numel + f0) = pm;
+                    *reinterpret_cast<u16x4*>(a.wq_planes + 2 * d.numel + f0) = pl;
                 } else {
 #pragma unroll
-                    for (int k = 0; k < W; ++k) split3_store(o4[k], a.wq_planes, d.numel, e0 + k);
+                    for (int k = 0; k < W; ++k)
+                        split3_store(o4[k], a.wq_planes, d.numel, d.Cin > 0 ? rdo::frag_index(e0 + k, d.rows, d.KH, d.KW, d.Cin) : e0 + k);
                 }
             }
         }
@@ -247,7 +250,8 @@ __global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const
         if (ci < cdim && co < d.rows) {
             const long o = ((long)ci * taps + tapf) * d.rows + co;
             wd[o] = tile[tx][ty + 8 * k];
-            if (wd_planes) split3_store(tile[tx][ty + 8 * k], wd_planes, d.numel, o);
+            // wd is the weight [Cin][KH][KW][Cout] of the dgrad conv: its planes go in that conv's fragment order
+            if (wd_planes) split3_store(tile[tx][ty + 8 * k], wd_planes, d.numel, rdo::frag_index(o, d.Cin, d.KH, d.KW, d.rows));
         }
     }
 }

@@ -9,8 +9,8 @@
 //   x*w ~= x1w1 + x1w2 + x2w1 + x1w3 + x2w2 + x3w1          dropped terms <= 3 * 2^-24 |x w|  (fp32-rounding level)
 //
 // Each bf16 product is exact in fp32 and the MFMA accumulates in fp32, so the result has fp32-level accuracy at 16/6 the
-// fp32-MFMA rate.  Weights arrive pre-split ([3][Cout][KH][KW][Cin] bf16, rdo_split_bf16x3); activations are split in the
-// loader.
+// fp32-MFMA rate.  Weights arrive pre-split in fragment order ([3][Cin/16][KH][KW][Cout][16] bf16, rdo_split_bf16x3_conv /
+// the AdaRound step; rdo::frag_index); activations are split in the loader.
 #include <utility>
 
 #include "rdo_common.h"
@@ -27,7 +27,7 @@ constexpr int BK = 32;
 
 struct X6Args {
     const float* x;
-    const u16* wp;        // [3][Cout*KH*KW*Cin] bf16 planes
+    const u16* wp;        // [3][Cin/16][KH][KW][Cout][16] bf16 planes (fragment order)
     const float* bias;
     const float* aux;
     const float* residual;
@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         const int row = r >> 1, ch = r & 1;
         const int n = n0 + row;
         b_ok[j] = live && n < a.Cout;
-        wbase[j] = (long)pl * a.wplane + (long)(n < a.Cout ? n : 0) * a.KH * a.KW * a.Cin + 8 * ch;
+        wbase[j] = (long)pl * a.wplane + (long)(n < a.Cout ? n : 0) * 16 + 8 * ch;      // fragment order: + stage block
         b_lds[j] = live ? 3 * APLANE + pl * BPLANE + chunk_off16(row, ch) : -1;
     }
 
@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         const int r = e - pl * (BN * 2);
         const int row = r >> 1, ch = (r & 1) ^ ((row >> 3) & 1);
         const int n = n0 + row < a.Cout ? n0 + row : 0;      // rows past Cout feed only columns that are never stored
-        dma_src[j] = (int)(pl * a.wplane) + n * a.KH * a.KW * a.Cin + 8 * ch;
+        dma_src[j] = (int)(pl * a.wplane) + n * 16 + 8 * ch;      // fragment order (rdo::frag_index): + stage block
     }
 
     f32x16 acc[TM][TN];
@@ -221,8 +221,16 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
         }
     };
     retap();
-    int bcur = ltap * a.Cin + lc;      // DMA cursor (one stage ahead): element offset tap * Cin + channel of the stage being fetched
-    auto badvance = [&]() { bcur += KS; };   // Cin % 16 == 0: tap * Cin + c simply keeps counting along the OHWI row
+    // stage block of (tap, channel slice) in the fragment-ordered planes: ((slice * taps + tap) * Cout) * 16 elements
+    const int ktaps = a.KH * a.KW;
+    auto wblock = [&](int tap, int c) { return (long)(((c / KS) * ktaps + tap) * a.Cout) * 16; };
+    int btap = ltap, bc = lc;          // DMA cursor (one stage ahead of the load cursor)
+    long bcur = wblock(btap, bc);
+    auto badvance = [&]() {
+        bc += KS;
+        if (bc >= a.Cin) { bc = 0; ++btap; }
+        bcur = wblock(btap, bc);
+    };
     auto dma_b = [&](auto jc, int buf) {
         constexpr int j = decltype(jc)::value;
         typedef __attribute__((address_space(3))) void lds_void;
@@ -241,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
     };
     auto load_b = [&](auto jc) {
         constexpr int j = decltype(jc)::value;
-        const long off = wbase[j] + (long)ltap * a.Cin + lc;
+        const long off = wbase[j] + wblock(ltap, lc);
         rb[j] = *reinterpret_cast<const bf16x8*>(a.wp + (b_ok[j] ? off : 0));
     };
     auto store_a = [&](int t, int buf) {
@@ -401,7 +409,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
         const int r = e - pl * (BN * 2);
         const int row = r >> 1, ch = (r & 1) ^ ((row >> 3) & 1);
         const int n = n0 + row < a.Cout ? n0 + row : 0;
-        dma_src[j] = (int)(pl * a.wplane) + n * a.KH * a.KW * a.Cin + 8 * ch;
+        dma_src[j] = (int)(pl * a.wplane) + n * 16 + 8 * ch;      // fragment order (rdo::frag_index): + stage block
     }
 
     f32x16 acc[TM][TN];
@@ -441,12 +449,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
         retap();
     };
     retap();
-    // element offset of stage s (relative to sbeg) along the OHWI weight row: tap * Cin + channel slice * 16
-    auto boff = [&](int s) {
-        const int g = sbeg + s;
-        const int cs = g / taps, tap = g - cs * taps;
-        return tap * a.Cin + cs * KS;
-    };
+    // stage s (relative to sbeg) in the fragment-ordered planes: stages are stored in exactly this kernel's order
+    // (channel slice, tap), each a contiguous [Cout][16] block
+    auto boff = [&](int s) { return (sbeg + s) * a.Cout * 16; };
 
     f32x4 ra[2];
     bool ra_ok[2];
@@ -634,7 +639,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v6_kernel(X6Args a) {
         const int r = e - pl * (BN * 2);
         const int row = r >> 1, ch = (r & 1) ^ ((row >> 3) & 1);
         const int n = n0 + row < a.Cout ? n0 + row : 0;
-        dma_src[j] = (int)(pl * a.wplane) + n * a.KH * a.KW * a.Cin + 8 * ch;
+        dma_src[j] = (int)(pl * a.wplane) + n * 16 + 8 * ch;      // fragment order (rdo::frag_index): + stage block
     }
     // halo row of this lane's output pixels (tap kw reads row hb + kw)
     int hb[TM];
@@ -683,12 +688,9 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v6_kernel(X6Args a) {
         *reinterpret_cast<bf16x4*>(st + APLANE) = p1;
         *reinterpret_cast<bf16x4*>(st + 2 * APLANE) = p2;
     };
-    // weight row offset of stage t (relative to the first stage of this workgroup): (kh * 3 + kw) * Cin + channel slice * 16
-    auto boff = [&](int t) {
-        const int G = gbeg + t / 3, kw = t - (t / 3) * 3;
-        const int cs = G / a.KH, kh = G - cs * a.KH;
-        return (kh * 3 + kw) * a.Cin + cs * KS;
-    };
+    // stage t (relative to the first stage of this workgroup) in the fragment-ordered planes: group (channel slice, kh) and kw
+    // are stored in exactly this order, each stage a contiguous [Cout][16] block
+    auto boff = [&](int t) { return (gbeg * 3 + t) * a.Cout * 16; };
     auto dma_b = [&](int j, int buf, int t) {
         typedef __attribute__((address_space(3))) void lds_void;
         typedef const __attribute__((address_space(1))) void glb_void;
@@ -823,7 +825,29 @@ __global__ __launch_bounds__(256) void split_bf16x3_kernel(const float* w, long 
     }
 }
 
+__global__ __launch_bounds__(256) void split_bf16x3_conv_kernel(const float* w, long n, int Cout, int KH, int KW, int Cin, u16* planes) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        u16 h, m, l;
+        split3(w[i], h, m, l);
+        const long f = rdo::frag_index(i, Cout, KH, KW, Cin);
+        planes[f] = h; planes[n + f] = m; planes[2 * n + f] = l;
+    }
+}
+
 }  // namespace
+
+extern "C" int rdo_split_bf16x3_conv(const float* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, void* planes, void* stream) {
+    RDO_REQUIRE(w && planes && Cout > 0 && KH > 0 && KW > 0 && Cin > 0, "rdo_split_bf16x3_conv: bad argument");
+    u16* p = reinterpret_cast<u16*>(planes);
+    const long n = (long)Cout * KH * KW * Cin;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            long g = rdo::ceil_div(n, 256);
+            hipLaunchKernelGGL(split_bf16x3_conv_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, w, n, Cout, KH, KW, Cin, p);
+            return rdo::check_launch("split_bf16x3_conv");
+        },
+        stream, "split_bf16x3", 0.0, 10.0 * n);
+}
 
 extern "C" int rdo_split_bf16x3(const float* w, int64_t n, void* planes, void* stream) {
     RDO_REQUIRE(w && planes && n > 0, "rdo_split_bf16x3: bad argument");

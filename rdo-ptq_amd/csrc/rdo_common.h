@@ -49,6 +49,22 @@ inline int check_launch(const char* what) {
     } while (0)
 
 constexpr int kWave = 64;
+
+// bf16x6 weight planes ("fragment order"): element (co, kh, kw, ci) of a conv weight [Cout][KH][KW][Cin] lives at
+//   plane + ((((ci / 16) * KH + kh) * KW + kw) * Cout + co) * 16 + ci % 16
+// i.e. [channel slice of 16][kh][kw][Cout][16]: the 192 x 16 weight tile of one K stage of conv_fwd_x6 is one contiguous run, so
+// the LDS-DMA of a stage reads whole cache lines (with the [Cout][KH][KW][Cin] order every 32-byte piece came from its own line:
+// 2-4x the L2 -> CU traffic, measured as 10 % of the kernel time).  Cin % 16 != 0 (never consumed by the x6 kernels): linear order.
+__host__ __device__ inline long frag_index(long e, int Cout, int KH, int KW, int Cin) {
+    if (Cin % 16 != 0) return e;
+    long t = e / Cin;
+    const int ci = (int)(e - t * Cin);
+    const int kw = (int)(t % KW);
+    t /= KW;
+    const int kh = (int)(t % KH);
+    const long co = t / KH;
+    return (((((long)(ci >> 4) * KH + kh) * KW + kw) * Cout + co) << 4) + (ci & 15);
+}
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 }  // namespace rdo

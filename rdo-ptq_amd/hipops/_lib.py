@@ -38,6 +38,7 @@ _SIGS = {
     "rdo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, C.c_int64, P, P]),
     "rdo_conv2d_fwd_uses_bf16x6": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_split_bf16x3": (C.c_int, [P, C.c_int64, P, P]),
+    "rdo_split_bf16x3_conv": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "rdo_conv2d_fwd_bf16x6": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, C.c_int64, P]),
     "rdo_conv2d_fwd_bf16x6_ksplit": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_fwd_workspace": (C.c_int64, [C.POINTER(ConvDesc)]),

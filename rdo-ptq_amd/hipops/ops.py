@@ -51,7 +51,20 @@ def uses_bf16x6(x_shape, w_shape, stride, pad):
 
 
 def split_bf16x3(w, planes=None):
-    """fp32 tensor -> int16 tensor [3, *w.shape] holding the exact bf16 split w = p0 + p1 + p2."""
+    """Conv weight in kernel layout [Cout,KH,KW,Cin] (or [C,C] = 1x1) -> int16 tensor of 3 * w.numel() bf16 values: the exact
+    split w = p0 + p1 + p2, each plane in the fragment order the bf16x6 kernels read ([Cin/16][KH][KW][Cout][16])."""
+    if w.dim() == 2:
+        w = w.reshape(w.shape[0], 1, 1, w.shape[1])
+    if w.dim() != 4:
+        raise ValueError("split_bf16x3: expected a conv weight [Cout,KH,KW,Cin]")
+    planes = torch.empty((3,) + tuple(w.shape), device=w.device, dtype=torch.int16) if planes is None else planes
+    co, kh, kw, ci = w.shape
+    L.check(L.lib().rdo_split_bf16x3_conv(_ptr(w), co, kh, kw, ci, _ptr(planes), _stream()), "rdo_split_bf16x3_conv")
+    return planes
+
+
+def split_bf16x3_linear(w, planes=None):
+    """Element order kept: planes[p].view_as(w) is plane p (generic helper, not a conv operand)."""
     planes = torch.empty((3,) + tuple(w.shape), device=w.device, dtype=torch.int16) if planes is None else planes
     L.check(L.lib().rdo_split_bf16x3(_ptr(w), w.numel(), _ptr(planes), _stream()), "rdo_split_bf16x3")
     return planes

@@ -119,9 +119,9 @@ class _Op:
 
     def refresh_planes(self):
         if self.wq_planes is not None:
-            ops.split_bf16x3(self.wq, self.wq_planes)
+            ops.split_bf16x3(self.wq4(), self.wq_planes)
         if self.wd_planes is not None:
-            ops.split_bf16x3(self.wd, self.wd_planes)
+            ops.split_bf16x3(self.wd4(), self.wd_planes)
 
     def wq4(self):
         return self.wq.reshape(self.w4)

@@ -141,9 +141,13 @@ def test_split_bf16_conv_path_has_fp32_accuracy(ops, H, Cin, Cout, K, s, p):
     w = torch.randn(Cout, K, K, Cin, device="cuda", generator=g) / (Cin * K * K) ** 0.5
     b = torch.randn(Cout, device="cuda", generator=g)
     assert ops.uses_bf16x6(tuple(x.shape), tuple(w.shape), s, p)
-    planes = ops.split_bf16x3(w)
-    resum = sum((planes[i].to(torch.int32) << 16).view(torch.float32) for i in range(3))
+    lin = ops.split_bf16x3_linear(w)
+    resum = sum((lin[i].to(torch.int32) << 16).view(torch.float32) for i in range(3))
     assert torch.equal(resum, w)
+    # the conv operand is the same split in fragment order [Cin/16][KH][KW][Cout][16] (include/rdo_ptq_hip.h)
+    planes = ops.split_bf16x3(w)
+    expect = lin.reshape(3, Cout, K, K, Cin // 16, 16).permute(0, 4, 2, 3, 1, 5).reshape(3, -1)
+    assert torch.equal(planes.reshape(3, -1), expect)
     y32 = ops.conv2d_fwd(x, w, b, s, p)
     y6 = ops.conv2d_fwd(x, w, b, s, p, wplanes=planes)
     ref = torch.nn.functional.conv2d(x[:1].permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), s, p)

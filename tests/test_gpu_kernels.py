@@ -372,3 +372,30 @@ def test_integration_md_ctypes_stub_runs_as_written():
     torch.cuda.synchronize()
     ref = F.leaky_relu(F.conv2d(x.permute(0, 3, 1, 2), w.permute(0, 3, 1, 2), b, stride=2, padding=1), 0.01).permute(0, 2, 3, 1)
     torch.testing.assert_close(y.cpu(), ref, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("shape", [(32, 3, 3, 48), (16, 1, 1, 16), (24, 5, 5, 32)])
+def test_adaround_step_writes_fragment_ordered_planes(shape):
+    """rdo_adaround_step's optional bf16 planes of the new wq / wd equal rdo_split_bf16x3_conv of those tensors (wd is the
+    weight [Cin][KH][KW][Cout] of the dgrad conv)."""
+    from hipops import ops
+    g = torch.Generator().manual_seed(11)
+    w = (torch.randn(shape, generator=g) * 0.1).cuda()
+    co, kh, kw, ci = shape
+    delta, zp = ops.uaq_init_minmax(w.reshape(co, -1), 256)
+    d = ops.ada_desc(w)
+    alpha = ops.adaround_init_alpha(d, w, delta)
+    m, v = torch.zeros_like(w), torch.zeros_like(w)
+    wq, wd = torch.empty_like(w), torch.empty_like(w)
+    wqp = torch.zeros((3,) + shape, dtype=torch.int16, device="cuda")
+    wdp = torch.zeros((3,) + shape, dtype=torch.int16, device="cuda")
+    slabs = (torch.randn((2,) + shape, generator=g) * 1e-2).cuda()
+    sched = torch.tensor([[10.0, 1.0, 1e-3, 1.0]], device="cuda")
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    log = torch.zeros(1, 32, device="cuda")
+    ops.adaround_step(d, w, delta, zp, slabs, 1.0, 0.01, sched, it, alpha, m, v, wq, wd, log, wqp, wdp)
+    torch.cuda.synchronize()
+    assert torch.equal(wqp, ops.split_bf16x3(wq))
+    wd4 = wd.reshape(ci, kh, kw, co)
+    torch.testing.assert_close(wd4, wq.flip(1, 2).permute(3, 1, 2, 0).contiguous(), rtol=0, atol=0)
+    assert torch.equal(wdp.reshape(3, -1), ops.split_bf16x3(wd4).reshape(3, -1))

@@ -12,7 +12,6 @@ from hipops import ops, _lib  # noqa: E402
 
 lib = _lib.lib()
 P = C.c_void_p
-lib.rdo_split_bf16x3.argtypes = [P, C.c_int64, P, P]
 
 
 
@@ -39,7 +38,7 @@ for H, Cin, Cout, K, s, p in [(16, 32, 192, 3, 1, 1), (128, 192, 192, 3, 1, 1), 
     out6 = torch.empty_like(out32)
     planes = torch.empty(3 * w.numel(), dtype=torch.int16, device="cuda")
     st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(lib.rdo_split_bf16x3(w.data_ptr(), w.numel(), planes.data_ptr(), st))
+    ops.split_bf16x3(w, planes)
     ws = ops._scratch(x.device, 1 << 26)
     f6 = lambda: _lib.check(lib.rdo_conv2d_fwd_bf16x6(C.byref(d), x.data_ptr(), planes.data_ptr(), None, None, None, out6.data_ptr(), None, ws.data_ptr(), ws.numel(), st))
     f32 = lambda: ops.conv2d_fwd(x, w, None, s, p, out=out32)
