@@ -314,7 +314,9 @@ __global__ __launch_bounds__(256) void uaq_minmax_kernel(const float* w, long in
         float dl = (float)(((double)mx - (double)mn) / (double)(n_levels - 1));
         dl = fmaxf(dl, 1e-8f);
         delta[blockIdx.x] = dl;
-        zp[blockIdx.x] = rintf((float)(-(double)mn) / dl);
+        // the reference writes (-x_min / delta) with a Python float on the left: torch evaluates that as delta.reciprocal() * (-x_min)
+        // in fp32 (Tensor.__rdiv__), one rounding more than a division -- it decides the ties at x.5 (symmetric weight ranges)
+        zp[blockIdx.x] = rintf(__fmul_rn(__frcp_rn(dl), -mn));
     }
 }
 

@@ -142,7 +142,11 @@ class UniformAffineQuantizer(nn.Module):
                 amax = torch.maximum(lo.abs(), hi)
                 lo, hi = torch.where(lo < 0, -amax, torch.zeros_like(lo)), amax
             delta = torch.maximum(((hi.double() - lo.double()) / (L - 1)).float(), eps)
-            return delta, (-lo / delta).round()
+            if m == "gaussian":
+                return delta, (-lo / delta).round()                 # tensor / tensor in the reference (quantizer.py:335)
+            # 'max' family: the reference divides a Python float by the tensor, which torch evaluates as
+            # delta.reciprocal() * (-x_min) (quantizer.py:296) -- one more rounding, it decides ties at x.5
+            return delta, (delta.reciprocal() * (-lo)).round()
         if m not in ("mse", "l1", "l2"):
             raise NotImplementedError(m)
         hi0, lo0 = flat.amax(1, keepdim=True), flat.amin(1, keepdim=True)

@@ -4,6 +4,7 @@ import io
 import math
 import types
 
+import numpy as np
 import pytest
 import torch
 import torch.nn as nn
@@ -373,3 +374,59 @@ def test_main2_flow_with_activation_quantised_calibration():
     qnn.model.g_s[-1][0].set_quant_state(True, False)
     psnr, bpp = evaluate_images(qnn.eval(), [torch.rand(1, 3, 64, 64, generator=g)], p=64)
     assert math.isfinite(psnr) and math.isfinite(bpp)
+
+
+def test_config0_one_shot_uniform_ptq_mbt2018_mean_full_width():
+    """BASELINE config 0 (the quantiser-maths plumbing case): mbt2018-mean at its full width (N=192, M=320), W8A8 one-shot
+    min/max PTQ in the spirit of light-uniform-PTQ/quantize.py:116-159 -- ONE forward initialises the scales, the weights become
+    uint8 levels -- on 16 random 256x256 crops.  Every layer's scales and nearest-rounded weights are compared with the oracle
+    (torch CPU, bit-exact scales, weights to 1 ulp of a level), the integer export round-trips, and the W8 / W8A8 model evaluates."""
+    import lic
+    from oracle import rdo_oracle as O
+    from quantization import QuantModel, QuantModule
+    from quantization.export import dequantize, integer_state
+    from test_datasets import evaluate_images
+    torch.manual_seed(192)
+    model = lic.MeanScaleHyperprior(N=192, M=320).cuda().eval()
+    g = torch.Generator().manual_seed(16)
+    crops = torch.rand(16, 3, 256, 256, generator=g)
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, True)
+    with torch.no_grad():
+        out = qnn(crops[:4].cuda())                        # the one forward: lazy scale init of every weight quantiser
+    assert torch.isfinite(out["x_hat"]).all()
+    st = integer_state(qnn)
+    mods = dict(qnn.named_modules())
+    n = 0
+    for name, entry in st.items():
+        m = mods[name]
+        w = m.org_weight.detach().cpu()
+        tconv = m.kind == "tconv"
+        if m.kind == "gdn":
+            continue                                       # gamma is quantised through its re-parametrisation (covered elsewhere)
+        d, z = O.uaq_init(w, 8, True, "max", tconv=tconv)
+        np.testing.assert_array_equal(entry["delta"].reshape(-1).numpy(), d.reshape(-1).numpy())
+        np.testing.assert_array_equal(entry["zero_point"].reshape(-1).numpy(), z.reshape(-1).numpy())
+        ref = O.uaq_fakequant(w, d, z, 256)
+        got = dequantize(entry)
+        assert entry["levels"].dtype == torch.uint8
+        # w / delta within an ulp of x.5 may round the other way on the GPU: at most one level, on a vanishing share of weights
+        diff = (got - ref).abs()
+        assert float((diff > 1e-7).float().mean()) < 1e-4 and float((diff / d.expand_as(w).abs()).max()) < 1.0 + 1e-3, name
+        torch.testing.assert_close(got, m.weight_quantizer(m.org_weight).cpu(), rtol=0, atol=1e-7)
+        n += 1
+    assert n == 14                                         # 4 + 4 + 3 + 3 convs / transposed convs of mbt2018-mean
+    imgs = [crops[i:i + 1] for i in range(4)]
+    psnr_fp, bpp_fp = evaluate_images(model, imgs, p=64)
+    qnn.set_quant_state(True, False)
+    psnr_w8, bpp_w8 = evaluate_images(qnn, imgs, p=64)
+    qnn.set_quant_state(True, True)
+    qnn.model.g_s[-1].set_quant_state(True, False)
+    psnr_w8a8, bpp_w8a8 = evaluate_images(qnn, imgs, p=64)
+    for v in (psnr_fp, bpp_fp, psnr_w8, bpp_w8, psnr_w8a8, bpp_w8a8):
+        assert math.isfinite(v)
+    assert abs(psnr_w8 - psnr_fp) < 1.0 and abs(bpp_w8 - bpp_fp) < 0.05 * bpp_fp + 0.02
