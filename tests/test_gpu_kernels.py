@@ -282,6 +282,28 @@ def test_product_uaq_matches_reference_goldens(golden_dir, tag, tconv, method, c
     np.testing.assert_allclose(out.cpu().numpy(), qz[key + "_out"], rtol=3e-7, atol=float(d_ref.max()) * 1e-6)  # 1 ulp of delta scales every level
 
 
+@pytest.mark.parametrize("tag,tconv", [("conv", False), ("tconv", True), ("lin", False)])
+@pytest.mark.parametrize("cw", [True, False])
+@pytest.mark.parametrize("bits", [8, 6, 4])
+def test_product_uaq_zero_points_on_symmetric_ranges(golden_dir, tag, tconv, cw, bits):
+    """The HIP min/max init on channels whose range is exactly symmetric (-min/delta on x.5) reproduces the reference's zero
+    points bit for bit (tests/golden/quantizer_ties.npz, made by the reference's UniformAffineQuantizer)."""
+    import os
+    from quantization.quantizer import UniformAffineQuantizer
+    fx = np.load(os.path.join(golden_dir, "quantizer_ties.npz"))
+    w = torch.from_numpy(fx[f"w_{tag}"]).cuda()
+    key = f"uaq_{tag}_{'cw' if cw else 'lw'}_{bits}"
+    q = UniformAffineQuantizer(n_bits=bits, channel_wise=cw, scale_method="max", tconv=tconv)
+    out = q(w)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(q.delta.cpu().numpy().reshape(-1), fx[key + "_delta"].reshape(-1))
+    np.testing.assert_array_equal(q.zero_point.cpu().numpy().reshape(-1), fx[key + "_zp"].reshape(-1))
+    d = float(fx[key + "_delta"].max())
+    # values within an ulp of a rounding boundary may land one level apart; everything else is exact
+    diff = np.abs(out.cpu().numpy() - fx[key + "_out"])
+    assert float((diff > 1e-7).mean()) < 2e-3 and float(diff.max()) <= d * (1 + 1e-5)
+
+
 @pytest.mark.parametrize("tag", ["a4", "a3", "a2"])
 def test_product_actquantizer_matches_reference_goldens(golden_dir, tag):
     import os

@@ -32,6 +32,21 @@ def test_uaq_init_and_fakequant(qz, tag, tconv, method, cw, bits):
     np.testing.assert_array_equal(out.numpy(), qz[key + "_out"])
 
 
+@pytest.mark.parametrize("tag,tconv", [("conv", False), ("tconv", True), ("lin", False)])
+@pytest.mark.parametrize("cw", [True, False])
+@pytest.mark.parametrize("bits", [8, 6, 4])
+def test_uaq_max_init_on_symmetric_ranges(golden_dir, tag, tconv, cw, bits):
+    """Channels with min = -max put -min/delta on x.5: the zero point then depends on torch evaluating the reference's
+    `-x_min / delta` (Python float over tensor, quantizer.py:296) as delta.reciprocal() * (-x_min).  Vectors from the reference."""
+    fx = np.load(os.path.join(golden_dir, "quantizer_ties.npz"))
+    w = T(fx[f"w_{tag}"])
+    key = f"uaq_{tag}_{'cw' if cw else 'lw'}_{bits}"
+    delta, zp = O.uaq_init(w, bits, cw, "max", tconv=tconv)
+    np.testing.assert_array_equal(delta.numpy().reshape(-1), fx[key + "_delta"].reshape(-1))
+    np.testing.assert_array_equal(zp.numpy().reshape(-1), fx[key + "_zp"].reshape(-1))
+    np.testing.assert_array_equal(O.uaq_fakequant(w, delta, zp, 2 ** bits).numpy(), fx[key + "_out"])
+
+
 def test_uaq_gaussian(qz):
     w = T(qz["w_conv"])
     delta, zp = O.uaq_init(w, 8, False, "gaussian")

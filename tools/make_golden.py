@@ -195,6 +195,38 @@ def golden_quantizers(out_dir):
     print("quantizers.npz", len(fx), "arrays")
 
 
+def golden_quantizer_ties(out_dir):
+    """Scale inits on weights whose per-channel ranges are exactly symmetric (min = -max, as kaiming-uniform initialised layers
+    nearly are): -min/delta sits on x.5 and the zero point is decided by how the reference's expression is evaluated
+    (quantizer.py:296: a Python float divided by a tensor = reciprocal-multiply in torch)."""
+    from quantization.quantizer import UniformAffineQuantizer
+    g = torch.Generator().manual_seed(77)
+    fx = {}
+    w_conv = (torch.rand(24, 16, 3, 3, generator=g) * 2 - 1) * torch.rand(24, 1, 1, 1, generator=g)
+    w_tconv = (torch.rand(12, 20, 5, 5, generator=g) * 2 - 1) * 0.05
+    w_lin = (torch.rand(40, 32, generator=g) * 2 - 1) * torch.rand(40, 1, generator=g)
+    # force min = -max per output channel
+    for w, dim in ((w_conv, 0), (w_tconv, 1), (w_lin, 0)):
+        wt = w.transpose(0, dim) if dim else w
+        flat = wt.reshape(wt.shape[0], -1)
+        mx = flat.abs().amax(1)
+        idx = flat.abs().argmax(1)
+        for c in range(flat.shape[0]):
+            flat[c, idx[c]] = mx[c]
+            flat[c, (idx[c] + 1) % flat.shape[1]] = -mx[c]
+    fx["w_conv"], fx["w_tconv"], fx["w_lin"] = map(_np, (w_conv, w_tconv, w_lin))
+    for tag, w, tconv in (("conv", w_conv, False), ("tconv", w_tconv, True), ("lin", w_lin, False)):
+        for cw in (True, False):
+            for bits in (8, 6, 4):
+                q = UniformAffineQuantizer(n_bits=bits, channel_wise=cw, scale_method="max", tconv=tconv)
+                y = q(w)
+                key = f"uaq_{tag}_{'cw' if cw else 'lw'}_{bits}"
+                fx[key + "_delta"], fx[key + "_zp"], fx[key + "_out"] = _np(torch.as_tensor(q.delta)), _np(
+                    torch.as_tensor(q.zero_point)), _np(y)
+    np.savez_compressed(os.path.join(out_dir, "quantizer_ties.npz"), **fx)
+    print("quantizer_ties.npz", len(fx), "arrays")
+
+
 def golden_temp_decay(out_dir):
     from quantization.utils import LinearTempDecay
     fx = {}
@@ -885,6 +917,7 @@ def main():
         return
     golden_bd(a.out)
     golden_quantizers(a.out)
+    golden_quantizer_ties(a.out)
     golden_temp_decay(a.out)
     golden_model_surgery(a.out)
     golden_blocks(a.out)
