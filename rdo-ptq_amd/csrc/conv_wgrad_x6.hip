@@ -333,6 +333,258 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
     }
 }
 
+// ---- eight-wave variant: the same 192 x 192 tile and LDS images, but 512 threads ---------------------------------------------------
+// One wave per SIMD cannot keep the matrix pipe busy (tools/mfma_probe.hip: a wgrad-shaped loop reaches 0.35 of the nominal rate
+// with one workgroup of four waves per CU and 0.56-0.59 with two waves per SIMD), and the 144 accumulators + 144 KiB of LDS of the
+// four-wave kernel allow nothing else.  Here each of 8 waves owns 48 x 96 of the tile as 3 x 6 tiles of v_mfma_f32_16x16x32_bf16
+// (72 accumulators; one MFMA spans the whole 32-pixel step), so the CU runs two waves per SIMD from ONE workgroup with the same
+// 144 KiB double buffer.  The 768 loader blocks (4 pixels x 4 channels) of a step go 2 : 1 to waves 0-3 : 4-7 -- a SIMD hosts one
+// wave of each kind (waves are dealt to SIMDs cyclically), so the loader work is balanced per SIMD.
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+
+template <bool SQ>
+__global__ __launch_bounds__(512, 2) void conv_wgrad_x6w8_kernel(WgX6Args a) {
+    constexpr int TCO = 192, TCI = 192, NT = 512;
+    constexpr int TM = 3, TN = 6;                                             // 16 x 16 tiles per wave: 48 (co) x 96 (ci)
+    constexpr int YPLANE = TCO / 4 * GROUPB, XPLANE = TCI / 4 * GROUPB;
+    constexpr int STAGE = 3 * (YPLANE + XPLANE);
+    constexpr int QY = TCO / 4, QX = TCI / 4;
+    constexpr int NBLK = 2;                                                   // block 1 only on waves 0-3
+    static_assert((QY + QX) * 8 == NT + NT / 2, "768 blocks: one per thread plus one more for the first 256 threads");
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lc = lane >> 4;
+    const int wco0 = (wave >> 1) * 48, wci0 = (wave & 1) * 96;
+    const bool has2 = wave < 4;
+
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int chunk = lid / gridDim.y;
+    int t = lid - chunk * gridDim.y;
+    const int tci = t % a.tiles_ci; t /= a.tiles_ci;
+    const int tco = t % a.tiles_co; t /= a.tiles_co;
+    const int tap = t;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int co0 = tco * TCO, ci0 = tci * TCI;
+
+    const int mbeg = chunk * a.mchunk;
+    const int mend = min(a.M, mbeg + a.mchunk);
+    const int nsteps = mend > mbeg ? (mend - mbeg + PK - 1) / PK : 0;
+    const int HoWo = a.Ho * a.Wo;
+
+    // blocks: e = tid + 512 j over [dY quads | X quads] x 8 pixel groups of 4 (j = 1: blocks 512 .. 767, waves 0-3 only)
+    bool blk_x[NBLK];
+    int blk_pg[NBLK], blk_c[NBLK], blk_lds[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+        const int e = tid + NT * j;
+        const int ee = e < (QY + QX) * 8 ? e : 0;
+        blk_x[j] = ee >= QY * 8;
+        const int r = blk_x[j] ? ee - QY * 8 : ee;
+        const int nq = blk_x[j] ? QX : QY;
+        blk_pg[j] = r / nq;
+        const int cq = r - blk_pg[j] * nq;
+        blk_c[j] = 4 * cq;
+        blk_lds[j] = (blk_x[j] ? 3 * YPLANE : 0) + chunk_off(4 * cq, blk_pg[j] >> 1) + (blk_pg[j] & 1) * 8;
+    }
+
+    f32x4acc acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 rq[NBLK][4];
+    const auto rsrc_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const auto rsrc_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.dy), 0, (int)a.dy_bytes, 0x00020000);
+    constexpr unsigned OOB = 0xfffffff0u;
+
+    int st_step[NBLK], st_m[NBLK], st_off[NBLK], st_wo[NBLK], st_ho[NBLK], st_hi[NBLK], st_wi0[NBLK];
+#pragma unroll
+    for (int j = 0; j < NBLK; ++j) {
+        st_step[j] = 0;
+        const int m = mbeg + 4 * blk_pg[j];
+        st_m[j] = m;
+        if (!blk_x[j]) {
+            st_off[j] = m * a.Cout + co0 + blk_c[j];
+            st_wo[j] = st_ho[j] = st_hi[j] = st_wi0[j] = 0;
+        } else {
+            const int mm = m < a.M ? m : 0;
+            const int b = mm / HoWo;
+            const int rem = mm - b * HoWo;
+            const int ho = rem / a.Wo, wo = rem - ho * a.Wo;
+            st_wo[j] = wo; st_ho[j] = ho;
+            st_hi[j] = ho * a.stride - a.pad + kh;
+            st_wi0[j] = wo * a.stride - a.pad + kw;
+            st_off[j] = ((b * a.H + st_hi[j]) * a.W + st_wi0[j]) * a.Cin + ci0 + blk_c[j];
+        }
+    }
+    const int x_step = PK * a.stride * a.Cin;
+    const int x_row = (a.stride * a.W - a.Wo * a.stride) * a.Cin;
+    const int x_img = (a.H * a.W - a.Ho * a.stride * a.W) * a.Cin;
+    auto advance = [&](auto jc) {
+        constexpr int j = decltype(jc)::value;
+        st_m[j] += PK;
+        if (!blk_x[j]) {
+            st_off[j] += PK * a.Cout;
+            return;
+        }
+        st_wo[j] += PK;
+        st_off[j] += x_step;
+        st_wi0[j] += PK * a.stride;
+        while (st_wo[j] >= a.Wo) {
+            st_wo[j] -= a.Wo;
+            st_wi0[j] -= a.Wo * a.stride;
+            st_off[j] += x_row;
+            st_hi[j] += a.stride;
+            if (++st_ho[j] >= a.Ho) {
+                st_ho[j] = 0;
+                st_hi[j] -= a.Ho * a.stride;
+                st_off[j] += x_img;
+            }
+        }
+    };
+    auto load_block = [&](auto jc, int s) {
+        constexpr int j = decltype(jc)::value;
+        if (s > st_step[j]) {
+            advance(jc);
+            st_step[j] = s;
+        }
+        const int m = st_m[j];
+        const bool inrange = m < mend;
+        if (!blk_x[j]) {
+            const bool okc = inrange && co0 + blk_c[j] < a.Cout;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const bool ok = okc && m + p < mend;
+                rq[j][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rsrc_y, ok ? (unsigned)(st_off[j] + p * a.Cout) * 4u : OOB, 0, 0));
+            }
+        } else {
+            const bool okr = inrange && ci0 + blk_c[j] < a.Cin && (unsigned)st_hi[j] < (unsigned)a.H;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const int wi = st_wi0[j] + p * a.stride;
+                const bool ok = okr && m + p < mend && (unsigned)wi < (unsigned)a.W;
+                rq[j][p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                                         rsrc_x, ok ? (unsigned)(st_off[j] + p * a.stride * a.Cin) * 4u : OOB, 0, 0));
+            }
+        }
+    };
+    // split + transpose-store channel cc of block j: three 8-byte runs (4 consecutive pixels) into row (4cq + cc)
+    auto store_part = [&](auto jc, auto ccc, int buf) {
+        constexpr int j = decltype(jc)::value;
+        constexpr int cc = decltype(ccc)::value;
+        bf16x4 p0, p1, p2;
+        float v0 = rq[j][0][cc], v1 = rq[j][1][cc], v2 = rq[j][2][cc], v3 = rq[j][3][cc];
+        if constexpr (SQ) {
+            const bool q = blk_x[j];
+            v0 = q ? v0 * v0 : v0; v1 = q ? v1 * v1 : v1; v2 = q ? v2 * v2 : v2; v3 = q ? v3 * v3 : v3;
+        }
+        split3_x4(v0, v1, v2, v3, p0, p1, p2);
+        char* st = smem + buf * STAGE + blk_lds[j] + cc * 64;
+        const int plane = blk_x[j] ? XPLANE : YPLANE;
+        *reinterpret_cast<bf16x4*>(st) = p0;
+        *reinterpret_cast<bf16x4*>(st + plane) = p1;
+        *reinterpret_cast<bf16x4*>(st + 2 * plane) = p2;
+    };
+    using J0 = std::integral_constant<int, 0>;
+    using J1 = std::integral_constant<int, 1>;
+    auto store_block = [&](auto jc, int buf) {
+        store_part(jc, std::integral_constant<int, 0>{}, buf);
+        store_part(jc, std::integral_constant<int, 1>{}, buf);
+        store_part(jc, std::integral_constant<int, 2>{}, buf);
+        store_part(jc, std::integral_constant<int, 3>{}, buf);
+    };
+
+    if (nsteps > 0) {
+        load_block(J0{}, 0);
+        if (has2) load_block(J1{}, 0);
+        store_block(J0{}, 0);
+        if (has2) store_block(J1{}, 0);
+        load_block(J0{}, nsteps > 1 ? 1 : 0);
+        if (has2) load_block(J1{}, nsteps > 1 ? 1 : 0);
+    }
+    __syncthreads();
+
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+
+    // fragments: lane (l16, lc) holds row l16 of a 16-row tile, pixels 8 lc .. 8 lc + 7 of the step (16-byte chunk lc of the row)
+    int fa_off[TM], fb_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa_off[i] = chunk_off(wco0 + i * 16 + l16, lc);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb_off[j] = 3 * YPLANE + chunk_off(wci0 + j * 16 + l16, lc);
+
+    // Per step: the A fragments (all three planes) once, the B fragments in three thirds of the N range (2 tiles each) through two
+    // register sets -- the next third is read while the current one is multiplied; 18 slots of 6 MFMAs.  The loader's work rides in
+    // the slots: transpose-stores of step s+1 into the other buffer, then that block's global loads for step s+2.
+    bf16x8 fa[3][TM], fb[2][3][2];
+    auto read_b = [&](auto setc, const char* st, int third) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[S][p][j] = *reinterpret_cast<const bf16x8*>(st + p * XPLANE + fb_off[2 * third + j]);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        const int s2 = s + 2 < nsteps ? s + 2 : nsteps - 1;
+        const char* st = smem + buf * STAGE;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(st + p * YPLANE + fa_off[i]);
+        read_b(S0{}, st, 0);
+        [&]<int... SL>(std::integer_sequence<int, SL...>) {
+            (([&] {
+                 constexpr int T = SL / 6, Q = SL % 6, SET = T & 1;
+                 if constexpr (Q == 0 && T < 2) {
+                     if constexpr (SET == 0) read_b(S1{}, st, T + 1);
+                     else read_b(S0{}, st, T + 1);
+                 }
+#pragma unroll
+                 for (int i = 0; i < TM; ++i)
+#pragma unroll
+                     for (int j = 0; j < 2; ++j)
+                         acc[i][2 * T + j] =
+                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T + j], 0, 0, 0);
+                 if constexpr (SL >= 1 && SL < 5) store_part(J0{}, std::integral_constant<int, SL - 1>{}, buf ^ 1);
+                 if constexpr (SL == 5) load_block(J0{}, s2);
+                 if constexpr (SL >= 7 && SL < 11) { if (has2) store_part(J1{}, std::integral_constant<int, SL - 7>{}, buf ^ 1); }
+                 if constexpr (SL == 11) { if (has2) load_block(J1{}, s2); }
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
+        }
+        (std::make_integer_sequence<int, 18>{});
+        __syncthreads();
+    }
+
+    const long wsize = (long)a.Cout * a.KH * a.KW * a.Cin;
+    float* slab = a.slabs + (long)chunk * wsize;
+    const int taps = a.KH * a.KW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + wci0 + j * 16 + l16;
+        if (ci >= a.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wco0 + i * 16 + 4 * lc + r;
+                if (co < a.Cout) slab[((long)co * taps + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+    }
+}
+
 }  // namespace
 
 // called by rdo_conv2d_wgrad (conv_wgrad.hip) for the shapes rdo_conv2d_wgrad_uses_bf16x6 accepts
@@ -360,6 +612,22 @@ int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy,
         attr_set = true;
     }
     dim3 grid((unsigned)nsplit, (unsigned)(a.KH * a.KW * a.tiles_co * a.tiles_ci));
+    // default: the eight-wave kernel (two waves per SIMD); RDO_WGX6_W8=0 selects the four-wave one (A/B: tools/wgrad_x6_check.py)
+    static const int w8 = getenv("RDO_WGX6_W8") ? atoi(getenv("RDO_WGX6_W8")) : 1;
+    if (w8) {
+        static bool attr8 = false;
+        if (!attr8) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6w8_kernel<false>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6w8_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6w8, %zu B LDS) failed", lds);
+            attr8 = true;
+        }
+        if (a.square_input) hipLaunchKernelGGL((conv_wgrad_x6w8_kernel<true>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_x6w8_kernel<false>), grid, dim3(512), lds, s, a);
+        return rdo::check_launch("conv_wgrad_x6w8");
+    }
     if (a.square_input) hipLaunchKernelGGL((conv_wgrad_x6_kernel<T, T, true>), grid, dim3(256), lds, s, a);
     else hipLaunchKernelGGL((conv_wgrad_x6_kernel<T, T, false>), grid, dim3(256), lds, s, a);
     return rdo::check_launch("conv_wgrad_x6");
