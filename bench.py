@@ -213,6 +213,9 @@ def gpu_leg(a, rank, world, device):
                 agg[tag] = agg.get(tag, 0.0) + m
             log(f"  unit {uname:24s} {sum(ms):7.3f} ms  " + " ".join(f"{k}={v:.3f}" for k, v in sorted(agg.items(), key=lambda kv: -kv[1])[:5]))
         e._done += 1
+        if getattr(e, "plan_a2", None) is not None:
+            info += e.plan_a2.op_info()
+            ms += e.plan_a2.profile()
         if e.plan_b is not None:
             if torch.distributed.is_initialized():
                 torch.distributed.all_reduce(e.bucket, group=e.group)

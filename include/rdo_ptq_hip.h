@@ -53,6 +53,13 @@ typedef struct rdo_conv_desc {
 
 const char* rdo_version(void);
 const char* rdo_last_error(void);
+/* Kernel-variant switches for A/B measurements and parity tests (process-wide; the defaults are what ships).  Keys:
+ *   "wgrad_x6_w8"  1 (default): eight-wave bf16x6 weight-gradient kernel, 0: the four-wave one
+ *   "conv_x6"      1 (default): large convolutions on the split-bf16 MFMA path, 0: everything on the fp32 MFMA
+ *   "fwd_x6_ver"   forward bf16x6 kernel generation (default: newest)
+ * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */
+int rdo_set_tuning(const char* key, int32_t value);
+int rdo_get_tuning(const char* key);
 
 /* ---- K1/K2/K3: convolution as implicit GEMM on fp32 MFMA -------- replaces F.conv2d at quant_layer.py:123 (and the
  * 1x1 `F.conv2d(x**2, gamma, beta)` of f_gdn, quant_layer.py:147).  `pre` (nullable) receives acc+bias before the
@@ -140,14 +147,18 @@ int rdo_uaq_fakequant(const rdo_ada_desc* d, const float* w, const float* delta,
 int rdo_uaq_init_minmax(const float* w, int32_t rows, int64_t inner, int32_t n_levels, float* delta, float* zp,
                         void* stream);
 
-/* ---- K6: dynamic per-channel 8-bit activation quant-dequant (ActQuant)                    quantizer.py:81-117 */
-int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, float* out, float* ws_minmax /* 2*C floats */,
-                            void* stream);
+/* ---- K6: dynamic per-channel activation quant-dequant (ActQuant)                          quantizer.py:81-117
+ * zp = min_c, r = max(max_c - zp, 1e-6), out = round(clamp((x - zp)/r, -1, 1) * (2^n_bits - 1)) / (2^n_bits - 1) * r + zp.
+ * The reference hard-wires n_bits = 8 (`b_w=8`, quantizer.py:81); other widths (BASELINE config "W10A10") are an extension. */
+int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, int32_t n_bits, float* out,
+                            float* ws_minmax /* 2*C floats */, void* stream);
 
 /* ---- K7: mini-batch assembly: out[b] = keep ? cache_q[idx[b]] : cache_fp[idx[b]], keep ~ counter RNG(seed, iter, i)
- * replaces cached_inps[..][idx] + torch.where(torch.rand_like(x) < p, x_q, x_fp)                layer_opt.py:289-292 */
+ * replaces cached_inps[..][idx] + torch.where(torch.rand_like(x) < p, x_q, x_fp)                layer_opt.py:289-292
+ * i = element index in the GLOBAL mini-batch: (batch_offset + b) * per_image + offset.  A data-parallel rank that holds rows
+ * [batch_offset, batch_offset + B) of the global mini-batch draws exactly the mask slice a single process would (same seed). */
 int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr,
-                     int32_t B, int64_t per_image, float prob, uint32_t seed, float* out, void* stream);
+                     int32_t B, int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out, void* stream);
 
 /* ---- K8: lp_loss(pred, tgt[idx]) forward + gradient, p = 2: loss = sum((pred-tgt)^2)/(npix), sum over channels
  * grad = coef * 2 (pred - tgt) / npix ; `coef` = 2 reproduces rec_loss + (degenerate) task_loss of SURVEY 3.4.
@@ -157,10 +168,12 @@ int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* 
 
 /* general task exponent (main2.py:52 --task_loss -> LossFunction.metric, layer_opt.py:150,274): adds
  *   coef2 * sum d^2 / npix + coefp * sum |d|^p / npix   to the loss slot and writes its gradient; p >= 1.
- * (coef2, coefp) = (1, 1) is rec_loss + task_loss on the same tensors, (0, 1) the task term alone.                           */
+ * (coef2, coefp) = (1, 1) is rec_loss + task_loss on the same tensors, (0, 1) the task term alone.  `loss_out_p` (nullable):
+ * when given, the |d|^p term is logged there and only the p = 2 term goes to loss_out (the reference's 500-iteration log
+ * prints task and rec apart, layer_opt.py:168-170).                                                                           */
 int rdo_lp_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
                      int32_t B, int64_t per_image, int32_t C, float coef2, float coefp, float p, float* grad,
-                     float* loss_out, void* stream);
+                     float* loss_out, float* loss_out_p, void* stream);
 
 /* ---- K9: element-wise helpers on NHWC tensors */
 int rdo_lrelu_fwd(const float* x, int64_t n, float* out, void* stream);                         /* nn.LeakyReLU(0.01) */

@@ -356,7 +356,7 @@ extern "C" int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d);
 // 1 when rdo_conv2d_fwd would take the split-bf16 path for this shape if weight planes are supplied: problems that fill the
 // chip with 128 x 192 tiles, split over K if necessary (rdo_conv2d_fwd_bf16x6_ksplit).  RDO_CONV_X6=0 disables it.
 extern "C" int rdo_conv2d_fwd_uses_bf16x6(const rdo_conv_desc* d) {
-    static const bool enabled = !(getenv("RDO_CONV_X6") && atoi(getenv("RDO_CONV_X6")) == 0);
+    const bool enabled = rdo::tuning(rdo::T_CONV_X6) != 0;
     if (!d || !enabled) return 0;
     return rdo_conv2d_fwd_bf16x6_ksplit(d) >= 1;
 }

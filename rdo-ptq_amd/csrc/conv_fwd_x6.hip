@@ -891,7 +891,7 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
     a.csteps = (d->Cin + BK - 1) / BK;
     a.epilogue = d->epilogue; a.square_input = d->square_input; a.add_residual = d->add_residual;
     a.wplane = (long)d->Cout * d->KH * d->KW * d->Cin;
-    a.xcd_mode = getenv("RDO_XCD") ? atoi(getenv("RDO_XCD")) : 1;
+    a.xcd_mode = rdo::tuning(rdo::T_XCD);
     int ks = rdo_conv2d_fwd_bf16x6_ksplit(d);
     if (ks < 1) ks = 1;
     if (ks > 1 && (!workspace || (long)ks * a.M * a.Cout > workspace_floats)) ks = 1;
@@ -903,7 +903,7 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
             // default: v6 where its geometry applies, else v5.  RDO_X6_VER=5 forces v5; 3 / 4 select the earlier register-staged /
             // LDS-DMA variants of the same tile (kept for A/B measurements);
             // the LDS-DMA loaders address the weight planes with 32-bit element offsets
-            static const int ver_env = getenv("RDO_X6_VER") ? atoi(getenv("RDO_X6_VER")) : 6;
+            const int ver_env = rdo::tuning(rdo::T_FWD_X6_VER);
             const int ver = (ver_env != 3 && 3 * a.wplane >= (1L << 31)) ? 3 : (ver_env >= 5 ? 5 : ver_env);
             // v6 (the three kw taps share one activation image) takes the stride-1 3-wide kernels whose tiles are whole image rows
             const bool v6_ok = a.stride == 1 && a.KW == 3 && a.pad == 1 && a.Cin % 16 == 0 && a.M % 128 == 0 && a.W >= 16 &&

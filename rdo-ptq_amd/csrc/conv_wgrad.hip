@@ -238,7 +238,7 @@ int rdo_launch_thin_wgrad(const rdo_conv_desc* d, const float* x, const float* d
 // 1 when rdo_conv2d_wgrad runs this shape on the split-bf16 MFMA path (conv_wgrad_x6.hip): big-tile problems whose output
 // rows are a multiple of 4 pixels wide and whose channel counts allow 16-byte quads.  RDO_CONV_X6=0 disables it.
 extern "C" int rdo_conv2d_wgrad_uses_bf16x6(const rdo_conv_desc* d) {
-    static const bool enabled = !(getenv("RDO_CONV_X6") && atoi(getenv("RDO_CONV_X6")) == 0);
+    const bool enabled = rdo::tuning(rdo::T_CONV_X6) != 0;
     if (!d || !enabled || g_force_big == 0) return 0;
     // the x6 loader addresses both tensors with 32-bit byte offsets (buffer loads)
     const bool fits = (double)d->B * d->H * d->W * d->Cin * 4.0 < 4.0e9 && (double)d->B * d->Ho * d->Wo * d->Cout * 4.0 < 4.0e9;

@@ -613,7 +613,7 @@ int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy,
     }
     dim3 grid((unsigned)nsplit, (unsigned)(a.KH * a.KW * a.tiles_co * a.tiles_ci));
     // default: the eight-wave kernel (two waves per SIMD); RDO_WGX6_W8=0 selects the four-wave one (A/B: tools/wgrad_x6_check.py)
-    static const int w8 = getenv("RDO_WGX6_W8") ? atoi(getenv("RDO_WGX6_W8")) : 1;
+    const int w8 = rdo::tuning(rdo::T_WGRAD_X6_W8);
     if (w8) {
         static bool attr8 = false;
         if (!attr8) {

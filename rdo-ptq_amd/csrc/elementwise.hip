@@ -19,8 +19,8 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
 
 // ---- K7: gather + QDrop (layer_opt.py:289-292).  keep = u32(seed, iter, i) < floor(p * 2^32) takes the quantised-prefix input.
 __global__ __launch_bounds__(256) void gather_qdrop_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
-                                                           const int32_t* iter_ptr, int B, long per_image, unsigned long long thr,
-                                                           uint32_t seed, float* out) {
+                                                           const int32_t* iter_ptr, int B, int batch_offset, long per_image,
+                                                           unsigned long long thr, uint32_t seed, float* out) {
     const int it = *iter_ptr;
     const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
     const long quads = per_image / 4;
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void gather_qdrop_kernel(const float* cq, cons
         const long src = (long)idx_table[(long)it * B + b] * per_image + off;
         const f32x4 q = *reinterpret_cast<const f32x4*>(cq + src);
         const f32x4 f = *reinterpret_cast<const f32x4*>(cfp + src);
-        const uint32_t i0 = (uint32_t)((long)b * per_image + off);
+        const uint32_t i0 = (uint32_t)((long)(batch_offset + b) * per_image + off);     // element index in the GLOBAL mini-batch
         f32x4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = ((unsigned long long)lowbias32((i0 + e) ^ key) < thr) ? q[e] : f[e];
@@ -71,11 +71,11 @@ __global__ __launch_bounds__(256) void lp2_kernel(const float* pred, const float
 // task term with main2.py's --task_loss exponent (layer_opt.py:133,150) in one pass
 __global__ __launch_bounds__(256) void lp_kernel(const float* pred, const float* tgt, const int32_t* idx_table,
                                                  const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef2,
-                                                 float coefp, float pw, float* grad, float* loss_out) {
+                                                 float coefp, float pw, float* grad, float* loss_out, float* loss_out_p) {
     const int it = *iter_ptr;
     const long quads = per_image / 4;
     const long total = (long)B * quads;
-    float acc = 0.f;
+    float acc = 0.f, accp = 0.f;                                 // the p = 2 term and the |d|^p term, logged apart on request
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int b = (int)(t / quads);
         const long off = (t - (long)b * quads) * 4;
@@ -86,18 +86,30 @@ __global__ __launch_bounds__(256) void lp_kernel(const float* pred, const float*
         for (int e = 0; e < 4; ++e) {
             const float d = p[e] - y[e], a = fabsf(d);
             const float am1 = powf(a, pw - 1.f);                 // |d|^(p-1); pow(0, 0) = 1 and the sign factor below is 0
-            acc += coef2 * d * d + coefp * am1 * a;
+            acc += coef2 * d * d;
+            accp += coefp * am1 * a;
             const float sg = (float)((d > 0.f) - (d < 0.f));
             g[e] = (coef2 * 2.f * d + coefp * pw * am1 * sg) * inv_npix;
         }
         *reinterpret_cast<f32x4*>(grad + (long)b * per_image + off) = g;
     }
-    __shared__ float red[4];
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __shared__ float red[8];
+    for (int o = 32; o > 0; o >>= 1) {
+        acc += __shfl_down(acc, o, 64);
+        accp += __shfl_down(accp, o, 64);
+    }
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = acc; red[4 + (threadIdx.x >> 6)] = accp; }
     __syncthreads();
-    if (threadIdx.x == 0 && loss_out)
-        atomicAdd(loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), (red[0] + red[1] + red[2] + red[3]) * inv_npix);
+    if (threadIdx.x == 0) {
+        const float s2 = (red[0] + red[1] + red[2] + red[3]) * inv_npix, sp = (red[4] + red[5] + red[6] + red[7]) * inv_npix;
+        const long slot = (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1));
+        if (loss_out_p) {
+            atomicAdd(loss_out_p + slot, sp);
+            if (loss_out) atomicAdd(loss_out + slot, s2);
+        } else if (loss_out) {
+            atomicAdd(loss_out + slot, s2 + sp);
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void lrelu_bwd_kernel(const float* g, const float* y, long n4, float slope, float* out) {
@@ -276,14 +288,14 @@ __global__ __launch_bounds__(256) void aq_minmax_kernel(const float* x, long npi
     (void)pix_per_block;
 }
 
-__global__ __launch_bounds__(256) void aq_apply_kernel(const float* x, long n, int C, const unsigned* ws, float* out) {
+__global__ __launch_bounds__(256) void aq_apply_kernel(const float* x, long n, int C, const unsigned* ws, float bit_range, float* out) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         const int c = (int)(i % C);
         const float zp = ord2f(ws[c]);
         const float rng = fmaxf(ord2f(ws[C + c]) - zp, 1e-6f);
         const float xn = x[i] - zp;
-        const float q = rintf(fminf(fmaxf(xn / rng, -1.f), 1.f) * 255.f);
-        out[i] = (q / 255.f) * rng + zp;
+        const float q = rintf(fminf(fmaxf(xn / rng, -1.f), 1.f) * bit_range);
+        out[i] = (q / bit_range) * rng + zp;
     }
 }
 
@@ -292,18 +304,19 @@ __global__ __launch_bounds__(256) void aq_apply_kernel(const float* x, long n, i
 extern "C" {
 
 int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
-                     int64_t per_image, float prob, uint32_t seed, float* out, void* stream) {
+                     int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out, void* stream) {
     RDO_REQUIRE(cache_q && cache_fp && idx_table && iter_ptr && out, "rdo_gather_qdrop: null pointer");
+    RDO_REQUIRE(batch_offset >= 0, "rdo_gather_qdrop: negative batch_offset");
     RDO_REQUIRE(B > 0 && per_image > 0 && per_image % 4 == 0, "rdo_gather_qdrop: per_image (%ld) must be a multiple of 4",
                 (long)per_image);
-    RDO_REQUIRE((long)B * per_image < (1L << 32), "rdo_gather_qdrop: batch tensor exceeds the 32-bit RNG counter");
+    RDO_REQUIRE((long)(batch_offset + B) * per_image < (1L << 32), "rdo_gather_qdrop: batch tensor exceeds the 32-bit RNG counter");
     RDO_REQUIRE(prob >= 0.f && prob <= 1.f, "rdo_gather_qdrop: prob out of [0,1]");
     double t = floor((double)prob * 4294967296.0);
     const unsigned long long thr = (unsigned long long)(t > 4294967296.0 ? 4294967296.0 : t);
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(gather_qdrop_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, cache_q, cache_fp,
-                               idx_table, iter_ptr, B, (long)per_image, thr, seed, out);
+                               idx_table, iter_ptr, B, batch_offset, (long)per_image, thr, seed, out);
             return rdo::check_launch("gather_qdrop");
         },
         stream, "gather_qdrop", 0.0, 12.0 * B * per_image);
@@ -324,7 +337,8 @@ int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* 
 }
 
 int rdo_lp_loss_grad(const float* pred, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
-                     int64_t per_image, int32_t C, float coef2, float coefp, float p, float* grad, float* loss_out, void* stream) {
+                     int64_t per_image, int32_t C, float coef2, float coefp, float p, float* grad, float* loss_out,
+                     float* loss_out_p, void* stream) {
     RDO_REQUIRE(pred && tgt_cache && idx_table && iter_ptr && grad, "rdo_lp_loss_grad: null pointer");
     RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_lp_loss_grad: bad shape");
     RDO_REQUIRE(p >= 1.f, "rdo_lp_loss_grad: exponent %g < 1 has no finite gradient at zero", (double)p);
@@ -332,7 +346,7 @@ int rdo_lp_loss_grad(const float* pred, const float* tgt_cache, const int32_t* i
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(lp_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, pred, tgt_cache, idx_table,
-                               iter_ptr, B, (long)per_image, inv_npix, coef2, coefp, p, grad, loss_out);
+                               iter_ptr, B, (long)per_image, inv_npix, coef2, coefp, p, grad, loss_out, loss_out_p);
             return rdo::check_launch("lp_loss_grad");
         },
         stream, "lp_loss_grad", 0.0, 12.0 * B * per_image);
@@ -456,15 +470,17 @@ int rdo_iter_advance(int32_t* iter_ptr, void* stream) {
         stream);
 }
 
-int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, float* out, float* ws_minmax, void* stream) {
+int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, int32_t n_bits, float* out, float* ws_minmax, void* stream) {
     RDO_REQUIRE(x && out && ws_minmax && npix > 0 && C > 0, "rdo_actquant_perchannel: bad argument");
+    RDO_REQUIRE(n_bits >= 2 && n_bits <= 16, "rdo_actquant_perchannel: n_bits %d outside [2, 16]", n_bits);
+    const float bit_range = (float)((1 << n_bits) - 1);
     unsigned* ws = reinterpret_cast<unsigned*>(ws_minmax);
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(aq_init_kernel, dim3((unsigned)rdo::ceil_div(C, 256)), dim3(256), 0, s, ws, C);
             long g = npix < 1024 ? npix : 1024;
             hipLaunchKernelGGL(aq_minmax_kernel, dim3((unsigned)g), dim3(256), 0, s, x, (long)npix, C, ws);
-            hipLaunchKernelGGL(aq_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, s, x, (long)npix * C, C, ws, out);
+            hipLaunchKernelGGL(aq_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, s, x, (long)npix * C, C, ws, bit_range, out);
             return rdo::check_launch("actquant_perchannel");
         },
         stream);

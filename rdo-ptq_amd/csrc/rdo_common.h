@@ -50,6 +50,11 @@ inline int check_launch(const char* what) {
 
 constexpr int kWave = 64;
 
+// Process-wide kernel-variant switches (rdo_set_tuning / rdo_get_tuning; initialised once from the RDO_* environment variables
+// of the same meaning so that command-line A/B runs keep working).
+enum Tune { T_WGRAD_X6_W8 = 0, T_CONV_X6, T_FWD_X6_VER, T_XCD, T_COUNT };
+int tuning(Tune t);
+
 // bf16x6 weight planes ("fragment order"): element (co, kh, kw, ci) of a conv weight [Cout][KH][KW][Cin] lives at
 //   plane + ((((ci / 16) * KH + kh) * KW + kw) * Cout + co) * 16 + ci % 16
 // i.e. [channel slice of 16][kh][kw][Cout][16]: the 192 x 16 weight tile of one K stage of conv_fwd_x6 is one contiguous run, so

@@ -1,6 +1,11 @@
 // Error state, version, and the unit executor (recorded op list -> per-iteration replay / hipGraph).
 #include "rdo_common.h"
 
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+
 namespace rdo {
 
 static thread_local std::string g_err;
@@ -18,6 +23,33 @@ int set_error(int code, const char* fmt, ...) {
     return code;
 }
 
+namespace {
+struct TuneDef { const char* key; const char* env; int dflt; };
+constexpr TuneDef kTune[T_COUNT] = {{"wgrad_x6_w8", "RDO_WGX6_W8", 1}, {"conv_x6", "RDO_CONV_X6", 1},
+                                    {"fwd_x6_ver", "RDO_X6_VER", 6}, {"xcd", "RDO_XCD", 1}};
+std::atomic<int> g_tune[T_COUNT];
+std::once_flag g_tune_once;
+void tune_init() {
+    std::call_once(g_tune_once, [] {
+        for (int i = 0; i < T_COUNT; ++i) {
+            const char* e = getenv(kTune[i].env);
+            g_tune[i].store(e ? atoi(e) : kTune[i].dflt);
+        }
+    });
+}
+int tune_index(const char* key) {
+    if (!key) return -1;
+    for (int i = 0; i < T_COUNT; ++i)
+        if (!strcmp(key, kTune[i].key)) return i;
+    return -1;
+}
+}  // namespace
+
+int tuning(Tune t) {
+    tune_init();
+    return g_tune[t].load(std::memory_order_relaxed);
+}
+
 }  // namespace rdo
 
 struct rdo_plan {
@@ -32,6 +64,21 @@ extern "C" {
 
 const char* rdo_version(void) { return "rdo-ptq-hip 0.1 (gfx950)"; }
 const char* rdo_last_error(void) { return rdo::g_err.c_str(); }
+
+int rdo_set_tuning(const char* key, int32_t value) {
+    const int i = rdo::tune_index(key);
+    RDO_REQUIRE(i >= 0, "rdo_set_tuning: unknown key '%s'", key ? key : "(null)");
+    rdo::tune_init();
+    rdo::g_tune[i].store(value);
+    return RDO_OK;
+}
+
+int rdo_get_tuning(const char* key) {
+    const int i = rdo::tune_index(key);
+    if (i < 0) return -1;
+    rdo::tune_init();
+    return rdo::g_tune[i].load();
+}
 
 rdo_plan* rdo_plan_create(void) { return new rdo_plan(); }
 

@@ -35,6 +35,8 @@ P = C.c_void_p
 _SIGS = {
     "rdo_version": (C.c_char_p, []),
     "rdo_last_error": (C.c_char_p, []),
+    "rdo_set_tuning": (C.c_int, [C.c_char_p, C.c_int32]),
+    "rdo_get_tuning": (C.c_int, [C.c_char_p]),
     "rdo_conv2d_fwd": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, C.c_int64, P, P]),
     "rdo_conv2d_fwd_uses_bf16x6": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_split_bf16x3": (C.c_int, [P, C.c_int64, P, P]),
@@ -53,10 +55,10 @@ _SIGS = {
     "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rdo_uaq_fakequant": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, P]),
     "rdo_uaq_init_minmax": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, P, P, P]),
-    "rdo_actquant_perchannel": (C.c_int, [P, C.c_int64, C.c_int32, P, P, P]),
-    "rdo_gather_qdrop": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_float, C.c_uint32, P, P]),
+    "rdo_actquant_perchannel": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),
+    "rdo_gather_qdrop": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_uint32, P, P]),
     "rdo_lp2_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, P, P, P]),
-    "rdo_lp_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, P, P, P]),
+    "rdo_lp_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, P, P, P, P]),
     "rdo_lrelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
     "rdo_lrelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_relu_fwd": (C.c_int, [P, C.c_int64, P, P]),

@@ -87,6 +87,11 @@ def wgrad_nsplit(x_shape, w_shape, stride, pad):
     return int(L.lib().rdo_conv2d_wgrad_nsplit(C.byref(d)))
 
 
+def wgrad_uses_bf16x6(x_shape, w_shape, stride, pad):
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    return bool(L.lib().rdo_conv2d_wgrad_uses_bf16x6(C.byref(d)))
+
+
 def conv2d_wgrad(x, dy, w_shape, stride=1, pad=0, square_input=False, slabs=None):
     d = conv_desc(x.shape, w_shape, stride, pad, square_input=square_input)
     ns = int(L.lib().rdo_conv2d_wgrad_nsplit(C.byref(d))) if slabs is None else slabs.shape[0]
@@ -167,19 +172,29 @@ def adaround_apply(d, w, delta, zp, dalpha, grad_scale, round_weight, sched, ite
                                        _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _stream()), "rdo_adaround_apply")
 
 
-def actquant_perchannel(x, out=None, ws=None):
-    """x: [..., C] channels-last; per-channel dynamic 8-bit quant-dequant."""
+def set_tuning(key, value):
+    """Process-wide kernel-variant switch (include/rdo_ptq_hip.h: rdo_set_tuning); returns the previous value."""
+    prev = int(L.lib().rdo_get_tuning(key.encode()))
+    L.check(L.lib().rdo_set_tuning(key.encode(), int(value)), f"rdo_set_tuning({key})")
+    return prev
+
+
+def actquant_perchannel(x, out=None, ws=None, n_bits=8):
+    """x: [..., C] channels-last; per-channel dynamic quant-dequant (8 bit = the reference's hard-wired width)."""
     Cc = x.shape[-1]
     npix = x.numel() // Cc
     out = torch.empty_like(x) if out is None else out
     ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32) if ws is None else ws
-    L.check(L.lib().rdo_actquant_perchannel(_ptr(x), npix, Cc, _ptr(out), _ptr(ws), _stream()), "rdo_actquant_perchannel")
+    L.check(L.lib().rdo_actquant_perchannel(_ptr(x), npix, Cc, int(n_bits), _ptr(out), _ptr(ws), _stream()), "rdo_actquant_perchannel")
     return out
 
 
-def gather_qdrop(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out):
+def gather_qdrop(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, batch_offset=0):
+    """`batch_offset`: row of the global mini-batch this (data-parallel) rank's first row is -- the QDrop counter runs over the
+    global batch, so N ranks with one seed draw the mask a single process would."""
     per_image = cache_q[0].numel()
-    L.check(L.lib().rdo_gather_qdrop(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, per_image, prob, seed,
+    L.check(L.lib().rdo_gather_qdrop(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,
+                                     prob, seed,
                                      _ptr(out), _stream()), "rdo_gather_qdrop")
     return out
 
@@ -192,12 +207,14 @@ def lp2_loss_grad(pred, tgt_cache, idx_table, iter_ptr, coef, grad, loss_log):
     return grad
 
 
-def lp_loss_grad(pred, tgt_cache, idx_table, iter_ptr, coef2, coefp, p, grad, loss_log):
-    """coef2 * lp_loss(., p=2) + coefp * lp_loss(., p=p) of the same (pred, tgt) pair, and its gradient."""
+def lp_loss_grad(pred, tgt_cache, idx_table, iter_ptr, coef2, coefp, p, grad, loss_log, loss_log_p=None):
+    """coef2 * lp_loss(., p=2) + coefp * lp_loss(., p=p) of the same (pred, tgt) pair, and its gradient.  With `loss_log_p`
+    the |d|^p term is logged there and only the p = 2 term in `loss_log`."""
     B = pred.shape[0]
     per_image = pred[0].numel()
     L.check(L.lib().rdo_lp_loss_grad(_ptr(pred), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
-                                     pred.shape[-1], coef2, coefp, p, _ptr(grad), _ptr(loss_log), _stream()), "rdo_lp_loss_grad")
+                                     pred.shape[-1], coef2, coefp, p, _ptr(grad), _ptr(loss_log), _ptr(loss_log_p), _stream()),
+            "rdo_lp_loss_grad")
     return grad
 
 

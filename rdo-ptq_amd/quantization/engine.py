@@ -138,7 +138,7 @@ class _Op:
 class UnitEngine:
     def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
                  warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
-                 use_graph=True, force_dp_split=False, task_p=2.0):
+                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=True):
         if kind not in UNIT_KINDS:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
@@ -151,8 +151,13 @@ class UnitEngine:
         self.weight, self.input_prob, self.seed = float(weight), float(input_prob), int(seed) & 0xFFFFFFFF
         self.include_act = include_act_func
         self.use_graph = use_graph
+        self.batch_offset = int(batch_offset)  # first row of this rank's share of the global mini-batch (QDrop counter)
+        self.dp_overlap = bool(dp_overlap)
         self.dev = cache_q.device
         n = cache_q.shape[0]
+        if idx_table is None and self.B > n:
+            # fewer cached samples than the batch: the reference's randperm(n)[:batch_size] simply yields all n (layer_opt.py:289)
+            self.B = n
         if idx_table is None:
             # same CPU-generator stream as the reference: one torch.randperm(n) per iteration (layer_opt.py:289)
             idx_table = torch.stack([torch.randperm(n)[:self.B] for _ in range(self.iters)])
@@ -165,6 +170,8 @@ class UnitEngine:
         self.sched = ops.make_sched(self.iters, warmup, b_range, lr, self.dev)
         self.it = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self.loss_log = torch.zeros(self.iters, L.LOG_SLOTS, device=self.dev)      # kernels spread atomics over the slots
+        self.task_log = torch.zeros(self.iters, L.LOG_SLOTS, device=self.dev)      # task term where it is a separate quantity
+        self._task_is_rec = False              # True: task == rec on the same tensors, both logged as 2 * rec in loss_log
         self.round_log = torch.zeros(self.iters, L.LOG_SLOTS, device=self.dev)
         self.group = group
         self.world = 1
@@ -204,13 +211,19 @@ class UnitEngine:
             if op.need_dgrad and (op.stride != 1 or 2 * op.pad != op.K - 1):
                 raise NotImplementedError("calibration engine: dgrad is built for stride-1 'same' convolutions only")
         self.ops = o
+        # Data parallel: one flat bucket of d(rec+task)/d(alpha) per unit.  The op whose weight gradient is the LAST kernel of the
+        # backward pass (the block's first conv) sits at the end of the bucket: everything in front of it is complete before that
+        # wgrad starts, so its all-reduce overlaps the wgrad (two recorded plans, `_split_point`).
+        self._late = {"rb": "conv1", "rbws": "conv1", "rbu": "subpel_conv"}.get(k) if (self.split and self.dp_overlap) else None
         if self.split:
             total = sum(op.numel() for op in o.values())
             self.bucket = torch.zeros(total, device=self.dev)
+            order = [n for n in o if n != self._late] + ([self._late] if self._late else [])
             off = 0
-            for op in o.values():
-                op.dalpha = self.bucket[off:off + op.numel()]
-                off += op.numel()
+            for n in order:
+                o[n].dalpha = self.bucket[off:off + o[n].numel()]
+                off += o[n].numel()
+            self._early_numel = total - (o[self._late].numel() if self._late else 0)
 
     def _buf(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
@@ -302,13 +315,14 @@ class UnitEngine:
     def _loss(self, pred, grad):
         # rec_loss + task_loss on the same tensors (fp_out is the identity for these coders)
         if self.task_p == 2.0:
+            self._task_is_rec = True
             ops.lp2_loss_grad(pred, self.co, self.idx, self.it, 2.0, grad, self.loss_log)
         else:
-            ops.lp_loss_grad(pred, self.co, self.idx, self.it, 1.0, 1.0, self.task_p, grad, self.loss_log)
+            ops.lp_loss_grad(pred, self.co, self.idx, self.it, 1.0, 1.0, self.task_p, grad, self.loss_log, self.task_log)
 
     def _forward_backward(self):
         o, t, x = self.ops, self.t, self.x_in
-        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x)
+        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, self.batch_offset)
         if self.kind == "layer" and o["layer"].is_gdn:
             # a GDN / IGDN that is its own unit (sequential Minnen2018-style coders): only gamma is trained, no dx needed
             op = o["layer"]
@@ -347,6 +361,7 @@ class UnitEngine:
             ops.lrelu_bwd(t["dout"], t["pre2"], t["dpre2"])
             self._wgrad(c2, t["h1"], t["dpre2"])
             self._dgrad(c2, t["dpre2"], t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+            self._split_point()
             self._wgrad(c1, x, t["dh1"])
         elif self.kind == "rbws":
             c1, c2, g = o["conv1"], o["conv2"], o["gdn"]
@@ -363,6 +378,7 @@ class UnitEngine:
             self._gdn_backward(g, t["dout"], t["c2"], t["norm"], t["t"], t["acc"], t["dc2"], inverse=False)
             self._wgrad(c2, t["h1"], t["dc2"])
             self._dgrad(c2, t["dc2"], t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+            self._split_point()
             self._wgrad(c1, x, t["dh1"])
         elif self.kind == "rbu":
             sp, cv, g, up = o["subpel_conv"], o["conv"], o["igdn"], o["upsample"]
@@ -380,6 +396,7 @@ class UnitEngine:
             self._wgrad(cv, t["h1"], t["dc"])
             self._dgrad(cv, t["dc"], t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
             ops.pixel_unshuffle(t["dh1"], r, t["dsp"])
+            self._split_point()
             self._wgrad(sp, x, t["dsp"])
 
     def _gdn_backward(self, g, dout, xin, norm, tbuf, acc, dx, inverse):
@@ -390,10 +407,29 @@ class UnitEngine:
         ops.gdn_bwd_dx(dout, xin, norm, acc, inverse, dx)
         self._wgrad(g, xin, tbuf, square=True)                        # dgamma'[k][i] = sum_m t_k x_i^2
 
+    def _grad_ops(self, names):
+        for n in names:
+            op = self.ops[n]
+            ops.adaround_grad(op.desc, op.w, op.alpha, op.delta, op.zp, op.slabs, op.dalpha)
+
+    def _split_point(self):
+        """Called by the backward pass right before its last weight-gradient kernel.  Data-parallel recording only: the gradients
+        of every other op are final here -> chain them into the front of the bucket, close plan A and continue in plan A2, so
+        that `run` can start the all-reduce of the front while the last wgrad computes."""
+        if self._late is None or self.plan_a2 is not None:
+            return
+        self._grad_ops([n for n in self.ops if n != self._late])
+        self._rec_ctx.__exit__(None, None, None)
+        self.plan_a2 = Plan()
+        self._rec_ctx = self.plan_a2.record()
+        self._rec_ctx.__enter__()
+
     def _record(self):
         self.plan_a = Plan()
-        self.plan_b = None
-        with self.plan_a.record():
+        self.plan_a2 = self.plan_b = None
+        self._rec_ctx = self.plan_a.record()
+        self._rec_ctx.__enter__()
+        try:
             self._forward_backward()
             if not self.split:
                 for op in self.ops.values():
@@ -401,9 +437,13 @@ class UnitEngine:
                     ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
                                       op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
                 ops.iter_advance(self.it)
+            elif self.plan_a2 is not None:
+                self._grad_ops([self._late])
             else:
-                for op in self.ops.values():
-                    ops.adaround_grad(op.desc, op.w, op.alpha, op.delta, op.zp, op.slabs, op.dalpha)
+                self._grad_ops(list(self.ops))
+        finally:
+            self._rec_ctx.__exit__(None, None, None)
+            self._rec_ctx = None
         if self.split:
             self.plan_b = Plan()
             with self.plan_b.record():
@@ -422,23 +462,52 @@ class UnitEngine:
         if not self.split:
             self.plan_a.run(n, graph=self.use_graph)
         else:
+            dist = torch.distributed
+            comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
             for _ in range(n):
                 self.plan_a.run(1, graph=self.use_graph)
-                if self.world > 1 or (torch.distributed.is_available() and torch.distributed.is_initialized()):
-                    torch.distributed.all_reduce(self.bucket, op=torch.distributed.ReduceOp.SUM, group=self.group)
+                if self.plan_a2 is None:
+                    if comm:
+                        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+                else:
+                    # the collective runs on the process group's own stream (RCCL) behind plan A; plan A2 -- the last weight
+                    # gradient of the backward pass -- is launched right behind plan A on the compute stream and overlaps it
+                    w1 = dist.all_reduce(self.bucket[:self._early_numel], op=dist.ReduceOp.SUM, group=self.group,
+                                         async_op=True) if comm else None
+                    self.plan_a2.run(1, graph=self.use_graph)
+                    w2 = dist.all_reduce(self.bucket[self._early_numel:], op=dist.ReduceOp.SUM, group=self.group,
+                                         async_op=True) if comm else None
+                    if comm:
+                        w1.wait()
+                        w2.wait()
                 self.plan_b.run(1, graph=self.use_graph)
         self._done = done + n
         return n
 
+    def _data_terms(self):
+        """(rec, task) per iteration on the device, averaged over the data-parallel ranks."""
+        rec, task = self.loss_log.sum(1), self.task_log.sum(1)
+        if self._task_is_rec:
+            rec = rec * 0.5
+            task = rec.clone()
+        if self.world > 1:
+            both = torch.stack([rec, task])
+            torch.distributed.all_reduce(both, group=self.group)
+            rec, task = both[0] / self.world, both[1] / self.world
+        return rec, task
+
     def logs(self):
         """(total, rec+task, round) per iteration as CPU tensors (synchronises)."""
-        rt = self.loss_log.sum(1)
-        if self.world > 1:
-            torch.distributed.all_reduce(rt, group=self.group)
-            rt /= self.world
-        rt = rt.cpu()
+        rec, task = self._data_terms()
+        rt = (rec + task).cpu()
         rd = self.round_log.sum(1).cpu()
         return rt + rd, rt, rd
+
+    def logs_terms(self):
+        """(rec, task, round, b) per iteration as CPU tensors: the four numbers of the reference's periodic log line
+        (layer_opt.py:168-170); b is the temperature of the schedule table (0 while the rounding loss is off)."""
+        rec, task = self._data_terms()
+        return rec.cpu(), task.cpu(), self.round_log.sum(1).cpu(), self.sched[:, 0].cpu()
 
     def alpha_of(self, name):
         """Trained alpha in the logical weight shape (OIHW view of the OHWI storage; [Cin,Cout,KH,KW] for transposed convs)."""

@@ -34,7 +34,7 @@ class BaseQuantBlock(nn.Module):
                 m.set_quant_state(weight_quant, act_quant)
 
     def _aq(self, x):
-        return ActQuantizer(x) if (self.use_act_quant and self.trained) else x
+        return ActQuantizer(x, self.act_quantizer.dynamic_bits) if (self.use_act_quant and self.trained) else x
 
 
 def _lrelu(x):
@@ -182,8 +182,9 @@ class QuantWindowAttention(BaseQuantBlock):
             n = window * window
             probs = torch.empty((B * (H // window) * (W // window), n, n, self.num_heads), device=qkv.device, dtype=torch.float32)
             ops.window_attention(d, qkv, bias, probs=probs, compute_out=False)
-            probs = ops.actquant_perchannel(probs)                       # per head, as ActQuantizer on [B_, heads, N, N]
-            o = ActQuantizer(ops.window_attention_pv(d, qkv, probs).view(B, H * W, C))
+            nb = self.act_quantizer.dynamic_bits
+            probs = ops.actquant_perchannel(probs, n_bits=nb)            # per head, as ActQuantizer on [B_, heads, N, N]
+            o = ActQuantizer(ops.window_attention_pv(d, qkv, probs).view(B, H * W, C), nb)
         else:
             o = ops.window_attention(d, qkv, bias).view(B, H * W, C)
         return self.proj(o)

@@ -62,19 +62,21 @@ def _scale_shape(w: torch.Tensor, tconv: bool):
 
 
 # ----------------------------------------------------------------------------- activation quantisation
-def ActQuant(x: torch.Tensor):
-    """Dynamic 8-bit per-channel quant-dequant of a detached copy (channel = dim 1 for 4-D, last dim for 3-D, dim 1 for 2-D)."""
+def ActQuant(x: torch.Tensor, n_bits: int = 8):
+    """Dynamic per-channel quant-dequant of a detached copy (channel = dim 1 for 4-D, last dim for 3-D, dim 1 for 2-D).
+    The reference hard-wires 8 bits (`Handle_Parameter(param, b_w=8)`, quantizer.py:81) whatever --n_bits_a says; `n_bits` is
+    the extension BASELINE config "W10A10" needs (UniformAffineQuantizer(dynamic_bits=10))."""
     x = x.detach()
     if x.dim() == 4:
         xr = x.permute(0, 2, 3, 1).contiguous()
-        return ops.actquant_perchannel(xr).permute(0, 3, 1, 2)
+        return ops.actquant_perchannel(xr, n_bits=n_bits).permute(0, 3, 1, 2)
     if x.dim() in (2, 3):
-        return ops.actquant_perchannel(x.contiguous())
-    return ops.actquant_perchannel(x.reshape(-1, 1).contiguous()).reshape(x.shape)
+        return ops.actquant_perchannel(x.contiguous(), n_bits=n_bits)
+    return ops.actquant_perchannel(x.reshape(-1, 1).contiguous(), n_bits=n_bits).reshape(x.shape)
 
 
-def ActQuantizer(x: torch.Tensor):
-    return ActQuant(x)
+def ActQuantizer(x: torch.Tensor, n_bits: int = 8):
+    return ActQuant(x, n_bits)
 
 
 # ----------------------------------------------------------------------------- uniform affine quantiser
@@ -82,8 +84,13 @@ class UniformAffineQuantizer(nn.Module):
     """Asymmetric uniform fake-quantiser; scales are initialised lazily on the first weight it sees."""
 
     def __init__(self, n_bits: int = 8, symmetric: bool = False, channel_wise: bool = False, scale_method: str = "max",
-                 leaf_param: bool = False, tconv: bool = False, act: bool = False, prob: float = 1.0):
+                 leaf_param: bool = False, tconv: bool = False, act: bool = False, prob: float = 1.0,
+                 dynamic_bits: int = None):
         super().__init__()
+        # width of the dynamic activation grid: None = the reference's fixed 8 bits (its ActQuant ignores n_bits_a,
+        # quantizer.py:81,158-159); an explicit value is this build's extension (e.g. 10 for W10A10)
+        assert dynamic_bits is None or 2 <= dynamic_bits <= MAX_BITS, "bitwidth not supported"
+        self.dynamic_bits = 8 if dynamic_bits is None else int(dynamic_bits)
         # the reference stops at 8 bits (quantizer.py:139); BASELINE config 3 (W10A10) needs wider weight grids, which the
         # kernels handle unchanged (levels are fp32-valued integers): accepted up to 16 bits as an extension
         assert 2 <= n_bits <= MAX_BITS, "bitwidth not supported"
@@ -130,23 +137,29 @@ class UniformAffineQuantizer(nn.Module):
         vectorised over channels (the reference loops over channels in Python, quantizer.py:260-265)."""
         m, L = self.scale_method, self.n_levels
         eps = torch.tensor(1e-8, device=flat.device)
-        if "max" in m or m == "gaussian":
-            if m == "gaussian":
-                mu, var = flat.mean(1), flat.var(1)
-                lo, hi = torch.clamp(mu - 6 * var, max=0), torch.clamp(mu + 6 * var, min=0)
-            else:
-                lo, hi = torch.clamp(flat.amin(1), max=0), torch.clamp(flat.amax(1), min=0)
-                if "scale" in m:
-                    lo, hi = lo * (self.n_bits + 2) / 8, hi * (self.n_bits + 2) / 8
+        if m == "gaussian":
+            # tensor arithmetic in fp32 throughout, as in the reference (quantizer.py:318-335; its 'scale' branch is dead there)
+            mu, var = flat.mean(1), flat.var(1)
+            lo, hi = torch.clamp(mu - 6 * var, max=0), torch.clamp(mu + 6 * var, min=0)
             if self.sym:
                 amax = torch.maximum(lo.abs(), hi)
                 lo, hi = torch.where(lo < 0, -amax, torch.zeros_like(lo)), amax
-            delta = torch.maximum(((hi.double() - lo.double()) / (L - 1)).float(), eps)
-            if m == "gaussian":
-                return delta, (-lo / delta).round()                 # tensor / tensor in the reference (quantizer.py:335)
-            # 'max' family: the reference divides a Python float by the tensor, which torch evaluates as
-            # delta.reciprocal() * (-x_min) (quantizer.py:296) -- one more rounding, it decides ties at x.5
-            return delta, (delta.reciprocal() * (-lo)).round()
+            delta = torch.maximum((hi - lo) / (L - 1), eps)
+            return delta, (-lo / delta).round()
+        if "max" in m:
+            # the reference holds x_min / x_max as Python floats (double) from here on: scaling, symmetrisation and the range
+            # are evaluated in double and rounded to fp32 ONCE (quantizer.py:282-293); doing the scaling in fp32 can move delta
+            # by an ulp and flip a zero point that sits on x.5
+            lo, hi = torch.clamp(flat.amin(1), max=0).double(), torch.clamp(flat.amax(1), min=0).double()
+            if "scale" in m:
+                lo, hi = lo * (self.n_bits + 2) / 8, hi * (self.n_bits + 2) / 8
+            if self.sym:
+                amax = torch.maximum(lo.abs(), hi)
+                lo, hi = torch.where(lo < 0, -amax, torch.zeros_like(lo)), amax
+            delta = torch.maximum(((hi - lo) / (L - 1)).float(), eps)
+            # the reference divides a Python float by the tensor, which torch evaluates as delta.reciprocal() * (-x_min)
+            # (quantizer.py:296) -- one more rounding, it decides ties at x.5
+            return delta, (delta.reciprocal() * (-lo).float()).round()
         if m not in ("mse", "l1", "l2"):
             raise NotImplementedError(m)
         hi0, lo0 = flat.amax(1, keepdim=True), flat.amin(1, keepdim=True)
@@ -169,7 +182,7 @@ class UniformAffineQuantizer(nn.Module):
     # -- forward ---------------------------------------------------------------------------------------------------
     def forward(self, x: torch.Tensor, act: bool = False):
         if act:
-            return ActQuantizer(x)
+            return ActQuantizer(x, getattr(self, "dynamic_bits", 8))
         if not self.inited:
             if self.leaf_param:
                 return x

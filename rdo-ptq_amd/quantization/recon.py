@@ -3,6 +3,7 @@
 The choreography around the hot loop is the reference's; the loop itself runs on `engine.UnitEngine`."""
 import logging
 import time
+import zlib
 
 import torch
 
@@ -51,17 +52,56 @@ def fp_out(module_list, x, round_after, batch=8):
 
 
 class LossFunction:
-    """Host-side restatement of the objective, used for logging/inspection only -- the engine evaluates the same terms
-    on the device (layer_opt.py:87-173)."""
+    """The objective of one reconstruction unit with the reference's call signature (layer_opt.py:87-173; the block variant,
+    block_opt.py:87-173, sums the rounding term over the block's QuantModules).  The calibration engine evaluates the same three
+    terms on the device inside the recorded iteration; this class is the inspection / logging form of it on torch tensors
+    (used by the parity tests to evaluate the loss of a calibrated unit), not part of the hot loop."""
 
     def __init__(self, unit, round_loss="relaxation", weight=1., rec_loss="mse", max_count=2000, b_range=(10, 2),
                  decay_start=0.0, warmup=0.0, p=2., lmbda=None, metric=None):
         self.unit, self.round_loss, self.weight, self.rec_loss = unit, round_loss, weight, rec_loss
+        self.layer = self.block = unit                 # attribute names of the two reference classes
         self.loss_start = max_count * warmup
         self.p, self.lmbda, self.metric = p, lmbda, metric
         self.temp_decay = LinearTempDecay(max_count, rel_start_decay=warmup + (1 - warmup) * decay_start,
                                           start_b=b_range[0], end_b=b_range[1])
         self.count = 0
+
+    def _round_modules(self):
+        if isinstance(self.unit, QuantModule):
+            return [self.unit]
+        return [m for m in self.unit.modules() if isinstance(m, QuantModule) and m.org_weight is not None]
+
+    def __call__(self, pred, tgt, quant_net_out=None, cali_data=None, grad=None):
+        from .quantizer import lp_loss
+        self.count += 1
+        if self.rec_loss != "mse":
+            raise NotImplementedError("only rec_loss='mse' (the mode main2.py uses) is built")
+        rec_loss = lp_loss(pred, tgt, p=self.p)
+        task_loss = 0.
+        if quant_net_out is not None:
+            task_loss = lp_loss(quant_net_out, cali_data, p=self.metric)
+        b = self.temp_decay(self.count)
+        if self.count < self.loss_start or self.round_loss == "none":
+            b = round_loss = 0
+        elif self.round_loss == "relaxation":
+            round_loss = 0
+            for m in self._round_modules():
+                round_vals = m.weight_quantizer.get_soft_targets()
+                round_loss += self.weight * (1 - ((round_vals - .5).abs() * 2).pow(b)).sum()
+        else:
+            raise NotImplementedError
+        total_loss = round_loss + rec_loss + task_loss
+        if self.count % 500 == 0:
+            logging.info("Total loss:\t{:.3f} ( task:{:.3f}, rec:{:.3f}, round:{:.3f})\tb={:.2f}\tcount={}".format(
+                float(total_loss), float(task_loss), float(rec_loss), float(round_loss), b, self.count))
+        return total_loss
+
+
+def unit_seed(unit_name: str) -> int:
+    """Seed of the QDrop stream of one unit: the process seed (main2.py seed_all -> torch.manual_seed) mixed with a CRC of the
+    unit's name -- reproducible from run to run (Python's str hash is salted per process) and distinct per unit."""
+    return (torch.initial_seed() ^ zlib.crc32(unit_name.encode())) & 0xFFFFFFFF
 
 
 def _unit_modules(unit):
@@ -93,8 +133,14 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
         raise ValueError("--task_loss < 1 has no finite gradient at zero error")
     rank, world_size = dp.world()
     if world_size > 1:                      # data parallel: this rank calibrates on its shard with its share of the batch
+        if batch_size % world_size != 0:
+            raise ValueError(f"data-parallel calibration: batch_size {batch_size} is not a multiple of the world size "
+                             f"{world_size} (the global mini-batch is split evenly; pass a multiple, e.g. {world_size * max(1, batch_size // world_size)})")
+        if cali_data.size(0) % world_size != 0:
+            raise ValueError(f"data-parallel calibration: {cali_data.size(0)} calibration images do not split evenly over "
+                             f"{world_size} ranks (uneven shards would weight samples unequally)")
         cali_data = dp.shard(cali_data)
-        batch_size = max(1, batch_size // world_size)
+        batch_size = batch_size // world_size
     t0 = time.time()
     # dynamic activation quantisation makes cached values depend on the caching batch: keep the reference's batch of 1 then
     cache_bs = 1 if act_quant else max(1, min(32, cali_data.size(0)))
@@ -120,7 +166,7 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     kind, mods = _unit_modules(unit)
     # the CLI --lr is ignored by the reference (Adam default 1e-3, layer_opt.py:253-254); kept that way.
     common = dict(batch_size=batch_size, iters=iters, weight=weight, b_range=b_range, warmup=warmup, input_prob=input_prob,
-                  lr=1e-3, seed=torch.initial_seed() ^ (hash(unit_name) & 0xFFFF), include_act_func=include_act_func,
+                  lr=1e-3, seed=unit_seed(unit_name), include_act_func=include_act_func, batch_offset=rank * batch_size,
                   task_p=float(task_p))
     if kind == "rstb" or task_cache is not None:
         eng = TapeEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), tail=module_list, tail_round=tail_round,
@@ -129,10 +175,11 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
         eng = UnitEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), **common)
     eng.run()
     if logging.getLogger().isEnabledFor(logging.INFO) and iters >= 500:
-        total, rt, rd = eng.logs()
+        rec, task, rd, b = eng.logs_terms()
         for c in range(500, iters + 1, 500):
-            logging.info("Total loss:\t{:.3f} ( task:{:.3f}, rec:{:.3f}, round:{:.3f})\tcount={}".format(
-                float(total[c - 1]), float(rt[c - 1]) / 2, float(rt[c - 1]) / 2, float(rd[c - 1]), c))
+            logging.info("Total loss:\t{:.3f} ( task:{:.3f}, rec:{:.3f}, round:{:.3f})\tb={:.2f}\tcount={}".format(
+                float(rec[c - 1] + task[c - 1] + rd[c - 1]), float(task[c - 1]), float(rec[c - 1]), float(rd[c - 1]),
+                float(b[c - 1]), c))
     eng.finish()
     for m in ([unit] if not is_block else unit.modules()):
         if isinstance(m, (QuantModule, BaseQuantBlock)):

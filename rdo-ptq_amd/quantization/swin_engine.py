@@ -122,8 +122,10 @@ class TapeEngine(UnitEngine):
             o[pre + "mlp.fc1"] = _Op(pre + "mlp.fc1", blk.mlp.fc1, True)
             o[pre + "mlp.fc2"] = _Op(pre + "mlp.fc2", blk.mlp.fc2, True)
         self.ops = o
+        self._late = None                      # one bucket, one all-reduce (no early/late split for the tape units)
         if self.split:
             total = sum(op.numel() for op in o.values())
+            self._early_numel = total
             self.bucket = torch.zeros(total, device=self.dev)
             off = 0
             for op in o.values():
@@ -370,7 +372,7 @@ class TapeEngine(UnitEngine):
         from .quant_block import QuantRSTB
         self.tape, self.G, self._aliased = [], {}, set()
         x = self.x_in
-        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x)
+        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, self.batch_offset)
         y = self._unit_forward(x)
         n_unit = len(self.tape)
         plain = not self.tail and not self.tail_round                 # fp_out is the identity: task == rec (coef 2)
@@ -389,9 +391,9 @@ class TapeEngine(UnitEngine):
                 ops.round_(z, out=zr)                                  # round_ste: identity gradient
             dz = self._buf(*z.shape)
             if self.task_p == 2.0:
-                ops.lp2_loss_grad(zr, self.task_cache, self.idx, self.it, 1.0, dz, self.loss_log)
+                ops.lp2_loss_grad(zr, self.task_cache, self.idx, self.it, 1.0, dz, self.task_log)
             else:
-                ops.lp_loss_grad(zr, self.task_cache, self.idx, self.it, 0.0, 1.0, self.task_p, dz, self.loss_log)
+                ops.lp_loss_grad(zr, self.task_cache, self.idx, self.it, 0.0, 1.0, self.task_p, dz, self.task_log)
             if z is y:                                                 # round-only tail: both terms meet at the unit output
                 ops.add(dz, dy, out=dy)
             else:

@@ -100,7 +100,9 @@ def save_inp_oup_data(model: QuantModel, layer: Union[QuantModule, BaseQuantBloc
     """-> ((inp_q, inp_fp), out_fp) if input_prob else ((inp,), out).  Everything stays on the model's device."""
     device = next(model.parameters()).device
     grab = GetLayerInpOut(model, layer, device=device, asym=asym, act_quant=act_quant, input_prob=input_prob)
-    parts = [grab(cali_data[i:i + batch_size]) for i in range(0, cali_data.size(0) - batch_size + 1, batch_size)]
+    # every sample is cached, the last (short) batch included: the reference caches with batch 1 and drops nothing
+    # (utils.py:112-121 there iterate range(size / batch_size) with batch_size = 1, layer_opt.py:212)
+    parts = [grab(cali_data[i:i + batch_size]) for i in range(0, cali_data.size(0), batch_size)]
     cols = [torch.cat([p[k] for p in parts]) for k in range(len(parts[0]))]
     if not keep_gpu:
         cols = [c.cpu() for c in cols]

@@ -114,3 +114,38 @@ def test_bd_rate_matches_reference(golden_dir):
             for pw in (0, 1):
                 np.testing.assert_allclose(bd_rate.BD_RATE(*a, piecewise=pw), g[f"c{c}_bdrate_{pw}"], rtol=1e-10)
                 np.testing.assert_allclose(bd_rate.BD_PSNR(*a, piecewise=pw), g[f"c{c}_bdpsnr_{pw}"], rtol=1e-10)
+
+
+def test_dp_batch_must_split_evenly(monkeypatch):
+    """reconstruct() refuses a global mini-batch (or calibration set) that does not split evenly over the ranks instead of
+    silently changing the effective batch."""
+    import torch
+    from quantization import recon
+    monkeypatch.setattr(recon.dp, "world", lambda group=None: (0, 3))
+    cali = torch.zeros(6, 3, 8, 8)
+    with pytest.raises(ValueError, match="multiple of the world size"):
+        recon.reconstruct(None, None, "g_a.0", cali, batch_size=4, iters=1)
+    with pytest.raises(ValueError, match="split evenly"):
+        recon.reconstruct(None, None, "g_a.0", cali[:5], batch_size=3, iters=1)
+
+
+def test_unit_seed_is_reproducible_and_distinct():
+    """QDrop seeds come from a CRC of the unit name, not from Python's per-process salted str hash."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import torch; torch.manual_seed(1005); "
+            "from quantization.recon import unit_seed; print(unit_seed('g_a.0'), unit_seed('g_s.0'), unit_seed('0'))" % os.path.join(ROOT, "rdo-ptq_amd"))
+    outs = {subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, check=True,
+                           env=dict(os.environ, PYTHONHASHSEED=str(h))).stdout.strip() for h in (1, 2)}
+    assert len(outs) == 1
+    a, b, c = (int(v) for v in outs.pop().split())
+    assert len({a, b, c}) == 3
+
+
+def test_tuning_switches_round_trip():
+    from hipops import _lib
+    h = _lib.lib()
+    assert h.rdo_get_tuning(b"wgrad_x6_w8") == 1 and h.rdo_get_tuning(b"conv_x6") == 1
+    assert h.rdo_set_tuning(b"wgrad_x6_w8", 0) == 0 and h.rdo_get_tuning(b"wgrad_x6_w8") == 0
+    assert h.rdo_set_tuning(b"wgrad_x6_w8", 1) == 0
+    assert h.rdo_set_tuning(b"no_such_key", 1) != 0 and h.rdo_get_tuning(b"no_such_key") == -1

@@ -140,6 +140,12 @@ def test_engine_task_loss_exponent(recon, tag, kind, task_p):
     torch.cuda.synchronize()
     total = eng.logs()[0]
     np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=2e-4, atol=1e-7)
+    # the four numbers of the reference's periodic log line (layer_opt.py:168-170), term by term
+    rec, task, rd, b = eng.logs_terms()
+    np.testing.assert_allclose(rec.numpy(), np.array(log.rec), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(task.numpy(), np.array(log.task), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(rd.numpy(), np.array(log.round), rtol=2e-4, atol=1e-7)
+    np.testing.assert_allclose(b.numpy(), np.array(log.b), rtol=1e-6)
     flips = tot = 0
     for n, op in ops_o.items():
         a_gpu = eng.alpha_of(n).cpu()
@@ -167,6 +173,12 @@ def test_lp_loss_kernel_matches_autograd():
         ops.lp_loss_grad(pred.cuda(), tgt.cuda(), idx.cuda(), torch.zeros(1, dtype=torch.int32, device="cuda"), c2, cp, p, grad, log)
         torch.testing.assert_close(grad.cpu(), pr.grad, rtol=2e-5, atol=1e-7)
         torch.testing.assert_close(log.sum().cpu(), loss.detach(), rtol=1e-5, atol=0)
+        # with a second log the |d|^p term goes there and only the p = 2 term stays in the first
+        log2, logp = torch.zeros(1, 32, device="cuda"), torch.zeros(1, 32, device="cuda")
+        ops.lp_loss_grad(pred.cuda(), tgt.cuda(), idx.cuda(), torch.zeros(1, dtype=torch.int32, device="cuda"), c2, cp, p, grad, log2, logp)
+        dd = pred - tgt[idx[0].long()]
+        torch.testing.assert_close(log2.sum().cpu(), c2 * dd.pow(2).sum(-1).mean(), rtol=1e-5, atol=1e-7)
+        torch.testing.assert_close(logp.sum().cpu(), cp * dd.abs().pow(p).sum(-1).mean(), rtol=1e-5, atol=1e-7)
 
 
 def test_engine_rejects_cpu_tensors(recon):

@@ -1,0 +1,121 @@
+"""BASELINE config 1 at full width through the public API, as tests: the whole `main2.py` flow of
+tools/e2e_fullsize.py on Cheng2020-anchor N=192, and every <= 16x16 layer unit of that model on the HIP engine against
+`oracle.reconstruct_unit` on the same caches, index stream and QDrop masks (the CPU oracle finishes these units in seconds; the
+128^2 / 64^2 block units are covered by the torch-autograd step tests of tests/test_gpu_x6_parity.py and test_gpu_fullsize.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SEED = 1005
+
+
+@pytest.fixture(scope="module")
+def cheng192():
+    """Oracle Cheng2020-anchor N=192 (seeded), its unit schedule and the captured (input, output) of every unit for 4 crops."""
+    from oracle import lic_oracle as L
+    from oracle.cheng_units import capture_io, schedule
+    torch.manual_seed(SEED)
+    model = L.Cheng2020Anchor(N=192).eval()
+    g = torch.Generator().manual_seed(SEED)
+    with torch.no_grad():      # variance-preserving weights so that every unit sees O(1) activations
+        for name, p in model.named_parameters():
+            if p.dim() == 4 and "entropy_bottleneck" not in name:
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 2 * (3.0 / p[0].numel()) ** 0.5)
+    sched = schedule(model)
+    x = torch.rand(4, 3, 256, 256, generator=g)
+    return sched, capture_io(model, sched, x)
+
+
+SMALL_LAYER_UNITS = ["g_a.6", "h_a.0", "h_a.2", "h_a.4", "h_a.6", "h_a.8", "h_s.0", "h_s.2.0", "h_s.4", "h_s.6.0", "h_s.8",
+                     "entropy_parameters.0", "entropy_parameters.2", "entropy_parameters.4", "context_prediction"]
+
+
+@pytest.mark.parametrize("name", SMALL_LAYER_UNITS)
+def test_small_layer_units_n192_match_oracle(cheng192, name):
+    from helpers import WQ, AQ
+    from oracle import rdo_oracle as O
+    from quantization.engine import UnitEngine
+    from quantization.quant_layer import QuantModule
+    sched, io = cheng192
+    (kind, ops_o, mod), = [(k, o, m) for n, k, o, m in sched if n == name]
+    assert kind == "layer"
+    inp, out = io[name]
+    assert max(out.shape[2:]) <= 16
+    g = torch.Generator().manual_seed(7)
+    inp_q = inp + 1e-3 * torch.randn(inp.shape, generator=g)
+    iters, B = 12, 4
+    idx = np.stack([np.random.RandomState(i).permutation(4) for i in range(iters)])
+    op = ops_o["layer"]
+    op.init_scale()
+    log = O.reconstruct_unit(kind, ops_o, inp_q, inp, out, iters=iters, batch_size=B, idx_stream=idx,
+                             mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5), input_prob=0.5,
+                             weight=0.01, b_range=(20, 2), warmup=0.2)
+    conv = nn.Conv2d(mod.in_channels, mod.out_channels, mod.kernel_size, stride=mod.stride, padding=mod.padding)
+    with torch.no_grad():
+        conv.weight.copy_(mod.weight)
+        conv.bias.copy_(mod.bias)
+    qm = QuantModule(conv.cuda(), WQ, AQ).cuda()
+    if op.act == "lrelu":
+        qm.activation_function = nn.LeakyReLU(inplace=True)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    eng = UnitEngine("layer", {"layer": qm}, nh(inp_q), nh(inp), nh(out), batch_size=B, iters=iters, weight=0.01, b_range=(20, 2),
+                     warmup=0.2, input_prob=0.5, seed=SEED, idx_table=torch.from_numpy(idx))
+    e = eng.ops["layer"]
+    np.testing.assert_array_equal(e.delta.cpu().numpy(), op.delta.reshape(-1).numpy())
+    np.testing.assert_array_equal(e.zp.cpu().numpy(), op.zp.reshape(-1).numpy())
+    eng.run()
+    torch.cuda.synchronize()
+    total, rt, rd = eng.logs()
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=3e-4, atol=1e-7)
+    np.testing.assert_allclose(rd.numpy(), np.array(log.round), rtol=2e-4, atol=1e-7)
+    a_gpu, a_ref = eng.alpha_of("layer").cpu(), op.alpha
+    assert a_gpu.shape == a_ref.shape
+    # Adam normalises the gradient: an element whose gradient is at the fp32 noise level may move by up to lr per step in either
+    # implementation, so bound the FRACTION of such elements and the hard rounding decisions
+    far = ((a_gpu - a_ref).abs() > 2e-3).float().mean()
+    flips = ((a_gpu >= 0) != (a_ref >= 0)).float().mean()
+    assert float(far) < 2e-3 and float(flips) < 5e-3, (float(far), float(flips))
+    assert float((a_gpu - a_ref).abs().max()) <= 2.5e-2          # 12 steps of lr 1e-3, both directions
+
+
+def test_full_size_main2_flow():
+    """recon_model over the 29 units of Cheng2020-anchor N=192 through layer_/block_reconstruction, then W8 and W8A8 evaluation:
+    unit count, finite metrics, and the calibrated model no further from the FP32 model than nearest rounding was (with a few
+    iterations AdaRound's hard rounding still equals nearest rounding except for weights at the decision boundary)."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_fullsize
+    r = e2e_fullsize.run_flow(images=8, iters=24, batch=4, eval_hw=(256, 384), n_eval=1, log=lambda *_: None)
+    assert r["n_units"] == 29
+    for k in ("psnr_fp", "bpp_fp", "psnr_w8_rtn", "bpp_w8_rtn", "psnr_w8", "bpp_w8", "psnr_w8a8", "bpp_w8a8", "fid_rtn", "fid_w8", "fid_w8a8"):
+        assert np.isfinite(r[k]), k
+    assert r["fid_w8"] >= r["fid_rtn"] - 1.0
+    assert r["fid_w8a8"] >= 20.0
+    from quantization import QuantModule
+    assert all(m.trained for m in r["qnn"].modules() if isinstance(m, QuantModule) and m.org_weight is not None)
+
+
+def test_cache_keeps_every_image_with_a_short_last_batch():
+    """40 calibration images cached with batch 32: the trailing 8 must be kept (the reference caches with batch 1
+    and drops nothing, layer_opt.py:212)."""
+    import lic
+    from helpers import WQ, AQ
+    from quantization import QuantModel
+    from quantization.utils import save_inp_oup_data
+    torch.manual_seed(3)
+    model = lic.Cheng2020Anchor(N=8).cuda().eval()
+    qnn = QuantModel(model=model, weight_quant_params=WQ, act_quant_params=AQ, is_cheng=True).cuda().eval()
+    cali = torch.rand(40, 3, 64, 64, device="cuda")
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:4])
+    unit = qnn.model.g_a[1]
+    (inp_q, inp_fp), out_fp = save_inp_oup_data(qnn, unit, cali, True, False, batch_size=32, input_prob=True)
+    assert inp_q.shape[0] == inp_fp.shape[0] == out_fp.shape[0] == 40
+    (iq1, if1), of1 = save_inp_oup_data(qnn, unit, cali[32:], True, False, batch_size=8, input_prob=True)
+    assert torch.equal(inp_fp[32:], if1) and torch.equal(out_fp[32:], of1)

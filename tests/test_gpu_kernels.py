@@ -282,6 +282,28 @@ def test_product_uaq_matches_reference_goldens(golden_dir, tag, tconv, method, c
     np.testing.assert_allclose(out.cpu().numpy(), qz[key + "_out"], rtol=3e-7, atol=float(d_ref.max()) * 1e-6)  # 1 ulp of delta scales every level
 
 
+@pytest.mark.parametrize("tag", ["conv", "lin"])
+@pytest.mark.parametrize("method,sym", [("max_scale", False), ("max", True), ("max_scale", True)])
+@pytest.mark.parametrize("cw", [True, False])
+@pytest.mark.parametrize("bits", [8, 6, 4])
+def test_product_uaq_scaled_and_symmetric_init(golden_dir, tag, method, sym, cw, bits):
+    """'max_scale' / symmetric inits of the product quantiser vs the reference's vectors: the range is scaled and mirrored in
+    double and rounded to fp32 once, so delta and the (tie-prone) zero points agree bit for bit."""
+    import os
+    from quantization.quantizer import UniformAffineQuantizer
+    fx = np.load(os.path.join(golden_dir, "quantizer_ties.npz"))
+    w = torch.from_numpy(fx[f"w_{tag}"]).cuda()
+    key = f"uaq_{tag}_{method}{'_sym' if sym else ''}_{'cw' if cw else 'lw'}_{bits}"
+    q = UniformAffineQuantizer(n_bits=bits, symmetric=sym, channel_wise=cw, scale_method=method)
+    out = q(w)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(q.delta.cpu().numpy().reshape(-1), fx[key + "_delta"].reshape(-1))
+    np.testing.assert_array_equal(q.zero_point.cpu().numpy().reshape(-1), fx[key + "_zp"].reshape(-1))
+    d = float(fx[key + "_delta"].max())
+    diff = np.abs(out.cpu().numpy() - fx[key + "_out"])
+    assert float((diff > 1e-7).mean()) < 2e-3 and float(diff.max()) <= d * (1 + 1e-5)
+
+
 @pytest.mark.parametrize("tag,tconv", [("conv", False), ("tconv", True), ("lin", False)])
 @pytest.mark.parametrize("cw", [True, False])
 @pytest.mark.parametrize("bits", [8, 6, 4])
@@ -302,6 +324,31 @@ def test_product_uaq_zero_points_on_symmetric_ranges(golden_dir, tag, tconv, cw,
     # values within an ulp of a rounding boundary may land one level apart; everything else is exact
     diff = np.abs(out.cpu().numpy() - fx[key + "_out"])
     assert float((diff > 1e-7).mean()) < 2e-3 and float(diff.max()) <= d * (1 + 1e-5)
+
+
+@pytest.mark.parametrize("bits", [10, 6, 16])
+def test_actquant_other_widths_match_oracle(bits):
+    """Activation grids other than the reference's hard-wired 8 bits (BASELINE config "W10A10"): the kernel with n_bits against
+    the oracle's Handle_Parameter(b_w) (quantizer.py:81-97 with its `b_w` argument lifted), 4-D and 3-D layouts, and through
+    UniformAffineQuantizer(dynamic_bits=...)."""
+    from oracle import rdo_oracle as O
+    from quantization.quantizer import ActQuantizer, UniformAffineQuantizer
+    g = torch.Generator().manual_seed(bits)
+    a4 = torch.randn(2, 5, 6, 7, generator=g) * 3
+    a4[:, 2] = 0.25
+    a3 = torch.randn(2, 9, 6, generator=g)
+    for a in (a4, a3):
+        ref = O.act_quant(a, b_w=bits)
+        got = ActQuantizer(a.cuda(), bits).cpu()
+        step = float((a.max() - a.min())) / (2 ** bits - 1)
+        diff = (got - ref).abs()
+        # a value within fp32 rounding of a grid boundary may land one level apart
+        assert float((diff > 1e-6).float().mean()) < 5e-3 and float(diff.max()) <= step * (1 + 1e-4)
+        q = UniformAffineQuantizer(n_bits=bits, channel_wise=True, scale_method="max", leaf_param=False, act=True, dynamic_bits=bits)
+        assert torch.equal(q(a.cuda(), True).cpu(), got)
+    # default stays the reference's 8 bits whatever n_bits says (quantizer.py:81,158-159)
+    q8 = UniformAffineQuantizer(n_bits=4, channel_wise=True, scale_method="max", leaf_param=False, act=True)
+    assert torch.equal(q8(a4.cuda(), True).cpu(), ActQuantizer(a4.cuda()).cpu())
 
 
 @pytest.mark.parametrize("tag", ["a4", "a3", "a2"])

@@ -47,6 +47,22 @@ def test_uaq_max_init_on_symmetric_ranges(golden_dir, tag, tconv, cw, bits):
     np.testing.assert_array_equal(O.uaq_fakequant(w, delta, zp, 2 ** bits).numpy(), fx[key + "_out"])
 
 
+@pytest.mark.parametrize("tag", ["conv", "lin"])
+@pytest.mark.parametrize("method,sym", [("max_scale", False), ("max", True), ("max_scale", True)])
+@pytest.mark.parametrize("cw", [True, False])
+@pytest.mark.parametrize("bits", [8, 6, 4])
+def test_uaq_scaled_and_symmetric_init_on_tie_prone_ranges(golden_dir, tag, method, sym, cw, bits):
+    """'max_scale' scales the range by (n_bits+2)/8 in Python double before the single rounding to fp32 (quantizer.py:284-293);
+    symmetric grids mirror the larger side.  Vectors from the reference on weights whose -min/delta sits on x.5."""
+    fx = np.load(os.path.join(golden_dir, "quantizer_ties.npz"))
+    w = T(fx[f"w_{tag}"])
+    key = f"uaq_{tag}_{method}{'_sym' if sym else ''}_{'cw' if cw else 'lw'}_{bits}"
+    delta, zp = O.uaq_init(w, bits, cw, method, sym=sym)
+    np.testing.assert_array_equal(delta.numpy().reshape(-1), fx[key + "_delta"].reshape(-1))
+    np.testing.assert_array_equal(zp.numpy().reshape(-1), fx[key + "_zp"].reshape(-1))
+    np.testing.assert_array_equal(O.uaq_fakequant(w, delta, zp, 2 ** bits).numpy(), fx[key + "_out"])
+
+
 def test_uaq_gaussian(qz):
     w = T(qz["w_conv"])
     delta, zp = O.uaq_init(w, 8, False, "gaussian")

@@ -223,6 +223,16 @@ def golden_quantizer_ties(out_dir):
                 key = f"uaq_{tag}_{'cw' if cw else 'lw'}_{bits}"
                 fx[key + "_delta"], fx[key + "_zp"], fx[key + "_out"] = _np(torch.as_tensor(q.delta)), _np(
                     torch.as_tensor(q.zero_point)), _np(y)
+    # 'max_scale' (range * (n_bits+2)/8, evaluated in Python double) and symmetric grids on the same tie-prone weights
+    for tag, w, tconv in (("conv", w_conv, False), ("lin", w_lin, False)):
+        for method, sym in (("max_scale", False), ("max", True), ("max_scale", True)):
+            for cw in (True, False):
+                for bits in (8, 6, 4):
+                    q = UniformAffineQuantizer(n_bits=bits, symmetric=sym, channel_wise=cw, scale_method=method, tconv=tconv)
+                    y = q(w)
+                    key = f"uaq_{tag}_{method}{'_sym' if sym else ''}_{'cw' if cw else 'lw'}_{bits}"
+                    fx[key + "_delta"], fx[key + "_zp"], fx[key + "_out"] = _np(torch.as_tensor(q.delta)), _np(
+                        torch.as_tensor(q.zero_point)), _np(y)
     np.savez_compressed(os.path.join(out_dir, "quantizer_ties.npz"), **fx)
     print("quantizer_ties.npz", len(fx), "arrays")
 
