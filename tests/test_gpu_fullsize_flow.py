@@ -58,8 +58,8 @@ def test_small_layer_units_n192_match_oracle(cheng192, name):
                              weight=0.01, b_range=(20, 2), warmup=0.2)
     conv = nn.Conv2d(mod.in_channels, mod.out_channels, mod.kernel_size, stride=mod.stride, padding=mod.padding)
     with torch.no_grad():
-        conv.weight.copy_(mod.weight)
-        conv.bias.copy_(mod.bias)
+        conv.weight.copy_(op.weight)          # the oracle op's own copy (MaskedConv2d masks mod.weight in place on forward)
+        conv.bias.copy_(op.bias)
     qm = QuantModule(conv.cuda(), WQ, AQ).cuda()
     if op.act == "lrelu":
         qm.activation_function = nn.LeakyReLU(inplace=True)
