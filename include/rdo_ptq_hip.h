@@ -241,6 +241,42 @@ int rdo_neg_log2_sum(const float* lik, int64_t n, float scale, float* out /* += 
 int rdo_sq_diff_sum(const float* a, const float* b, int64_t n, float scale, int32_t clamp01_a, float* out /* += */,
                     void* stream);                                                                    /* MSE numerator */
 
+/* ---- "P3" tensors and fused unit tails (round 2) ----------------------------------------------------------------------------
+ * A P3 tensor is an fp32 NHWC activation stored as its EXACT three-way bf16 split, planes[p][n] (p = 0..2, n = B*H*W*C elements,
+ * x = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)).  The split-bf16 GEMM kernels read it by LDS-DMA,
+ * so the conversion work is done once per element by the PRODUCER instead of once per use inside the K loops.  Producers:
+ * rdo_conv2d_fwd_p3 (epilogue), rdo_gather_qdrop_p3, rdo_loss_act_bwd, rdo_loss_gdn_bwd, rdo_gdn_bwd_dx_p3, rdo_pixel_shuffle_p3,
+ * rdo_split_p3 (from an fp32 tensor). */
+int rdo_split_p3(const float* x, int64_t n /* multiple of 8 */, void* planes /* 3*n bf16 */, void* stream);
+/* 1: rdo_conv2d_fwd_p3 accepts this shape (a large problem of rdo_conv2d_fwd_uses_bf16x6 with Cin % 16 == 0, Cout % 8 == 0, no
+ * square_input) */
+int rdo_conv2d_fwd_p3_supported(const rdo_conv_desc* d);
+/* rdo_conv2d_fwd (same epilogues, same results to fp32 accumulation order) with the activation given as P3 planes and the weight as
+ * fragment-ordered planes (rdo_split_bf16x3_conv / rdo_adaround_step).  Any of out / pre / out_planes may be NULL (at least one is
+ * required); out_planes receives the P3 form of `out`. */
+int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
+                      const float* residual, float* out, float* pre, void* out_planes, float* workspace, int64_t workspace_floats,
+                      void* stream);
+/* rdo_gather_qdrop writing the mini-batch as P3 planes (and as fp32 when `out` != NULL) */
+int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
+                        int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out, void* out_planes, void* stream);
+/* Tail of a unit whose last op is a conv (+ activation) (+ residual):   out = act(pre) + residual ; d = out - tgt[idx]
+ *   loss_out[*iter][slot] += coef * sum d^2 / npix ; grad_out = coef * 2 d / npix ; dpre = grad_out * act'(pre)
+ * i.e. the activation epilogue of the conv, rdo_lp2_loss_grad and rdo_lrelu_bwd / rdo_relu_bwd in one pass (layer_opt.py:133,150,
+ * 303-306).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU.  out / grad_out / dpre / dpre_planes are optional outputs. */
+int rdo_loss_act_bwd(const float* pre, const float* residual, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
+                     int32_t B, int64_t per_image, int32_t C, float coef, int32_t act, float* out, float* grad_out, float* dpre,
+                     void* dpre_planes, float* loss_out, void* stream);
+/* Tail of a unit that ends in GDN / IGDN (+ residual):  out = x * norm^(-1/2 | +1/2) + residual ; loss and grad_out as above ;
+ *   t = dL/dnorm = -1/2 g x norm^-3/2 (GDN) | 1/2 g x norm^-1/2 (IGDN)      = GDN epilogue + rdo_lp2_loss_grad + rdo_gdn_bwd_t */
+int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, const float* tgt_cache, const int32_t* idx_table,
+                     const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef, int32_t inverse, float* out,
+                     float* grad_out, float* t, void* t_planes, float* loss_out, void* stream);
+int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t inverse, float* dx,
+                      void* dx_planes, void* stream);                       /* rdo_gdn_bwd_dx with fp32 and / or P3 output */
+/* F.pixel_shuffle(x, 2) on NHWC: [B,H,W,4C] -> [B,2H,2W,C] as fp32 and / or P3 planes */
+int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream);
+
 /* ---- unit executor: a recorded sequence of the calls above, replayed per calibration iteration with no host work.
  * Python records the per-iteration op list once per unit (layer_reconstruction / block_reconstruction, layer_opt.py:287-309);
  * rdo_plan_run() enqueues `n_iters` iterations, through a captured hipGraph when `use_graph` != 0. */

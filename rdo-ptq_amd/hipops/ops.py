@@ -453,3 +453,72 @@ def make_sched(iters, warmup, b_range, lr=1e-3, device="cuda"):
         rows[i, 2] = lr / (1 - 0.9 ** count)
         rows[i, 3] = math.sqrt(1 - 0.999 ** count)
     return rows.to(device)
+
+
+# ----------------------------------------------------------------------------- P3 tensors and fused unit tails
+def p3_empty(shape, device):
+    """Planes of a P3 tensor (exact three-way bf16 split of an fp32 NHWC tensor of `shape`): int16 [3, *shape]."""
+    return torch.empty((3,) + tuple(shape), device=device, dtype=torch.int16)
+
+
+def p3_to_float(planes):
+    """p0 + p1 + p2 as fp32 (exact)."""
+    return sum((planes[i].to(torch.int32) << 16).view(torch.float32) for i in range(3))
+
+
+def split_p3(x, planes=None):
+    planes = p3_empty(x.shape, x.device) if planes is None else planes
+    L.check(L.lib().rdo_split_p3(_ptr(x), x.numel(), _ptr(planes), _stream()), "rdo_split_p3")
+    return planes
+
+
+def conv_p3_supported(x_shape, w_shape, stride, pad, square_input=False):
+    d = conv_desc(x_shape, w_shape, stride, pad, square_input=square_input)
+    return bool(L.lib().rdo_conv2d_fwd_p3_supported(C.byref(d)))
+
+
+def conv2d_fwd_p3(xp, w_shape, wplanes, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, out=None, pre=None,
+                  out_planes=None):
+    """Conv on a P3 input (`xp` = planes [3,B,H,W,Cin]) with fragment-ordered weight planes; writes whichever of out / pre /
+    out_planes is given."""
+    x_shape = tuple(xp.shape[1:])
+    d = conv_desc(x_shape, w_shape, stride, pad, epilogue, False, residual is not None)
+    need = int(L.lib().rdo_conv2d_fwd_workspace(C.byref(d)))
+    ws = _scratch(xp.device, need) if need else None
+    L.check(L.lib().rdo_conv2d_fwd_p3(C.byref(d), _ptr(xp), _ptr(wplanes), _ptr(bias), _ptr(aux), _ptr(residual), _ptr(out), _ptr(pre),
+                                      _ptr(out_planes), _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "rdo_conv2d_fwd_p3")
+    return out
+
+
+def gather_qdrop_p3(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, out_planes, batch_offset=0):
+    per_image = cache_q[0].numel()
+    L.check(L.lib().rdo_gather_qdrop_p3(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,
+                                        prob, seed, _ptr(out), _ptr(out_planes), _stream()), "rdo_gather_qdrop_p3")
+
+
+ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
+
+
+def loss_act_bwd(pre, residual, tgt_cache, idx_table, iter_ptr, coef, act, loss_log, out=None, grad_out=None, dpre=None, dpre_planes=None):
+    B, per_image = pre.shape[0], pre[0].numel()
+    L.check(L.lib().rdo_loss_act_bwd(_ptr(pre), _ptr(residual), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
+                                     pre.shape[-1], coef, int(act), _ptr(out), _ptr(grad_out), _ptr(dpre), _ptr(dpre_planes),
+                                     _ptr(loss_log), _stream()), "rdo_loss_act_bwd")
+
+
+def loss_gdn_bwd(x, norm, residual, tgt_cache, idx_table, iter_ptr, coef, inverse, loss_log, grad_out, t=None, t_planes=None, out=None):
+    B, per_image = x.shape[0], x[0].numel()
+    L.check(L.lib().rdo_loss_gdn_bwd(_ptr(x), _ptr(norm), _ptr(residual), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
+                                     x.shape[-1], coef, int(inverse), _ptr(out), _ptr(grad_out), _ptr(t), _ptr(t_planes), _ptr(loss_log),
+                                     _stream()), "rdo_loss_gdn_bwd")
+
+
+def gdn_bwd_dx_p3(g, x, norm, acc, inverse, dx=None, dx_planes=None):
+    L.check(L.lib().rdo_gdn_bwd_dx_p3(_ptr(g), _ptr(x), _ptr(norm), _ptr(acc), g.numel(), int(inverse), _ptr(dx), _ptr(dx_planes),
+                                      _stream()), "rdo_gdn_bwd_dx_p3")
+
+
+def pixel_shuffle_p3(x, out=None, out_planes=None):
+    """[B,H,W,4C] -> [B,2H,2W,C] (r = 2) as fp32 and / or planes."""
+    B, H, W, CC = x.shape
+    L.check(L.lib().rdo_pixel_shuffle_p3(_ptr(x), B, H, W, CC // 4, _ptr(out), _ptr(out_planes), _stream()), "rdo_pixel_shuffle_p3")

@@ -1,0 +1,172 @@
+"""P3 tensors (exact three-way bf16 splits, the operand format of the LDS-DMA conv kernels) and the fused unit-tail kernels:
+each new entry point against the chain of separate kernels it replaces (which the rest of the suite pins to fp64 / torch / the
+oracle).  The plane-input conv walks K in the same order as the fp32-input bf16x6 kernels and every bf16 product is exact, so the
+two agree to the last bit; the fused tails execute the same fp32 operations element by element."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+N = 192
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from hipops import ops as o
+    return o
+
+
+@pytest.fixture(scope="module")
+def L():
+    from hipops import _lib
+    return _lib
+
+
+def test_split_p3_is_exact(ops):
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.randn(4, 16, 16, 64, device="cuda", generator=g) * torch.logspace(-12, 6, 64, device="cuda")
+    x[0, 0, 0, :8] = torch.tensor([0.0, -0.0, 1.0, -1.0, 3e-20, 65504.0, 1e-30, -7.5], device="cuda")
+    pl = ops.split_p3(x)
+    assert pl.shape == (3,) + tuple(x.shape) and pl.dtype == torch.int16
+    assert torch.equal(ops.p3_to_float(pl), x)
+    # plane 0 is the RNE bf16 of x
+    assert torch.equal(pl[0], x.to(torch.bfloat16).view(torch.int16))
+
+
+CONV_SHAPES = [(128, N, N, 3, 1, 1), (64, N, 4 * N, 3, 1, 1), (64, N, N, 3, 1, 1), (128, N, N, 3, 2, 1), (128, N, N, 1, 1, 0),
+               (32, N, N, 3, 1, 1), (64, 32, N, 5, 1, 2), (128, N, 320, 5, 2, 2), (32, N, 4 * N, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("H,Cin,Cout,K,s,p", CONV_SHAPES)
+def test_conv_p3_equals_fp32_input_x6(ops, L, H, Cin, Cout, K, s, p):
+    g = torch.Generator(device="cuda").manual_seed(H + Cout + K)
+    x = torch.randn(4, H, H, Cin, device="cuda", generator=g) * 3
+    w = torch.randn(Cout, K, K, Cin, device="cuda", generator=g) / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    assert ops.conv_p3_supported(tuple(x.shape), tuple(w.shape), s, p)
+    wpl = ops.split_bf16x3(w)
+    xp = ops.split_p3(x)
+    ref = ops.conv2d_fwd(x, w, b, s, p, wplanes=wpl)
+    out = torch.empty_like(ref)
+    opl = ops.p3_empty(ref.shape, "cuda")
+    ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, s, p, out=out, out_planes=opl)
+    assert torch.equal(out, ref)
+    assert torch.equal(ops.p3_to_float(opl), ref)
+    # planes only (no fp32 output at all)
+    opl2 = ops.p3_empty(ref.shape, "cuda")
+    ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, s, p, out_planes=opl2)
+    assert torch.equal(opl2, opl)
+
+
+@pytest.mark.parametrize("H,Cout", [(128, N), (64, N)])
+def test_conv_p3_epilogues(ops, L, H, Cout):
+    g = torch.Generator(device="cuda").manual_seed(H)
+    x = torch.randn(4, H, H, N, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, N, device="cuda", generator=g) / 41.6
+    b = torch.randn(Cout, device="cuda", generator=g)
+    aux = torch.randn(4, H, H, Cout, device="cuda", generator=g)
+    res = torch.randn(4, H, H, Cout, device="cuda", generator=g)
+    wpl, xp = ops.split_bf16x3(w), ops.split_p3(x)
+    for epi, a, r, want_pre in ((L.EPI_LRELU, None, res, True), (L.EPI_LRELU_BWD, aux, None, False), (L.EPI_RELU, None, None, False),
+                                (L.EPI_RELU_BWD, aux, res, False), (L.EPI_NONE, None, res, False)):
+        pre_ref = torch.empty(4, H, H, Cout, device="cuda") if want_pre else None
+        ref = ops.conv2d_fwd(x, w, b, 1, 1, epilogue=epi, aux=a, residual=r, pre=pre_ref, wplanes=wpl)
+        out = torch.empty_like(ref)
+        pre = torch.empty_like(ref) if want_pre else None
+        opl = ops.p3_empty(ref.shape, "cuda")
+        ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, 1, 1, epilogue=epi, aux=a, residual=r, out=out, pre=pre, out_planes=opl)
+        assert torch.equal(out, ref), epi
+        assert torch.equal(ops.p3_to_float(opl), ref), epi
+        if want_pre:
+            assert torch.equal(pre, pre_ref)
+
+
+def test_gather_qdrop_p3(ops):
+    n, B, shape = 8, 4, (32, 32, N)
+    g = torch.Generator(device="cuda").manual_seed(2)
+    cq = torch.randn(n, *shape, device="cuda", generator=g)
+    cf = torch.randn(n, *shape, device="cuda", generator=g)
+    idx = torch.tensor([[3, 7, 1, 0], [2, 2, 5, 6]], dtype=torch.int32, device="cuda")
+    it = torch.ones(1, dtype=torch.int32, device="cuda")
+    ref = torch.empty(B, *shape, device="cuda")
+    ops.gather_qdrop(cq, cf, idx, it, B, 0.5, 77, ref, batch_offset=4)
+    out = torch.empty_like(ref)
+    pl = ops.p3_empty(ref.shape, "cuda")
+    ops.gather_qdrop_p3(cq, cf, idx, it, B, 0.5, 77, out, pl, batch_offset=4)
+    assert torch.equal(out, ref) and torch.equal(ops.p3_to_float(pl), ref)
+    pl2 = ops.p3_empty(ref.shape, "cuda")
+    ops.gather_qdrop_p3(cq, cf, idx, it, B, 0.5, 77, None, pl2, batch_offset=4)
+    assert torch.equal(pl2, pl)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_loss_act_bwd_equals_unfused_chain(ops, act, with_res):
+    g = torch.Generator(device="cuda").manual_seed(act * 2 + with_res)
+    n, B, shape = 6, 4, (16, 16, 48)
+    pre = torch.randn(B, *shape, device="cuda", generator=g)
+    res = torch.randn(B, *shape, device="cuda", generator=g) if with_res else None
+    tgt = torch.randn(n, *shape, device="cuda", generator=g)
+    idx = torch.tensor([[5, 0, 3, 3]], dtype=torch.int32, device="cuda")
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    # unfused: activation (+ residual), lp2 loss / gradient, activation backward
+    o = {0: lambda t: t.clone(), 1: ops.lrelu, 2: ops.relu}[act](pre)
+    if with_res:
+        o = ops.add(o, res)
+    gref = torch.empty_like(pre)
+    log_ref = torch.zeros(1, 32, device="cuda")
+    ops.lp2_loss_grad(o, tgt, idx, it, 2.0, gref, log_ref)
+    dref = {0: lambda a, b: a.clone(), 1: ops.lrelu_bwd, 2: ops.relu_bwd}[act](gref, pre)
+    out, gout, dpre = torch.empty_like(pre), torch.empty_like(pre), torch.empty_like(pre)
+    pl = ops.p3_empty(pre.shape, "cuda")
+    log = torch.zeros(1, 32, device="cuda")
+    ops.loss_act_bwd(pre, res, tgt, idx, it, 2.0, act, log, out=out, grad_out=gout, dpre=dpre, dpre_planes=pl)
+    assert torch.equal(out, o) and torch.equal(gout, gref) and torch.equal(dpre, dref)
+    assert torch.equal(ops.p3_to_float(pl), dref)
+    torch.testing.assert_close(log.sum(), log_ref.sum(), rtol=1e-5, atol=0)
+    # planes as the only gradient output
+    pl2 = ops.p3_empty(pre.shape, "cuda")
+    ops.loss_act_bwd(pre, res, tgt, idx, it, 2.0, act, torch.zeros(1, 32, device="cuda"), dpre_planes=pl2)
+    assert torch.equal(pl2, pl)
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_loss_gdn_bwd_equals_unfused_chain(ops, L, inverse):
+    g = torch.Generator(device="cuda").manual_seed(5 + inverse)
+    n, B, H, C = 6, 4, 16, 48
+    x = torch.randn(B, H, H, C, device="cuda", generator=g)
+    gam = (0.1 * torch.eye(C, device="cuda") + 0.002 * torch.rand(C, C, device="cuda", generator=g)).reshape(C, 1, 1, C).contiguous()
+    beta = 0.5 + torch.rand(C, device="cuda", generator=g)
+    res = torch.randn(B, H, H, C, device="cuda", generator=g)
+    tgt = torch.randn(n, H, H, C, device="cuda", generator=g)
+    idx = torch.tensor([[1, 4, 2, 0]], dtype=torch.int32, device="cuda")
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    norm = torch.empty_like(x)
+    o = ops.conv2d_fwd(x, gam, beta, 1, 0, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN, aux=x, residual=res, square_input=True, pre=norm)
+    gref = torch.empty_like(x)
+    log_ref = torch.zeros(1, 32, device="cuda")
+    ops.lp2_loss_grad(o, tgt, idx, it, 2.0, gref, log_ref)
+    tref = ops.gdn_bwd_t(gref, x, norm, inverse)
+    out, gout, t = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
+    tpl = ops.p3_empty(x.shape, "cuda")
+    log = torch.zeros(1, 32, device="cuda")
+    ops.loss_gdn_bwd(x, norm, res, tgt, idx, it, 2.0, inverse, log, gout, t=t, t_planes=tpl, out=out)
+    assert torch.equal(out, o) and torch.equal(gout, gref) and torch.equal(t, tref)
+    assert torch.equal(ops.p3_to_float(tpl), tref)
+    torch.testing.assert_close(log.sum(), log_ref.sum(), rtol=1e-5, atol=0)
+    acc = torch.randn(x.shape, device="cuda", generator=g)
+    dref = ops.gdn_bwd_dx(gref, x, norm, acc, inverse)
+    dx = torch.empty_like(x)
+    dpl = ops.p3_empty(x.shape, "cuda")
+    ops.gdn_bwd_dx_p3(gref, x, norm, acc, inverse, dx=dx, dx_planes=dpl)
+    assert torch.equal(dx, dref) and torch.equal(ops.p3_to_float(dpl), dref)
+
+
+def test_pixel_shuffle_p3(ops):
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.randn(2, 8, 12, 4 * 48, device="cuda", generator=g)
+    ref = ops.pixel_shuffle(x, 2)
+    out = torch.empty_like(ref)
+    pl = ops.p3_empty(ref.shape, "cuda")
+    ops.pixel_shuffle_p3(x, out=out, out_planes=pl)
+    assert torch.equal(out, ref) and torch.equal(ops.p3_to_float(pl), ref)
+    assert torch.equal(ref, torch.nn.functional.pixel_shuffle(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))

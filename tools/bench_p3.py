@@ -1,0 +1,43 @@
+#!/usr/bin/env python3
+"""Event timing of the plane-input conv (rdo_conv2d_fwd_p3) against the fp32-input bf16x6 kernels on the Cheng2020 N=192 shapes.
+usage: python tools/bench_p3.py"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "rdo-ptq_amd"))
+from hipops import ops  # noqa: E402
+
+SHAPES = [(4, 128, 192, 192, 3, 1, 1), (4, 64, 192, 768, 3, 1, 1), (4, 64, 192, 192, 3, 1, 1), (4, 128, 192, 192, 3, 2, 1),
+          (4, 32, 192, 192, 3, 1, 1), (4, 128, 192, 192, 1, 1, 0), (4, 32, 192, 768, 3, 1, 1)]
+
+
+def timeit(fn, n=30):
+    for _ in range(5):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+for (B, H, Cin, Cout, K, s, p) in SHAPES:
+    torch.manual_seed(1)
+    x = torch.randn(B, H, H, Cin, device="cuda")
+    w = torch.randn(Cout, K, K, Cin, device="cuda") / (Cin * K * K) ** 0.5
+    b = torch.randn(Cout, device="cuda")
+    wpl, xp = ops.split_bf16x3(w), ops.split_p3(x)
+    out = ops.conv2d_fwd(x, w, b, s, p, wplanes=wpl)
+    opl = ops.p3_empty(out.shape, "cuda")
+    gf = 2.0 * out.numel() * Cin * K * K / 1e9
+    t_old = timeit(lambda: ops.conv2d_fwd(x, w, b, s, p, out=out, wplanes=wpl))
+    t_p3 = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, s, p, out=out))
+    t_p3b = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, s, p, out=out, out_planes=opl))
+    t_p3p = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, s, p, out_planes=opl))
+    print(f"B={B} H={H} {Cin}->{Cout} k{K} s{s}: fp32-in x6 {t_old:7.1f} us ({gf / t_old * 1e-3:6.1f} TF) | p3 out {t_p3:7.1f} us ({gf / t_p3 * 1e-3:6.1f} TF)"
+          f" | out+planes {t_p3b:7.1f} | planes only {t_p3p:7.1f}")
