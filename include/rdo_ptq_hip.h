@@ -57,6 +57,9 @@ const char* rdo_last_error(void);
  *   "wgrad_x6_w8"  1 (default): eight-wave bf16x6 weight-gradient kernel, 0: the four-wave one
  *   "conv_x6"      1 (default): large convolutions on the split-bf16 MFMA path, 0: everything on the fp32 MFMA
  *   "fwd_x6_ver"   forward bf16x6 kernel generation (default: newest)
+ *   "xcd"          1 (default): XCD-aware tile numbering in the bf16x6 kernels
+ *   "x6p_ablate"   diagnostic bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
+ *                  8 no fragment reads
  * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */
 int rdo_set_tuning(const char* key, int32_t value);
 int rdo_get_tuning(const char* key);
@@ -242,15 +245,18 @@ int rdo_sq_diff_sum(const float* a, const float* b, int64_t n, float scale, int3
                     void* stream);                                                                    /* MSE numerator */
 
 /* ---- "P3" tensors and fused unit tails (round 2) ----------------------------------------------------------------------------
- * A P3 tensor is an fp32 NHWC activation stored as its EXACT three-way bf16 split, planes[p][n] (p = 0..2, n = B*H*W*C elements,
- * x = p0 + p1 + p2 with p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)).  The split-bf16 GEMM kernels read it by LDS-DMA,
- * so the conversion work is done once per element by the PRODUCER instead of once per use inside the K loops.  Producers:
- * rdo_conv2d_fwd_p3 (epilogue), rdo_gather_qdrop_p3, rdo_loss_act_bwd, rdo_loss_gdn_bwd, rdo_gdn_bwd_dx_p3, rdo_pixel_shuffle_p3,
- * rdo_split_p3 (from an fp32 tensor). */
-int rdo_split_p3(const float* x, int64_t n /* multiple of 8 */, void* planes /* 3*n bf16 */, void* stream);
-/* 1: rdo_conv2d_fwd_p3 accepts this shape (a large problem of rdo_conv2d_fwd_uses_bf16x6 with Cin % 16 == 0, Cout % 8 == 0, no
+ * A P3 tensor is an fp32 NHWC activation [M pixels][C channels] (C % 16 == 0) stored as its EXACT three-way bf16 split
+ * x = p0 + p1 + p2 (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)), in "slice-major" planes [3][C/16][M][16]:
+ *     element (m, c) of plane p  at   p * M * C + ((c / 16) * M + m) * 16 + c % 16
+ * The split-bf16 GEMM kernels read it by LDS-DMA -- a K stage is the 16 channels of one slice for a run of pixels, i.e. contiguous
+ * 32-byte records -- so the conversion work is done once per element by the PRODUCER instead of once per use inside the K loops.
+ * Producers: rdo_conv2d_fwd_p3 (epilogue), rdo_gather_qdrop_p3, rdo_loss_act_bwd, rdo_loss_gdn_bwd, rdo_gdn_bwd_dx_p3,
+ * rdo_pixel_shuffle_p3, rdo_split_p3 (from an fp32 tensor). */
+int rdo_split_p3(const float* x, int64_t npix, int32_t C, void* planes /* 3*npix*C bf16 */, void* stream);
+/* 1: rdo_conv2d_fwd_p3 accepts this shape (a large problem of rdo_conv2d_fwd_uses_bf16x6 with Cin % 16 == 0, Cout % 16 == 0, no
  * square_input) */
 int rdo_conv2d_fwd_p3_supported(const rdo_conv_desc* d);
+int64_t rdo_conv2d_fwd_p3_workspace(const rdo_conv_desc* d);   /* floats of split-K scratch rdo_conv2d_fwd_p3 wants (0: none) */
 /* rdo_conv2d_fwd (same epilogues, same results to fp32 accumulation order) with the activation given as P3 planes and the weight as
  * fragment-ordered planes (rdo_split_bf16x3_conv / rdo_adaround_step).  Any of out / pre / out_planes may be NULL (at least one is
  * required); out_planes receives the P3 form of `out`. */
@@ -259,7 +265,8 @@ int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* 
                       void* stream);
 /* rdo_gather_qdrop writing the mini-batch as P3 planes (and as fp32 when `out` != NULL) */
 int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
-                        int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out, void* out_planes, void* stream);
+                        int32_t batch_offset, int64_t per_image, int32_t C, float prob, uint32_t seed, float* out, void* out_planes,
+                        void* stream);
 /* Tail of a unit whose last op is a conv (+ activation) (+ residual):   out = act(pre) + residual ; d = out - tgt[idx]
  *   loss_out[*iter][slot] += coef * sum d^2 / npix ; grad_out = coef * 2 d / npix ; dpre = grad_out * act'(pre)
  * i.e. the activation epilogue of the conv, rdo_lp2_loss_grad and rdo_lrelu_bwd / rdo_relu_bwd in one pass (layer_opt.py:133,150,
@@ -272,8 +279,8 @@ int rdo_loss_act_bwd(const float* pre, const float* residual, const float* tgt_c
 int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, const float* tgt_cache, const int32_t* idx_table,
                      const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef, int32_t inverse, float* out,
                      float* grad_out, float* t, void* t_planes, float* loss_out, void* stream);
-int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t inverse, float* dx,
-                      void* dx_planes, void* stream);                       /* rdo_gdn_bwd_dx with fp32 and / or P3 output */
+int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t C, int32_t inverse,
+                      float* dx, void* dx_planes, void* stream);            /* rdo_gdn_bwd_dx with fp32 and / or P3 output */
 /* F.pixel_shuffle(x, 2) on NHWC: [B,H,W,4C] -> [B,2H,2W,C] as fp32 and / or P3 planes */
 int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream);
 

@@ -1,17 +1,25 @@
 // Forward / dgrad conv of the LARGE problems on "P3" activation tensors: the fp32 activation is already stored as its exact
-// three-way bf16 split (x = p0 + p1 + p2, planes [3][pixels][C], written by the producing kernel), so BOTH operands of the bf16x6
-// GEMM (see conv_fwd_x6.hip) arrive in LDS by LDS-DMA and the K loop contains no conversion arithmetic at all.  In the fp32-input
-// kernels every activation quad was split in the loader -- 44 vector instructions, once per (tap x N tile) use, in front of the
-// MFMAs of an in-order wave; here the split is done once per element by the producer's epilogue.
+// three-way bf16 split (x = p0 + p1 + p2), written by the producing kernel, so BOTH operands of the bf16x6 GEMM (see
+// conv_fwd_x6.hip) arrive in LDS by LDS-DMA and the K loop contains no conversion arithmetic at all.  In the fp32-input kernels
+// every activation quad was split in the loader -- 44 vector instructions, once per (tap x N tile) use, in front of the MFMAs of an
+// in-order wave; here the split is done once per element by the producer's epilogue.
 //
-// Same tile as conv_fwd_x6v5: 128 x 192 per 256-thread workgroup (wave tile 64 x 96 = 2 x 3 tiles of v_mfma_f32_32x32x16_bf16),
-// K stage 16 channels of one tap, channel-slice-outer / taps-inner stage order, fragment reads pipelined one stage ahead, two
-// workgroups per CU, XCD-aware tile numbering, optional split over K.  New:
-//   * A tile by LDS-DMA: wave w fetches rows 32w..32w+31 of each plane (one 1-KiB piece per plane and stage), chunk swizzle on the
-//     per-lane SOURCE address, padding / ragged rows read a 16-byte zero page.
-//   * Epilogue through LDS: the accumulators of 64 tile rows are staged as fp32 [64][192], then every thread finishes 8
-//     consecutive channels of one pixel: 16-byte loads of bias / aux / residual, 16-byte stores of out / pre, and the three bf16
-//     planes of the result (what the next conv, or the weight gradient, consumes) -- one 16-byte store per plane.
+// P3 layout ("slice-major planes", rdo_ptq_hip.h): element (pixel m, channel c) of a tensor with M pixels and C channels lives at
+//     plane * M * C + ((c >> 4) * M + m) * 16 + (c & 15)            i.e. planes [3][C/16][pixel][16]
+// One K stage of the kernel reads the 16 channels of ONE slice for a run of pixels, and consecutive pixels of a slice are consecutive
+// 32-byte records: every 1-KiB LDS-DMA piece is a contiguous KiB of memory.  (With pixel-major planes [pixel][C] a stage touched 32
+// bytes of every 128-byte line, 4x the L2 -> CU traffic.)
+//
+// Kernel: 256 x 192 tile on eight waves (4 x 2, wave tile 64 x 96 = 2 x 3 tiles of v_mfma_f32_32x32x16_bf16), ONE workgroup per CU,
+// K stage = 16 channels of one tap (channel slice outer, taps inner), THREE LDS stage buffers: the DMA of stage t+2 is issued at the
+// top of stage t and has two full stages to land (counted vmcnt, raw s_barrier).  Why: ablating a two-buffer 128 x 192 version of
+// this kernel (tuning key "x6p_ablate") on the 4 x 128^2, 192 -> 192, 3x3 conv gave 230 us complete, 132 us with MFMAs + fragment
+// reads only and 150 us with the DMA stream only -- one L2 round trip (~1.4 us) per stage, fully exposed because every stage ended
+// in vmcnt(0) + barrier.  The bigger tile also halves the weight-tile traffic per MFMA.
+//
+// Epilogue through LDS: the accumulators of 128 tile rows are staged as fp32, then every thread finishes the 16 channels of one
+// slice of one pixel (consecutive lanes on consecutive pixels = the P3 record order): bias / aux / residual, fp32 out / pre, and the
+// three bf16 planes of the result, two 16-byte stores per plane.
 #include <utility>
 
 #include "rdo_common.h"
@@ -29,7 +37,7 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __attribute__((aligned(64))) unsigned g_zero_page[16];      // zero-initialised: source of masked DMA lanes
 
 struct X6PArgs {
-    const u16* xp;        // activation planes [3][B*H*W][Cin] bf16
+    const u16* xp;        // activation planes (P3 layout of [B*H*W][Cin])
     long xplane;          // elements per activation plane
     const u16* wp;        // weight planes, fragment order [3][Cin/16][KH][KW][Cout][16]
     long wplane;
@@ -38,7 +46,7 @@ struct X6PArgs {
     const float* residual;
     float* out;           // nullable
     float* pre;           // nullable
-    u16* outp;            // nullable: result planes [3][M][Cout]
+    u16* outp;            // nullable: result planes (P3 layout of [M][Cout])
     long oplane;
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int M;
@@ -46,6 +54,7 @@ struct X6PArgs {
     int xcd_mode;
     float* partial;       // split-K: raw accumulators [ksplit][M][Cout]
     int ksplit;
+    int ablate;           // diagnostic bit mask (tuning key "x6p_ablate"): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads
 };
 
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) {
@@ -55,7 +64,7 @@ __device__ __forceinline__ float lo_f(unsigned pk) { return __builtin_bit_cast(f
 __device__ __forceinline__ float hi_f(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
 
 // exact three-way split of 8 consecutive channels -> one 16-byte run per plane
-__device__ __forceinline__ void split3_x8(const float (&v)[8], u32x4& p0, u32x4& p1, u32x4& p2) {
+__device__ __forceinline__ void split3_x8(const float* v, u32x4& p0, u32x4& p1, u32x4& p2) {
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float a = v[2 * k], b = v[2 * k + 1];
@@ -97,56 +106,71 @@ __device__ __forceinline__ float activate(const X6PArgs& a, float v, float aux) 
     }
 }
 
-// finish 8 consecutive channels [n, n+8) of output pixel m from their raw sums `v` (bias not yet added)
-__device__ __forceinline__ void finish8(const X6PArgs& a, int m, int n, float (&v)[8]) {
+// finish the 16 channels [n, n+16) (one slice, n % 16 == 0) of output pixel m from their raw sums `v` (bias not yet added)
+__device__ __forceinline__ void finish16(const X6PArgs& a, int m, int n, float (&v)[16]) {
     const long o = (long)m * a.Cout + n;
     if (a.bias) {
-        const f32x4 b0 = *reinterpret_cast<const f32x4*>(a.bias + n), b1 = *reinterpret_cast<const f32x4*>(a.bias + n + 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + n + 4 * c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[4 * c + k] += b4[k];
+        }
     }
     if (a.pre) {
-        *reinterpret_cast<f32x4*>(a.pre + o) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(a.pre + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.pre + o + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
     }
     if (a.epilogue != RDO_EPI_NONE) {
-        f32x4 x0 = {0.f, 0.f, 0.f, 0.f}, x1 = x0;
-        if (a.aux) { x0 = *reinterpret_cast<const f32x4*>(a.aux + o); x1 = *reinterpret_cast<const f32x4*>(a.aux + o + 4); }
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] = activate(a, v[k], x0[k]); v[4 + k] = activate(a, v[4 + k], x1[k]); }
+        for (int c = 0; c < 4; ++c) {
+            f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
+            if (a.aux) x4 = *reinterpret_cast<const f32x4*>(a.aux + o + 4 * c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[4 * c + k] = activate(a, v[4 * c + k], x4[k]);
+        }
     }
     if (a.add_residual) {
-        const f32x4 r0 = *reinterpret_cast<const f32x4*>(a.residual + o), r1 = *reinterpret_cast<const f32x4*>(a.residual + o + 4);
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { v[k] += r0[k]; v[4 + k] += r1[k]; }
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 r4 = *reinterpret_cast<const f32x4*>(a.residual + o + 4 * c);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[4 * c + k] += r4[k];
+        }
     }
     if (a.out) {
-        *reinterpret_cast<f32x4*>(a.out + o) = f32x4{v[0], v[1], v[2], v[3]};
-        *reinterpret_cast<f32x4*>(a.out + o + 4) = f32x4{v[4], v[5], v[6], v[7]};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.out + o + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
     }
     if (a.outp) {
-        u32x4 p0, p1, p2;
-        split3_x8(v, p0, p1, p2);
-        *reinterpret_cast<u32x4*>(a.outp + o) = p0;
-        *reinterpret_cast<u32x4*>(a.outp + a.oplane + o) = p1;
-        *reinterpret_cast<u32x4*>(a.outp + 2 * a.oplane + o) = p2;
+        u16* dst = a.outp + ((long)(n >> 4) * a.M + m) * 16;        // P3 record of (slice n / 16, pixel m): 32 bytes per plane
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            u32x4 p0, p1, p2;
+            split3_x8(v + 8 * h, p0, p1, p2);
+            *reinterpret_cast<u32x4*>(dst + 8 * h) = p0;
+            *reinterpret_cast<u32x4*>(dst + a.oplane + 8 * h) = p1;
+            *reinterpret_cast<u32x4*>(dst + 2 * a.oplane + 8 * h) = p2;
+        }
     }
 }
 
-__global__ __launch_bounds__(256, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
-    constexpr int BM = 128, BN = 192, KS = 16;
+__global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
+    constexpr int BM = 256, BN = 192, KS = 16;
     constexpr int TM = 2, TN = 3;
     constexpr int APLANE = BM * 32, BPLANE = BN * 32;
-    constexpr int STAGE = 3 * (APLANE + BPLANE);           // 30 KiB
-    constexpr int NB = 5;                                  // weight DMA pieces per wave (18 over 4 waves, two repeated)
+    constexpr int STAGE = 3 * (APLANE + BPLANE);           // 42 KiB
+    constexpr int RING = 3;
+    constexpr int SROW = 196;                              // staging row stride in floats: 16-byte aligned, conflict-free b128 reads down a column
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][STAGE]; reused by the epilogue as fp32 [64][192]
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [RING][STAGE]; reused by the epilogue as fp32 [128][SROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
     const int li = lane & 31, lh = lane >> 5;
     const TileId tile = xcd_tile_id(a.xcd_mode);
     const int m0 = tile.m * BM, n0 = tile.n * BN;
+    const long Min = (long)a.B * a.H * a.W;
 
     // ---- A loader: this lane fetches 16-byte chunk (lane & 1) of tile row 32 * wave + (lane >> 1), for each of the three planes
     const int arow = wave * 32 + (lane >> 1);
@@ -165,11 +189,12 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
     }
     const u16* const zero = reinterpret_cast<const u16*>(g_zero_page);
 
-    // ---- B loader (as conv_fwd_x6v5): piece k = wave + 4 j of the 18 KiB [plane][row][chunk] image
-    int dma_src[NB];
+    // ---- B loader: pieces wave, wave + 8 and wave + 16 of the 18 KiB [plane][row][chunk] image (waves 2..7 repeat their second piece)
+    int dma_src[3], dma_k[3];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
+    for (int j = 0; j < 3; ++j) {
+        const int k = wave + 8 * j < 18 ? wave + 8 * j : wave + 8;
+        dma_k[j] = k;
         const int e = k * 64 + lane;
         const int pl = e / (BN * 2);
         const int r = e - pl * (BN * 2);
@@ -198,29 +223,33 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
     int ccs = sbeg / taps;
     int ctap = sbeg - ccs * taps;
     int ckh = ctap / a.KW, ckw = ctap - ckh * a.KW;
-    int cstage = 0;                                          // stage index (relative to sbeg) the cursor points at
-    auto dma_stage_a = [&](int buf) {                        // A image of the cursor's stage -> LDS buffer `buf`
-        const int hi = hi0 + ckh, wi = wi0 + ckw;
-        const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        const long off = ((long)(apix0 + hi * a.W + wi)) * a.Cin + ccs * KS + achunk * 8;
-        const u16* src = ok ? a.xp + off : zero;
-        const long pstep = ok ? a.xplane : 0;
-        char* dst = smem + buf * STAGE + wave * 1024;
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(src + pstep), (lds_void*)(dst + APLANE), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((glb_void*)(src + 2 * pstep), (lds_void*)(dst + 2 * APLANE), 16, 0, 0);
-    };
-    auto dma_b = [&](int j, int buf) {                       // weight piece j of the cursor's stage
-        const int k = wave + 4 * j < 18 ? wave + 4 * j : wave + 4 * j - 2;
-        char* dst = smem + buf * STAGE + 3 * APLANE + k * 1024;
-        __builtin_amdgcn_global_load_lds((glb_void*)(a.wp + dma_src[j] + (long)(sbeg + cstage) * a.Cout * 16), (lds_void*)dst, 16, 0, 0);
-    };
-    auto cursor_next = [&]() {                               // advance to the next stage, clamped at the last one
-        if (cstage + 1 >= nsteps) return;
-        ++cstage;
-        ++ckw;
-        if (ckw == a.KW) { ckw = 0; ++ckh; }
-        if (ckh == a.KH) { ckh = 0; ++ccs; }
+    int cstage = 0;
+    // six DMA instructions per wave and stage (three activation planes, three weight pieces): the vmcnt bookkeeping below counts on it
+    auto dma_stage = [&](int buf) {
+        char* const base = smem + buf * STAGE;
+        if (!(a.ablate & 1)) {
+            const int hi = hi0 + ckh, wi = wi0 + ckw;
+            const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            const long off = ((long)ccs * Min + (apix0 + hi * a.W + wi)) * 16 + achunk * 8;
+            const u16* src = ok ? a.xp + off : zero;
+            const long pstep = ok ? a.xplane : 0;
+            char* dst = base + wave * 1024;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + pstep), (lds_void*)(dst + APLANE), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(src + 2 * pstep), (lds_void*)(dst + 2 * APLANE), 16, 0, 0);
+        }
+        if (!(a.ablate & 2)) {
+            const u16* wsrc = a.wp + (long)(sbeg + cstage) * a.Cout * 16;
+#pragma unroll
+            for (int j = 0; j < 3; ++j)
+                __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_src[j]), (lds_void*)(base + 3 * APLANE + dma_k[j] * 1024), 16, 0, 0);
+        }
+        if (cstage + 1 < nsteps) {                           // advance, clamped at the last stage (tail stages re-fetch it: harmless)
+            ++cstage;
+            ++ckw;
+            if (ckw == a.KW) { ckw = 0; ++ckh; }
+            if (ckh == a.KH) { ckh = 0; ++ccs; }
+        }
     };
 
     int fa_off[3][TM], fb_off[3][TN];
@@ -231,166 +260,177 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb_off[p][j] = 3 * APLANE + p * BPLANE + chunk_off16(wn0 + j * 32 + li, lh);
     }
-    bf16x8 fa0[2][TM], fb0[2][TN], fa12[2][TM], fb12[2][TN];
-    auto read_a = [&](bf16x8 (&dst)[TM], int p, int buf) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i) dst[i] = *reinterpret_cast<const bf16x8*>(smem + buf * STAGE + fa_off[p][i]);
-    };
-    auto read_b = [&](bf16x8 (&dst)[TN], int p, int buf) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) dst[j] = *reinterpret_cast<const bf16x8*>(smem + buf * STAGE + fb_off[p][j]);
-    };
-    auto mma = [&](const bf16x8 (&fa)[TM], const bf16x8 (&fb)[TN]) {
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
-    };
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};             // products (A plane, B plane), small terms first
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
 
-    // prologue: images of stages 0 and 1 in LDS, fragments of stage 0 in registers; the cursor then points at stage 2
-    dma_stage_a(0);
+    dma_stage(0);
+    dma_stage(1);
+    int buf = 0;
+    for (int t = 0; t < nsteps; ++t) {
+        // stage t has landed for this wave once at most the six youngest DMAs (stage t+1) are outstanding; the barrier extends that to
+        // every wave and also tells that nobody still reads buffer (t+2) % 3 = (t-1) % 3
+        if (a.ablate & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        dma_stage(buf >= 1 ? buf - 1 : RING - 1);            // (t + 2) % 3
+        const char* st = smem + buf * STAGE;
+        bf16x8 fa[3][TM], fb[3][TN];
 #pragma unroll
-    for (int j = 0; j < NB; ++j) dma_b(j, 0);
-    cursor_next();
-    dma_stage_a(1);
+        for (int p = 0; p < 3; ++p) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) dma_b(j, 1);
-    cursor_next();
-    __syncthreads();
-    read_a(fa0[0], 0, 0); read_b(fb0[0], 0, 0);
-    read_a(fa12[0], 1, 0); read_b(fb12[0], 1, 0);
-    read_a(fa12[1], 2, 0); read_b(fb12[1], 2, 0);
-    __syncthreads();      // every wave holds stage 0's fragments before buffer 0 is overwritten with stage 2
-
-    // stage t: MFMAs of stage t from registers | fragments of stage t+1 from buffer (t+1)&1 | DMA of stage t+2 into buffer t&1
-    auto stage = [&](auto parc) {
-        constexpr int PAR = decltype(parc)::value, NXT = PAR ^ 1;
-        read_a(fa0[NXT], 0, NXT); read_b(fb0[NXT], 0, NXT);
-        // slot 0: (A2, B0)
-        mma(fa12[1], fb0[PAR]);
-        read_a(fa12[1], 2, NXT);
-        dma_stage_a(PAR);
-        dma_b(0, PAR);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 1: (A0, B2)
-        mma(fa0[PAR], fb12[1]);
-        read_b(fb12[1], 2, NXT);
-        dma_b(1, PAR);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 2: (A1, B0)
-        mma(fa12[0], fb0[PAR]);
-        dma_b(2, PAR);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 3: (A1, B1)
-        mma(fa12[0], fb12[0]);
-        read_a(fa12[0], 1, NXT);
-        dma_b(3, PAR);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 4: (A0, B1)
-        mma(fa0[PAR], fb12[0]);
-        read_b(fb12[0], 1, NXT);
-        dma_b(4, PAR);
-        __builtin_amdgcn_sched_barrier(0);
-        // slot 5: (A0, B0)
-        mma(fa0[PAR], fb0[PAR]);
-        cursor_next();
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();
-    };
-    int t = 0;
-    for (; t + 1 < nsteps; t += 2) {
-        stage(std::integral_constant<int, 0>{});
-        stage(std::integral_constant<int, 1>{});
+            for (int i = 0; i < TM; ++i) fa[p][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[p][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+        if (!(a.ablate & 8)) {
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(st + fa_off[p][i]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(st + fb_off[p][j]);
+            }
+        }
+        if (!(a.ablate & 4)) {
+#pragma unroll
+            for (int s = 0; s < 6; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[s]][i], fb[PB[s]][j], acc[i][j], 0, 0, 0);
+        }
+        buf = buf + 1 == RING ? 0 : buf + 1;
     }
-    if (t < nsteps) stage(std::integral_constant<int, 0>{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail DMAs still target LDS: drain before the epilogue reuses it
+    __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue through LDS: two passes of 64 tile rows (pass p: MFMA row tile p of every wave)
-    float* const stg = reinterpret_cast<float*>(smem);       // [64][192] fp32 = 48 KiB
+    // ---- epilogue through LDS: two passes of 128 tile rows (pass i: MFMA row tile i of every wave), then every thread finishes the 16
+    // channels of one slice for one pixel, consecutive lanes on consecutive pixels (the P3 record order)
+    float* const stg = reinterpret_cast<float*>(smem);       // [128][SROW] fp32 = 98 KiB
     const long part_base = (long)tile.z * a.M * a.Cout;
 #pragma unroll
     for (int pass = 0; pass < TM; ++pass) {
-        if (pass) __syncthreads();                           // the previous pass has been read out
+        if (pass) __syncthreads();
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                stg[((wave >> 1) * 32 + rr) * BN + wn0 + j * 32 + li] = acc[pass][j][r];
+                stg[((wave >> 1) * 32 + rr) * SROW + wn0 + j * 32 + li] = acc[pass][j][r];
             }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < 6; ++k) {
-            const int q = tid + 256 * k;                     // 64 rows x 24 chunks of 8 channels
-            const int row = q / 24, ch = q - row * 24;
+        for (int k = 0; k < 3; ++k) {
+            const int q = tid + 512 * k;                     // 128 rows x 12 slices of 16 channels
+            const int row = q & 127, sl = q >> 7;
             const int m = m0 + (row >> 5) * 64 + pass * 32 + (row & 31);
-            const int n = n0 + ch * 8;
+            const int n = n0 + sl * 16;
             if (m >= a.M || n >= a.Cout) continue;
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(stg + row * BN + ch * 8);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(stg + row * BN + ch * 8 + 4);
+            float v[16];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(stg + row * SROW + sl * 16 + 4 * c);
+                v[4 * c] = t4[0]; v[4 * c + 1] = t4[1]; v[4 * c + 2] = t4[2]; v[4 * c + 3] = t4[3];
+            }
             if (a.partial) {
                 float* dst = a.partial + part_base + (long)m * a.Cout + n;
-                *reinterpret_cast<f32x4*>(dst) = v0;
-                *reinterpret_cast<f32x4*>(dst + 4) = v1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(dst + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
             } else {
-                float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
-                finish8(a, m, n, v);
+                finish16(a, m, n, v);
             }
         }
     }
 }
 
-// split-K second pass: sum the partial accumulators, then the same per-8-channel finish (planes included)
+// split-K second pass: sum the partial accumulators, then the same per-slice finish (planes included); lanes along pixels
 __global__ __launch_bounds__(256) void x6p_splitk_epilogue_kernel(X6PArgs a) {
-    const int cpr = a.Cout / 8;                              // chunks per row
-    const long total = (long)a.M * cpr;
+    const int spr = a.Cout / 16;                             // slices per row
+    const long total = (long)a.M * spr;
     const long slab = (long)a.M * a.Cout;
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
-        const int m = (int)(q / cpr), n = (int)(q - (long)m * cpr) * 8;
+        const int sl = (int)(q / a.M), m = (int)(q - (long)sl * a.M), n = sl * 16;
         const float* src = a.partial + (long)m * a.Cout + n;
-        f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+        float v[16];
+#pragma unroll
+        for (int c = 0; c < 16; ++c) v[c] = 0.f;
         for (int z = 0; z < a.ksplit; ++z) {
-            s0 += *reinterpret_cast<const f32x4*>(src + z * slab);
-            s1 += *reinterpret_cast<const f32x4*>(src + z * slab + 4);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 t4 = *reinterpret_cast<const f32x4*>(src + z * slab + 4 * c);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[4 * c + k] += t4[k];
+            }
         }
-        float v[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
-        finish8(a, m, n, v);
+        finish16(a, m, n, v);
     }
 }
 
-// fp32 NHWC tensor -> its three bf16 planes (producer of last resort for tensors that no fused kernel writes as planes)
-__global__ __launch_bounds__(256) void split_p3_kernel(const float* x, long n8, u16* planes, long pstride) {
-    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n8; q += (long)gridDim.x * blockDim.x) {
-        const f32x4 a0 = *reinterpret_cast<const f32x4*>(x + q * 8), a1 = *reinterpret_cast<const f32x4*>(x + q * 8 + 4);
+// fp32 NHWC tensor [M][C] -> P3 planes (producer of last resort for tensors that no fused kernel writes as planes)
+__global__ __launch_bounds__(256) void split_p3_kernel(const float* x, long M, int C, u16* planes) {
+    const int spr = C / 16;
+    const long total = M * spr * 2;                          // half slices of 8 channels
+    const long pstride = M * C;
+    for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < total; q += (long)gridDim.x * blockDim.x) {
+        const int h = (int)(q & 1);
+        const long r = q >> 1;
+        const int sl = (int)(r % spr);
+        const long m = r / spr;
+        const float* src = x + m * C + sl * 16 + 8 * h;
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
         const float v[8] = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
         u32x4 p0, p1, p2;
         split3_x8(v, p0, p1, p2);
-        *reinterpret_cast<u32x4*>(planes + q * 8) = p0;
-        *reinterpret_cast<u32x4*>(planes + pstride + q * 8) = p1;
-        *reinterpret_cast<u32x4*>(planes + 2 * pstride + q * 8) = p2;
+        u16* dst = planes + ((long)sl * M + m) * 16 + 8 * h;
+        *reinterpret_cast<u32x4*>(dst) = p0;
+        *reinterpret_cast<u32x4*>(dst + pstride) = p1;
+        *reinterpret_cast<u32x4*>(dst + 2 * pstride) = p2;
     }
 }
 
 }  // namespace
 
-extern "C" int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d);
 extern "C" int rdo_conv2d_fwd_uses_bf16x6(const rdo_conv_desc* d);
 
-extern "C" int rdo_split_p3(const float* x, int64_t n, void* planes, void* stream) {
-    RDO_REQUIRE(x && planes && n > 0 && n % 8 == 0, "rdo_split_p3: n (%ld) must be a positive multiple of 8", (long)n);
+// K split of the plane kernel: enough 256 x 192 x (K / ks) workgroups for one per CU, at least 12 K stages per split, at most 9 splits
+static int p3_ksplit(const rdo_conv_desc* d) {
+    const long M = (long)d->B * d->Ho * d->Wo;
+    const long tiles = rdo::ceil_div(M, 256) * rdo::ceil_div(d->Cout, 192);
+    const long stages = (long)d->KH * d->KW * (d->Cin / 16);
+    int best = 0;
+    for (int ks = 1; ks <= 9; ++ks)
+        if (tiles * ks >= 192 && stages / ks >= 12) {
+            best = ks;
+            if (tiles * ks >= 256) break;
+        }
+    return best;
+}
+
+extern "C" int rdo_split_p3(const float* x, int64_t npix, int32_t C, void* planes, void* stream) {
+    RDO_REQUIRE(x && planes && npix > 0 && C > 0 && C % 16 == 0, "rdo_split_p3: C (%d) must be a positive multiple of 16", C);
     u16* p = reinterpret_cast<u16*>(planes);
+    const double n = (double)npix * C;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            long g = rdo::ceil_div(n / 8, 256);
-            hipLaunchKernelGGL(split_p3_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, x, (long)(n / 8), p, (long)n);
+            long g = rdo::ceil_div(npix * (C / 8), 256);
+            hipLaunchKernelGGL(split_p3_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(256), 0, s, x, (long)npix, C, p);
             return rdo::check_launch("split_p3");
         },
         stream, "split_p3", 0.0, 10.0 * n);
 }
 
 extern "C" int rdo_conv2d_fwd_p3_supported(const rdo_conv_desc* d) {
-    if (!d || d->square_input || d->Cin % 16 != 0 || d->Cout % 8 != 0) return 0;
+    if (!d || d->square_input || d->Cin % 16 != 0 || d->Cout % 16 != 0) return 0;
     if ((double)d->B * d->H * d->W * d->Cin * 3.0 >= 2147483648.0 || (double)d->Cout * d->KH * d->KW * d->Cin * 3.0 >= 2147483648.0) return 0;
-    return rdo_conv2d_fwd_uses_bf16x6(d);
+    if (!rdo::tuning(rdo::T_CONV_X6)) return 0;
+    return p3_ksplit(d) >= 1;
+}
+
+extern "C" int64_t rdo_conv2d_fwd_p3_workspace(const rdo_conv_desc* d) {
+    if (!d || !rdo_conv2d_fwd_p3_supported(d)) return 0;
+    const int ks = p3_ksplit(d);
+    return ks > 1 ? (int64_t)ks * d->B * d->Ho * d->Wo * d->Cout : 0;
 }
 
 extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
@@ -417,7 +457,8 @@ extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, c
     a.oplane = (long)a.M * a.Cout;
     a.epilogue = d->epilogue; a.add_residual = d->add_residual;
     a.xcd_mode = rdo::tuning(rdo::T_XCD);
-    int ks = rdo_conv2d_fwd_bf16x6_ksplit(d);
+    a.ablate = rdo::tuning(rdo::T_X6P_ABLATE);
+    int ks = p3_ksplit(d);
     if (ks < 1) ks = 1;
     if (ks > 1 && (!workspace || (long)ks * a.M * a.Cout > workspace_floats)) ks = 1;
     a.ksplit = ks;
@@ -428,7 +469,7 @@ extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, c
                                                  6.0 * (out_planes != nullptr));
     return rdo::dispatch(
         [a](hipStream_t s) {
-            constexpr size_t lds = (size_t)2 * 3 * (128 + 192) * 32;
+            constexpr size_t lds = (size_t)3 * 3 * (256 + 192) * 32;
             static bool attr = false;
             if (!attr) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -436,15 +477,15 @@ extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, c
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6p) failed");
                 attr = true;
             }
-            dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
-            hipLaunchKernelGGL(conv_fwd_x6p_kernel, grid, dim3(256), lds, s, a);
+            dim3 grid((unsigned)rdo::ceil_div(a.M, 256), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
+            hipLaunchKernelGGL(conv_fwd_x6p_kernel, grid, dim3(512), lds, s, a);
             if (int rc = rdo::check_launch("conv_fwd_x6p")) return rc;
             if (a.ksplit > 1) {
-                long g = rdo::ceil_div((long)a.M * a.Cout / 8, 256);
+                long g = rdo::ceil_div((long)a.M * a.Cout / 16, 256);
                 hipLaunchKernelGGL(x6p_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
                 return rdo::check_launch("x6p_splitk_epilogue");
             }
             return RDO_OK;
         },
-        stream, "conv_fwd_x6_p3_128x192", flops, bytes);
+        stream, "conv_fwd_x6_p3_256x192", flops, bytes);
 }

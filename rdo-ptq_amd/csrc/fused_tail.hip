@@ -38,8 +38,11 @@ __device__ __forceinline__ unsigned cvt_pk(float a, float b) {
 __device__ __forceinline__ float lo_f(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
 __device__ __forceinline__ float hi_f(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
 
-// exact three-way split of a quad -> one 8-byte store per plane at element offset e
-__device__ __forceinline__ void store_p3(u16* planes, long pstride, long e, const f32x4& v) {
+// exact three-way split of a quad of channels [c0, c0 + 4) of pixel m -> one 8-byte store per plane, P3 slice-major layout
+// (rdo_ptq_hip.h): element (m, c) of a tensor with M pixels and C channels at plane * M * C + ((c >> 4) * M + m) * 16 + (c & 15)
+__device__ __forceinline__ void store_p3(u16* planes, long M, int C, long m, int c0, const f32x4& v) {
+    const long pstride = M * C;
+    const long e = ((long)(c0 >> 4) * M + m) * 16 + (c0 & 15);
     const unsigned h01 = cvt_pk(v[0], v[1]), h23 = cvt_pk(v[2], v[3]);
     const float r0 = v[0] - lo_f(h01), r1 = v[1] - hi_f(h01), r2 = v[2] - lo_f(h23), r3 = v[3] - hi_f(h23);
     const unsigned m01 = cvt_pk(r0, r1), m23 = cvt_pk(r2, r3);
@@ -47,6 +50,11 @@ __device__ __forceinline__ void store_p3(u16* planes, long pstride, long e, cons
     *reinterpret_cast<u32x2*>(planes + e) = u32x2{h01, h23};
     *reinterpret_cast<u32x2*>(planes + pstride + e) = u32x2{m01, m23};
     *reinterpret_cast<u32x2*>(planes + 2 * pstride + e) = u32x2{cvt_pk(s0, s1), cvt_pk(s2, s3)};
+}
+// element offset e of an NHWC tensor with C channels -> (pixel, first channel of the quad)
+__device__ __forceinline__ void store_p3_at(u16* planes, long M, int C, long e, const f32x4& v) {
+    const long m = e / C;
+    store_p3(planes, M, C, m, (int)(e - m * C), v);
 }
 
 __device__ __forceinline__ void block_loss_add(float acc, float scale, float* loss_out, int it) {
@@ -59,7 +67,7 @@ __device__ __forceinline__ void block_loss_add(float acc, float scale, float* lo
 }
 
 __global__ __launch_bounds__(256) void gather_qdrop_p3_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
-                                                              const int32_t* iter_ptr, int B, int batch_offset, long per_image,
+                                                              const int32_t* iter_ptr, int B, int batch_offset, long per_image, int C,
                                                               unsigned long long thr, uint32_t seed, float* out, u16* planes) {
     const int it = *iter_ptr;
     const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
@@ -77,13 +85,13 @@ __global__ __launch_bounds__(256) void gather_qdrop_p3_kernel(const float* cq, c
         for (int e = 0; e < 4; ++e) o[e] = ((unsigned long long)lowbias32((i0 + e) ^ key) < thr) ? q[e] : f[e];
         const long dst = (long)b * per_image + off;
         if (out) *reinterpret_cast<f32x4*>(out + dst) = o;
-        store_p3(planes, total * 4, dst, o);
+        store_p3_at(planes, total * 4 / C, C, dst, o);
     }
 }
 
 // act: 0 none, 1 LeakyReLU(0.01), 2 ReLU
 __global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, const float* res, const float* tgt, const int32_t* idx_table,
-                                                           const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef,
+                                                           const int32_t* iter_ptr, int B, long per_image, int C, float inv_npix, float coef,
                                                            int act, float* out, float* gout, float* dpre, u16* dpre_planes,
                                                            float* loss_out) {
     const int it = *iter_ptr;
@@ -114,13 +122,13 @@ __global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, con
             for (int k = 0; k < 4; ++k) g[k] = p[k] > 0.f ? g[k] : slope * g[k];
         }
         if (dpre) *reinterpret_cast<f32x4*>(dpre + e) = g;
-        if (dpre_planes) store_p3(dpre_planes, total * 4, e, g);
+        if (dpre_planes) store_p3_at(dpre_planes, total * 4 / C, C, e, g);
     }
     block_loss_add(acc, inv_npix * coef, loss_out, it);
 }
 
 __global__ __launch_bounds__(256) void loss_gdn_bwd_kernel(const float* x, const float* nrm, const float* res, const float* tgt,
-                                                           const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
+                                                           const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image, int C,
                                                            float inv_npix, float coef, int inverse, float* out, float* gout, float* tbuf,
                                                            u16* t_planes, float* loss_out) {
     const int it = *iter_ptr;
@@ -152,13 +160,13 @@ __global__ __launch_bounds__(256) void loss_gdn_bwd_kernel(const float* x, const
         for (int k = 0; k < 4; ++k)       // GDN: y = x n^-1/2 -> dy/dn = -1/2 x n^-3/2 ; IGDN: y = x n^1/2 -> dy/dn = 1/2 x n^-1/2
             tv[k] = inverse ? (0.5f * g[k] * xv[k]) * r[k] : (-0.5f * g[k] * xv[k]) * (r[k] * r[k] * r[k]);
         if (tbuf) *reinterpret_cast<f32x4*>(tbuf + e) = tv;
-        if (t_planes) store_p3(t_planes, total * 4, e, tv);
+        if (t_planes) store_p3_at(t_planes, total * 4 / C, C, e, tv);
     }
     block_loss_add(acc, inv_npix * coef, loss_out, it);
 }
 
 __global__ __launch_bounds__(256) void gdn_bwd_dx_p3_kernel(const float* g, const float* x, const float* nrm, const float* acc, long n4,
-                                                            int inverse, float* dx, u16* dx_planes) {
+                                                            int C, int inverse, float* dx, u16* dx_planes) {
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
         const long e = q * 4;
         const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e), xv = *reinterpret_cast<const f32x4*>(x + e);
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(256) void gdn_bwd_dx_p3_kernel(const float* g, cons
             o[k] = gv[k] * f + 2.f * xv[k] * av[k];
         }
         if (dx) *reinterpret_cast<f32x4*>(dx + e) = o;
-        if (dx_planes) store_p3(dx_planes, n4 * 4, e, o);
+        if (dx_planes) store_p3_at(dx_planes, n4 * 4 / C, C, e, o);
     }
 }
 
@@ -181,7 +189,6 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_p3_kernel(const float* x, 
                                                                 u16* planes) {
     const int cq = C / 4;
     const long total = npix_small * cq;
-    const long pstride = npix_small * 4 * C;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
         const int q = (int)(t % cq);
         const long p = t / cq;                             // small pixel (b, h, w)
@@ -198,7 +205,7 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_p3_kernel(const float* x, 
             const f32x4 o = {v[0][j], v[1][j], v[2][j], v[3][j]};
             const long e = big0 + (j >> 1) * row + (j & 1) * C;
             if (out) *reinterpret_cast<f32x4*>(out + e) = o;
-            if (planes) store_p3(planes, pstride, e, o);
+            if (planes) store_p3(planes, npix_small * 4, C, e / C, 4 * q, o);
         }
     }
 }
@@ -208,9 +215,10 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_p3_kernel(const float* x, 
 extern "C" {
 
 int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
-                        int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out, void* out_planes, void* stream) {
+                        int32_t batch_offset, int64_t per_image, int32_t C, float prob, uint32_t seed, float* out, void* out_planes,
+                        void* stream) {
     RDO_REQUIRE(cache_q && cache_fp && idx_table && iter_ptr && out_planes, "rdo_gather_qdrop_p3: null pointer");
-    RDO_REQUIRE(B > 0 && batch_offset >= 0 && per_image > 0 && per_image % 4 == 0, "rdo_gather_qdrop_p3: bad shape");
+    RDO_REQUIRE(B > 0 && batch_offset >= 0 && per_image > 0 && C > 0 && C % 16 == 0 && per_image % C == 0, "rdo_gather_qdrop_p3: bad shape");
     RDO_REQUIRE((long)(batch_offset + B) * per_image < (1L << 32), "rdo_gather_qdrop_p3: batch tensor exceeds the 32-bit RNG counter");
     RDO_REQUIRE(prob >= 0.f && prob <= 1.f, "rdo_gather_qdrop_p3: prob out of [0,1]");
     double t = floor((double)prob * 4294967296.0);
@@ -219,7 +227,7 @@ int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(gather_qdrop_p3_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, cache_q, cache_fp,
-                               idx_table, iter_ptr, B, batch_offset, (long)per_image, thr, seed, out, pl);
+                               idx_table, iter_ptr, B, batch_offset, (long)per_image, C, thr, seed, out, pl);
             return rdo::check_launch("gather_qdrop_p3");
         },
         stream, "gather_qdrop_p3", 0.0, (8.0 + (out ? 4.0 : 0.0) + 6.0) * B * per_image);
@@ -229,7 +237,8 @@ int rdo_loss_act_bwd(const float* pre, const float* residual, const float* tgt_c
                      int32_t B, int64_t per_image, int32_t C, float coef, int32_t act, float* out, float* grad_out, float* dpre,
                      void* dpre_planes, float* loss_out, void* stream) {
     RDO_REQUIRE(pre && tgt_cache && idx_table && iter_ptr && (dpre || dpre_planes || grad_out), "rdo_loss_act_bwd: null pointer");
-    RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_loss_act_bwd: bad shape");
+    RDO_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && per_image > 0 && per_image % C == 0, "rdo_loss_act_bwd: bad shape");
+    RDO_REQUIRE(!dpre_planes || C % 16 == 0, "rdo_loss_act_bwd: P3 output needs C % 16 == 0");
     RDO_REQUIRE(act >= 0 && act <= 2, "rdo_loss_act_bwd: act %d (0 none, 1 LeakyReLU(0.01), 2 ReLU)", act);
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
     u16* pl = reinterpret_cast<u16*>(dpre_planes);
@@ -237,7 +246,7 @@ int rdo_loss_act_bwd(const float* pre, const float* residual, const float* tgt_c
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(loss_act_bwd_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, pre, residual, tgt_cache,
-                               idx_table, iter_ptr, B, (long)per_image, inv_npix, coef, act, out, grad_out, dpre, pl, loss_out);
+                               idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, act, out, grad_out, dpre, pl, loss_out);
             return rdo::check_launch("loss_act_bwd");
         },
         stream, "loss_act_bwd", 0.0,
@@ -248,27 +257,29 @@ int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, c
                      const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef, int32_t inverse, float* out,
                      float* grad_out, float* t, void* t_planes, float* loss_out, void* stream) {
     RDO_REQUIRE(x && norm && tgt_cache && idx_table && iter_ptr && grad_out && (t || t_planes), "rdo_loss_gdn_bwd: null pointer");
-    RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_loss_gdn_bwd: bad shape");
+    RDO_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && per_image > 0 && per_image % C == 0, "rdo_loss_gdn_bwd: bad shape");
+    RDO_REQUIRE(!t_planes || C % 16 == 0, "rdo_loss_gdn_bwd: P3 output needs C % 16 == 0");
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
     u16* pl = reinterpret_cast<u16*>(t_planes);
     const double n = (double)B * per_image;
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(loss_gdn_bwd_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, x, norm, residual, tgt_cache,
-                               idx_table, iter_ptr, B, (long)per_image, inv_npix, coef, inverse, out, grad_out, t, pl, loss_out);
+                               idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, inverse, out, grad_out, t, pl, loss_out);
             return rdo::check_launch("loss_gdn_bwd");
         },
         stream, "loss_gdn_bwd", 0.0,
         n * (16.0 + 4.0 * ((residual != nullptr) + (out != nullptr) + (t != nullptr)) + (pl ? 6.0 : 0.0)));
 }
 
-int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t inverse, float* dx,
-                      void* dx_planes, void* stream) {
-    RDO_REQUIRE(g && x && norm && acc && (dx || dx_planes) && n > 0 && n % 4 == 0, "rdo_gdn_bwd_dx_p3: bad argument");
+int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t C, int32_t inverse,
+                      float* dx, void* dx_planes, void* stream) {
+    RDO_REQUIRE(g && x && norm && acc && (dx || dx_planes) && n > 0 && C > 0 && C % 4 == 0 && n % C == 0, "rdo_gdn_bwd_dx_p3: bad argument");
+    RDO_REQUIRE(!dx_planes || C % 16 == 0, "rdo_gdn_bwd_dx_p3: P3 output needs C % 16 == 0");
     u16* pl = reinterpret_cast<u16*>(dx_planes);
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(gdn_bwd_dx_p3_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, g, x, norm, acc, (long)(n / 4), inverse, dx, pl);
+            hipLaunchKernelGGL(gdn_bwd_dx_p3_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, g, x, norm, acc, (long)(n / 4), C, inverse, dx, pl);
             return rdo::check_launch("gdn_bwd_dx_p3");
         },
         stream, "gdn_bwd_dx", 0.0, (double)n * (16.0 + (dx ? 4.0 : 0.0) + (pl ? 6.0 : 0.0)));
@@ -276,6 +287,7 @@ int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const f
 
 int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream) {
     RDO_REQUIRE(x && (out || out_planes) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "rdo_pixel_shuffle_p3: bad argument");
+    RDO_REQUIRE(!out_planes || C % 16 == 0, "rdo_pixel_shuffle_p3: P3 output needs C % 16 == 0");
     u16* pl = reinterpret_cast<u16*>(out_planes);
     const long nps = (long)B * H * W, npl = nps * 4;
     return rdo::dispatch(

@@ -457,18 +457,27 @@ def make_sched(iters, warmup, b_range, lr=1e-3, device="cuda"):
 
 # ----------------------------------------------------------------------------- P3 tensors and fused unit tails
 def p3_empty(shape, device):
-    """Planes of a P3 tensor (exact three-way bf16 split of an fp32 NHWC tensor of `shape`): int16 [3, *shape]."""
-    return torch.empty((3,) + tuple(shape), device=device, dtype=torch.int16)
+    """Planes of a P3 tensor for an fp32 NHWC tensor of `shape` [..., C] (C % 16 == 0): int16 [3, C/16, pixels, 16] -- slice-major
+    planes, include/rdo_ptq_hip.h."""
+    Cc = shape[-1]
+    if Cc % 16:
+        raise ValueError(f"P3 tensors need a channel count that is a multiple of 16, got {Cc}")
+    npix = 1
+    for d in shape[:-1]:
+        npix *= int(d)
+    return torch.empty((3, Cc // 16, npix, 16), device=device, dtype=torch.int16)
 
 
-def p3_to_float(planes):
-    """p0 + p1 + p2 as fp32 (exact)."""
-    return sum((planes[i].to(torch.int32) << 16).view(torch.float32) for i in range(3))
+def p3_to_float(planes, shape):
+    """p0 + p1 + p2 as an fp32 tensor of `shape` (exact)."""
+    x = sum((planes[i].to(torch.int32) << 16).view(torch.float32) for i in range(3))      # [C/16, pixels, 16]
+    return x.permute(1, 0, 2).reshape(shape).contiguous()
 
 
 def split_p3(x, planes=None):
     planes = p3_empty(x.shape, x.device) if planes is None else planes
-    L.check(L.lib().rdo_split_p3(_ptr(x), x.numel(), _ptr(planes), _stream()), "rdo_split_p3")
+    Cc = x.shape[-1]
+    L.check(L.lib().rdo_split_p3(_ptr(x), x.numel() // Cc, Cc, _ptr(planes), _stream()), "rdo_split_p3")
     return planes
 
 
@@ -477,13 +486,12 @@ def conv_p3_supported(x_shape, w_shape, stride, pad, square_input=False):
     return bool(L.lib().rdo_conv2d_fwd_p3_supported(C.byref(d)))
 
 
-def conv2d_fwd_p3(xp, w_shape, wplanes, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, out=None, pre=None,
+def conv2d_fwd_p3(xp, x_shape, w_shape, wplanes, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, out=None, pre=None,
                   out_planes=None):
-    """Conv on a P3 input (`xp` = planes [3,B,H,W,Cin]) with fragment-ordered weight planes; writes whichever of out / pre /
-    out_planes is given."""
-    x_shape = tuple(xp.shape[1:])
+    """Conv on a P3 input (`xp` = planes of the NHWC tensor of shape `x_shape`) with fragment-ordered weight planes; writes whichever
+    of out / pre / out_planes is given."""
     d = conv_desc(x_shape, w_shape, stride, pad, epilogue, False, residual is not None)
-    need = int(L.lib().rdo_conv2d_fwd_workspace(C.byref(d)))
+    need = int(L.lib().rdo_conv2d_fwd_p3_workspace(C.byref(d)))
     ws = _scratch(xp.device, need) if need else None
     L.check(L.lib().rdo_conv2d_fwd_p3(C.byref(d), _ptr(xp), _ptr(wplanes), _ptr(bias), _ptr(aux), _ptr(residual), _ptr(out), _ptr(pre),
                                       _ptr(out_planes), _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "rdo_conv2d_fwd_p3")
@@ -493,7 +501,7 @@ def conv2d_fwd_p3(xp, w_shape, wplanes, bias=None, stride=1, pad=0, epilogue=L.E
 def gather_qdrop_p3(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, out_planes, batch_offset=0):
     per_image = cache_q[0].numel()
     L.check(L.lib().rdo_gather_qdrop_p3(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,
-                                        prob, seed, _ptr(out), _ptr(out_planes), _stream()), "rdo_gather_qdrop_p3")
+                                        cache_q.shape[-1], prob, seed, _ptr(out), _ptr(out_planes), _stream()), "rdo_gather_qdrop_p3")
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
@@ -514,8 +522,8 @@ def loss_gdn_bwd(x, norm, residual, tgt_cache, idx_table, iter_ptr, coef, invers
 
 
 def gdn_bwd_dx_p3(g, x, norm, acc, inverse, dx=None, dx_planes=None):
-    L.check(L.lib().rdo_gdn_bwd_dx_p3(_ptr(g), _ptr(x), _ptr(norm), _ptr(acc), g.numel(), int(inverse), _ptr(dx), _ptr(dx_planes),
-                                      _stream()), "rdo_gdn_bwd_dx_p3")
+    L.check(L.lib().rdo_gdn_bwd_dx_p3(_ptr(g), _ptr(x), _ptr(norm), _ptr(acc), g.numel(), g.shape[-1], int(inverse), _ptr(dx),
+                                      _ptr(dx_planes), _stream()), "rdo_gdn_bwd_dx_p3")
 
 
 def pixel_shuffle_p3(x, out=None, out_planes=None):

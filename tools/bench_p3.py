@@ -31,13 +31,22 @@ for (B, H, Cin, Cout, K, s, p) in SHAPES:
     x = torch.randn(B, H, H, Cin, device="cuda")
     w = torch.randn(Cout, K, K, Cin, device="cuda") / (Cin * K * K) ** 0.5
     b = torch.randn(Cout, device="cuda")
+    if not ops.conv_p3_supported(tuple(x.shape), tuple(w.shape), s, p):
+        print(f"B={B} H={H} {Cin}->{Cout} k{K} s{s}: not on the plane path")
+        continue
     wpl, xp = ops.split_bf16x3(w), ops.split_p3(x)
     out = ops.conv2d_fwd(x, w, b, s, p, wplanes=wpl)
     opl = ops.p3_empty(out.shape, "cuda")
     gf = 2.0 * out.numel() * Cin * K * K / 1e9
     t_old = timeit(lambda: ops.conv2d_fwd(x, w, b, s, p, out=out, wplanes=wpl))
-    t_p3 = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, s, p, out=out))
-    t_p3b = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, s, p, out=out, out_planes=opl))
-    t_p3p = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(w.shape), wpl, b, s, p, out_planes=opl))
-    print(f"B={B} H={H} {Cin}->{Cout} k{K} s{s}: fp32-in x6 {t_old:7.1f} us ({gf / t_old * 1e-3:6.1f} TF) | p3 out {t_p3:7.1f} us ({gf / t_p3 * 1e-3:6.1f} TF)"
-          f" | out+planes {t_p3b:7.1f} | planes only {t_p3p:7.1f}")
+    t_p3 = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, b, s, p, out=out))
+    t_p3b = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, b, s, p, out=out, out_planes=opl))
+    t_p3p = timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, b, s, p, out_planes=opl))
+    abl = []
+    if os.environ.get("P3_ABLATE"):
+        for m in (1, 2, 3, 4, 8, 12, 15):
+            ops.set_tuning("x6p_ablate", m)
+            abl.append((m, timeit(lambda: ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, b, s, p, out=out))))
+        ops.set_tuning("x6p_ablate", 0)
+    print(f"B={B} H={H} {Cin}->{Cout} k{K} s{s}: fp32-in x6 {t_old:7.1f} us ({gf / t_old * 1e3:6.1f} TF) | p3 out {t_p3:7.1f} us ({gf / t_p3 * 1e3:6.1f} TF)"
+          f" | out+planes {t_p3b:7.1f} | planes only {t_p3p:7.1f}" + "".join(f" | abl{m}: {t:6.1f}" for m, t in abl))
