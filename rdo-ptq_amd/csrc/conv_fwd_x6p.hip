@@ -106,6 +106,19 @@ __device__ __forceinline__ float activate(const X6PArgs& a, float v, float aux) 
     }
 }
 
+// the three P3 records of (slice n / 16, pixel m) from 16 finished channel values: 32 bytes per plane
+__device__ __forceinline__ void store_slice(const X6PArgs& a, int m, int n, const float (&v)[16]) {
+    u16* dst = a.outp + ((long)(n >> 4) * a.M + m) * 16;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        u32x4 p0, p1, p2;
+        split3_x8(v + 8 * h, p0, p1, p2);
+        *reinterpret_cast<u32x4*>(dst + 8 * h) = p0;
+        *reinterpret_cast<u32x4*>(dst + a.oplane + 8 * h) = p1;
+        *reinterpret_cast<u32x4*>(dst + 2 * a.oplane + 8 * h) = p2;
+    }
+}
+
 // finish the 16 channels [n, n+16) (one slice, n % 16 == 0) of output pixel m from their raw sums `v` (bias not yet added)
 __device__ __forceinline__ void finish16(const X6PArgs& a, int m, int n, float (&v)[16]) {
     const long o = (long)m * a.Cout + n;
@@ -142,17 +155,7 @@ __device__ __forceinline__ void finish16(const X6PArgs& a, int m, int n, float (
 #pragma unroll
         for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.out + o + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
     }
-    if (a.outp) {
-        u16* dst = a.outp + ((long)(n >> 4) * a.M + m) * 16;        // P3 record of (slice n / 16, pixel m): 32 bytes per plane
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            u32x4 p0, p1, p2;
-            split3_x8(v + 8 * h, p0, p1, p2);
-            *reinterpret_cast<u32x4*>(dst + 8 * h) = p0;
-            *reinterpret_cast<u32x4*>(dst + a.oplane + 8 * h) = p1;
-            *reinterpret_cast<u32x4*>(dst + 2 * a.oplane + 8 * h) = p2;
-        }
-    }
+    if (a.outp) store_slice(a, m, n, v);
 }
 
 __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
@@ -224,32 +227,40 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
     int ctap = sbeg - ccs * taps;
     int ckh = ctap / a.KW, ckw = ctap - ckh * a.KW;
     int cstage = 0;
-    // six DMA instructions per wave and stage (three activation planes, three weight pieces): the vmcnt bookkeeping below counts on it
-    auto dma_stage = [&](int buf) {
-        char* const base = smem + buf * STAGE;
-        if (!(a.ablate & 1)) {
-            const int hi = hi0 + ckh, wi = wi0 + ckw;
-            const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-            const long off = ((long)ccs * Min + (apix0 + hi * a.W + wi)) * 16 + achunk * 8;
-            const u16* src = ok ? a.xp + off : zero;
-            const long pstep = ok ? a.xplane : 0;
-            char* dst = base + wave * 1024;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(src + pstep), (lds_void*)(dst + APLANE), 16, 0, 0);
-            __builtin_amdgcn_global_load_lds((glb_void*)(src + 2 * pstep), (lds_void*)(dst + 2 * APLANE), 16, 0, 0);
-        }
-        if (!(a.ablate & 2)) {
-            const u16* wsrc = a.wp + (long)(sbeg + cstage) * a.Cout * 16;
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-                __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_src[j]), (lds_void*)(base + 3 * APLANE + dma_k[j] * 1024), 16, 0, 0);
-        }
+    // six DMA instructions per wave and stage (three activation planes, three weight pieces): the vmcnt bookkeeping below counts on
+    // it.  dma_prepare computes the stage's source addresses, dma_issue(j) issues instruction j, dma_advance moves the cursor.
+    const u16* asrc = zero;
+    long apstep = 0;
+    const u16* wsrc = a.wp;
+    auto dma_prepare = [&]() {
+        const int hi = hi0 + ckh, wi = wi0 + ckw;
+        const bool ok = (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        const long off = ((long)ccs * Min + (apix0 + hi * a.W + wi)) * 16 + achunk * 8;
+        asrc = ok ? a.xp + off : zero;
+        apstep = ok ? a.xplane : 0;
+        wsrc = a.wp + (long)(sbeg + cstage) * a.Cout * 16;
         if (cstage + 1 < nsteps) {                           // advance, clamped at the last stage (tail stages re-fetch it: harmless)
             ++cstage;
             ++ckw;
             if (ckw == a.KW) { ckw = 0; ++ckh; }
             if (ckh == a.KH) { ckh = 0; ++ccs; }
         }
+    };
+    auto dma_issue = [&](auto jc, int buf) {
+        constexpr int j = decltype(jc)::value;
+        char* const base = smem + buf * STAGE;
+        if constexpr (j < 3) {
+            if (!(a.ablate & 1))
+                __builtin_amdgcn_global_load_lds((glb_void*)(asrc + j * apstep), (lds_void*)(base + wave * 1024 + j * APLANE), 16, 0, 0);
+        } else {
+            if (!(a.ablate & 2))
+                __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_src[j - 3]), (lds_void*)(base + 3 * APLANE + dma_k[j - 3] * 1024), 16, 0, 0);
+        }
+    };
+    auto dma_all = [&](int buf) {
+        dma_prepare();
+        [&]<int... J>(std::integer_sequence<int, J...>) { (dma_issue(std::integral_constant<int, J>{}, buf), ...); }
+        (std::make_integer_sequence<int, 6>{});
     };
 
     int fa_off[3][TM], fb_off[3][TN];
@@ -260,11 +271,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) fb_off[p][j] = 3 * APLANE + p * BPLANE + chunk_off16(wn0 + j * 32 + li, lh);
     }
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};             // products (A plane, B plane), small terms first
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    // the second-dispatched half of the workgroup (waves 4-7, the SIMD partners of waves 0-3) issues its DMAs in the LAST three MFMA
+    // slots of a stage, the first half in the FIRST three: while one wave of a SIMD is held up issuing DMAs its partner multiplies
+    const bool late = wave >= 4;
 
-    dma_stage(0);
-    dma_stage(1);
+    dma_all(0);
+    dma_all(1);
     int buf = 0;
     for (int t = 0; t < nsteps; ++t) {
         // stage t has landed for this wave once at most the six youngest DMAs (stage t+1) are outstanding; the barrier extends that to
@@ -272,43 +284,63 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
         if (a.ablate & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        dma_stage(buf >= 1 ? buf - 1 : RING - 1);            // (t + 2) % 3
+        const int nb = buf >= 1 ? buf - 1 : RING - 1;        // (t + 2) % 3
         const char* st = smem + buf * STAGE;
         bf16x8 fa[3][TM], fb[3][TN];
+        auto rd_a = [&](int p) {
 #pragma unroll
-        for (int p = 0; p < 3; ++p) {
+            for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(st + fa_off[p][i]);
+        };
+        auto rd_b = [&](int p) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[p][i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(st + fb_off[p][j]);
+        };
+        auto mma = [&](int pa, int pb) {
+            if (a.ablate & 4) return;
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[p][j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-        }
-        if (!(a.ablate & 8)) {
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(st + fa_off[p][i]);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(st + fb_off[p][j]);
-            }
-        }
-        if (!(a.ablate & 4)) {
-#pragma unroll
-            for (int s = 0; s < 6; ++s)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[PA[s]][i], fb[PB[s]][j], acc[i][j], 0, 0, 0);
-        }
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][i], fb[pb][j], acc[i][j], 0, 0, 0);
+        };
+        using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+        using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+        dma_prepare();
+        // fragments in the order the products need them: (A2,B0) (A0,B2) (A1,B0) (A1,B1) (A0,B1) (A0,B0), small terms first
+        rd_a(2); rd_b(0);
+        rd_a(0); rd_b(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(2, 0);
+        rd_a(1);
+        if (!late) { dma_issue(I0{}, nb); dma_issue(I1{}, nb); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 2);
+        rd_b(1);
+        if (!late) { dma_issue(I2{}, nb); dma_issue(I3{}, nb); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 0);
+        if (!late) { dma_issue(I4{}, nb); dma_issue(I5{}, nb); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 1);
+        if (late) { dma_issue(I0{}, nb); dma_issue(I1{}, nb); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 1);
+        if (late) { dma_issue(I2{}, nb); dma_issue(I3{}, nb); }
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 0);
+        if (late) { dma_issue(I4{}, nb); dma_issue(I5{}, nb); }
+        __builtin_amdgcn_sched_barrier(0);
         buf = buf + 1 == RING ? 0 : buf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail DMAs still target LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_barrier();
 
-    // ---- epilogue through LDS: two passes of 128 tile rows (pass i: MFMA row tile i of every wave), then every thread finishes the 16
-    // channels of one slice for one pixel, consecutive lanes on consecutive pixels (the P3 record order)
+    // ---- epilogue through LDS: two passes of 128 tile rows (pass i: MFMA row tile i of every wave).  Per pass: (1) consecutive lanes
+    // along the CHANNELS finish quads -- bias, activation, residual, coalesced 16-byte loads / stores of the fp32 tensors -- and put
+    // the finished values back into the staging tile; (2) consecutive lanes along the PIXELS split the 16 channels of one slice and
+    // write the three P3 records (32 contiguous bytes per plane and pixel, consecutive pixels adjacent).
     float* const stg = reinterpret_cast<float*>(smem);       // [128][SROW] fp32 = 98 KiB
     const long part_base = (long)tile.z * a.M * a.Cout;
+    const bool need_planes = a.outp != nullptr && a.partial == nullptr;
 #pragma unroll
     for (int pass = 0; pass < TM; ++pass) {
         if (pass) __syncthreads();
@@ -320,25 +352,47 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
                 stg[((wave >> 1) * 32 + rr) * SROW + wn0 + j * 32 + li] = acc[pass][j][r];
             }
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const int q = tid + 512 * k;                     // 128 rows x 12 slices of 16 channels
-            const int row = q & 127, sl = q >> 7;
+#pragma unroll 4
+        for (int k = 0; k < 12; ++k) {
+            const int q = tid + 512 * k;                     // 128 rows x 48 quads of channels
+            const int row = q / 48, c4 = q - row * 48;
             const int m = m0 + (row >> 5) * 64 + pass * 32 + (row & 31);
-            const int n = n0 + sl * 16;
+            const int n = n0 + c4 * 4;
             if (m >= a.M || n >= a.Cout) continue;
-            float v[16];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                const f32x4 t4 = *reinterpret_cast<const f32x4*>(stg + row * SROW + sl * 16 + 4 * c);
-                v[4 * c] = t4[0]; v[4 * c + 1] = t4[1]; v[4 * c + 2] = t4[2]; v[4 * c + 3] = t4[3];
-            }
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SROW + c4 * 4);
+            const long o = (long)m * a.Cout + n;
             if (a.partial) {
-                float* dst = a.partial + part_base + (long)m * a.Cout + n;
+                *reinterpret_cast<f32x4*>(a.partial + part_base + o) = v;
+                continue;
+            }
+            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.pre) *reinterpret_cast<f32x4*>(a.pre + o) = v;
+            if (a.epilogue != RDO_EPI_NONE) {
+                f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
+                if (a.aux) x4 = *reinterpret_cast<const f32x4*>(a.aux + o);
 #pragma unroll
-                for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(dst + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
-            } else {
-                finish16(a, m, n, v);
+                for (int e = 0; e < 4; ++e) v[e] = activate(a, v[e], x4[e]);
+            }
+            if (a.add_residual) v += *reinterpret_cast<const f32x4*>(a.residual + o);
+            if (a.out) *reinterpret_cast<f32x4*>(a.out + o) = v;
+            if (need_planes) *reinterpret_cast<f32x4*>(stg + row * SROW + c4 * 4) = v;
+        }
+        if (need_planes) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int q = tid + 512 * k;                 // 128 rows x 12 slices of 16 channels
+                const int row = q & 127, sl = q >> 7;
+                const int m = m0 + (row >> 5) * 64 + pass * 32 + (row & 31);
+                const int n = n0 + sl * 16;
+                if (m >= a.M || n >= a.Cout) continue;
+                float v[16];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(stg + row * SROW + sl * 16 + 4 * c);
+                    v[4 * c] = t4[0]; v[4 * c + 1] = t4[1]; v[4 * c + 2] = t4[2]; v[4 * c + 3] = t4[3];
+                }
+                store_slice(a, m, n, v);
             }
         }
     }
