@@ -59,7 +59,7 @@ const char* rdo_last_error(void);
  *   "fwd_x6_ver"   forward bf16x6 kernel generation (default: newest)
  *   "xcd"          1 (default): XCD-aware tile numbering in the bf16x6 kernels
  *   "x6p_ablate"   diagnostic bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
- *                  8 no fragment reads
+ *                  8 no fragment reads, 16 rotate the K order per tile (results stay right)
  * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */
 int rdo_set_tuning(const char* key, int32_t value);
 int rdo_get_tuning(const char* key);

@@ -223,8 +223,13 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     // DMA cursor (wave-uniform): (channel slice, kh, kw) of the next stage to fetch; stages run channel slice outer, taps inner
-    int ccs = sbeg / taps;
-    int ctap = sbeg - ccs * taps;
+    // Optional rotation of the K order per tile (ablate bit 16): stage s of this workgroup is stage (s + rot) mod nsteps of its K
+    // range.  Measured SLOWER (4 x 128^2 conv: 217 vs 204 us): the workgroups of an XCD walking the weight stream together is what lets
+    // one L2 fill serve all of them -- kept only as a diagnostic.
+    const int rot = (a.ablate & 16) ? (int)(((unsigned)tile.m * 37u + (unsigned)tile.n * 11u) % (unsigned)nsteps) : 0;
+    int cabs = sbeg + rot;                                   // absolute stage (channel slice * taps + tap) under the cursor
+    int ccs = cabs / taps;
+    int ctap = cabs - ccs * taps;
     int ckh = ctap / a.KW, ckw = ctap - ckh * a.KW;
     int cstage = 0;
     // six DMA instructions per wave and stage (three activation planes, three weight pieces): the vmcnt bookkeeping below counts on
@@ -238,12 +243,20 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
         const long off = ((long)ccs * Min + (apix0 + hi * a.W + wi)) * 16 + achunk * 8;
         asrc = ok ? a.xp + off : zero;
         apstep = ok ? a.xplane : 0;
-        wsrc = a.wp + (long)(sbeg + cstage) * a.Cout * 16;
+        wsrc = a.wp + (long)cabs * a.Cout * 16;
         if (cstage + 1 < nsteps) {                           // advance, clamped at the last stage (tail stages re-fetch it: harmless)
             ++cstage;
+            ++cabs;
             ++ckw;
             if (ckw == a.KW) { ckw = 0; ++ckh; }
             if (ckh == a.KH) { ckh = 0; ++ccs; }
+            if (cabs == sbeg + nsteps) {                     // wrap to the start of this workgroup's K range
+                cabs = sbeg;
+                ccs = sbeg / taps;
+                const int tp = sbeg - ccs * taps;
+                ckh = tp / a.KW;
+                ckw = tp - ckh * a.KW;
+            }
         }
     };
     auto dma_issue = [&](auto jc, int buf) {

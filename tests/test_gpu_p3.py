@@ -54,7 +54,7 @@ def test_conv_p3_equals_fp32_input_x6(ops, L, H, Cin, Cout, K, s, p):
     # workgroups differently the partial sums are added in a different order
     assert float((out - ref).abs().max()) <= 2e-6 * float(ref.abs().max())
     if H == 128 and K == 3 and s == 1:
-        assert torch.equal(out, ref)           # no K split on either side: bit-identical
+        assert torch.equal(out, ref)                            # no K split on either side: bit-identical
     assert torch.equal(ops.p3_to_float(opl, ref.shape), out)
     # planes only (no fp32 output at all)
     opl2 = ops.p3_empty(ref.shape, "cuda")
