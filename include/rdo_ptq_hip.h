@@ -134,6 +134,19 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
  * rdo_split_bf16x3_conv would produce for wq [rows][KH][KW][Cin] and for wd [Cin][KH][KW][rows]), written in the same pass so that
  * the split-precision conv path needs no separate refresh launch. */
 
+/* rdo_adaround_step for all (<= 8) weight tensors of a unit in one launch (plus one launch for their dgrad layouts), numel % 4 == 0.
+ * advance_iter (nullable): device iteration counter to increment once the step is done -- replaces a trailing rdo_iter_advance. */
+typedef struct rdo_ada_step_item {
+    rdo_ada_desc d;
+    const float *w, *delta, *zp, *slabs;
+    int32_t nsplit;
+    float *alpha, *adam_m, *adam_v, *wq, *wd /* nullable */;
+    void *wq_planes /* nullable */, *wd_planes /* nullable */;
+} rdo_ada_step_item;
+int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, float grad_scale, float round_weight,
+                            const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
+                            void* stream);
+
 /* only the data-gradient half (slab reduce + chain rule -> dalpha_data), for the all-reduce bucket of the DP path */
 int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,
                       const float* slabs, int nsplit, float* dalpha, void* stream);
@@ -283,6 +296,8 @@ int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const f
                       float* dx, void* dx_planes, void* stream);            /* rdo_gdn_bwd_dx with fp32 and / or P3 output */
 /* F.pixel_shuffle(x, 2) on NHWC: [B,H,W,4C] -> [B,2H,2W,C] as fp32 and / or P3 planes */
 int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream);
+/* its gradient: [B,2H,2W,C] -> [B,H,W,4C] (= rdo_pixel_shuffle(..., inverse = 1) for r = 2, 16-byte accesses on both sides) */
+int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* stream);
 
 /* ---- unit executor: a recorded sequence of the calls above, replayed per calibration iteration with no host work.
  * Python records the per-iteration op list once per unit (layer_reconstruction / block_reconstruction, layer_opt.py:287-309);

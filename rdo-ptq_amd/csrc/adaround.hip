@@ -79,7 +79,7 @@ __device__ __forceinline__ void emit(const rdo_ada_desc& d, long e, float q, flo
 // One thread per 4 consecutive weight elements (16-byte accesses on every stream: w, alpha, m, v, nsplit slabs, wq).
 // The dgrad layout wd is produced afterwards by wd_transpose_kernel (LDS-tiled, coalesced on both sides).
 template <int W>   // W = 4: float4 streams (numel % 4 == 0); W = 1: scalar fallback for odd-sized tensors
-__global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
+__device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, const long nblk) {
     typedef float vec_t __attribute__((ext_vector_type(W)));
     const rdo_ada_desc d = a.d;
     const long inner = d.numel / d.rows;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
     }
     float rl_local = 0.f;
     const long nq = d.numel / W;
-    for (long qi = (long)blockIdx.x * blockDim.x + threadIdx.x; qi < nq; qi += (long)gridDim.x * blockDim.x) {
+    for (long qi = bid * blockDim.x + threadIdx.x; qi < nq; qi += nblk * blockDim.x) {
         const long e0 = qi * W;
         const vec_t wv4 = *reinterpret_cast<const vec_t*>(a.w + e0);
         vec_t al4 = *reinterpret_cast<const vec_t*>(a.alpha + e0);
@@ -221,16 +221,35 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
         __syncthreads();
         if (threadIdx.x == 0) {
             const float t = red[0] + red[1] + red[2] + red[3];
-            if (t != 0.f) atomicAdd(a.round_loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), t);
+            if (t != 0.f) atomicAdd(a.round_loss_out + (long)it * RDO_LOG_SLOTS + (bid & (RDO_LOG_SLOTS - 1)), t);
         }
     }
 }
 
+template <int W>
+__global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
+    ada_step_body<W>(a, blockIdx.x, gridDim.x);
+}
+
+// every weight tensor of a unit in ONE launch (the AdaRound step of a block unit was 3-5 launches of 6-36 us, each a few hundred
+// workgroups that left most of the chip idle): block ranges [blk_end[t-1], blk_end[t]) belong to tensor t
+constexpr int kMaxBatch = 8;
+struct AdaBatch {
+    AdaArgs a[kMaxBatch];
+    int blk_end[kMaxBatch];
+    int n;
+};
+__global__ __launch_bounds__(256) void ada_step_batch_kernel(AdaBatch b) {
+    int t = 0;
+    while (t + 1 < b.n && (int)blockIdx.x >= b.blk_end[t]) ++t;
+    const int beg = t ? b.blk_end[t - 1] : 0;
+    ada_step_body<4>(b.a[t], (long)blockIdx.x - beg, (long)b.blk_end[t] - beg);
+}
+
 // wd[ci][KH-1-kh][KW-1-kw][co] = wq[co][kh][kw][ci]: 32x32 tiles through LDS, 128-byte segments on both sides
-__global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const float* wq, float* wd, unsigned short* wd_planes) {
+__device__ __forceinline__ void wd_transpose_body(const rdo_ada_desc& d, const float* wq, float* wd, unsigned short* wd_planes, int bid) {
     const int taps = d.KH * d.KW, cdim = d.Cin;
     const int ctiles = (cdim + 31) / 32;
-    int bid = blockIdx.x;
     const int ct = bid % ctiles; bid /= ctiles;
     const int tap = bid % taps;
     const int rt = bid / taps;
@@ -255,6 +274,20 @@ __global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const
         }
     }
 }
+__global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const float* wq, float* wd, unsigned short* wd_planes) {
+    wd_transpose_body(d, wq, wd, wd_planes, blockIdx.x);
+}
+// batched form; also advances the device iteration counter when asked to (the launch does not read it, and every kernel of the
+// iteration that does has completed before this one starts: stream order)
+__global__ __launch_bounds__(256) void wd_transpose_batch_kernel(AdaBatch b, int32_t* advance) {
+    int t = 0;
+    while (t + 1 < b.n && (int)blockIdx.x >= b.blk_end[t]) ++t;
+    const int beg = t ? b.blk_end[t - 1] : 0;
+    wd_transpose_body(b.a[t].d, b.a[t].wq, b.a[t].wd, b.a[t].wd_planes, (int)blockIdx.x - beg);
+    if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
+}
+
+__global__ void iter_advance1_kernel(int32_t* it) { *it += 1; }
 
 __global__ __launch_bounds__(256) void ada_fwd_kernel(rdo_ada_desc d, const float* w, const float* alpha, const float* delta,
                                                       const float* zp, int mode /*0 hard,1 soft,2 nearest*/, float* wq,
@@ -440,6 +473,47 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
     a.wq_planes = static_cast<unsigned short*>(wq_planes);
     a.wd_planes = wd ? static_cast<unsigned short*>(wd_planes) : nullptr;
     return run_step(a, stream);
+}
+
+int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, float grad_scale, float round_weight,
+                            const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
+                            void* stream) {
+    RDO_REQUIRE(items && n >= 1 && n <= kMaxBatch && sched && iter_ptr, "rdo_adaround_step_batch: bad argument (1 <= n <= %d)", kMaxBatch);
+    AdaBatch b{}, bw{};
+    int blocks = 0, wblocks = 0;
+    double bytes = 0.0;
+    for (int i = 0; i < n; ++i) {
+        const rdo_ada_step_item& it = items[i];
+        if (int rc = check_desc(&it.d, "rdo_adaround_step_batch")) return rc;
+        RDO_REQUIRE(it.d.numel % 4 == 0, "rdo_adaround_step_batch: numel %ld of item %d is not a multiple of 4", (long)it.d.numel, i);
+        RDO_REQUIRE(it.w && it.delta && it.zp && it.slabs && it.nsplit >= 1 && it.alpha && it.adam_m && it.adam_v && it.wq,
+                    "rdo_adaround_step_batch: null pointer in item %d", i);
+        AdaArgs& a = b.a[i];
+        a.d = it.d; a.w = it.w; a.delta = it.delta; a.zp = it.zp; a.slabs = it.slabs; a.nsplit = it.nsplit;
+        a.grad_scale = grad_scale; a.round_weight = round_weight; a.sched = sched; a.iter_ptr = iter_ptr;
+        a.alpha = it.alpha; a.m = it.adam_m; a.v = it.adam_v; a.wq = it.wq; a.wd = it.wd; a.round_loss_out = round_loss_out; a.mode = 0;
+        a.wq_planes = static_cast<unsigned short*>(it.wq_planes);
+        a.wd_planes = it.wd ? static_cast<unsigned short*>(it.wd_planes) : nullptr;
+        blocks += (int)grid_for(it.d.numel / 4);
+        b.blk_end[i] = blocks;
+        bytes += 4.0 * it.d.numel * (it.nsplit + 9.0);
+        if (it.wd && it.d.Cin > 0) {
+            bw.a[bw.n] = a;
+            wblocks += (int)(rdo::ceil_div(it.d.rows, 32) * it.d.KH * it.d.KW * rdo::ceil_div(it.d.Cin, 32));
+            bw.blk_end[bw.n++] = wblocks;
+        }
+    }
+    b.n = n;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(ada_step_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
+            if (bw.n > 0)
+                hipLaunchKernelGGL(wd_transpose_batch_kernel, dim3((unsigned)wblocks), dim3(256), 0, s, bw, advance_iter);
+            else if (advance_iter)
+                hipLaunchKernelGGL(iter_advance1_kernel, dim3(1), dim3(1), 0, s, advance_iter);
+            return rdo::check_launch("ada_step_batch");
+        },
+        stream, "ada_step", 0.0, bytes);
 }
 
 int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,

@@ -160,6 +160,22 @@ def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_
                                       _ptr(wd), _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _stream()), "rdo_adaround_step")
 
 
+def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None):
+    """items: list of dicts(d, w, delta, zp, slabs, alpha, m, v, wq, wd, wq_planes, wd_planes) -- one fused AdaRound step for every
+    weight tensor of a unit (<= 8, numel % 4 == 0); `advance_iter`: the device iteration counter to increment afterwards."""
+    arr = (L.AdaStepItem * len(items))()
+    dp = lambda t: None if t is None else _ptr(t).value
+    for k, it in enumerate(items):
+        a = arr[k]
+        a.d = it["d"]
+        a.w, a.delta, a.zp, a.slabs = dp(it["w"]), dp(it["delta"]), dp(it["zp"]), dp(it["slabs"])
+        a.nsplit = it["slabs"].shape[0]
+        a.alpha, a.adam_m, a.adam_v, a.wq, a.wd = dp(it["alpha"]), dp(it["m"]), dp(it["v"]), dp(it["wq"]), dp(it.get("wd"))
+        a.wq_planes, a.wd_planes = dp(it.get("wq_planes")), dp(it.get("wd_planes"))
+    L.check(L.lib().rdo_adaround_step_batch(arr, len(items), grad_scale, round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(round_log),
+                                            _ptr(advance_iter), _stream()), "rdo_adaround_step_batch")
+
+
 def adaround_grad(d, w, alpha, delta, zp, slabs, dalpha):
     L.check(L.lib().rdo_adaround_grad(C.byref(d), _ptr(w), _ptr(alpha), _ptr(delta), _ptr(zp), _ptr(slabs), slabs.shape[0],
                                       _ptr(dalpha), _stream()), "rdo_adaround_grad")
@@ -530,3 +546,11 @@ def pixel_shuffle_p3(x, out=None, out_planes=None):
     """[B,H,W,4C] -> [B,2H,2W,C] (r = 2) as fp32 and / or planes."""
     B, H, W, CC = x.shape
     L.check(L.lib().rdo_pixel_shuffle_p3(_ptr(x), B, H, W, CC // 4, _ptr(out), _ptr(out_planes), _stream()), "rdo_pixel_shuffle_p3")
+
+
+def pixel_unshuffle2(x, out=None):
+    """[B,2H,2W,C] -> [B,H,W,4C]: gradient of the r = 2 pixel shuffle (16-byte accesses on both sides)."""
+    B, Hr, Wr, Cc = x.shape
+    out = torch.empty((B, Hr // 2, Wr // 2, 4 * Cc), device=x.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_pixel_unshuffle2(_ptr(x), B, Hr // 2, Wr // 2, Cc, _ptr(out), _stream()), "rdo_pixel_unshuffle2")
+    return out

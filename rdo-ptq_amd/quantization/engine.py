@@ -138,7 +138,7 @@ class _Op:
 class UnitEngine:
     def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
                  warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
-                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=True):
+                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=True, fuse_tail=True, batch_step=True):
         if kind not in UNIT_KINDS:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
@@ -153,6 +153,8 @@ class UnitEngine:
         self.use_graph = use_graph
         self.batch_offset = int(batch_offset)  # first row of this rank's share of the global mini-batch (QDrop counter)
         self.dp_overlap = bool(dp_overlap)
+        self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
+        self.fuse_tail = bool(fuse_tail)       # False: the separate epilogue / loss / activation-backward kernels (A/B, tests)
         self.dev = cache_q.device
         n = cache_q.shape[0]
         if idx_table is None and self.B > n:
@@ -320,15 +322,43 @@ class UnitEngine:
         else:
             ops.lp_loss_grad(pred, self.co, self.idx, self.it, 1.0, 1.0, self.task_p, grad, self.loss_log, self.task_log)
 
+    @property
+    def fused(self):
+        """Fused unit tails (csrc/fused_tail.hip) cover the reference's default objective: rec_loss + task_loss with exponent 2."""
+        return self.task_p == 2.0 and self.fuse_tail
+
+    def _shuffle(self, x, r, out):
+        if r == 2 and x.shape[-1] % 16 == 0:
+            return ops.pixel_shuffle_p3(x, out=out)
+        return ops.pixel_shuffle(x, r, out)
+
+    def _unshuffle(self, x, r, out):
+        if r == 2 and x.shape[-1] % 4 == 0:
+            return ops.pixel_unshuffle2(x, out)
+        return ops.pixel_unshuffle(x, r, out)
+
+    def _tail_act(self, pre, res, act, dpre, gout=None):
+        """out = act(pre) + res, rec + task loss against the cached FP output, dL/dout (if wanted) and dL/dpre in one pass."""
+        self._task_is_rec = True
+        ops.loss_act_bwd(pre, res, self.co, self.idx, self.it, 2.0, act, self.loss_log, grad_out=gout, dpre=dpre)
+
+    def _tail_gdn(self, x, norm, res, inverse, gout, tbuf):
+        self._task_is_rec = True
+        ops.loss_gdn_bwd(x, norm, res, self.co, self.idx, self.it, 2.0, inverse, self.loss_log, gout, t=tbuf)
+
     def _forward_backward(self):
         o, t, x = self.ops, self.t, self.x_in
         ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, self.batch_offset)
         if self.kind == "layer" and o["layer"].is_gdn:
             # a GDN / IGDN that is its own unit (sequential Minnen2018-style coders): only gamma is trained, no dx needed
             op = o["layer"]
-            self._conv(op, x, t["y"], epilogue=L.EPI_IGDN if op.inverse else L.EPI_GDN, aux=x, pre=t["norm"], square=True)
-            self._loss(t["y"], t["dy"])
-            ops.gdn_bwd_t(t["dy"], x, t["norm"], op.inverse, t["t"])
+            if self.fused:
+                self._conv(op, x, t["norm"], square=True)                                        # norm pool only
+                self._tail_gdn(x, t["norm"], None, op.inverse, t["dy"], t["t"])
+            else:
+                self._conv(op, x, t["y"], epilogue=L.EPI_IGDN if op.inverse else L.EPI_GDN, aux=x, pre=t["norm"], square=True)
+                self._loss(t["y"], t["dy"])
+                ops.gdn_bwd_t(t["dy"], x, t["norm"], op.inverse, t["t"])
             self._wgrad(op, x, t["t"], square=True)
         elif self.kind == "layer":
             op = o["layer"]
@@ -336,14 +366,19 @@ class UnitEngine:
                 s_, q_, Hu, Wu = self.tc_geom
                 x = ops.zero_insert(x, s_, q_, q_, Hu, Wu, out=t["xu"])
             epi = op.qm.fused_epilogue() if self.include_act else None
-            if epi is not None:
+            if epi is None and self.include_act and type(op.qm.activation_function).__name__ != "StraightThrough":
+                raise NotImplementedError("calibration engine: only LeakyReLU(0.01) or ReLU may be fused into a layer unit")
+            if self.fused:
+                self._conv(op, x, t["y"])                                                         # pre-activation
+                act = {None: ops.ACT_NONE, L.EPI_LRELU: ops.ACT_LRELU, L.EPI_RELU: ops.ACT_RELU}[epi]
+                self._tail_act(t["y"], None, act, t["dpre"])
+                self._wgrad(op, x, t["dpre"])
+            elif epi is not None:
                 self._conv(op, x, t["y"], epilogue=epi)
                 self._loss(t["y"], t["dy"])
                 (ops.lrelu_bwd if epi == L.EPI_LRELU else ops.relu_bwd)(t["dy"], t["y"], t["dpre"])
                 self._wgrad(op, x, t["dpre"])
             else:
-                if self.include_act and type(op.qm.activation_function).__name__ != "StraightThrough":
-                    raise NotImplementedError("calibration engine: only LeakyReLU(0.01) or ReLU may be fused into a layer unit")
                 self._conv(op, x, t["y"])
                 self._loss(t["y"], t["dy"])
                 self._wgrad(op, x, t["dy"])
@@ -354,11 +389,15 @@ class UnitEngine:
             if "skip" in o:
                 self._conv(o["skip"], x, t["sk"])
                 res = t["sk"]
-            self._conv(c2, t["h1"], t["out"], epilogue=L.EPI_LRELU, residual=res, pre=t["pre2"])
-            self._loss(t["out"], t["dout"])
+            if self.fused:
+                self._conv(c2, t["h1"], t["pre2"])
+                self._tail_act(t["pre2"], res, ops.ACT_LRELU, t["dpre2"], gout=t["dout"] if "skip" in o else None)
+            else:
+                self._conv(c2, t["h1"], t["out"], epilogue=L.EPI_LRELU, residual=res, pre=t["pre2"])
+                self._loss(t["out"], t["dout"])
+                ops.lrelu_bwd(t["dout"], t["pre2"], t["dpre2"])
             if "skip" in o:
                 self._wgrad(o["skip"], x, t["dout"])
-            ops.lrelu_bwd(t["dout"], t["pre2"], t["dpre2"])
             self._wgrad(c2, t["h1"], t["dpre2"])
             self._dgrad(c2, t["dpre2"], t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
             self._split_point()
@@ -371,8 +410,12 @@ class UnitEngine:
             if "skip" in o:
                 self._conv(o["skip"], x, t["sk"])
                 res = t["sk"]
-            self._conv(g, t["c2"], t["out"], epilogue=L.EPI_GDN, aux=t["c2"], residual=res, pre=t["norm"], square=True)
-            self._loss(t["out"], t["dout"])
+            if self.fused:
+                self._conv(g, t["c2"], t["norm"], square=True)
+                self._tail_gdn(t["c2"], t["norm"], res, False, t["dout"], t["t"])
+            else:
+                self._conv(g, t["c2"], t["out"], epilogue=L.EPI_GDN, aux=t["c2"], residual=res, pre=t["norm"], square=True)
+                self._loss(t["out"], t["dout"])
             if "skip" in o:
                 self._wgrad(o["skip"], x, t["dout"])
             self._gdn_backward(g, t["dout"], t["c2"], t["norm"], t["t"], t["acc"], t["dc2"], inverse=False)
@@ -384,33 +427,55 @@ class UnitEngine:
             sp, cv, g, up = o["subpel_conv"], o["conv"], o["igdn"], o["upsample"]
             r = self.r
             self._conv(sp, x, t["sp"], epilogue=L.EPI_LRELU)       # LeakyReLU commutes with the pixel shuffle
-            ops.pixel_shuffle(t["sp"], r, t["h1"])
+            self._shuffle(t["sp"], r, t["h1"])
             self._conv(cv, t["h1"], t["c"])
             self._conv(up, x, t["up"])
-            ops.pixel_shuffle(t["up"], r, t["ups"])
-            self._conv(g, t["c"], t["out"], epilogue=L.EPI_IGDN, aux=t["c"], residual=t["ups"], pre=t["norm"], square=True)
-            self._loss(t["out"], t["dout"])
-            ops.pixel_unshuffle(t["dout"], r, t["dup"])
+            self._shuffle(t["up"], r, t["ups"])
+            if self.fused:
+                self._conv(g, t["c"], t["norm"], square=True)
+                self._tail_gdn(t["c"], t["norm"], t["ups"], True, t["dout"], t["t"])
+            else:
+                self._conv(g, t["c"], t["out"], epilogue=L.EPI_IGDN, aux=t["c"], residual=t["ups"], pre=t["norm"], square=True)
+                self._loss(t["out"], t["dout"])
+            self._unshuffle(t["dout"], r, t["dup"])
             self._wgrad(up, x, t["dup"])
             self._gdn_backward(g, t["dout"], t["c"], t["norm"], t["t"], t["acc"], t["dc"], inverse=True)
             self._wgrad(cv, t["h1"], t["dc"])
             self._dgrad(cv, t["dc"], t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
-            ops.pixel_unshuffle(t["dh1"], r, t["dsp"])
+            self._unshuffle(t["dh1"], r, t["dsp"])
             self._split_point()
             self._wgrad(sp, x, t["dsp"])
 
     def _gdn_backward(self, g, dout, xin, norm, tbuf, acc, dx, inverse):
-        ops.gdn_bwd_t(dout, xin, norm, inverse, tbuf)
+        if not self.fused:                                           # the fused tail has already written t
+            ops.gdn_bwd_t(dout, xin, norm, inverse, tbuf)
         if ops.uses_bf16x6(tuple(tbuf.shape), tuple(g.wd4().shape), 1, 0):
             g.enable_planes(False, True)
         ops.conv2d_fwd(tbuf, g.wd4(), None, 1, 0, out=acc, wplanes=g.wd_planes)   # t . gamma'  (wd = gamma'^T as [C][1][1][C])
-        ops.gdn_bwd_dx(dout, xin, norm, acc, inverse, dx)
+        if xin.shape[-1] % 4 == 0:
+            ops.gdn_bwd_dx_p3(dout, xin, norm, acc, inverse, dx=dx)   # 16-byte accesses
+        else:
+            ops.gdn_bwd_dx(dout, xin, norm, acc, inverse, dx)
         self._wgrad(g, xin, tbuf, square=True)                        # dgamma'[k][i] = sum_m t_k x_i^2
 
     def _grad_ops(self, names):
         for n in names:
             op = self.ops[n]
             ops.adaround_grad(op.desc, op.w, op.alpha, op.delta, op.zp, op.slabs, op.dalpha)
+
+    def _step_ops(self):
+        """AdaRound step of every op of the unit + iteration counter: one batched launch (+ one for the dgrad layouts) when the
+        tensors allow it, else one launch per op.  The bf16 planes of the new weights are written by the same launches."""
+        opl = list(self.ops.values())
+        if self.batch_step and len(opl) <= 8 and all(op.numel() % 4 == 0 for op in opl):
+            items = [dict(d=op.desc, w=op.w, delta=op.delta, zp=op.zp, slabs=op.slabs, alpha=op.alpha, m=op.m, v=op.v, wq=op.wq,
+                          wd=op.wd, wq_planes=op.wq_planes, wd_planes=op.wd_planes) for op in opl]
+            ops.adaround_step_batch(items, 1.0, self.weight, self.sched, self.it, self.round_log, advance_iter=self.it)
+            return
+        for op in opl:
+            ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
+                              op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
+        ops.iter_advance(self.it)
 
     def _split_point(self):
         """Called by the backward pass right before its last weight-gradient kernel.  Data-parallel recording only: the gradients
@@ -432,11 +497,7 @@ class UnitEngine:
         try:
             self._forward_backward()
             if not self.split:
-                for op in self.ops.values():
-                    # the bf16 planes of the new weights (split-precision conv path) are written by the same launch
-                    ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
-                                      op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
-                ops.iter_advance(self.it)
+                self._step_ops()
             elif self.plan_a2 is not None:
                 self._grad_ops([self._late])
             else:

@@ -322,3 +322,26 @@ def test_engine_ten_bit_weights_match_oracle(golden_dir):
     ent = integer_state(qm)[""]
     assert ent["levels"].dtype == torch.int32 and int(ent["levels"].max()) > 255 and int(ent["levels"].max()) <= 1023
     torch.testing.assert_close(dequantize(ent).cuda(), qm.weight_quantizer(qm.weight).detach(), rtol=0, atol=1e-6)
+
+
+@pytest.mark.parametrize("tag,kind", RECON_UNITS)
+def test_fused_tails_and_batched_step_change_nothing(recon, tag, kind):
+    """The fused unit tails (csrc/fused_tail.hip) and the one-launch AdaRound step execute the same fp32 operations as the chains
+    of separate kernels they replace: trained alphas are bit-identical, the logged loss differs only in summation order."""
+    from quantization.engine import UnitEngine
+    fx = recon
+    _, _, B, iters = (int(v) for v in fx["meta"])
+    idx = torch.from_numpy(fx[f"{tag}/idx"])
+    res = []
+    for fuse, batch in ((True, True), (False, False), (True, False)):
+        unit, k, mods = product_unit(fx, tag, kind)
+        eng = UnitEngine(k, mods, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]), batch_size=B,
+                         iters=iters, input_prob=0.5, seed=SEED, idx_table=idx, fuse_tail=fuse, batch_step=batch)
+        assert eng.fused == fuse
+        eng.run()
+        torch.cuda.synchronize()
+        res.append(({n: eng.alpha_of(n).clone() for n in eng.ops}, eng.logs()[0]))
+    for other in res[1:]:
+        for n in res[0][0]:
+            assert torch.equal(res[0][0][n], other[0][n]), n
+        torch.testing.assert_close(res[0][1], other[1], rtol=1e-5, atol=1e-9)
