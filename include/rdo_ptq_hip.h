@@ -276,6 +276,10 @@ int64_t rdo_conv2d_fwd_p3_workspace(const rdo_conv_desc* d);   /* floats of spli
 int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
                       const float* residual, float* out, float* pre, void* out_planes, float* workspace, int64_t workspace_floats,
                       void* stream);
+/* rdo_conv2d_wgrad with both operands as P3 planes (x: [B*H*W][Cin], dy: [B*Ho*Wo][Cout]); same slabs, same nsplit rule
+ * (rdo_conv2d_wgrad_nsplit).  Supported for the shapes of rdo_conv2d_wgrad_uses_bf16x6 with Cin % 16 == Cout % 16 == 0, no square_input. */
+int rdo_conv2d_wgrad_p3_supported(const rdo_conv_desc* d);
+int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes, const void* dy_planes, float* slabs, int nsplit, void* stream);
 /* rdo_gather_qdrop writing the mini-batch as P3 planes (and as fp32 when `out` != NULL) */
 int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
                         int32_t batch_offset, int64_t per_image, int32_t C, float prob, uint32_t seed, float* out, void* out_planes,

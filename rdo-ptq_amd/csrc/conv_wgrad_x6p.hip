@@ -1,0 +1,286 @@
+// Weight gradient of the LARGE problems on "P3" tensors (exact three-way bf16 splits in slice-major planes, rdo_ptq_hip.h):
+//   dw[co][tap][ci] = sum_m dy[m][co] * x[pix(m, tap)][ci]      on v_mfma_f32_16x16x32_bf16, six products, fp32 accumulate.
+//
+// The fp32-input kernel (conv_wgrad_x6.hip) spends 4.6 vector instructions per MFMA in its loader: it splits both operands for
+// every tap workgroup again and transposes them in registers, because the MFMA wants 8 consecutive PIXELS per lane while NHWC memory
+// has channels contiguous.  Here both operands arrive by LDS-DMA exactly as they lie in memory -- [pixel][channel] records of the
+// planes the producers wrote -- and the transposition is done by the LDS itself: ds_read_b64_tr_b16 hands every lane the four pixels
+// of its channel.  The K loop contains no conversion and no permutation arithmetic.
+//
+// Tile 192 (co) x 192 (ci) per tap, 512 threads: wave (w >> 1, w & 1) owns 48 x 96 as 3 x 6 MFMA tiles, 32 pixels per stage.
+// LDS image of a stage, per operand and plane: [3 channel sub-tiles of 64][32 pixels][8 chunks of 16 B] = 12 KiB, i.e. 72 KiB per
+// stage, double buffered.  A DMA piece is 8 pixels x 128 bytes of one sub-tile (1 KiB, lane l -> pixel l >> 3, chunk l & 7); waves
+// 0-3 fetch dY, waves 4-7 fetch X, nine pieces each per stage, all for ONE pixel row per lane.  The DMA of stage s+1 is issued at
+// the top of stage s: a full stage (216 MFMAs per SIMD) to land.
+// Bank conflicts: chunk position c' = c ^ 2 ((pixel >> 1) & 3) (applied on the per-lane SOURCE address); a transposed read of a
+// 32-lane half covers 8 consecutive pixels x 32 bytes and then touches all 64 banks once.
+// K slots: the MFMA sums over 32 k values and both operands may use ANY common assignment of pixels to k slots.  Lane group g
+// (lanes 16g..16g+15) holds pixels 4g..4g+3 (first read) and 16+4g..16+4g+3 (second read) of the stage.
+#include <utility>
+
+#include "rdo_common.h"
+
+namespace {
+
+typedef float f32x4acc __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned short u16;
+
+__device__ __attribute__((aligned(64))) unsigned g_zero_page_w[16];
+
+constexpr int PK = 32;
+constexpr int SUBB = 32 * 128;                 // bytes of one [32 pixels][64 channels] sub-tile image
+constexpr int PLANEB = 3 * SUBB;               // 192 channels of one plane
+constexpr int OPB = 3 * PLANEB;                // one operand (three planes)
+constexpr int STAGEB = 2 * OPB;                // 72 KiB
+
+struct WgPArgs {
+    const u16* xp;
+    const u16* yp;
+    long xplane, yplane;       // elements per plane
+    float* slabs;
+    int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
+    int M, Min, mchunk, nsplit;
+    int tiles_co, tiles_ci;
+};
+
+__device__ __forceinline__ bf16x8 tr_pair(const char* p) {
+    typedef __attribute__((address_space(3))) s16x4 lds_v4;
+    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p));
+    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 16 * 128));      // pixels + 16
+    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+}
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
+    constexpr int T = 192;
+    constexpr int TM = 3, TN = 6;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][STAGEB]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lc = lane >> 4;
+    const int wco0 = (wave >> 1) * 48, wci0 = (wave & 1) * 96;
+
+    // XCD-aware numbering, tap fastest (as conv_wgrad_x6.hip)
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int chunk = lid / gridDim.y;
+    int t = lid - chunk * gridDim.y;
+    const int tci = t % a.tiles_ci; t /= a.tiles_ci;
+    const int tco = t % a.tiles_co; t /= a.tiles_co;
+    const int tap = t;
+    const int kh = tap / a.KW, kw = tap - kh * a.KW;
+    const int co0 = tco * T, ci0 = tci * T;
+
+    const int mbeg = chunk * a.mchunk;
+    const int mend = min(a.M, mbeg + a.mchunk);
+    const int nsteps = mend > mbeg ? (mend - mbeg + PK - 1) / PK : 0;
+    const int HoWo = a.Ho * a.Wo;
+
+    // ---- loader: waves 0-3 fetch dY, waves 4-7 fetch X; this lane always serves pixel row 8 (wave & 3) + (lane >> 3) of the stage
+    const bool ldx = wave >= 4;
+    const int prow = (wave & 3) * 8 + (lane >> 3);
+    const int cpos = lane & 7;
+    const int csrc = cpos ^ (2 * ((prow >> 1) & 3));                     // source chunk that belongs at LDS position cpos
+    const u16* const zero = reinterpret_cast<const u16*>(g_zero_page_w);
+    // element offset of this lane's chunk inside a plane, without the pixel: sub-tile `sub` adds 4 slices
+    const int ch0 = (ldx ? ci0 : co0) + 8 * csrc;                        // first channel of the chunk in sub-tile 0
+    const int Cop = ldx ? a.Cin : a.Cout;
+    const long Mop = ldx ? a.Min : a.M;
+    const long pstride = ldx ? a.xplane : a.yplane;
+    const u16* const opbase = ldx ? a.xp : a.yp;
+    // running output-pixel position of this lane (advances by 32 per stage)
+    int st_m = mbeg + prow;
+    int st_wo = 0, st_ho = 0, st_hi = 0, st_wi = 0, st_pix = 0;
+    if (ldx) {
+        const int mm = st_m < a.M ? st_m : 0;
+        const int b = mm / HoWo;
+        const int rem = mm - b * HoWo;
+        st_ho = rem / a.Wo;
+        st_wo = rem - st_ho * a.Wo;
+        st_hi = st_ho * a.stride - a.pad + kh;
+        st_wi = st_wo * a.stride - a.pad + kw;
+        st_pix = (b * a.H + st_hi) * a.W + st_wi;
+    }
+    auto advance = [&]() {
+        st_m += PK;
+        if (!ldx) return;
+        st_wo += PK;
+        st_wi += PK * a.stride;
+        st_pix += PK * a.stride;
+        while (st_wo >= a.Wo) {
+            st_wo -= a.Wo;
+            st_wi -= a.Wo * a.stride;
+            st_pix += (a.stride * a.W - a.Wo * a.stride);
+            st_hi += a.stride;
+            if (++st_ho >= a.Ho) {
+                st_ho = 0;
+                st_hi -= a.Ho * a.stride;
+                st_pix += (a.H * a.W - a.Ho * a.stride * a.W);
+            }
+        }
+    };
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto dma_stage = [&](int buf) {
+        bool ok = st_m < mend;
+        long pix = st_m;
+        if (ldx) {
+            ok = ok && (unsigned)st_hi < (unsigned)a.H && (unsigned)st_wi < (unsigned)a.W;
+            pix = st_pix;
+        }
+        char* dst = smem + buf * STAGEB + (ldx ? OPB : 0) + (wave & 3) * 1024;
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub) {
+            const int ch = ch0 + 64 * sub;
+            const bool okc = ok && ch < Cop;
+            const u16* src = okc ? opbase + ((long)(ch >> 4) * Mop + pix) * 16 + (ch & 15) : zero;
+            const long ps = okc ? pstride : 0;
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+                __builtin_amdgcn_global_load_lds((glb_void*)(src + p * ps), (lds_void*)(dst + p * PLANEB + sub * SUBB), 16, 0, 0);
+        }
+        advance();
+    };
+
+    f32x4acc acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addresses: lane (g = lane >> 4, q = (lane >> 2) & 3, p4 = lane & 3) supplies pixel 4g + q, channels 4 p4 .. 4 p4 + 3
+    const int fr = 4 * lc + ((lane >> 2) & 3);                           // pixel row of the first read
+    const int p4 = lane & 3;
+    const int fsw = 2 * ((fr >> 1) & 3);
+    int fa_off[TM], fb_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int c = wco0 + 16 * i;                                     // first channel of the tile inside the 192-wide image
+        const int chunkpos = (2 * ((c & 63) >> 4) + (p4 >> 1)) ^ fsw;
+        fa_off[i] = (c >> 6) * SUBB + fr * 128 + chunkpos * 16 + (p4 & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = wci0 + 16 * j;
+        const int chunkpos = (2 * ((c & 63) >> 4) + (p4 >> 1)) ^ fsw;
+        fb_off[j] = OPB + (c >> 6) * SUBB + fr * 128 + chunkpos * 16 + (p4 & 1) * 8;
+    }
+    (void)l16;
+
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+
+    if (nsteps > 0) dma_stage(0);
+    bf16x8 fa[3][TM], fb[2][3][2];
+    auto read_b = [&](auto setc, const char* st, int third) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[S][p][j] = tr_pair(st + p * PLANEB + fb_off[2 * third + j]);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of stage s have landed
+        __builtin_amdgcn_s_barrier();                                    // ... everybody's have, and nobody reads buffer buf ^ 1 any more
+        if (s + 1 < nsteps) dma_stage(buf ^ 1);
+        const char* st = smem + buf * STAGEB;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
+        read_b(S0{}, st, 0);
+        [&]<int... SL>(std::integer_sequence<int, SL...>) {
+            (([&] {
+                 constexpr int T3 = SL / 6, Q = SL % 6, SET = T3 & 1;
+                 if constexpr (Q == 0 && T3 < 2) {
+                     if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
+                     else read_b(S0{}, st, T3 + 1);
+                 }
+#pragma unroll
+                 for (int i = 0; i < TM; ++i)
+#pragma unroll
+                     for (int j = 0; j < 2; ++j)
+                         acc[i][2 * T3 + j] =
+                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
+        }
+        (std::make_integer_sequence<int, 18>{});
+    }
+
+    const long wsize = (long)a.Cout * a.KH * a.KW * a.Cin;
+    float* slab = a.slabs + (long)chunk * wsize;
+    const int taps = a.KH * a.KW;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + wci0 + j * 16 + l16;
+        if (ci >= a.Cin) continue;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wco0 + i * 16 + 4 * lc + r;
+                if (co < a.Cout) slab[((long)co * taps + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int rdo_conv2d_wgrad_uses_bf16x6(const rdo_conv_desc* d);
+extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d);
+
+extern "C" int rdo_conv2d_wgrad_p3_supported(const rdo_conv_desc* d) {
+    if (!d || d->square_input || d->Cin % 16 != 0 || d->Cout % 16 != 0) return 0;
+    if ((double)d->B * d->H * d->W * d->Cin >= 2147483648.0 || (double)d->B * d->Ho * d->Wo * d->Cout >= 2147483648.0) return 0;
+    return rdo_conv2d_wgrad_uses_bf16x6(d);
+}
+
+extern "C" int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes, const void* dy_planes, float* slabs, int nsplit,
+                                   void* stream) {
+    RDO_REQUIRE(d && x_planes && dy_planes && slabs && nsplit >= 1, "rdo_conv2d_wgrad_p3: bad argument");
+    RDO_REQUIRE(rdo_conv2d_wgrad_p3_supported(d), "rdo_conv2d_wgrad_p3: shape not on the split-bf16 plane path (rdo_conv2d_wgrad_p3_supported)");
+    constexpr int T = 192;
+    WgPArgs a{};
+    a.xp = reinterpret_cast<const u16*>(x_planes);
+    a.yp = reinterpret_cast<const u16*>(dy_planes);
+    a.slabs = slabs;
+    a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;
+    a.M = d->B * d->Ho * d->Wo;
+    a.Min = d->B * d->H * d->W;
+    a.xplane = (long)a.Min * a.Cin;
+    a.yplane = (long)a.M * a.Cout;
+    a.nsplit = nsplit;
+    // same chunking as rdo_conv2d_wgrad: whole 32-pixel steps per chunk
+    long mchunk = rdo::ceil_div(rdo::ceil_div((long)a.M, nsplit), 32) * 32;
+    a.mchunk = (int)mchunk;
+    RDO_REQUIRE((long)nsplit * mchunk >= a.M, "rdo_conv2d_wgrad_p3: nsplit too small");
+    a.tiles_co = (int)rdo::ceil_div(a.Cout, T);
+    a.tiles_ci = (int)rdo::ceil_div(a.Cin, T);
+    const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
+    const double bytes = 6.0 * (a.xplane + a.yplane) + 4.0 * nsplit * (double)a.Cout * a.KH * a.KW * a.Cin;
+    return rdo::dispatch(
+        [a](hipStream_t s) {
+            constexpr size_t lds = (size_t)2 * STAGEB;
+            static bool attr = false;
+            if (!attr) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)lds) != hipSuccess)
+                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6p) failed");
+                attr = true;
+            }
+            dim3 grid((unsigned)a.nsplit, (unsigned)(a.KH * a.KW * a.tiles_co * a.tiles_ci));
+            hipLaunchKernelGGL(conv_wgrad_x6p_kernel, grid, dim3(512), lds, s, a);
+            return rdo::check_launch("conv_wgrad_x6p");
+        },
+        stream, "conv_wgrad_x6_p3_192x192", flops, bytes);
+}

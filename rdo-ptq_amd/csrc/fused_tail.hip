@@ -258,7 +258,7 @@ int rdo_loss_act_bwd(const float* pre, const float* residual, const float* tgt_c
                      int32_t B, int64_t per_image, int32_t C, float coef, int32_t act, float* out, float* grad_out, float* dpre,
                      void* dpre_planes, float* loss_out, void* stream) {
     RDO_REQUIRE(pre && tgt_cache && idx_table && iter_ptr && (dpre || dpre_planes || grad_out), "rdo_loss_act_bwd: null pointer");
-    RDO_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && per_image > 0 && per_image % C == 0, "rdo_loss_act_bwd: bad shape");
+    RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_loss_act_bwd: bad shape");
     RDO_REQUIRE(!dpre_planes || C % 16 == 0, "rdo_loss_act_bwd: P3 output needs C % 16 == 0");
     RDO_REQUIRE(act >= 0 && act <= 2, "rdo_loss_act_bwd: act %d (0 none, 1 LeakyReLU(0.01), 2 ReLU)", act);
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
@@ -278,7 +278,7 @@ int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, c
                      const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef, int32_t inverse, float* out,
                      float* grad_out, float* t, void* t_planes, float* loss_out, void* stream) {
     RDO_REQUIRE(x && norm && tgt_cache && idx_table && iter_ptr && grad_out && (t || t_planes), "rdo_loss_gdn_bwd: null pointer");
-    RDO_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && per_image > 0 && per_image % C == 0, "rdo_loss_gdn_bwd: bad shape");
+    RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_loss_gdn_bwd: bad shape");
     RDO_REQUIRE(!t_planes || C % 16 == 0, "rdo_loss_gdn_bwd: P3 output needs C % 16 == 0");
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
     u16* pl = reinterpret_cast<u16*>(t_planes);
@@ -295,7 +295,7 @@ int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, c
 
 int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t C, int32_t inverse,
                       float* dx, void* dx_planes, void* stream) {
-    RDO_REQUIRE(g && x && norm && acc && (dx || dx_planes) && n > 0 && C > 0 && C % 4 == 0 && n % C == 0, "rdo_gdn_bwd_dx_p3: bad argument");
+    RDO_REQUIRE(g && x && norm && acc && (dx || dx_planes) && n > 0 && n % 4 == 0 && C > 0 && n % C == 0, "rdo_gdn_bwd_dx_p3: bad argument");
     RDO_REQUIRE(!dx_planes || C % 16 == 0, "rdo_gdn_bwd_dx_p3: P3 output needs C % 16 == 0");
     u16* pl = reinterpret_cast<u16*>(dx_planes);
     return rdo::dispatch(

@@ -452,7 +452,7 @@ class UnitEngine:
         if ops.uses_bf16x6(tuple(tbuf.shape), tuple(g.wd4().shape), 1, 0):
             g.enable_planes(False, True)
         ops.conv2d_fwd(tbuf, g.wd4(), None, 1, 0, out=acc, wplanes=g.wd_planes)   # t . gamma'  (wd = gamma'^T as [C][1][1][C])
-        if xin.shape[-1] % 4 == 0:
+        if xin.numel() % 4 == 0:
             ops.gdn_bwd_dx_p3(dout, xin, norm, acc, inverse, dx=dx)   # 16-byte accesses
         else:
             ops.gdn_bwd_dx(dout, xin, norm, acc, inverse, dx)

@@ -175,3 +175,28 @@ def test_pixel_shuffle_p3(ops):
     ops.pixel_shuffle_p3(x, out=out, out_planes=pl)
     assert torch.equal(out, ref) and torch.equal(ops.p3_to_float(pl, ref.shape), ref)
     assert torch.equal(ref, torch.nn.functional.pixel_shuffle(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+
+
+WGRAD_SHAPES = [(4, 128, 192, 192, 3, 1, 1), (4, 64, 192, 768, 3, 1, 1), (4, 64, 192, 192, 3, 1, 1), (4, 128, 192, 192, 3, 2, 1),
+                (4, 32, 192, 192, 3, 1, 1), (2, 64, 320, 192, 5, 2, 2), (4, 32, 192, 320, 5, 2, 2), (4, 16, 192, 768, 3, 1, 1)]
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,K,s,p", WGRAD_SHAPES)
+def test_wgrad_p3_matches_fp64_and_fp32_input_kernel(ops, B, H, Cin, Cout, K, s, p):
+    """Plane-input weight gradient (LDS-DMA + transposed LDS reads) against fp64 over all output channels, and against the
+    fp32-input bf16x6 kernel (same exact products, different summation order inside a 32-pixel step)."""
+    from test_gpu_x6_parity import wgrad_fp64
+    g = torch.Generator(device="cuda").manual_seed(H * 31 + Cout + K)
+    x = torch.randn(B, H, H, Cin, device="cuda", generator=g)
+    Ho = (H + 2 * p - K) // s + 1
+    dy = torch.randn(B, Ho, Ho, Cout, device="cuda", generator=g) * 0.1
+    wshape = (Cout, K, K, Cin)
+    assert ops.wgrad_p3_supported(tuple(x.shape), wshape, s, p)
+    ref6 = ops.reduce_slabs(ops.conv2d_wgrad(x, dy, wshape, s, p))
+    slabs = ops.conv2d_wgrad_p3(ops.split_p3(x), tuple(x.shape), ops.split_p3(dy), wshape, s, p)
+    dw = ops.reduce_slabs(slabs)
+    ref = wgrad_fp64(x, dy, K, s, p)
+    scale = float(ref.abs().max())
+    e = float((dw.double() - ref).abs().max()) / scale
+    e6 = float((ref6.double() - ref).abs().max()) / scale
+    assert e < 1e-5 and e < 2.0 * e6 + 2e-7, (e, e6)

@@ -50,3 +50,21 @@ for (B, H, Cin, Cout, K, s, p) in SHAPES:
         ops.set_tuning("x6p_ablate", 0)
     print(f"B={B} H={H} {Cin}->{Cout} k{K} s{s}: fp32-in x6 {t_old:7.1f} us ({gf / t_old * 1e3:6.1f} TF) | p3 out {t_p3:7.1f} us ({gf / t_p3 * 1e3:6.1f} TF)"
           f" | out+planes {t_p3b:7.1f} | planes only {t_p3p:7.1f}" + "".join(f" | abl{m}: {t:6.1f}" for m, t in abl))
+
+
+print("---- weight gradient: fp32-input x6 (eight-wave) vs plane input")
+for (B, H, Cin, Cout, K, s, p) in SHAPES:
+    torch.manual_seed(1)
+    x = torch.randn(B, H, H, Cin, device="cuda")
+    Ho = (H + 2 * p - K) // s + 1
+    dy = torch.randn(B, Ho, Ho, Cout, device="cuda") * 0.1
+    wshape = (Cout, K, K, Cin)
+    if not ops.wgrad_p3_supported(tuple(x.shape), wshape, s, p):
+        print(f"B={B} H={H} {Cin}->{Cout} k{K} s{s}: not on the plane path")
+        continue
+    slabs = ops.conv2d_wgrad(x, dy, wshape, s, p)
+    xp, dyp = ops.split_p3(x), ops.split_p3(dy)
+    gf = 2.0 * dy.numel() * Cin * K * K / 1e9
+    t_old = timeit(lambda: ops.conv2d_wgrad(x, dy, wshape, s, p, slabs=slabs))
+    t_new = timeit(lambda: ops.conv2d_wgrad_p3(xp, tuple(x.shape), dyp, wshape, s, p, slabs=slabs))
+    print(f"B={B} H={H} {Cin}->{Cout} k{K} s{s}: nsplit {slabs.shape[0]:3d}  fp32-in {t_old:7.1f} us ({gf / t_old * 1e3:6.1f} TF) | p3 {t_new:7.1f} us ({gf / t_new * 1e3:6.1f} TF)")
