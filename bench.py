@@ -74,7 +74,9 @@ def parse():
     ap.add_argument("--crop", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=6, help="timed oracle iterations per unit for cpu_baseline")
+    ap.add_argument("--cpu-iters", type=int, default=20, help="timed oracle iterations per unit for cpu_baseline")
+    ap.add_argument("--sustain-steps", type=int, default=1000,
+                    help="steps run AFTER the timed region in windows of 100 to report a sustained rate (0: skip)")
     return ap.parse_args()
 
 
@@ -163,7 +165,8 @@ def gpu_leg(a, rank, world, device):
     log(f"caches built in {t_cache:.1f}s; recording engines")
     force_dp = bool(os.environ.get("RDO_BENCH_FORCE_DP"))    # exercise the grad -> RCCL all-reduce -> apply sequence on 1 rank
     unit_wall = bool(os.environ.get("RDO_BENCH_UNIT_WALL"))   # diagnostic: per-unit wall time of graph replays after the timed region
-    iters = a.warmup + a.steps + 1 + (a.steps if unit_wall else 0)   # +1: the event-profiled iteration after the timed region
+    sustain = (a.sustain_steps // 100) * 100
+    iters = a.warmup + a.steps + sustain + 1 + (a.steps if unit_wall else 0)   # +1: the event-profiled iteration after the timed region
     gi = torch.Generator().manual_seed(77 + rank)
     engines = []
     for name, u in units:
@@ -196,6 +199,22 @@ def gpu_leg(a, rank, world, device):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     log(f"timed region done: {dt:.3f}s for {a.steps} steps")
+    # ---- sustained rate: the driver-sized timed region lasts a fraction of a second on a part whose clock moves with load and
+    # temperature; run on for `sustain` more steps in windows of 100 (each closed by the same barrier) and report them
+    windows = []
+    for _ in range(sustain // 100):
+        t1 = time.perf_counter()
+        for _, e in engines:
+            e.run(100)
+        barrier()
+        w = time.perf_counter() - t1
+        if dist:
+            tw = torch.tensor([w], device=device, dtype=torch.float64)
+            dist.all_reduce(tw, op=dist.ReduceOp.MAX)
+            w = float(tw.item())
+        windows.append(w / 100 * 1e3)
+    if windows:
+        log(f"sustained: {sum(windows) / len(windows):.3f} ms/step over {sustain} steps (windows {min(windows):.3f} .. {max(windows):.3f})")
     if unit_wall:
         for uname, e in engines:
             torch.cuda.synchronize()
@@ -227,9 +246,10 @@ def gpu_leg(a, rank, world, device):
     # sanity: losses finite
     for name, e in engines:
         tot, _, _ = e.logs()
-        if not torch.isfinite(tot[:a.warmup + a.steps]).all():
+        if not torch.isfinite(tot[:a.warmup + a.steps + sustain]).all():
             raise RuntimeError(f"non-finite loss in unit {name}")
-    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache)
+    p3_units = [n for n, e in engines if getattr(e, "p3_plan", None)]
+    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, p3_units=p3_units)
 
 
 # ----------------------------------------------------------------------------- CPU baseline (oracle = "port")
@@ -298,13 +318,15 @@ def main():
                        "gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[3] else None}
                    for t, v in sorted(res["per_tag"].items(), key=lambda kv: -kv[1][1])}
         traffic, traffic_src = None, None
-        try:        # HBM-side bytes per launch of the dominant kernel from the last committed rocprofv3 --pmc passes
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-            if dom in tj:
-                traffic = round((2 * tj[dom]["fetch_mib_raw"] + tj[dom]["write_mib"]) * 1048576)
-                traffic_src = "profiles/r01_traffic.json (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, bytes per launch)"
-        except Exception:
-            pass
+        for tf in ("r02_traffic.json", "r01_traffic.json"):   # HBM-side bytes per launch of the dominant kernel, last committed --pmc passes
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+                if dom in tj:
+                    traffic = round((2 * tj[dom]["fetch_mib_raw"] + tj[dom]["write_mib"]) * 1048576)
+                    traffic_src = f"profiles/{tf} (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, bytes per launch)"
+                    break
+            except Exception:
+                pass
         out = {
             "metric": "calibration images/sec (Cheng2020 W8A8 task-oriented RDO-PTQ, image-iterations over all units)",
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -315,7 +337,8 @@ def main():
                        "units": n_units, "batch_per_gpu": a.batch, "images_per_gpu": a.images,
                        "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
                        "gemm_arithmetic": "fp32-accurate: large convs on bf16 MFMA with exact 3-way operand split (6 products, "
-                                          "fp32 accumulate), all others on fp32 MFMA",
+                                          "fp32 accumulate; operands of the 128^2 units pre-split by their producers = P3 tensors), "
+                                          "all others on fp32 MFMA",
                        "cache_build_s": round(res["t_cache"], 2)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
                          "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -324,6 +347,13 @@ def main():
                          "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3)},
             "kernels": kernels,
         }
+        if res["windows"]:
+            w = res["windows"]
+            out["sustained_ms_per_step"] = round(sum(w) / len(w), 3)
+            out["sustained_steps"] = 100 * len(w)
+            out["sustained_value"] = round(n_units * a.batch * world / (sum(w) / len(w) * 1e-3), 2)
+            out["sustained_window_ms"] = {"min": round(min(w), 3), "max": round(max(w), 3), "windows_of": 100}
+        out["config"]["p3_units"] = res["p3_units"]
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_leg(a)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)

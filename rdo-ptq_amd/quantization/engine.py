@@ -138,7 +138,7 @@ class _Op:
 class UnitEngine:
     def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
                  warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
-                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=True, fuse_tail=True, batch_step=True):
+                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=True, fuse_tail=True, batch_step=True, use_p3=True):
         if kind not in UNIT_KINDS:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
@@ -153,6 +153,8 @@ class UnitEngine:
         self.use_graph = use_graph
         self.batch_offset = int(batch_offset)  # first row of this rank's share of the global mini-batch (QDrop counter)
         self.dp_overlap = bool(dp_overlap)
+        self.use_p3 = bool(use_p3)             # big units on P3 tensors (plane-input LDS-DMA GEMM kernels); False: fp32 activations only
+        self.P = {}                            # name -> planes of the P3 form of an activation buffer
         self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
         self.fuse_tail = bool(fuse_tail)       # False: the separate epilogue / loss / activation-backward kernels (A/B, tests)
         self.dev = cache_q.device
@@ -346,8 +348,135 @@ class UnitEngine:
         self._task_is_rec = True
         ops.loss_gdn_bwd(x, norm, res, self.co, self.idx, self.it, 2.0, inverse, self.loss_log, gout, t=tbuf)
 
+    # ------------------------------------------------------------------------------------------------------------------ P3 path
+    P3_MIN_OUT = 65536 * 192        # plane-input forward kernel pays off from 4 x 128^2 x 192 output elements (profiles/r02a)
+
+    def _p3(self, name, like):
+        if name not in self.P:
+            self.P[name] = ops.p3_empty(like.shape, self.dev)
+        return self.P[name]
+
+    def _conv_ok_p3(self, op, x_shape, dgrad=False):
+        if dgrad:
+            w4, stride, pad = tuple(op.wd4().shape), 1, op.K - 1 - op.pad
+        else:
+            w4, stride, pad = op.w4, op.stride, op.pad
+        if not ops.conv_p3_supported(tuple(x_shape), w4, stride, pad):
+            return False
+        d = ops.conv_desc(tuple(x_shape), w4, stride, pad)
+        return d.B * d.Ho * d.Wo * d.Cout >= self.P3_MIN_OUT
+
+    def _conv_p3(self, op, xp, x_shape, out=None, out_planes=None, epilogue=L.EPI_NONE, aux=None, residual=None, pre=None):
+        op.enable_planes(True, False)
+        ops.conv2d_fwd_p3(xp, tuple(x_shape), op.w4, op.wq_planes, op.beta if op.is_gdn else op.bias, op.stride, op.pad,
+                          epilogue=epilogue, aux=aux, residual=residual, out=out, pre=pre, out_planes=out_planes)
+
+    def _dgrad_p3(self, op, dyp, dy_shape, out=None, out_planes=None, epilogue=L.EPI_NONE, aux=None):
+        op.enable_planes(False, True)
+        ops.conv2d_fwd_p3(dyp, tuple(dy_shape), tuple(op.wd4().shape), op.wd_planes, None, 1, op.K - 1 - op.pad, epilogue=epilogue,
+                          aux=aux, out=out, out_planes=out_planes)
+
+    def _wgrad_p3(self, op, xp, x_shape, dyp):
+        if op.slabs is None:
+            self._slabs(op, x_shape)
+        ops.conv2d_wgrad_p3(xp, tuple(x_shape), dyp, op.w4, op.stride, op.pad, slabs=op.slabs)
+
+    def _gdn_backward_p3(self, g, dout, xin, norm, tp, acc, dxp):
+        """GDN / IGDN backward with t given as planes `tp` (written by the fused tail): acc = t . gamma' on the plane kernel, then
+        dx as planes only (its consumers are the plane-input weight gradient and dgrad)."""
+        self._dgrad_p3(g, tp, xin.shape, out=acc)
+        ops.gdn_bwd_dx_p3(dout, xin, norm, acc, g.inverse, dx_planes=dxp)
+
+    def _plan_p3(self):
+        """Which big convs of this unit run on P3 tensors (decided once, at record time)."""
+        o, k = self.ops, self.kind
+        if not (self.use_p3 and self.fused):
+            return None
+        xs = tuple(self.x_in.shape)
+        if k == "rb" and "skip" not in o:
+            c1, c2 = o["conv1"], o["conv2"]
+            hs = tuple(self.t["h1"].shape)
+            if (self._conv_ok_p3(c1, xs) and self._conv_ok_p3(c2, hs) and self._conv_ok_p3(c2, hs, dgrad=True)
+                    and ops.wgrad_p3_supported(xs, c1.w4, c1.stride, c1.pad) and ops.wgrad_p3_supported(hs, c2.w4, 1, c2.pad)):
+                return "rb"
+        if k in ("rbws", "rbu"):
+            cv, g = (o["conv2"], o["gdn"]) if k == "rbws" else (o["conv"], o["igdn"])
+            hs = tuple(self.t["h1"].shape)
+            if (hs[-1] % 16 == 0 and (k != "rbu" or self.r == 2) and self._conv_ok_p3(cv, hs) and self._conv_ok_p3(cv, hs, dgrad=True)
+                    and ops.wgrad_p3_supported(hs, cv.w4, 1, cv.pad) and self._conv_ok_p3(g, hs, dgrad=True)):
+                return k
+        return None
+
+    def _fb_rb_p3(self):
+        o, t, x = self.ops, self.t, self.x_in
+        c1, c2 = o["conv1"], o["conv2"]
+        xp, h1p = self._p3("x", x), self._p3("h1", t["h1"])
+        dp2p, dh1p = self._p3("dpre2", t["h1"]), self._p3("dh1", t["h1"])
+        ops.gather_qdrop_p3(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, xp, self.batch_offset)
+        self._conv_p3(c1, xp, x.shape, out=t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
+        self._conv_p3(c2, h1p, t["h1"].shape, out=t["pre2"])
+        self._task_is_rec = True
+        ops.loss_act_bwd(t["pre2"], x, self.co, self.idx, self.it, 2.0, ops.ACT_LRELU, self.loss_log, dpre_planes=dp2p)
+        self._wgrad_p3(c2, h1p, t["h1"].shape, dp2p)
+        self._dgrad_p3(c2, dp2p, t["h1"].shape, out_planes=dh1p, epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+        self._split_point()
+        self._wgrad_p3(c1, xp, x.shape, dh1p)
+
+    def _fb_gdn_block_p3(self):
+        """RBWS / RBU whose second conv and GDN run at >= 4 x 128^2 x 192: that conv, its weight gradient and dgrad, and the
+        gamma'^T GEMM of the GDN backward on P3 tensors; the (cheap or thin) first convs stay on fp32 activations."""
+        o, t, x = self.ops, self.t, self.x_in
+        rbu = self.kind == "rbu"
+        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, self.batch_offset)
+        if rbu:
+            sp, cv, g, up = o["subpel_conv"], o["conv"], o["igdn"], o["upsample"]
+            cname, dname = "c", "dc"
+        else:
+            c1, cv, g = o["conv1"], o["conv2"], o["gdn"]
+            cname, dname = "c2", "dc2"
+        h1p, tp, dcp = self._p3("h1", t["h1"]), self._p3("t", t["h1"]), self._p3(dname, t["h1"])
+        if rbu:
+            r = self.r
+            self._conv(sp, x, t["sp"], epilogue=L.EPI_LRELU)
+            ops.pixel_shuffle_p3(t["sp"], out=t["h1"], out_planes=h1p)
+            self._conv(up, x, t["up"])
+            self._shuffle(t["up"], r, t["ups"])
+            res = t["ups"]
+        else:
+            self._conv(c1, x, t["h1"], epilogue=L.EPI_LRELU)
+            ops.split_p3(t["h1"], h1p)
+            res = x
+            if "skip" in o:
+                self._conv(o["skip"], x, t["sk"])
+                res = t["sk"]
+        self._conv_p3(cv, h1p, t["h1"].shape, out=t[cname])
+        self._conv(g, t[cname], t["norm"], square=True)
+        self._task_is_rec = True
+        ops.loss_gdn_bwd(t[cname], t["norm"], res, self.co, self.idx, self.it, 2.0, rbu, self.loss_log, t["dout"], t=t["t"], t_planes=tp)
+        if rbu:
+            self._unshuffle(t["dout"], r, t["dup"])
+            self._wgrad(up, x, t["dup"])
+        elif "skip" in o:
+            self._wgrad(o["skip"], x, t["dout"])
+        self._gdn_backward_p3(g, t["dout"], t[cname], t["norm"], tp, t["acc"], dcp)
+        self._wgrad(g, t[cname], t["t"], square=True)
+        self._wgrad_p3(cv, h1p, t["h1"].shape, dcp)
+        self._dgrad_p3(cv, dcp, t["h1"].shape, out=t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+        if rbu:
+            self._unshuffle(t["dh1"], r, t["dsp"])
+            self._split_point()
+            self._wgrad(sp, x, t["dsp"])
+        else:
+            self._split_point()
+            self._wgrad(c1, x, t["dh1"])
+
     def _forward_backward(self):
         o, t, x = self.ops, self.t, self.x_in
+        self.p3_plan = self._plan_p3()
+        if self.p3_plan == "rb":
+            return self._fb_rb_p3()
+        if self.p3_plan in ("rbws", "rbu"):
+            return self._fb_gdn_block_p3()
         ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, self.batch_offset)
         if self.kind == "layer" and o["layer"].is_gdn:
             # a GDN / IGDN that is its own unit (sequential Minnen2018-style coders): only gamma is trained, no dx needed

@@ -214,3 +214,64 @@ def test_full_size_rbu_unit_step_matches_torch_autograd():
         y = _gdn_ref(c, o["igdn"], al["igdn"], inverse=True)
         return y + F.pixel_shuffle(F.conv2d(x, _soft_w(o["upsample"], al["upsample"]), o["upsample"].bias, padding=1), 2)
     _step_vs_autograd(eng, forward, cq, co, ["subpel_conv", "conv", "igdn", "upsample"])
+
+
+# ---- the same units on P3 tensors (plane-input kernels) and on fp32 activations ---------------------------------------------------
+def _p3_vs_fp32(make_blk, qcls, cq_shape, seed, plan):
+    """Three iterations of one full-size unit with use_p3 on / off: same losses (summation order aside), same alphas except where
+    Adam amplifies a gradient at the fp32 noise level."""
+    from quantization.engine import UnitEngine
+    from quantization.recon import _unit_modules
+    WQ = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    res = []
+    for use_p3 in (True, False):
+        torch.manual_seed(seed)
+        blk = make_blk()
+        unit = qcls(blk, WQ, dict(WQ, leaf_param=False)).cuda()
+        kind, mods = _unit_modules(unit)
+        g = torch.Generator(device="cuda").manual_seed(seed)
+        n = cq_shape[0]
+        cq = torch.randn(*cq_shape, device="cuda", generator=g)
+        cf = cq + 0.01 * torch.randn(cq.shape, device="cuda", generator=g)
+        with torch.no_grad():
+            co = blk(cf.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        idx = torch.stack([torch.arange(n, dtype=torch.int32)] * 3)
+        eng = UnitEngine(kind, mods, cq, cf, co, batch_size=n, iters=3, warmup=0.0, input_prob=0.5, seed=3, idx_table=idx, use_p3=use_p3)
+        assert eng.p3_plan == (plan if use_p3 else None)
+        eng.run()
+        torch.cuda.synchronize()
+        res.append(({k: eng.alpha_of(k).clone() for k in eng.ops}, eng.logs()[0]))
+        del eng
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=2e-5, atol=1e-9)
+    for k in res[0][0]:
+        bad = (res[0][0][k] - res[1][0][k]).abs() > 2e-4
+        assert float(bad.float().mean()) < 2e-3, (k, float(bad.float().mean()))
+
+
+def test_rb_unit_on_p3_tensors_matches_fp32_activations():
+    import lic
+    from quantization.quant_block import QuantRB
+    _p3_vs_fp32(lambda: lic.ResidualBlock(N, N).cuda(), QuantRB, (4, 128, 128, N), 31, "rb")
+
+
+def test_rbu_unit_on_p3_tensors_matches_fp32_activations():
+    import lic
+    from quantization.quant_block import QuantRBU
+
+    def mk():
+        blk = lic.ResidualBlockUpsample(N, N, 2)
+        _seed_gdn(blk.igdn, torch.Generator().manual_seed(5))
+        return blk.cuda()
+    _p3_vs_fp32(mk, QuantRBU, (4, 64, 64, N), 32, "rbu")
+
+
+def test_rbws_stem_unit_on_p3_tensors_matches_fp32_activations():
+    """g_a.0 of Cheng2020-anchor: 3 -> 192 at 256^2 -> 128^2 (thin RGB stem kernels feeding a P3 second conv and GDN backward)."""
+    import lic
+    from quantization.quant_block import QuantRBWS
+
+    def mk():
+        blk = lic.ResidualBlockWithStride(3, N, stride=2)
+        _seed_gdn(blk.gdn, torch.Generator().manual_seed(6))
+        return blk.cuda()
+    _p3_vs_fp32(mk, QuantRBWS, (4, 256, 256, 3), 33, "rbws")
