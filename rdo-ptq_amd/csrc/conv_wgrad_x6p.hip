@@ -189,7 +189,11 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
         const int buf = s & 1;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of stage s have landed
         __builtin_amdgcn_s_barrier();                                    // ... everybody's have, and nobody reads buffer buf ^ 1 any more
-        if (s + 1 < nsteps) dma_stage(buf ^ 1);
+        // The two waves of a SIMD (w and w + 4) run this loop in lock-step: if both issued their nine DMAs here, the matrix pipe would
+        // idle for the whole issue phase.  Waves 0-3 (dY) issue now, waves 4-7 (X) after their first six MFMA slots -- while one wave
+        // of a SIMD is held up issuing, its partner multiplies.  X still has two thirds of a stage to land.
+        const bool more = s + 1 < nsteps;
+        if (more && !ldx) dma_stage(buf ^ 1);
         const char* st = smem + buf * STAGEB;
 #pragma unroll
         for (int p = 0; p < 3; ++p)
@@ -209,6 +213,9 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
                      for (int j = 0; j < 2; ++j)
                          acc[i][2 * T3 + j] =
                              __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 if constexpr (SL == 5) {
+                     if (more && ldx) dma_stage(buf ^ 1);
+                 }
                  __builtin_amdgcn_sched_barrier(0);
              }()),
              ...);

@@ -20,6 +20,7 @@ Data parallel (world_size > 1): each rank holds its shard of the caches; per ite
 alphas of the unit is written into one flat bucket, all-reduced (RCCL over xGMI, SUM) and applied with scale 1/world_size;
 the rounding regulariser is data independent and is added locally after the reduction."""
 import math
+import os
 from collections import OrderedDict
 
 import torch
@@ -153,6 +154,8 @@ class UnitEngine:
         self.use_graph = use_graph
         self.batch_offset = int(batch_offset)  # first row of this rank's share of the global mini-batch (QDrop counter)
         self.dp_overlap = bool(dp_overlap)
+        if os.environ.get("RDO_USE_P3") is not None:
+            use_p3 = os.environ["RDO_USE_P3"] != "0"      # A/B switch for whole runs (bench.py)
         self.use_p3 = bool(use_p3)             # big units on P3 tensors (plane-input LDS-DMA GEMM kernels); False: fp32 activations only
         self.P = {}                            # name -> planes of the P3 form of an activation buffer
         self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
