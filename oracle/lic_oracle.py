@@ -373,3 +373,72 @@ class MeanScaleHyperprior(nn.Module):
         scales_hat, means_hat = self.h_s(z_hat).chunk(2, 1)
         y_hat, y_lik = self.gaussian_conditional(y, scales_hat, means=means_hat)
         return {"x_hat": self.g_s(y_hat), "likelihoods": {"y": y_lik, "z": z_lik}}
+
+
+class JointAutoregressiveHierarchicalPriors(MeanScaleHyperprior):
+    """Minnen, Balle, Toderici 2018 with the autoregressive context model ('mbt2018', BASELINE config 5), CompressAI topology and
+    child order (..., gaussian_conditional, entropy_parameters, context_prediction)  **[3P-unverified]**: the mean-scale model plus a
+    5x5 type-A masked convolution over the (de)quantised latent and a three-layer 1x1 network that maps [hyper | context] features to
+    (scales, means).  Training / evaluation forward (parallel masked conv on y_hat), not the sequential decoder."""
+
+    def __init__(self, N=192, M=192):
+        super().__init__(N=N, M=M)
+        self.entropy_parameters = nn.Sequential(nn.Conv2d(M * 12 // 3, M * 10 // 3, 1), nn.LeakyReLU(inplace=True),
+                                                nn.Conv2d(M * 10 // 3, M * 8 // 3, 1), nn.LeakyReLU(inplace=True),
+                                                nn.Conv2d(M * 8 // 3, M * 6 // 3, 1))
+        self.context_prediction = MaskedConv2d(M, 2 * M, kernel_size=5, padding=2, stride=1)
+
+    def forward(self, x):
+        y = self.g_a(x)
+        z_hat, z_lik = self.entropy_bottleneck(self.h_a(y))
+        hyper = self.h_s(z_hat)
+        y_hat = self.gaussian_conditional.quantize(y, "noise" if self.training else "dequantize")
+        ctx = self.context_prediction(y_hat)
+        scales_hat, means_hat = self.entropy_parameters(torch.cat((hyper, ctx), dim=1)).chunk(2, 1)
+        _, y_lik = self.gaussian_conditional(y, scales_hat, means=means_hat)
+        return {"x_hat": self.g_s(y_hat), "likelihoods": {"y": y_lik, "z": z_lik}}
+
+
+def mbt2018_forward_w8a8(model: JointAutoregressiveHierarchicalPriors, x, act_quant=True):
+    """The forward the reference's QuantModel produces for this model with nearest-rounded W8 weights (channel-wise 'max' scales)
+    and, with `act_quant`, its dynamic 8-bit activation quantiser behind every wrapped module (quant_layer.py:107-134): conv /
+    transposed conv / GDN, the following LeakyReLU fused in FRONT of the activation quantiser (quant_model.py:51-54), none on the
+    last decoder layer (main2.py:258-263) nor on the last module of the child order, context_prediction
+    (disable_network_output_quantization, quant_model.py:66-70), whose mask the wrapper bypasses."""
+    from .rdo_oracle import act_quant as aq, uaq_fakequant, uaq_init
+
+    def qw(w, tconv=False):
+        d, z = uaq_init(w, 8, True, "max", tconv=tconv)
+        return uaq_fakequant(w, d, z, 256)
+
+    def run(seq, h, last_plain=False):
+        mods = list(seq)
+        for i, m in enumerate(mods):
+            if isinstance(m, nn.LeakyReLU):
+                continue                                   # applied with the module in front of it
+            if isinstance(m, nn.ConvTranspose2d):
+                h = F.conv_transpose2d(h, qw(m.weight.data, True), m.bias, m.stride, m.padding, m.output_padding)
+            elif isinstance(m, nn.Conv2d):
+                h = F.conv2d(h, qw(m.weight.data), m.bias, m.stride, m.padding)
+            elif isinstance(m, GDN):
+                c = h.shape[1]
+                gamma = m.gamma_reparam(qw(m.gamma.data)).view(c, c, 1, 1)
+                pool = F.conv2d(h * h, gamma, m.beta_reparam(m.beta))
+                h = h * (pool.sqrt() if m.inverse else pool.rsqrt())
+            else:
+                raise TypeError(type(m))
+            if i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU):
+                h = F.leaky_relu(h, 0.01)
+            if act_quant and not (last_plain and i == len(mods) - 1):
+                h = aq(h)
+        return h
+    with torch.no_grad():
+        y = run(model.g_a, x)
+        z_hat, z_lik = model.entropy_bottleneck(run(model.h_a, y))
+        hyper = run(model.h_s, z_hat)
+        y_hat = model.gaussian_conditional.quantize(y, "dequantize")
+        cp = model.context_prediction
+        ctx = F.conv2d(y_hat, qw(cp.weight.data), cp.bias, cp.stride, cp.padding)     # unmasked, no activation quantiser
+        scales_hat, means_hat = run(model.entropy_parameters, torch.cat((hyper, ctx), dim=1)).chunk(2, 1)
+        _, y_lik = model.gaussian_conditional(y, scales_hat, means=means_hat)
+        return {"x_hat": run(model.g_s, y_hat, last_plain=True), "likelihoods": {"y": y_lik, "z": z_lik}}

@@ -180,3 +180,65 @@ def test_ms_ssim_matches_oracle(shape):
     assert abs(compute_msssim(x[:1].cuda(), y[:1].cuda()) - (-10 * math.log10(1 - float(MO.ms_ssim(x[:1], y[:1]))))) < 1e-3
     with pytest.raises(ValueError):
         ms_ssim(x[..., :160, :160].cuda(), y[..., :160, :160].cuda())
+
+
+@pytest.mark.parametrize("hw", [(512, 768), (1200, 1200)])
+def test_mbt2018_full_width_w8_w8a8_eval_matches_oracle(hw):
+    """BASELINE config 5 at full width: Minnen2018 with the autoregressive context model (N = M = 192), nearest-rounded W8 weights
+    and dynamic A8 activations, one Kodak-sized (768 x 512) and one Tecnick-sized (1200 x 1200) image through `evaluate_images`
+    (pad to 64, forward, crop, PSNR / bpp) on HIP against the oracle's restatement of the same quantised forward on the CPU.
+    fp tolerance: bpp 2e-4 relative, PSNR 0.01 dB (fp32 summation order; under W8A8 a value within float noise of a boundary of
+    the dynamic 8-bit grids may land one level apart and change a handful of rounded latents).  The image-parallel path (process
+    group of one rank) must reproduce the local numbers."""
+    import os
+    import lic
+    from oracle import lic_oracle as L
+    from quantization import BaseQuantBlock, QuantModel, QuantModule
+    from test_datasets import crop, evaluate_images, pad
+    torch.manual_seed(31)
+    ref = L.JointAutoregressiveHierarchicalPriors(N=192, M=192).eval()
+    g = torch.Generator().manual_seed(32)
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if name.endswith("gamma"):
+                c = p.shape[0]
+                p.copy_(torch.sqrt(0.1 * torch.eye(c) + 0.002 * torch.rand(c, c, generator=g) + 2.0 ** -36))
+            elif p.dim() == 4 and "entropy_bottleneck" not in name:
+                fan = p[0].numel()
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 2 * (3.0 / fan) ** 0.5)
+    ref.context_prediction.mask.fill_(1.0)          # the wrapper bypasses the mask (SURVEY 3.2): keep both sides unmasked
+    prod = lic.JointAutoregressiveHierarchicalPriors(N=192, M=192).eval()
+    _sync_state(prod, ref)
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    qnn = QuantModel(prod.cuda(), wq, dict(wq, leaf_param=False)).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    for m in qnn.modules():
+        if isinstance(m, (QuantModule, BaseQuantBlock)):
+            m.trained = True
+    x = torch.rand(1, 3, *hw, generator=g)
+    xp = pad(x, 64)
+
+    def oracle_metrics(act):
+        out = L.mbt2018_forward_w8a8(ref, xp, act_quant=act)
+        rec = crop(out["x_hat"], hw).clamp(0, 1)
+        psnr = 10 * math.log10(1.0 / float(((x - rec) ** 2).mean()))
+        bpp = sum(float((-torch.log2(v)).sum()) for v in out["likelihoods"].values()) / (xp.shape[2] * xp.shape[3])
+        return psnr, bpp
+
+    for act in (False, True):
+        qnn.set_quant_state(True, act)
+        qnn.model.g_s[-1].set_quant_state(True, False)
+        psnr, bpp = evaluate_images(qnn, [x], p=64, distributed=False)
+        psnr_o, bpp_o = oracle_metrics(act)
+        assert abs(bpp - bpp_o) <= 2e-4 * bpp_o, (act, bpp, bpp_o)
+        assert abs(psnr - psnr_o) <= 0.01, (act, psnr, psnr_o)
+    if not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29537")
+        torch.distributed.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        psnr_d, bpp_d = evaluate_images(qnn, [x], p=64)
+    finally:
+        torch.distributed.destroy_process_group()
+    assert abs(psnr_d - psnr) < 1e-4 and abs(bpp_d - bpp) < 1e-5 * bpp
