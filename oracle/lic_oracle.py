@@ -167,6 +167,18 @@ class MaskedConv2d(nn.Conv2d):
 
 
 # ----------------------------------------------------------------------------- entropy models (forward likelihood only)
+# Straight-through rounding for the differentiable EVALUATION forward used by the build's opt-in R + lambda*D task loss (the
+# reference sketches that loss and comments it out, layer_opt.py:146-148; CompressAI itself trains with additive noise).  Values
+# are unchanged; only the gradient of round() becomes the identity.  Off by default.
+STE_ROUND = False
+
+
+def _round(x):
+    if STE_ROUND and torch.is_grad_enabled() and x.requires_grad:
+        return x + (torch.round(x) - x).detach()
+    return torch.round(x)
+
+
 class EntropyBottleneck(nn.Module):
     """Factorised prior of Balle et al. 2018 (filters (3,3,3,3), init_scale 10)."""
 
@@ -203,7 +215,7 @@ class EntropyBottleneck(nn.Module):
         if self.training:
             out = v + torch.empty_like(v).uniform_(-0.5, 0.5)
         else:
-            out = torch.round(v - med) + med
+            out = _round(v - med) + med
         lower = self._logits_cumulative(out - 0.5)
         upper = self._logits_cumulative(out + 0.5)
         sign = -torch.sign(lower + upper).detach()
@@ -222,7 +234,7 @@ class GaussianConditional(nn.Module):
         if mode == "noise":
             return inputs + torch.empty_like(inputs).uniform_(-0.5, 0.5)
         out = inputs if means is None else inputs - means
-        out = torch.round(out)
+        out = _round(out)
         return out if means is None else out + means
 
     @staticmethod

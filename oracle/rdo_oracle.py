@@ -350,7 +350,8 @@ def reconstruct_unit(kind: str, ops: Dict[str, QOp], cached_q, cached_fp, cached
                      input_prob: float = 0.5, weight: float = 0.01, b_range=(20, 2), warmup: float = 0.2,
                      p: float = 2.0, task_p: float = 2.0, tail: Optional[Callable] = None,
                      fp_net_out: Optional[torch.Tensor] = None, lr: float = 1e-3,
-                     grad_hook: Optional[Callable[[List[torch.Tensor]], None]] = None) -> ReconLog:
+                     grad_hook: Optional[Callable[[List[torch.Tensor]], None]] = None,
+                     task_fn: Optional[Callable[[torch.Tensor, torch.Tensor], torch.Tensor]] = None) -> ReconLog:
     """layer_opt.py:236-315 / block_opt.py:228-321 -- AdaRound optimisation of one unit.
 
     * every op of the unit gets an AdaRoundQuantizer with soft targets (block_opt.py:239-243),
@@ -361,7 +362,9 @@ def reconstruct_unit(kind: str, ops: Dict[str, QOp], cached_q, cached_fp, cached
     * afterwards soft_targets=False (hard rounding) (layer_opt.py:313-315).
     `idx_stream[i]` replaces `torch.randperm(n)[:batch]` (:289) and `mask_fn(i, shape)` replaces
     `torch.rand_like(x) < input_prob` (:292) so runs are reproducible across implementations.
-    `grad_hook(list_of_alpha_grads)` is called between backward and step (data-parallel all-reduce point)."""
+    `grad_hook(list_of_alpha_grads)` is called between backward and step (data-parallel all-reduce point).
+    `task_fn(out_quant, idx)` replaces the lp task term: the build's opt-in R + lambda*D mode evaluates the rate-distortion loss of
+    the whole model with the unit's output substituted (the call the reference comments out, layer_opt.py:146-148)."""
     fwd = kind if callable(kind) else UNIT_FORWARD[kind]     # a callable (ops, x) -> y serves units outside the table (RSTB)
     for op in ops.values():
         op.to_adaround()
@@ -384,7 +387,7 @@ def reconstruct_unit(kind: str, ops: Dict[str, QOp], cached_q, cached_fp, cached
         out_quant = fwd(ops, cur_inp)
         net_out = out_quant if tail is None else tail(out_quant)
         rec = lp_loss(out_quant, cur_out, p=p)
-        task = lp_loss(net_out, fp_net_out[idx], p=task_p)
+        task = task_fn(out_quant, idx) if task_fn is not None else lp_loss(net_out, fp_net_out[idx], p=task_p)
         count = i + 1
         b = linear_temp_decay(count, iters, warmup, b_range[0], b_range[1])
         if count < loss_start:

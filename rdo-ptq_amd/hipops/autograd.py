@@ -1,0 +1,165 @@
+"""Input-gradient `torch.autograd.Function`s over the HIP kernels.
+
+The calibration engines hand-record their backward passes; everything else in this package runs without autograd.  These
+Functions exist for the two places where torch's tape is the natural driver: the opt-in R + lambda*D task loss of the calibration
+loop (`loss_mode='rd'`: the unit's soft-quantised output is pushed through the REST of the wrapped model and the
+rate-distortion loss of `losses.RateDistortionLoss` is differentiated back to it -- the term the reference sketches and comments
+out, layer_opt.py:146-148), and callers that want `QuantModule.forward` outputs with a `grad_fn` with respect to their INPUT.
+Weights are constants here (the FP / hard-quantised weights of the modules behind the unit): only input gradients are produced.
+
+Tensors cross this boundary as NCHW views of NHWC storage, like everywhere in the package; every forward and backward GEMM and
+every GDN / likelihood stage below is a librdoptq_hip kernel."""
+import math
+
+import torch
+
+from . import _lib as L
+from . import ops
+
+
+def _nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw(y):
+    return y.permute(0, 3, 1, 2)
+
+
+class Conv2dFn(torch.autograd.Function):
+    """y = act(conv2d(x, w) + b); `w_rows` = OHWI weight [Cout,KH,KW,Cin]; epilogue in {EPI_NONE, EPI_LRELU, EPI_RELU}."""
+
+    @staticmethod
+    def forward(ctx, x, w_rows, bias, stride, pad, epilogue):
+        xr = _nhwc(x)
+        y = ops.conv2d_fwd(xr, w_rows, bias, stride, pad, epilogue=epilogue)
+        ctx.geom = (stride, pad, epilogue, tuple(xr.shape))
+        ctx.save_for_backward(w_rows, y if epilogue != L.EPI_NONE else None)
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        stride, pad, epilogue, xs = ctx.geom
+        w_rows, y = ctx.saved_tensors
+        gr = _nhwc(g)
+        if epilogue == L.EPI_LRELU:
+            gr = ops.lrelu_bwd(gr, y)
+        elif epilogue == L.EPI_RELU:
+            gr = ops.relu_bwd(gr, y)
+        K = w_rows.shape[1]
+        if stride == 1 and 2 * pad == K - 1:
+            wd = w_rows.flip(1, 2).permute(3, 1, 2, 0).contiguous()          # [Cin][KH'][KW'][Cout], taps flipped
+            dx = ops.conv2d_fwd(gr, wd, None, 1, K - 1 - pad)
+        else:
+            # dgrad of a strided conv = the transposed conv with the same weight tensor read as [Cin_t = Cout][Cout_t = Cin][K][K]
+            out_pad = (xs[1] + 2 * pad - K) % stride
+            dx = ops.conv_transpose2d(gr, w_rows.permute(3, 1, 2, 0).contiguous(), None, stride, pad, out_pad)
+        return _nchw(dx), None, None, None, None, None
+
+
+class ConvTranspose2dFn(torch.autograd.Function):
+    """y = act(conv_transpose2d(x, W) + b); `w_t_rows` = to_rows(W, tconv=True) = [Cout,KH,KW,Cin] (un-flipped taps)."""
+
+    @staticmethod
+    def forward(ctx, x, w_t_rows, bias, stride, pad, output_padding, epilogue):
+        xr = _nhwc(x)
+        y = ops.conv_transpose2d(xr, w_t_rows, bias, stride, pad, output_padding, epilogue=epilogue)
+        ctx.geom = (stride, pad, epilogue)
+        ctx.save_for_backward(w_t_rows, y if epilogue != L.EPI_NONE else None)
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        stride, pad, epilogue = ctx.geom
+        w_t_rows, y = ctx.saved_tensors
+        gr = _nhwc(g)
+        if epilogue == L.EPI_LRELU:
+            gr = ops.lrelu_bwd(gr, y)
+        elif epilogue == L.EPI_RELU:
+            gr = ops.relu_bwd(gr, y)
+        # dx = conv2d(dy, W read as a conv weight [O = Cin_t][I = Cout_t][K][K]) with the same stride / padding
+        w_conv = w_t_rows.permute(3, 1, 2, 0).contiguous()                   # [Cin_t][KH][KW][Cout_t]
+        dx = ops.conv2d_fwd(gr, w_conv, None, stride, pad)
+        return _nchw(dx), None, None, None, None, None, None
+
+
+class GDNFn(torch.autograd.Function):
+    """y = x * (beta' + sum_j gamma'_ij x_j^2)^(-1/2 | +1/2); gamma_p [C,C] and beta_p [C] already re-parametrised."""
+
+    @staticmethod
+    def forward(ctx, x, gamma_p, beta_p, inverse):
+        xr = _nhwc(x)
+        c = xr.shape[-1]
+        norm = torch.empty_like(xr)
+        y = ops.conv2d_fwd(xr, gamma_p.reshape(c, 1, 1, c).contiguous(), beta_p.contiguous(), 1, 0,
+                           epilogue=L.EPI_IGDN if inverse else L.EPI_GDN, aux=xr, square_input=True, pre=norm)
+        ctx.inverse = bool(inverse)
+        ctx.save_for_backward(xr, norm, gamma_p)
+        return _nchw(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        xr, norm, gamma_p = ctx.saved_tensors
+        c = xr.shape[-1]
+        gr = _nhwc(g)
+        t = ops.gdn_bwd_t(gr, xr, norm, ctx.inverse)
+        acc = ops.conv2d_fwd(t, gamma_p.t().contiguous().reshape(c, 1, 1, c), None, 1, 0)      # t . gamma'
+        dx = ops.gdn_bwd_dx(gr, xr, norm, acc, ctx.inverse)
+        return _nchw(dx), None, None, None
+
+
+class GaussianLikelihoodFn(torch.autograd.Function):
+    """Likelihood of the (already rounded) latent under N(means, max(scales, bound)) integrated over the unit bin, with gradients
+    to y_hat, scales and means through rdo_gaussian_likelihood_bwd (which yields d(-log2 p); dp = -p ln2 d(-log2 p))."""
+
+    @staticmethod
+    def forward(ctx, yhat, scales, means, scale_bound):
+        yr, sr, mr = _nhwc(yhat), _nhwc(scales), _nhwc(means)
+        _, lik = ops.gaussian_likelihood(yr, sr, mr, scale_bound)
+        ctx.bound = scale_bound
+        ctx.save_for_backward(yr, sr, mr, lik)
+        return _nchw(lik)
+
+    @staticmethod
+    def backward(ctx, g):
+        yr, sr, mr, lik = ctx.saved_tensors
+        ds, dm = ops.gaussian_likelihood_bwd(yr, sr, mr, 1.0, ctx.bound)
+        f = _nhwc(g) * lik * (-math.log(2.0))
+        f = torch.where(lik > 1e-9, f, torch.zeros_like(f))                  # the likelihood floor has no gradient
+        ds, dm = ds * f, dm * f
+        return _nchw(-dm), _nchw(ds), _nchw(dm), None
+
+
+def round_ste(x):
+    return x + (torch.round(x) - x).detach()
+
+
+class NegLog2SumFn(torch.autograd.Function):
+    """scale * sum(-log2 p): the rate term of losses.RateDistortionLoss (rdo_neg_log2_sum) with its gradient."""
+
+    @staticmethod
+    def forward(ctx, lik, scale):
+        flat = lik.detach().contiguous().reshape(-1)
+        ctx.scale = scale
+        ctx.save_for_backward(lik)
+        return ops.neg_log2_sum(flat, scale).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (lik,) = ctx.saved_tensors
+        return g * (-ctx.scale / math.log(2.0)) / lik, None
+
+
+class SqDiffSumFn(torch.autograd.Function):
+    """scale * sum((a - b)^2): the distortion term (rdo_sq_diff_sum) with its gradient with respect to a."""
+
+    @staticmethod
+    def forward(ctx, a, b, scale):
+        ac, bc = a.detach().contiguous(), b.detach().contiguous()
+        ctx.scale = scale
+        ctx.save_for_backward(ac, bc)
+        return ops.sq_diff_sum(ac.reshape(-1), bc.reshape(-1), scale).reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ac, bc = ctx.saved_tensors
+        return g * (2.0 * ctx.scale) * (ac - bc), None, None

@@ -41,6 +41,20 @@ class EntropyBottleneck(nn.Module):
         return torch.cat(mats + bias + fac, dim=1).contiguous()
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad and not self.training:
+            # differentiable evaluation path (R + lambda*D task loss): rounding with a straight-through gradient; the hyper-latent
+            # is a few thousand values, its CDF network stays in torch
+            order = [1, 0] + list(range(2, x.dim()))
+            xt = x.permute(*order).contiguous()
+            flat = xt.reshape(xt.shape[0], 1, -1)
+            med = self.quantiles[:, :, 1:2].detach()
+            d = flat - med
+            q = d + (torch.round(d) - d).detach() + med
+            lo, hi = self._cdf_logits(q - 0.5), self._cdf_logits(q + 0.5)
+            sgn = -torch.sign(lo + hi).detach()
+            lik = (torch.sigmoid(sgn * hi) - torch.sigmoid(sgn * lo)).abs().clamp_min(self.likelihood_bound)
+            back = lambda t: t.reshape(xt.shape).permute(*order).contiguous()
+            return back(q), back(lik)
         if x.is_cuda and not self.training and self.filters == (3, 3, 3, 3) and x.dim() == 4:
             # eval path on the HIP kernel (NHWC element-wise); training-time noise stays in torch (not on the PTQ path)
             with torch.no_grad():
@@ -68,12 +82,23 @@ class GaussianConditional(nn.Module):
     def quantize(self, inputs, mode, means=None):
         if mode == "noise":
             return inputs + torch.empty_like(inputs).uniform_(-0.5, 0.5)
+        if torch.is_grad_enabled() and inputs.requires_grad:      # straight-through rounding on the differentiable evaluation path
+            from hipops.autograd import round_ste
+            return round_ste(inputs) if means is None else round_ste(inputs - means) + means
         if means is None:
             return torch.round(inputs)
         return torch.round(inputs - means) + means
 
     def forward(self, inputs, scales, means=None):
-        if inputs.is_cuda and not self.training and inputs.dim() == 4 and not torch.is_grad_enabled():
+        tracked = torch.is_grad_enabled() and (inputs.requires_grad or scales.requires_grad or (means is not None and means.requires_grad))
+        if tracked and inputs.is_cuda and not self.training and inputs.dim() == 4:
+            # differentiable evaluation path on the HIP likelihood kernels (forward + rdo_gaussian_likelihood_bwd), rounding with a
+            # straight-through gradient
+            from hipops.autograd import GaussianLikelihoodFn, round_ste
+            m = torch.zeros_like(inputs) if means is None else means
+            yhat = round_ste(inputs - m) + m
+            return yhat, GaussianLikelihoodFn.apply(yhat, scales, m, self.scale_bound)
+        if inputs.is_cuda and not self.training and inputs.dim() == 4 and not tracked:
             cl = lambda t: None if t is None else t.permute(0, 2, 3, 1).contiguous()
             yhat, lik = ops.gaussian_likelihood(cl(inputs), cl(scales), cl(means), self.scale_bound)
             return yhat.permute(0, 3, 1, 2), lik.permute(0, 3, 1, 2)

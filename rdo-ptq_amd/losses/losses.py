@@ -64,6 +64,14 @@ class RateDistortionLoss(nn.Module):
 
     def forward(self, output, target):
         N, _, H, W = target.size()
+        tracked = output["x_hat"].requires_grad or any(v.requires_grad for v in output["likelihoods"].values())
+        if torch.is_grad_enabled() and tracked and self.metric == "mse":
+            # differentiable form (the opt-in R + lambda*D task loss of the calibration loop): same reduction kernels, gradients
+            # through hipops.autograd; no MS-SSIM side value
+            from hipops.autograd import NegLog2SumFn, SqDiffSumFn
+            bpp = sum(NegLog2SumFn.apply(lik, 1.0 / (N * H * W)) for lik in output["likelihoods"].values())
+            mse = SqDiffSumFn.apply(output["x_hat"], target, 1.0 / target.numel())
+            return {"bpp_loss": bpp, "mse_loss": mse, "loss": self.lmbda * 255 ** 2 * mse + bpp}
         out = {"bpp_loss": bpp_of(output["likelihoods"], N * H * W), "mse_loss": mse_of(output["x_hat"], target)}
         big = min(target.shape[-2:]) > 160
         if self.metric == "mse":

@@ -139,7 +139,7 @@ class _Op:
 class UnitEngine:
     def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
                  warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
-                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=True, fuse_tail=True, batch_step=True, use_p3=True):
+                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=True, fuse_tail=True, batch_step=True, use_p3=True, rd=None):
         if kind not in UNIT_KINDS:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
@@ -159,6 +159,13 @@ class UnitEngine:
         self.use_p3 = bool(use_p3)             # big units on P3 tensors (plane-input LDS-DMA GEMM kernels); False: fp32 activations only
         self.P = {}                            # name -> planes of the P3 form of an activation buffer
         self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
+        # opt-in R + lambda*D task loss (loss_mode='rd'): dict(model=QuantModel, unit=module, cali=calibration images NCHW on the GPU,
+        # lmbda=float).  The unit output of every iteration is pushed through the REST of the wrapped model on torch's tape
+        # (hipops.autograd) and losses.RateDistortionLoss is differentiated back to it; rec_loss stays the lp term.
+        self.rd = rd
+        if rd is not None:
+            fuse_tail = use_p3 = False
+            self.use_p3 = False
         self.fuse_tail = bool(fuse_tail)       # False: the separate epilogue / loss / activation-backward kernels (A/B, tests)
         self.dev = cache_q.device
         n = cache_q.shape[0]
@@ -320,6 +327,18 @@ class UnitEngine:
                               wplanes=op.wd_planes)
 
     def _loss(self, pred, grad):
+        if self.rd is not None:
+            # rec_loss here; the task term is the rate-distortion loss of the whole model, evaluated on the host's tape between the
+            # two recorded plans and added to the gradient at the top of the second one
+            ops.lp2_loss_grad(pred, self.co, self.idx, self.it, 1.0, grad, self.loss_log)
+            self._rd_pred = pred
+            self.g_task = torch.zeros_like(pred)
+            self._rec_ctx.__exit__(None, None, None)
+            self.plan_rd = Plan()
+            self._rec_ctx = self.plan_rd.record()
+            self._rec_ctx.__enter__()
+            ops.add(grad, self.g_task, out=grad)
+            return
         # rec_loss + task_loss on the same tensors (fp_out is the identity for these coders)
         if self.task_p == 2.0:
             self._task_is_rec = True
@@ -623,7 +642,9 @@ class UnitEngine:
 
     def _record(self):
         self.plan_a = Plan()
-        self.plan_a2 = self.plan_b = None
+        self.plan_a2 = self.plan_b = self.plan_rd = None
+        if self.rd is not None and self.split:
+            raise NotImplementedError("calibration engine: loss_mode='rd' is single-process (no data-parallel split)")
         self._rec_ctx = self.plan_a.record()
         self._rec_ctx.__enter__()
         try:
@@ -652,7 +673,12 @@ class UnitEngine:
         n = self.iters - done if n_iters is None else int(n_iters)
         if n < 0 or done + n > self.iters:
             raise ValueError(f"cannot run {n} iterations: {done} of {self.iters} already done")
-        if not self.split:
+        if self.plan_rd is not None:
+            for k in range(n):
+                self.plan_a.run(1, graph=self.use_graph)          # gather, unit forward, rec_loss and its gradient
+                self._rd_tail(done + k)                           # task term: R + lambda*D of the whole model -> g_task
+                self.plan_rd.run(1, graph=self.use_graph)         # + g_task, backward, AdaRound step
+        elif not self.split:
             self.plan_a.run(n, graph=self.use_graph)
         else:
             dist = torch.distributed
@@ -676,6 +702,31 @@ class UnitEngine:
                 self.plan_b.run(1, graph=self.use_graph)
         self._done = done + n
         return n
+
+    def _rd_tail(self, i):
+        """Iteration i's task loss: the images of the mini-batch through the wrapped model with this unit's output replaced by the
+        engine's soft-quantised output, `RateDistortionLoss` (lambda * 255^2 * MSE + bpp) on the result, gradient back to that
+        output (HIP kernels under torch's tape: hipops.autograd).  The modules behind the unit are whatever the calibration flow
+        left them: trained ones hard-quantised, the others full precision (layer_opt.py:15-43)."""
+        from losses.losses import RateDistortionLoss
+        rd = self.rd
+        if not hasattr(self, "_idx_host"):
+            self._idx_host = self.idx.cpu()
+        x = rd["cali"].index_select(0, self._idx_host[i].to(rd["cali"].device, torch.long))
+        leaf = self._rd_pred.permute(0, 3, 1, 2).detach().requires_grad_(True)
+        handle = rd["unit"].register_forward_hook(lambda m, inp, out: leaf)
+        was_training = rd["model"].training
+        rd["model"].eval()
+        try:
+            with torch.enable_grad():
+                out = rd["model"](x)
+                loss = RateDistortionLoss(lmbda=rd["lmbda"], metric="mse")(out, x)["loss"]
+                loss.backward()
+        finally:
+            handle.remove()
+            rd["model"].train(was_training)
+        self.g_task.copy_(leaf.grad.permute(0, 2, 3, 1))
+        self.task_log[i, 0] += loss.detach()
 
     def _data_terms(self):
         """(rec, task) per iteration on the device, averaged over the data-parallel ranks."""

@@ -37,11 +37,19 @@ class BaseQuantBlock(nn.Module):
         return ActQuantizer(x, self.act_quantizer.dynamic_bits) if (self.use_act_quant and self.trained) else x
 
 
+def _tracked(*ts):
+    return torch.is_grad_enabled() and any(t.requires_grad for t in ts)
+
+
 def _lrelu(x):
+    if _tracked(x):                       # on torch's tape (hipops.autograd): element-wise glue between the HIP Functions
+        return torch.nn.functional.leaky_relu(x, 0.01)
     return _nchw_view(ops.lrelu(_nhwc(x)))
 
 
 def _add(a, b):
+    if _tracked(a, b):
+        return a + b
     return _nchw_view(ops.add(_nhwc(a), _nhwc(b)))
 
 
@@ -82,6 +90,8 @@ class QuantRBU(BaseQuantBlock):
     @staticmethod
     def _subpel(seq, x):
         y = seq[0](x)
+        if _tracked(y):
+            return torch.nn.functional.pixel_shuffle(y, seq[1].upscale_factor)
         return _nchw_view(ops.pixel_shuffle(_nhwc(y), seq[1].upscale_factor))
 
     def forward(self, x):

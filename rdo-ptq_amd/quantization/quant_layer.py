@@ -132,9 +132,46 @@ class QuantModule(nn.Module):
             return self.weight_quantizer(self.weight), self.bias
         return self.org_weight, self.org_bias
 
+    def _forward_autograd(self, input):
+        """Forward whose output carries a grad_fn with respect to the INPUT (hipops.autograd; weights are constants): what the
+        opt-in R + lambda*D task loss differentiates through the modules behind a unit.  The reference's dynamic activation
+        quantiser works on a detached clone (quantizer.py:99-100), so an activation-quantised output has no gradient there either."""
+        from hipops import autograd as A
+        if self.is_ps:
+            y = torch.nn.functional.pixel_shuffle(input, int(self.fwd_kwargs))
+            return torch.nn.functional.leaky_relu(y, 0.01) if isinstance(self.activation_function, nn.LeakyReLU) else y
+        weight, bias = self._weights()
+        weight = weight.detach()
+        bias = None if bias is None else bias.detach().contiguous()
+        epi = self.fused_epilogue() if self.se_module is None else None
+        fuse = epi is not None
+        epi = L.EPI_NONE if epi is None else epi
+        if self.kind == "conv":
+            stride, pad = self.conv_geometry()
+            out = A.Conv2dFn.apply(input, to_rows(weight), bias, stride, pad, epi)
+        elif self.kind == "tconv":
+            kw = self.fwd_kwargs
+            out = A.ConvTranspose2dFn.apply(input, to_rows(weight, tconv=True), bias, _sq(kw["stride"]), _sq(kw["padding"]),
+                                            _sq(kw["output_padding"]), epi)
+        elif self.kind == "gdn":
+            gp = self._reparam(self.fwd_kwargs["gamma_reparam"], weight)
+            bp = self._reparam(self.fwd_kwargs["beta_reparam"], bias)
+            out = A.GDNFn.apply(input, gp, bp, bool(self.fwd_kwargs["inverse"]))
+        else:
+            raise NotImplementedError(f"QuantModule({self.kind}): no autograd forward (conv / transposed conv / GDN / pixel shuffle only)")
+        if self.se_module is not None:
+            out = self.se_module(out)
+        if not fuse:
+            out = self.activation_function(out)
+        if not self.disable_act_quant and self.use_act_quant and self.trained:
+            out = self.act_quantizer(out, True)
+        return out
+
     def forward(self, input: torch.Tensor):
         if not input.is_cuda:
             raise RuntimeError("QuantModule.forward runs on librdoptq_hip only: move the model and data to the GPU")
+        if torch.is_grad_enabled() and input.requires_grad:
+            return self._forward_autograd(input)
         if self.is_ps:
             y = ops.pixel_shuffle(_nhwc(input), int(self.fwd_kwargs))
             return _nchw_view(ops.lrelu(y) if isinstance(self.activation_function, nn.LeakyReLU) else y)

@@ -164,10 +164,23 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     if not is_block and unit.org_weight is None:
         return None                                   # PixelShuffle units carry nothing to train (layer_opt.py:245-246)
     kind, mods = _unit_modules(unit)
+    # opt-in task loss: the R + lambda*D loss of the whole model that the reference sketches and comments out
+    # (layer_opt.py:146-148).  args.loss_mode = 'rd' (default 'lp' = the reference's lp_loss pair)
+    rd = None
+    if getattr(args, "loss_mode", "lp") == "rd":
+        if world_size > 1:
+            raise NotImplementedError("loss_mode='rd' is single-process")
+        rd = dict(model=model, unit=unit, cali=cali_data.to(next(model.parameters()).device), lmbda=float(getattr(args, "lmbda", 0.01)))
+    elif getattr(args, "loss_mode", "lp") != "lp":
+        raise ValueError(f"unknown loss_mode {args.loss_mode!r} ('lp' or 'rd')")
     # the CLI --lr is ignored by the reference (Adam default 1e-3, layer_opt.py:253-254); kept that way.
     common = dict(batch_size=batch_size, iters=iters, weight=weight, b_range=b_range, warmup=warmup, input_prob=input_prob,
                   lr=1e-3, seed=unit_seed(unit_name), include_act_func=include_act_func, batch_offset=rank * batch_size,
                   task_p=float(task_p))
+    if rd is not None:
+        if kind == "rstb" or task_cache is not None:
+            raise NotImplementedError("loss_mode='rd' is built for the Sequential-indexed coders (Cheng2020 / Minnen2018)")
+        common["rd"] = rd
     if kind == "rstb" or task_cache is not None:
         eng = TapeEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), tail=module_list, tail_round=tail_round,
                          task_cache=task_cache, **common)

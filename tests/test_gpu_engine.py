@@ -345,3 +345,104 @@ def test_fused_tails_and_batched_step_change_nothing(recon, tag, kind):
         for n in res[0][0]:
             assert torch.equal(res[0][0][n], other[0][n]), n
         torch.testing.assert_close(res[0][1], other[1], rtol=1e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("where", ["g_a.1", "g_s.2", "h_a.0"])
+def test_rd_task_loss_mode_matches_oracle(where):
+    """loss_mode='rd' (opt-in): task term = lambda * 255^2 * MSE(x_hat, x) + bpp of the WHOLE model with the unit's soft-quantised
+    output substituted -- the criterion the reference sketches and comments out (layer_opt.py:146-148, losses/losses.py:8-35).
+    Engine (HIP kernels under torch's tape for the modules behind the unit) against the oracle loop running the oracle model on the
+    CPU, for an analysis block, a synthesis block and a hyper-analysis layer of a toy Cheng2020; entropy models in evaluation mode
+    with straight-through rounding on both sides."""
+    import lic
+    from helpers import AQ, WQ
+    from oracle import lic_oracle as LO
+    from oracle import rdo_oracle as O
+    from oracle.cheng_units import schedule
+    from quantization import QuantModel
+    from quantization.engine import UnitEngine
+    from quantization.recon import _unit_modules
+    torch.manual_seed(41)
+    N, n_img, B, iters, lmbda = 8, 6, 2, 6, 0.0483
+    ref = LO.Cheng2020Anchor(N=N).eval()
+    g = torch.Generator().manual_seed(42)
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if name.endswith("gamma"):
+                c = p.shape[0]
+                p.copy_(torch.sqrt(0.1 * torch.eye(c) + 0.01 * torch.rand(c, c, generator=g) + 2.0 ** -36))
+            elif p.dim() == 4 and "entropy_bottleneck" not in name:
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 2 * (3.0 / p[0].numel()) ** 0.5)
+    ref.context_prediction.mask.fill_(1.0)                     # the wrapper bypasses the mask (SURVEY 3.2)
+    cali = torch.rand(n_img, 3, 64, 64, generator=g)
+    prod = lic.Cheng2020Anchor(N=N).eval()
+    sd = ref.state_dict()
+    with torch.no_grad():
+        for k, v in prod.state_dict().items():
+            v.copy_(sd[k])
+    qnn = QuantModel(prod.cuda(), WQ, AQ, is_cheng=True).cuda().eval()
+    qnn.set_quant_state(False, False)
+    # the unit, on both sides
+    sched = {n: (k, o, m) for n, k, o, m in schedule(ref)}
+    kind, ops_o, ref_mod = sched[where]
+    seq, pos = where.split(".")
+    unit = getattr(qnn.model, seq)[int(pos)]
+    # caches: FP input / output of the unit for every calibration image (the quantised-prefix input = FP + small noise)
+    store = {}
+    h = ref_mod.register_forward_hook(lambda m, i, o: store.update(inp=i[0].detach().clone(), out=o.detach().clone()))
+    with torch.no_grad():
+        ref(cali)
+    h.remove()
+    inp, out = store["inp"], store["out"]
+    if kind == "layer" and ops_o["layer"].act == "lrelu":
+        out = torch.nn.functional.leaky_relu(out, 0.01)
+    inp_q = inp + 1e-3 * torch.randn(inp.shape, generator=g)
+    idx = np.stack([np.random.RandomState(i).permutation(n_img)[:B] for i in range(iters)])
+
+    # ---- oracle: the loop of reconstruct_unit with the RD task term through the oracle model
+    LO.STE_ROUND = True
+    try:
+        def task_fn(out_quant, ix):
+            x = cali[ix]
+            y = out_quant
+            # a layer unit carries its fused LeakyReLU (quant_model.py:51-54): substitute behind the activation module
+            fused_act = kind == "layer" and ops_o["layer"].act == "lrelu"
+            hook_mod = getattr(ref, seq)[int(pos) + 1] if fused_act else ref_mod
+            hk = hook_mod.register_forward_hook(lambda m, i, o: y)
+            try:
+                o = ref(x)
+            finally:
+                hk.remove()
+            n_pix = x.shape[0] * x.shape[2] * x.shape[3]
+            bpp = sum((-torch.log2(v)).sum() for v in o["likelihoods"].values()) / n_pix
+            return lmbda * 255 ** 2 * ((o["x_hat"] - x) ** 2).mean() + bpp
+        log = O.reconstruct_unit(kind, ops_o, inp_q, inp, out, iters=iters, batch_size=B, idx_stream=idx,
+                                 mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5), input_prob=0.5, weight=0.01,
+                                 b_range=(20, 2), warmup=0.2, task_fn=task_fn)
+    finally:
+        LO.STE_ROUND = False
+
+    # ---- product engine in rd mode
+    k, mods = _unit_modules(unit)
+    assert k == kind
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    eng = UnitEngine(k, mods, nh(inp_q), nh(inp), nh(out), batch_size=B, iters=iters, weight=0.01, b_range=(20, 2), warmup=0.2,
+                     input_prob=0.5, seed=SEED, idx_table=torch.from_numpy(idx),
+                     rd=dict(model=qnn, unit=unit, cali=cali.cuda(), lmbda=lmbda))
+    for n_, op in eng.ops.items():
+        np.testing.assert_array_equal(op.delta.cpu().numpy(), ops_o[n_].init_scale().delta.reshape(-1).numpy())
+    eng.run()
+    torch.cuda.synchronize()
+    rec, task, rd_, _ = eng.logs_terms()
+    np.testing.assert_allclose(rec.numpy(), np.array(log.rec), rtol=3e-4, atol=1e-7)
+    # the rate term counts rounded latents: one latent within float noise of .5 moves the loss by a few bits of several thousand
+    np.testing.assert_allclose(task.numpy(), np.array(log.task), rtol=2e-3)
+    np.testing.assert_allclose(rd_.numpy(), np.array(log.round), rtol=2e-4, atol=1e-7)
+    flips = tot = 0
+    for n_, op in ops_o.items():
+        a_gpu = eng.alpha_of(n_).cpu()
+        far = ((a_gpu - op.alpha).abs() > 2e-3).float().mean()
+        assert float(far) < 2e-2, (n_, float(far))
+        flips += int(((a_gpu >= 0) != (op.alpha >= 0)).sum())
+        tot += a_gpu.numel()
+    assert flips <= 0.01 * tot
