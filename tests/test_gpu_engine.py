@@ -415,7 +415,10 @@ def test_rd_task_loss_mode_matches_oracle(where):
                 hk.remove()
             n_pix = x.shape[0] * x.shape[2] * x.shape[3]
             bpp = sum((-torch.log2(v)).sum() for v in o["likelihoods"].values()) / n_pix
-            return lmbda * 255 ** 2 * ((o["x_hat"] - x) ** 2).mean() + bpp
+            # reference quirk: the wrapped PixelShuffle carries a LeakyReLU, so the wrapped model's output is
+            # leaky_relu(x_hat); the product reproduces it, the oracle model mirrors it here
+            xh = torch.nn.functional.leaky_relu(o["x_hat"], 0.01)
+            return lmbda * 255 ** 2 * ((xh - x) ** 2).mean() + bpp
         log = O.reconstruct_unit(kind, ops_o, inp_q, inp, out, iters=iters, batch_size=B, idx_stream=idx,
                                  mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5), input_prob=0.5, weight=0.01,
                                  b_range=(20, 2), warmup=0.2, task_fn=task_fn)
