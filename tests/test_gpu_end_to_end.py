@@ -450,3 +450,35 @@ def test_config0_one_shot_uniform_ptq_mbt2018_mean_full_width():
     for v in (psnr_fp, bpp_fp, psnr_w8, bpp_w8, psnr_w8a8, bpp_w8a8):
         assert math.isfinite(v)
     assert abs(psnr_w8 - psnr_fp) < 1.0 and abs(bpp_w8 - bpp_fp) < 0.05 * bpp_fp + 0.02
+
+
+def test_reconstruction_with_rd_task_loss_mode():
+    """`args.loss_mode = 'rd'` through the public layer_/block_reconstruction surface: the task term of every iteration is the
+    R + lambda*D loss of the whole wrapped model (parity of the numbers: tests/test_gpu_engine.py::test_rd_task_loss_mode_matches_oracle)."""
+    import lic
+    from quantization import QuantModel, block_reconstruction, layer_reconstruction
+    torch.manual_seed(7)
+    model = lic.Cheng2020Anchor(N=8).cuda().eval()
+    cali = torch.rand(6, 3, 64, 64, generator=torch.Generator().manual_seed(8)).cuda()
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True).cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:2])
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020", loss_mode="rd")
+    kwargs = dict(cali_data=cali, batch_size=2, iters=4, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2), warmup=0.2,
+                  act_quant=False, opt_mode="mse", config=None, args=args)
+    blk, lay = qnn.model.g_a[1], qnn.model.h_a[0]
+    from quantization.recon import reconstruct          # what layer_/block_reconstruction delegate to; returns the engine for inspection
+    eng_b = reconstruct(qnn, blk, "1", is_block=True, **kwargs)
+    eng_l = reconstruct(qnn, lay, "0", is_block=False, **kwargs)
+    for eng in (eng_b, eng_l):
+        assert eng.rd is not None and eng.plan_rd is not None
+        rec, task, rd_, _ = eng.logs_terms()
+        assert torch.isfinite(rec).all() and torch.isfinite(task).all() and float(task.min()) > 0
+    assert blk.trained and lay.trained
+    with pytest.raises(ValueError):
+        layer_reconstruction(qnn, qnn.model.h_a[2], "2", **dict(kwargs, args=types.SimpleNamespace(lmbda=0.1, task_loss=2.0, loss_mode="nope")))
