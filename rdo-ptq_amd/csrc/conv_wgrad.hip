@@ -221,10 +221,7 @@ inline bool big_tiles(const rdo_conv_desc* d) {
     const long big_tiles_total = (long)d->KH * d->KW * rdo::ceil_div(d->Cout, 192) * rdo::ceil_div(d->Cin, 192);
     // many tiles (the 768 / 1152-channel sub-pixel convs): few pixel splits fill the chip, so short reductions still pay off
     const long min_m = big_tiles_total >= 32 ? 1024 : 4096;
-    // ... except with a very long reduction (the GDN dgamma GEMM at 4 x 128^2 pixels: 1x1, M = 65536): 128 pixel chunks of the one
-    // 192 x 192 tile on the bf16x6 kernel take ~35 us where the 64 x 64 fp32 kernel needed 178 us (27 TFLOP/s)
-    const bool long_single = big_tiles_total < 4 && M >= 32768;
-    return d->Cout >= 160 && d->Cin >= 160 && M >= min_m && (big_tiles_total >= 4 || long_single);
+    return d->Cout >= 160 && d->Cin >= 160 && M >= min_m && big_tiles_total >= 4;
 }
 
 inline int tiles_total(const rdo_conv_desc* d) {
@@ -263,8 +260,7 @@ extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d) {
     const long max_by_m = rdo::ceil_div(M, 128);
     if (ns > max_by_m) ns = max_by_m;
     if (ns < 1) ns = 1;
-    const long cap = (big_tiles(d) && tiles_total(d) < 4) ? 128 : 64;      // single-tile problems: more chunks, or most CUs idle
-    if (ns > cap) ns = cap;
+    if (ns > 64) ns = 64;
     return (int)ns;
 }
 
