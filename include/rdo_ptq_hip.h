@@ -134,16 +134,18 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
  * rdo_split_bf16x3_conv would produce for wq [rows][KH][KW][Cin] and for wd [Cin][KH][KW][rows]), written in the same pass so that
  * the split-precision conv path needs no separate refresh launch. */
 
-/* rdo_adaround_step for all (<= 8) weight tensors of a unit in one launch (plus one launch for their dgrad layouts), numel % 4 == 0.
+/* rdo_adaround_step (mode 0), rdo_adaround_grad (mode 1: slabs -> dalpha) or rdo_adaround_apply (mode 2: dalpha -> update) for all
+ * (<= 8) weight tensors of a unit in one launch (plus one launch for their dgrad layouts), numel % 4 == 0.
  * advance_iter (nullable): device iteration counter to increment once the step is done -- replaces a trailing rdo_iter_advance. */
 typedef struct rdo_ada_step_item {
     rdo_ada_desc d;
-    const float *w, *delta, *zp, *slabs;
+    const float *w, *delta, *zp, *slabs /* modes 0, 1 */;
     int32_t nsplit;
     float *alpha, *adam_m, *adam_v, *wq, *wd /* nullable */;
     void *wq_planes /* nullable */, *wd_planes /* nullable */;
+    float* dalpha;      /* modes 1 (out) and 2 (in): this tensor's slice of the data-parallel gradient bucket */
 } rdo_ada_step_item;
-int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, float grad_scale, float round_weight,
+int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
                             const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
                             void* stream);
 

@@ -475,10 +475,12 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
     return run_step(a, stream);
 }
 
-int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, float grad_scale, float round_weight,
+int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
                             const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
                             void* stream) {
-    RDO_REQUIRE(items && n >= 1 && n <= kMaxBatch && sched && iter_ptr, "rdo_adaround_step_batch: bad argument (1 <= n <= %d)", kMaxBatch);
+    RDO_REQUIRE(items && n >= 1 && n <= kMaxBatch, "rdo_adaround_step_batch: bad argument (1 <= n <= %d)", kMaxBatch);
+    RDO_REQUIRE(mode >= 0 && mode <= 2, "rdo_adaround_step_batch: mode %d (0 fused step, 1 gradient only, 2 apply)", mode);
+    RDO_REQUIRE(mode == 1 || (sched && iter_ptr), "rdo_adaround_step_batch: schedule / iteration counter missing");
     AdaBatch b{}, bw{};
     int blocks = 0, wblocks = 0;
     double bytes = 0.0;
@@ -486,18 +488,21 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, float gra
         const rdo_ada_step_item& it = items[i];
         if (int rc = check_desc(&it.d, "rdo_adaround_step_batch")) return rc;
         RDO_REQUIRE(it.d.numel % 4 == 0, "rdo_adaround_step_batch: numel %ld of item %d is not a multiple of 4", (long)it.d.numel, i);
-        RDO_REQUIRE(it.w && it.delta && it.zp && it.slabs && it.nsplit >= 1 && it.alpha && it.adam_m && it.adam_v && it.wq,
-                    "rdo_adaround_step_batch: null pointer in item %d", i);
+        RDO_REQUIRE(it.w && it.delta && it.zp && it.alpha, "rdo_adaround_step_batch: null pointer in item %d", i);
+        RDO_REQUIRE(mode == 2 || (it.slabs && it.nsplit >= 1), "rdo_adaround_step_batch: item %d has no gradient slabs", i);
+        RDO_REQUIRE(mode == 0 || it.dalpha, "rdo_adaround_step_batch: item %d has no dalpha buffer", i);
+        RDO_REQUIRE(mode == 1 || (it.adam_m && it.adam_v && it.wq), "rdo_adaround_step_batch: null optimiser state in item %d", i);
         AdaArgs& a = b.a[i];
         a.d = it.d; a.w = it.w; a.delta = it.delta; a.zp = it.zp; a.slabs = it.slabs; a.nsplit = it.nsplit;
+        a.dalpha_in = it.dalpha; a.dalpha_out = it.dalpha;
         a.grad_scale = grad_scale; a.round_weight = round_weight; a.sched = sched; a.iter_ptr = iter_ptr;
-        a.alpha = it.alpha; a.m = it.adam_m; a.v = it.adam_v; a.wq = it.wq; a.wd = it.wd; a.round_loss_out = round_loss_out; a.mode = 0;
+        a.alpha = it.alpha; a.m = it.adam_m; a.v = it.adam_v; a.wq = it.wq; a.wd = it.wd; a.round_loss_out = round_loss_out; a.mode = mode;
         a.wq_planes = static_cast<unsigned short*>(it.wq_planes);
         a.wd_planes = it.wd ? static_cast<unsigned short*>(it.wd_planes) : nullptr;
         blocks += (int)grid_for(it.d.numel / 4);
         b.blk_end[i] = blocks;
-        bytes += 4.0 * it.d.numel * (it.nsplit + 9.0);
-        if (it.wd && it.d.Cin > 0) {
+        bytes += 4.0 * it.d.numel * ((mode == 2 ? 1 : it.nsplit) + (mode == 1 ? 3.0 : 9.0));
+        if (mode != 1 && it.wd && it.d.Cin > 0) {
             bw.a[bw.n] = a;
             wblocks += (int)(rdo::ceil_div(it.d.rows, 32) * it.d.KH * it.d.KW * rdo::ceil_div(it.d.Cin, 32));
             bw.blk_end[bw.n++] = wblocks;

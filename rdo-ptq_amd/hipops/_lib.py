@@ -26,7 +26,7 @@ class AdaDesc(C.Structure):
 class AdaStepItem(C.Structure):
     _fields_ = [("d", AdaDesc), ("w", C.c_void_p), ("delta", C.c_void_p), ("zp", C.c_void_p), ("slabs", C.c_void_p),
                 ("nsplit", C.c_int32), ("alpha", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("wq", C.c_void_p),
-                ("wd", C.c_void_p), ("wq_planes", C.c_void_p), ("wd_planes", C.c_void_p)]
+                ("wd", C.c_void_p), ("wq_planes", C.c_void_p), ("wd_planes", C.c_void_p), ("dalpha", C.c_void_p)]
 
 
 class AttnDesc(C.Structure):
@@ -57,7 +57,7 @@ _SIGS = {
     "rdo_adaround_init_alpha": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P]),
     "rdo_adaround_fwd": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, P, P, P]),
     "rdo_adaround_step": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
-    "rdo_adaround_step_batch": (C.c_int, [C.POINTER(AdaStepItem), C.c_int32, C.c_float, C.c_float, P, P, P, P, P]),
+    "rdo_adaround_step_batch": (C.c_int, [C.POINTER(AdaStepItem), C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, P, P, P]),
     "rdo_adaround_grad": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, C.c_int, P, P]),
     "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rdo_uaq_fakequant": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, P]),

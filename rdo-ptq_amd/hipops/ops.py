@@ -160,19 +160,21 @@ def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_
                                       _ptr(wd), _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _stream()), "rdo_adaround_step")
 
 
-def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None):
-    """items: list of dicts(d, w, delta, zp, slabs, alpha, m, v, wq, wd, wq_planes, wd_planes) -- one fused AdaRound step for every
-    weight tensor of a unit (<= 8, numel % 4 == 0); `advance_iter`: the device iteration counter to increment afterwards."""
+def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None, mode=0):
+    """items: list of dicts(d, w, delta, zp, slabs, alpha, m, v, wq, wd, wq_planes, wd_planes[, dalpha]) -- one launch for every
+    weight tensor of a unit (<= 8, numel % 4 == 0): mode 0 the fused AdaRound step, 1 the data gradient into `dalpha`, 2 the update
+    from an (all-reduced) `dalpha`; `advance_iter`: the device iteration counter to increment afterwards."""
     arr = (L.AdaStepItem * len(items))()
     dp = lambda t: None if t is None else _ptr(t).value
     for k, it in enumerate(items):
         a = arr[k]
         a.d = it["d"]
         a.w, a.delta, a.zp, a.slabs = dp(it["w"]), dp(it["delta"]), dp(it["zp"]), dp(it["slabs"])
-        a.nsplit = it["slabs"].shape[0]
+        a.nsplit = it["slabs"].shape[0] if it.get("slabs") is not None else 0
         a.alpha, a.adam_m, a.adam_v, a.wq, a.wd = dp(it["alpha"]), dp(it["m"]), dp(it["v"]), dp(it["wq"]), dp(it.get("wd"))
         a.wq_planes, a.wd_planes = dp(it.get("wq_planes")), dp(it.get("wd_planes"))
-    L.check(L.lib().rdo_adaround_step_batch(arr, len(items), grad_scale, round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(round_log),
+        a.dalpha = dp(it.get("dalpha"))
+    L.check(L.lib().rdo_adaround_step_batch(arr, len(items), int(mode), grad_scale, round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(round_log),
                                             _ptr(advance_iter), _stream()), "rdo_adaround_step_batch")
 
 

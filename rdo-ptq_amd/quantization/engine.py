@@ -609,19 +609,27 @@ class UnitEngine:
             ops.gdn_bwd_dx(dout, xin, norm, acc, inverse, dx)
         self._wgrad(g, xin, tbuf, square=True)                        # dgamma'[k][i] = sum_m t_k x_i^2
 
+    def _items(self, opl):
+        return [dict(d=op.desc, w=op.w, delta=op.delta, zp=op.zp, slabs=op.slabs, alpha=op.alpha, m=op.m, v=op.v, wq=op.wq, wd=op.wd,
+                     wq_planes=op.wq_planes, wd_planes=op.wd_planes, dalpha=getattr(op, "dalpha", None)) for op in opl]
+
+    def _batchable(self, opl):
+        return self.batch_step and 1 <= len(opl) <= 8 and all(op.numel() % 4 == 0 for op in opl)
+
     def _grad_ops(self, names):
-        for n in names:
-            op = self.ops[n]
+        opl = [self.ops[n] for n in names]
+        if self._batchable(opl):
+            ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, mode=1)
+            return
+        for op in opl:
             ops.adaround_grad(op.desc, op.w, op.alpha, op.delta, op.zp, op.slabs, op.dalpha)
 
     def _step_ops(self):
         """AdaRound step of every op of the unit + iteration counter: one batched launch (+ one for the dgrad layouts) when the
         tensors allow it, else one launch per op.  The bf16 planes of the new weights are written by the same launches."""
         opl = list(self.ops.values())
-        if self.batch_step and len(opl) <= 8 and all(op.numel() % 4 == 0 for op in opl):
-            items = [dict(d=op.desc, w=op.w, delta=op.delta, zp=op.zp, slabs=op.slabs, alpha=op.alpha, m=op.m, v=op.v, wq=op.wq,
-                          wd=op.wd, wq_planes=op.wq_planes, wd_planes=op.wd_planes) for op in opl]
-            ops.adaround_step_batch(items, 1.0, self.weight, self.sched, self.it, self.round_log, advance_iter=self.it)
+        if self._batchable(opl):
+            ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, advance_iter=self.it)
             return
         for op in opl:
             ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
@@ -661,10 +669,15 @@ class UnitEngine:
         if self.split:
             self.plan_b = Plan()
             with self.plan_b.record():
-                for op in self.ops.values():
-                    ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, 1.0 / self.world, self.weight, self.sched,
-                                       self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
-                ops.iter_advance(self.it)
+                opl = list(self.ops.values())
+                if self._batchable(opl):
+                    ops.adaround_step_batch(self._items(opl), 1.0 / self.world, self.weight, self.sched, self.it, self.round_log,
+                                            advance_iter=self.it, mode=2)
+                else:
+                    for op in opl:
+                        ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, 1.0 / self.world, self.weight, self.sched,
+                                           self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
+                    ops.iter_advance(self.it)
 
     # ------------------------------------------------------------------------------------------------------------------
     def run(self, n_iters=None):
@@ -681,27 +694,54 @@ class UnitEngine:
         elif not self.split:
             self.plan_a.run(n, graph=self.use_graph)
         else:
-            dist = torch.distributed
-            comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
-            for _ in range(n):
-                self.plan_a.run(1, graph=self.use_graph)
-                if self.plan_a2 is None:
-                    if comm:
-                        dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
-                else:
-                    # the collective runs on the process group's own stream (RCCL) behind plan A; plan A2 -- the last weight
-                    # gradient of the backward pass -- is launched right behind plan A on the compute stream and overlaps it
-                    w1 = dist.all_reduce(self.bucket[:self._early_numel], op=dist.ReduceOp.SUM, group=self.group,
-                                         async_op=True) if comm else None
-                    self.plan_a2.run(1, graph=self.use_graph)
-                    w2 = dist.all_reduce(self.bucket[self._early_numel:], op=dist.ReduceOp.SUM, group=self.group,
-                                         async_op=True) if comm else None
-                    if comm:
-                        w1.wait()
-                        w2.wait()
-                self.plan_b.run(1, graph=self.use_graph)
+            self._run_dp(n)
         self._done = done + n
         return n
+
+    def _dp_iteration(self, graph):
+        """One data-parallel iteration on the current stream: plan A -> all-reduce of the front of the bucket (asynchronous, on the
+        process group's stream) overlapped with plan A2 = the last weight gradient -> all-reduce of the rest -> plan B."""
+        dist = torch.distributed
+        comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
+        self.plan_a.run(1, graph=graph)
+        if self.plan_a2 is None:
+            if comm:
+                dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+        else:
+            w1 = dist.all_reduce(self.bucket[:self._early_numel], op=dist.ReduceOp.SUM, group=self.group, async_op=True) if comm else None
+            self.plan_a2.run(1, graph=graph)
+            w2 = dist.all_reduce(self.bucket[self._early_numel:], op=dist.ReduceOp.SUM, group=self.group, async_op=True) if comm else None
+            if comm:
+                w1.wait()
+                w2.wait()
+        self.plan_b.run(1, graph=graph)
+
+    def _run_dp(self, n):
+        """n data-parallel iterations.  With the RCCL backend the whole iteration -- the recorded kernels of the three plans AND the
+        collectives -- is captured once into ONE graph (torch.cuda.graph: RCCL collectives are capturable) and replayed n times
+        with no host work in between; otherwise (gloo in the tests, capture refused) the host drives plan / collective / plan."""
+        dist = torch.distributed
+        comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
+        want = self.use_graph and os.environ.get("RDO_DP_GRAPH", "1") != "0" and (not comm or dist.get_backend(self.group) == "nccl")
+        if want and getattr(self, "_dp_graph", None) is None and not getattr(self, "_dp_graph_failed", False) and n > 1:
+            try:
+                self._dp_iteration(False)                           # one eager iteration: warms RCCL and every lazy initialisation
+                n -= 1
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._dp_iteration(False)
+                self._dp_graph = g
+            except Exception as e:      # pragma: no cover - depends on the RCCL / driver stack
+                import logging
+                logging.warning("data-parallel iteration could not be captured into a graph (%s): host-driven loop", e)
+                self._dp_graph_failed = True
+                torch.cuda.synchronize()
+        if getattr(self, "_dp_graph", None) is not None:
+            for _ in range(n):
+                self._dp_graph.replay()
+            return
+        for _ in range(n):
+            self._dp_iteration(self.use_graph)
 
     def _rd_tail(self, i):
         """Iteration i's task loss: the images of the mini-batch through the wrapped model with this unit's output replaced by the
