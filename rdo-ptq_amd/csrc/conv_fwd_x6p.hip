@@ -317,30 +317,41 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
         };
         using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
         using I3 = std::integral_constant<int, 3>; using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
-        dma_prepare();
+        auto dma6 = [&]() {
+            dma_prepare();
+            dma_issue(I0{}, nb); dma_issue(I1{}, nb); dma_issue(I2{}, nb); dma_issue(I3{}, nb); dma_issue(I4{}, nb); dma_issue(I5{}, nb);
+        };
+        // The SIMD partners (wave w and w + 4) leave the barrier together.  Shipped schedule: two DMAs per MFMA slot, waves 0-3 in slots
+        // 0-2, waves 4-7 in slots 3-5 (203 us on the 4 x 128^2 conv, MFMAs alone 170 us on that box).  ablate bit 32 selects the
+        // weight-gradient kernel's schedule instead -- waves 0-3 issue all six before their reads, waves 4-7 after three slots -- which
+        // is SLOWER here (220 us).
+        const bool old_sched = (a.ablate & 32) == 0;
+        if (old_sched) dma_prepare();
+        else if (!late) dma6();
         // fragments in the order the products need them: (A2,B0) (A0,B2) (A1,B0) (A1,B1) (A0,B1) (A0,B0), small terms first
         rd_a(2); rd_b(0);
         rd_a(0); rd_b(2);
         __builtin_amdgcn_sched_barrier(0);
         mma(2, 0);
         rd_a(1);
-        if (!late) { dma_issue(I0{}, nb); dma_issue(I1{}, nb); }
+        if (old_sched && !late) { dma_issue(I0{}, nb); dma_issue(I1{}, nb); }
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 2);
         rd_b(1);
-        if (!late) { dma_issue(I2{}, nb); dma_issue(I3{}, nb); }
+        if (old_sched && !late) { dma_issue(I2{}, nb); dma_issue(I3{}, nb); }
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 0);
-        if (!late) { dma_issue(I4{}, nb); dma_issue(I5{}, nb); }
+        if (old_sched && !late) { dma_issue(I4{}, nb); dma_issue(I5{}, nb); }
+        if (!old_sched && late) dma6();
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 1);
-        if (late) { dma_issue(I0{}, nb); dma_issue(I1{}, nb); }
+        if (old_sched && late) { dma_issue(I0{}, nb); dma_issue(I1{}, nb); }
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 1);
-        if (late) { dma_issue(I2{}, nb); dma_issue(I3{}, nb); }
+        if (old_sched && late) { dma_issue(I2{}, nb); dma_issue(I3{}, nb); }
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 0);
-        if (late) { dma_issue(I4{}, nb); dma_issue(I5{}, nb); }
+        if (old_sched && late) { dma_issue(I4{}, nb); dma_issue(I5{}, nb); }
         __builtin_amdgcn_sched_barrier(0);
         buf = buf + 1 == RING ? 0 : buf + 1;
     }
