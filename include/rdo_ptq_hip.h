@@ -58,6 +58,7 @@ const char* rdo_last_error(void);
  *   "conv_x6"      1 (default): large convolutions on the split-bf16 MFMA path, 0: everything on the fp32 MFMA
  *   "fwd_x6_ver"   forward bf16x6 kernel generation (default: newest)
  *   "xcd"          1 (default): XCD-aware tile numbering in the bf16x6 kernels
+ *   "graph_unroll" iterations per replayed graph in rdo_plan_run for long runs (default 8; 1: one graph launch per iteration)
  *   "x6p_ablate"   diagnostic bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
  *                  8 no fragment reads, 16 rotate the K order per tile (results stay right)
  * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */

@@ -27,7 +27,7 @@ namespace {
 struct TuneDef { const char* key; const char* env; int dflt; };
 constexpr TuneDef kTune[T_COUNT] = {{"wgrad_x6_w8", "RDO_WGX6_W8", 1}, {"conv_x6", "RDO_CONV_X6", 1},
                                     {"fwd_x6_ver", "RDO_X6_VER", 6}, {"xcd", "RDO_XCD", 1},
-                                    {"x6p_ablate", "RDO_X6P_ABLATE", 0}};
+                                    {"x6p_ablate", "RDO_X6P_ABLATE", 0}, {"graph_unroll", "RDO_GRAPH_UNROLL", 8}};
 std::atomic<int> g_tune[T_COUNT];
 std::once_flag g_tune_once;
 void tune_init() {
@@ -57,6 +57,8 @@ struct rdo_plan {
     std::vector<rdo::Op> ops;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
+    hipGraph_t graph_k = nullptr;        // kUnroll iterations in one graph: no inter-graph gap between them
+    hipGraphExec_t exec_k = nullptr;
     hipStream_t cap_stream = nullptr;
     bool recording = false;
 };
@@ -88,6 +90,8 @@ void rdo_plan_destroy(rdo_plan* p) {
     if (p->recording) { rdo::recorder().active = false; rdo::recorder().sink = nullptr; }
     if (p->exec) (void)hipGraphExecDestroy(p->exec);
     if (p->graph) (void)hipGraphDestroy(p->graph);
+    if (p->exec_k) (void)hipGraphExecDestroy(p->exec_k);
+    if (p->graph_k) (void)hipGraphDestroy(p->graph_k);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     delete p;
 }
@@ -98,6 +102,8 @@ int rdo_plan_begin_record(rdo_plan* p) {
     p->ops.clear();
     if (p->exec) { (void)hipGraphExecDestroy(p->exec); p->exec = nullptr; }
     if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
+    if (p->exec_k) { (void)hipGraphExecDestroy(p->exec_k); p->exec_k = nullptr; }
+    if (p->graph_k) { (void)hipGraphDestroy(p->graph_k); p->graph_k = nullptr; }
     p->recording = true;
     rdo::recorder().active = true;
     rdo::recorder().sink = &p->ops;
@@ -133,20 +139,37 @@ int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream) {
         }
         return RDO_OK;
     }
-    if (!p->exec) {
-        // Capture one iteration on a private stream (the caller's stream may be the legacy default stream).
+    auto capture = [&](int reps, hipGraph_t* g, hipGraphExec_t* ex) -> int {
+        // Capture on a private stream (the caller's stream may be the legacy default stream).
         if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipStreamCreate failed");
         if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipStreamBeginCapture failed");
-        int rc = run_ops(p, p->cap_stream);
-        hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph);
+        int rc = RDO_OK;
+        for (int r = 0; r < reps && rc == RDO_OK; ++r) rc = run_ops(p, p->cap_stream);
+        hipError_t e = hipStreamEndCapture(p->cap_stream, g);
         if (rc != RDO_OK) return rc;
         if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
-        e = hipGraphInstantiate(&p->exec, p->graph, nullptr, nullptr, 0);
+        e = hipGraphInstantiate(ex, *g, nullptr, nullptr, 0);
         if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        return RDO_OK;
+    };
+    // Long runs replay a graph of kUnroll iterations (every per-iteration scalar comes from device tables indexed by the device
+    // iteration counter, so consecutive iterations can live in one graph): the ~2 us gap between two graph launches and the per-
+    // launch host cost are paid once per kUnroll iterations -- it shows on the small units (45-160 us per iteration).
+    const int unroll = rdo::tuning(rdo::T_GRAPH_UNROLL);
+    int i = 0;
+    if (unroll > 1 && n_iters >= 2 * unroll) {
+        if (!p->exec_k)
+            if (int rc = capture(unroll, &p->graph_k, &p->exec_k)) return rc;
+        for (; i + unroll <= n_iters; i += unroll) {
+            hipError_t e = hipGraphLaunch(p->exec_k, s);
+            if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
+        }
     }
-    for (int i = 0; i < n_iters; ++i) {
+    if (i < n_iters && !p->exec)
+        if (int rc = capture(1, &p->graph, &p->exec)) return rc;
+    for (; i < n_iters; ++i) {
         hipError_t e = hipGraphLaunch(p->exec, s);
         if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
     }
