@@ -124,9 +124,14 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     // issue the global load of staging quad j for K step `s` (wave-uniform tap / channel slice)
     auto load_quad = [&](auto jc, int srel) {
         constexpr int j = decltype(jc)::value;
+        // K order: channel slice OUTER, taps INNER (as the bf16x6 kernels): the taps of one 32-channel slice read overlapping input
+        // rows back to back, so they are served from L1 / L2 -- with taps outer every tap re-fetched its rows through the fabric
+        // (g_s.7.0, 192 -> 12 at 4 x 128^2: rocprofv3 FETCH_SIZE 376 MiB for a 50 MB input)
         const int s = sbeg + srel;
-        const int tap = s / a.csteps;
-        const int c0 = (s - tap * a.csteps) * BK + 4 * q;
+        const int ktaps = a.KH * a.KW;
+        const int cs = s / ktaps;
+        const int tap = s - cs * ktaps;
+        const int c0 = cs * BK + 4 * q;
         const int kh = tap / a.KW, kw = tap - kh * a.KW;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         bool ok;
