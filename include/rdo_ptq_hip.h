@@ -303,8 +303,9 @@ int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const f
                       float* dx, void* dx_planes, void* stream);            /* rdo_gdn_bwd_dx with fp32 and / or P3 output */
 /* F.pixel_shuffle(x, 2) on NHWC: [B,H,W,4C] -> [B,2H,2W,C] as fp32 and / or P3 planes */
 int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream);
-/* its gradient: [B,2H,2W,C] -> [B,H,W,4C] (= rdo_pixel_shuffle(..., inverse = 1) for r = 2, 16-byte accesses on both sides) */
-int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* stream);
+/* its gradient: [B,2H,2W,C] -> [B,H,W,4C] (= rdo_pixel_shuffle(..., inverse = 1) for r = 2, 16-byte accesses on both sides), as fp32
+ * and / or P3 planes */
+int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream);
 
 /* ---- unit executor: a recorded sequence of the calls above, replayed per calibration iteration with no host work.
  * Python records the per-iteration op list once per unit (layer_reconstruction / block_reconstruction, layer_opt.py:287-309);

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_p3_kernel(const float* x, 
 
 // inverse (the gradient of the r = 2 pixel shuffle): [B,2H,2W,C] -> [B,H,W,4C]; one thread per (small pixel, quad of large channels):
 // four 16-byte loads from the four large pixels, 4 x 4 transpose, four 16-byte stores (16 consecutive channels of the small pixel)
-__global__ __launch_bounds__(256) void pixel_unshuffle2_kernel(const float* x, long npix_small, int H, int W, int C, float* out) {
+__global__ __launch_bounds__(256) void pixel_unshuffle2_kernel(const float* x, long npix_small, int H, int W, int C, float* out,
+                                                               u16* planes) {
     const int cq = C / 4;
     const long total = npix_small * cq;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -225,9 +226,12 @@ __global__ __launch_bounds__(256) void pixel_unshuffle2_kernel(const float* x, l
         f32x4 v[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(x + big0 + (j >> 1) * row + (j & 1) * C);
-        float* dst = out + p * (4L * C) + 16 * q;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(dst + 4 * i) = f32x4{v[0][i], v[1][i], v[2][i], v[3][i]};
+        for (int i = 0; i < 4; ++i) {
+            const f32x4 o = {v[0][i], v[1][i], v[2][i], v[3][i]};
+            if (out) *reinterpret_cast<f32x4*>(out + p * (4L * C) + 16 * q + 4 * i) = o;
+            if (planes) store_p3(planes, npix_small, 4 * C, p, 16 * q + 4 * i, o);
+        }
     }
 }
 
@@ -319,12 +323,13 @@ int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_
         stream, "pixel_shuffle", 0.0, (double)npl * C * (4.0 + (out ? 4.0 : 0.0) + (pl ? 6.0 : 0.0)));
 }
 
-int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* stream) {
-    RDO_REQUIRE(x && out && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "rdo_pixel_unshuffle2: bad argument");
+int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream) {
+    RDO_REQUIRE(x && (out || out_planes) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "rdo_pixel_unshuffle2: bad argument");
     const long nps = (long)B * H * W;
+    u16* pl = reinterpret_cast<u16*>(out_planes);
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid_for(nps * C / 4)), dim3(256), 0, s, x, nps, H, W, C, out);
+            hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid_for(nps * C / 4)), dim3(256), 0, s, x, nps, H, W, C, out, pl);
             return rdo::check_launch("pixel_unshuffle2");
         },
         stream, "pixel_shuffle", 0.0, (double)nps * C * 32.0);

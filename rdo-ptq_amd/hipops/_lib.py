@@ -103,7 +103,7 @@ _SIGS = {
     "rdo_loss_gdn_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P, P]),
     "rdo_gdn_bwd_dx_p3": (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),
     "rdo_pixel_shuffle_p3": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
-    "rdo_pixel_unshuffle2": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
+    "rdo_pixel_unshuffle2": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
     "rdo_plan_create": (P, []),
     "rdo_plan_destroy": (None, [P]),
     "rdo_plan_begin_record": (C.c_int, [P]),

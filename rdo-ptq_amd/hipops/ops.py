@@ -550,24 +550,10 @@ def pixel_shuffle_p3(x, out=None, out_planes=None):
     L.check(L.lib().rdo_pixel_shuffle_p3(_ptr(x), B, H, W, CC // 4, _ptr(out), _ptr(out_planes), _stream()), "rdo_pixel_shuffle_p3")
 
 
-def pixel_unshuffle2(x, out=None):
-    """[B,2H,2W,C] -> [B,H,W,4C]: gradient of the r = 2 pixel shuffle (16-byte accesses on both sides)."""
+def pixel_unshuffle2(x, out=None, out_planes=None):
+    """[B,2H,2W,C] -> [B,H,W,4C]: gradient of the r = 2 pixel shuffle (16-byte accesses on both sides), as fp32 and / or P3 planes."""
     B, Hr, Wr, Cc = x.shape
-    out = torch.empty((B, Hr // 2, Wr // 2, 4 * Cc), device=x.device, dtype=torch.float32) if out is None else out
-    L.check(L.lib().rdo_pixel_unshuffle2(_ptr(x), B, Hr // 2, Wr // 2, Cc, _ptr(out), _stream()), "rdo_pixel_unshuffle2")
+    if out is None and out_planes is None:
+        out = torch.empty((B, Hr // 2, Wr // 2, 4 * Cc), device=x.device, dtype=torch.float32)
+    L.check(L.lib().rdo_pixel_unshuffle2(_ptr(x), B, Hr // 2, Wr // 2, Cc, _ptr(out), _ptr(out_planes), _stream()), "rdo_pixel_unshuffle2")
     return out
-
-
-def wgrad_p3_supported(x_shape, w_shape, stride, pad):
-    d = conv_desc(x_shape, w_shape, stride, pad)
-    return bool(L.lib().rdo_conv2d_wgrad_p3_supported(C.byref(d)))
-
-
-def conv2d_wgrad_p3(xp, x_shape, dyp, w_shape, stride=1, pad=0, slabs=None):
-    """Weight-gradient slabs from P3 operands (planes of x [B,H,W,Cin] and of dy [B,Ho,Wo,Cout])."""
-    d = conv_desc(x_shape, w_shape, stride, pad)
-    ns = int(L.lib().rdo_conv2d_wgrad_nsplit(C.byref(d))) if slabs is None else slabs.shape[0]
-    if slabs is None:
-        slabs = torch.empty((ns,) + tuple(w_shape), device=xp.device, dtype=torch.float32)
-    L.check(L.lib().rdo_conv2d_wgrad_p3(C.byref(d), _ptr(xp), _ptr(dyp), _ptr(slabs), ns, _stream()), "rdo_conv2d_wgrad_p3")
-    return slabs

@@ -459,9 +459,19 @@ class UnitEngine:
         h1p, tp, dcp = self._p3("h1", t["h1"]), self._p3("t", t["h1"]), self._p3(dname, t["h1"])
         if rbu:
             r = self.r
-            self._conv(sp, x, t["sp"], epilogue=L.EPI_LRELU)
+            # the two 192 -> 768 sub-pixel convs and their weight gradients on planes as well when the shapes qualify
+            xs = tuple(x.shape)
+            sub_p3 = (x.shape[-1] % 16 == 0 and self._conv_ok_p3(sp, xs) and self._conv_ok_p3(up, xs)
+                      and ops.wgrad_p3_supported(xs, sp.w4, sp.stride, sp.pad) and ops.wgrad_p3_supported(xs, up.w4, up.stride, up.pad))
+            if sub_p3:
+                xp = self._p3("x", x)
+                ops.split_p3(x, xp)
+                self._conv_p3(sp, xp, xs, out=t["sp"], epilogue=L.EPI_LRELU)
+                self._conv_p3(up, xp, xs, out=t["up"])
+            else:
+                self._conv(sp, x, t["sp"], epilogue=L.EPI_LRELU)
+                self._conv(up, x, t["up"])
             ops.pixel_shuffle_p3(t["sp"], out=t["h1"], out_planes=h1p)
-            self._conv(up, x, t["up"])
             self._shuffle(t["up"], r, t["ups"])
             res = t["ups"]
         else:
@@ -476,8 +486,13 @@ class UnitEngine:
         self._task_is_rec = True
         ops.loss_gdn_bwd(t[cname], t["norm"], res, self.co, self.idx, self.it, 2.0, rbu, self.loss_log, t["dout"], t=t["t"], t_planes=tp)
         if rbu:
-            self._unshuffle(t["dout"], r, t["dup"])
-            self._wgrad(up, x, t["dup"])
+            if sub_p3:
+                dupp = self._p3("dup", t["dup"])
+                ops.pixel_unshuffle2(t["dout"], out_planes=dupp)
+                self._wgrad_p3(up, xp, xs, dupp)
+            else:
+                self._unshuffle(t["dout"], r, t["dup"])
+                self._wgrad(up, x, t["dup"])
         elif "skip" in o:
             self._wgrad(o["skip"], x, t["dout"])
         self._gdn_backward_p3(g, t["dout"], t[cname], t["norm"], tp, t["acc"], dcp)
@@ -485,9 +500,15 @@ class UnitEngine:
         self._wgrad_p3(cv, h1p, t["h1"].shape, dcp)
         self._dgrad_p3(cv, dcp, t["h1"].shape, out=t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
         if rbu:
-            self._unshuffle(t["dh1"], r, t["dsp"])
-            self._split_point()
-            self._wgrad(sp, x, t["dsp"])
+            if sub_p3:
+                dspp = self._p3("dsp", t["dsp"])
+                ops.pixel_unshuffle2(t["dh1"], out_planes=dspp)
+                self._split_point()
+                self._wgrad_p3(sp, xp, xs, dspp)
+            else:
+                self._unshuffle(t["dh1"], r, t["dsp"])
+                self._split_point()
+                self._wgrad(sp, x, t["dsp"])
         else:
             self._split_point()
             self._wgrad(c1, x, t["dh1"])

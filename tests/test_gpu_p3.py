@@ -175,6 +175,12 @@ def test_pixel_shuffle_p3(ops):
     ops.pixel_shuffle_p3(x, out=out, out_planes=pl)
     assert torch.equal(out, ref) and torch.equal(ops.p3_to_float(pl, ref.shape), ref)
     assert torch.equal(ref, torch.nn.functional.pixel_shuffle(x.permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1))
+    # and its gradient (pixel unshuffle), fp32 and planes
+    back = ops.pixel_unshuffle2(ref)
+    assert torch.equal(back, x)
+    bpl = ops.p3_empty(x.shape, "cuda")
+    ops.pixel_unshuffle2(ref, out_planes=bpl)
+    assert torch.equal(ops.p3_to_float(bpl, x.shape), x)
 
 
 WGRAD_SHAPES = [(4, 128, 192, 192, 3, 1, 1), (4, 64, 192, 768, 3, 1, 1), (4, 64, 192, 192, 3, 1, 1), (4, 128, 192, 192, 3, 2, 1),
