@@ -557,3 +557,18 @@ def pixel_unshuffle2(x, out=None, out_planes=None):
         out = torch.empty((B, Hr // 2, Wr // 2, 4 * Cc), device=x.device, dtype=torch.float32)
     L.check(L.lib().rdo_pixel_unshuffle2(_ptr(x), B, Hr // 2, Wr // 2, Cc, _ptr(out), _ptr(out_planes), _stream()), "rdo_pixel_unshuffle2")
     return out
+
+
+def wgrad_p3_supported(x_shape, w_shape, stride, pad):
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    return bool(L.lib().rdo_conv2d_wgrad_p3_supported(C.byref(d)))
+
+
+def conv2d_wgrad_p3(xp, x_shape, dyp, w_shape, stride=1, pad=0, slabs=None):
+    """Weight-gradient slabs from P3 operands (planes of x [B,H,W,Cin] and of dy [B,Ho,Wo,Cout])."""
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    ns = int(L.lib().rdo_conv2d_wgrad_nsplit(C.byref(d))) if slabs is None else slabs.shape[0]
+    if slabs is None:
+        slabs = torch.empty((ns,) + tuple(w_shape), device=xp.device, dtype=torch.float32)
+    L.check(L.lib().rdo_conv2d_wgrad_p3(C.byref(d), _ptr(xp), _ptr(dyp), _ptr(slabs), ns, _stream()), "rdo_conv2d_wgrad_p3")
+    return slabs
