@@ -59,6 +59,7 @@ const char* rdo_last_error(void);
  *   "fwd_x6_ver"   forward bf16x6 kernel generation (default: newest)
  *   "xcd"          1 (default): XCD-aware tile numbering in the bf16x6 kernels
  *   "graph_unroll" iterations per replayed graph in rdo_plan_run for long runs (default 8; 1: one graph launch per iteration)
+ *   "tail_grid"    most workgroups of a fused loss kernel (each ends with one atomic add into the 32-slot loss log)
  *   "x6p_ablate"   diagnostic bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
  *                  8 no fragment reads, 16 rotate the K order per tile (results stay right)
  * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */
@@ -277,6 +278,7 @@ int64_t rdo_conv2d_fwd_p3_workspace(const rdo_conv_desc* d);   /* floats of spli
  * fragment-ordered planes (rdo_split_bf16x3_conv / rdo_adaround_step).  Any of out / pre / out_planes may be NULL (at least one is
  * required); out_planes receives the P3 form of `out`. */
 int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
+                      const void* aux_planes /* nullable: P3 form of aux, enough for RDO_EPI_LRELU_BWD / _RELU_BWD (sign only) */,
                       const float* residual, float* out, float* pre, void* out_planes, float* workspace, int64_t workspace_floats,
                       void* stream);
 /* rdo_conv2d_wgrad with both operands as P3 planes (x: [B*H*W][Cin], dy: [B*Ho*Wo][Cout]); same slabs, same nsplit rule
@@ -291,9 +293,9 @@ int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32
  *   loss_out[*iter][slot] += coef * sum d^2 / npix ; grad_out = coef * 2 d / npix ; dpre = grad_out * act'(pre)
  * i.e. the activation epilogue of the conv, rdo_lp2_loss_grad and rdo_lrelu_bwd / rdo_relu_bwd in one pass (layer_opt.py:133,150,
  * 303-306).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU.  out / grad_out / dpre / dpre_planes are optional outputs. */
-int rdo_loss_act_bwd(const float* pre, const float* residual, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
-                     int32_t B, int64_t per_image, int32_t C, float coef, int32_t act, float* out, float* grad_out, float* dpre,
-                     void* dpre_planes, float* loss_out, void* stream);
+int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residual_planes /* nullable: the residual as P3 planes */,
+                     const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C,
+                     float coef, int32_t act, float* out, float* grad_out, float* dpre, void* dpre_planes, float* loss_out, void* stream);
 /* Tail of a unit that ends in GDN / IGDN (+ residual):  out = x * norm^(-1/2 | +1/2) + residual ; loss and grad_out as above ;
  *   t = dL/dnorm = -1/2 g x norm^-3/2 (GDN) | 1/2 g x norm^-1/2 (IGDN)      = GDN epilogue + rdo_lp2_loss_grad + rdo_gdn_bwd_t */
 int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, const float* tgt_cache, const int32_t* idx_table,

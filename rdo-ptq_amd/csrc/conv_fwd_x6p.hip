@@ -43,6 +43,7 @@ struct X6PArgs {
     long wplane;
     const float* bias;
     const float* aux;
+    const u16* auxp;      // alternative to aux for the sign-only epilogues (LRELU_BWD / RELU_BWD): P3 planes of the aux tensor (plane 0 is read)
     const float* residual;
     float* out;           // nullable
     float* pre;           // nullable
@@ -106,6 +107,18 @@ __device__ __forceinline__ float activate(const X6PArgs& a, float v, float aux) 
     }
 }
 
+// four aux values of channels [n, n+4) of pixel m: the fp32 tensor, or plane 0 of its P3 form (same sign as the value: enough for the
+// activation-backward masks)
+__device__ __forceinline__ f32x4 aux_quad(const X6PArgs& a, int m, int n, long o) {
+    if (a.aux) return *reinterpret_cast<const f32x4*>(a.aux + o);
+    if (a.auxp) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 b = *reinterpret_cast<const u32x2*>(a.auxp + ((long)(n >> 4) * a.M + m) * 16 + (n & 15));
+        return f32x4{lo_f(b[0]), hi_f(b[0]), lo_f(b[1]), hi_f(b[1])};
+    }
+    return f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
 // the three P3 records of (slice n / 16, pixel m) from 16 finished channel values: 32 bytes per plane
 __device__ __forceinline__ void store_slice(const X6PArgs& a, int m, int n, const float (&v)[16]) {
     u16* dst = a.outp + ((long)(n >> 4) * a.M + m) * 16;
@@ -137,8 +150,7 @@ __device__ __forceinline__ void finish16(const X6PArgs& a, int m, int n, float (
     if (a.epilogue != RDO_EPI_NONE) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
-            if (a.aux) x4 = *reinterpret_cast<const f32x4*>(a.aux + o + 4 * c);
+            const f32x4 x4 = aux_quad(a, m, n + 4 * c, o + 4 * c);
 #pragma unroll
             for (int k = 0; k < 4; ++k) v[4 * c + k] = activate(a, v[4 * c + k], x4[k]);
         }
@@ -243,6 +255,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
         const long off = ((long)ccs * Min + (apix0 + hi * a.W + wi)) * 16 + achunk * 8;
         asrc = ok ? a.xp + off : zero;
         apstep = ok ? a.xplane : 0;
+        if ((a.ablate & 64) && (ckh | ckw)) {                // diagnostic: activation tile fetched for tap (0,0) only (wrong results)
+            asrc = zero;
+            apstep = 0;
+        }
         wsrc = a.wp + (long)cabs * a.Cout * 16;
         if (cstage + 1 < nsteps) {                           // advance, clamped at the last stage (tail stages re-fetch it: harmless)
             ++cstage;
@@ -392,8 +408,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
             if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
             if (a.pre) *reinterpret_cast<f32x4*>(a.pre + o) = v;
             if (a.epilogue != RDO_EPI_NONE) {
-                f32x4 x4 = {0.f, 0.f, 0.f, 0.f};
-                if (a.aux) x4 = *reinterpret_cast<const f32x4*>(a.aux + o);
+                const f32x4 x4 = aux_quad(a, m, n, o);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = activate(a, v[e], x4[e]);
             }
@@ -512,22 +527,24 @@ extern "C" int64_t rdo_conv2d_fwd_p3_workspace(const rdo_conv_desc* d) {
 }
 
 extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
-                                 const float* residual, float* out, float* pre, void* out_planes, float* workspace,
-                                 int64_t workspace_floats, void* stream) {
+                                 const void* aux_planes, const float* residual, float* out, float* pre, void* out_planes,
+                                 float* workspace, int64_t workspace_floats, void* stream) {
     RDO_REQUIRE(d && x_planes && wplanes && (out || out_planes || pre), "rdo_conv2d_fwd_p3: null argument");
     RDO_REQUIRE(rdo_conv2d_fwd_p3_supported(d), "rdo_conv2d_fwd_p3: shape not on the split-bf16 plane path (rdo_conv2d_fwd_p3_supported)");
     const int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
     RDO_REQUIRE(ho == d->Ho && wo == d->Wo, "rdo_conv2d_fwd_p3: Ho/Wo (%d,%d) do not match geometry (%d,%d)", d->Ho, d->Wo, ho, wo);
     const int epi = d->epilogue;
     RDO_REQUIRE(epi >= RDO_EPI_NONE && epi <= RDO_EPI_RELU_BWD, "rdo_conv2d_fwd_p3: unknown epilogue %d", epi);
-    RDO_REQUIRE(epi == RDO_EPI_NONE || epi == RDO_EPI_LRELU || epi == RDO_EPI_RELU || aux != nullptr, "rdo_conv2d_fwd_p3: epilogue %d needs aux", epi);
+    RDO_REQUIRE(epi == RDO_EPI_NONE || epi == RDO_EPI_LRELU || epi == RDO_EPI_RELU || aux != nullptr ||
+                    (aux_planes != nullptr && (epi == RDO_EPI_LRELU_BWD || epi == RDO_EPI_RELU_BWD)),
+                "rdo_conv2d_fwd_p3: epilogue %d needs aux (aux_planes serve the activation-backward epilogues only)", epi);
     RDO_REQUIRE(!d->add_residual || residual != nullptr, "rdo_conv2d_fwd_p3: add_residual without residual");
     X6PArgs a{};
     a.xp = reinterpret_cast<const u16*>(x_planes);
     a.xplane = (long)d->B * d->H * d->W * d->Cin;
     a.wp = reinterpret_cast<const u16*>(wplanes);
     a.wplane = (long)d->Cout * d->KH * d->KW * d->Cin;
-    a.bias = bias; a.aux = aux; a.residual = residual; a.out = out; a.pre = pre;
+    a.bias = bias; a.aux = aux; a.auxp = aux ? nullptr : reinterpret_cast<const u16*>(aux_planes); a.residual = residual; a.out = out; a.pre = pre;
     a.outp = reinterpret_cast<u16*>(out_planes);
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad;

@@ -22,6 +22,13 @@ typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
+// loss kernels: every workgroup ends with one float atomic into one of the 32 log slots; same-address atomics serialise in L2, so the
+// grid is capped (grid-stride loops cover the rest)
+inline unsigned loss_grid(long blocks) {
+    const long cap = rdo::tuning(rdo::T_TAIL_GRID);
+    return (unsigned)(blocks < 1 ? 1 : (blocks > cap ? cap : blocks));
+}
+
 inline unsigned grid_for(long n) {
     long g = rdo::ceil_div(n, 256L);
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
@@ -38,25 +45,6 @@ __device__ __forceinline__ unsigned cvt_pk(float a, float b) {
 __device__ __forceinline__ float lo_f(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
 __device__ __forceinline__ float hi_f(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
 
-// exact three-way split of a quad of channels [c0, c0 + 4) of pixel m -> one 8-byte store per plane, P3 slice-major layout
-// (rdo_ptq_hip.h): element (m, c) of a tensor with M pixels and C channels at plane * M * C + ((c >> 4) * M + m) * 16 + (c & 15)
-__device__ __forceinline__ void store_p3(u16* planes, long M, int C, long m, int c0, const f32x4& v) {
-    const long pstride = M * C;
-    const long e = ((long)(c0 >> 4) * M + m) * 16 + (c0 & 15);
-    const unsigned h01 = cvt_pk(v[0], v[1]), h23 = cvt_pk(v[2], v[3]);
-    const float r0 = v[0] - lo_f(h01), r1 = v[1] - hi_f(h01), r2 = v[2] - lo_f(h23), r3 = v[3] - hi_f(h23);
-    const unsigned m01 = cvt_pk(r0, r1), m23 = cvt_pk(r2, r3);
-    const float s0 = r0 - lo_f(m01), s1 = r1 - hi_f(m01), s2 = r2 - lo_f(m23), s3 = r3 - hi_f(m23);
-    *reinterpret_cast<u32x2*>(planes + e) = u32x2{h01, h23};
-    *reinterpret_cast<u32x2*>(planes + pstride + e) = u32x2{m01, m23};
-    *reinterpret_cast<u32x2*>(planes + 2 * pstride + e) = u32x2{cvt_pk(s0, s1), cvt_pk(s2, s3)};
-}
-// element offset e of an NHWC tensor with C channels -> (pixel, first channel of the quad)
-__device__ __forceinline__ void store_p3_at(u16* planes, long M, int C, long e, const f32x4& v) {
-    const long m = e / C;
-    store_p3(planes, M, C, m, (int)(e - m * C), v);
-}
-
 __device__ __forceinline__ void block_loss_add(float acc, float scale, float* loss_out, int it) {
     __shared__ float red[4];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -66,34 +54,123 @@ __device__ __forceinline__ void block_loss_add(float acc, float scale, float* lo
         atomicAdd(loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), (red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
+// ---- pixel-major work split of the kernels that write (or read) planes ----------------------------------------------------------
+// A virtual block covers 64 pixels x one group of 32 channels (one 128-byte line of the fp32 tensors per pixel); a thread owns 8
+// consecutive channels of one pixel (quads at c0 and c0 + 4): two 16-byte fp32 accesses per tensor and ONE 16-byte access per plane.
+// Lanes 4p..4p+3 hold pixel p, so the plane stores of a wave are two runs of 16 consecutive 32-byte records (slices 2g and 2g+1)
+// instead of 8-byte pieces scattered over twelve slices, which is what a channel-major thread order produces.  (Measured at
+// 4 x 128^2 x 192, tools/bench_tails.py: 16-byte plane stores in this order 35 us for gather + planes; 8-byte stores -- channel-major,
+// or pixel-major with the two quads 16 channels apart so that the fp32 side is sector-complete -- 42-56 us.)
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int Q2 = 4;       // channel distance between the two quads of a thread
+
+struct Oct {
+    long m;     // pixel
+    int c0;     // first of the 8 channels
+};
+__device__ __forceinline__ bool oct_of(long vb, int ngroups, long M, int C, Oct& o) {
+    const int grp = (int)(vb % ngroups);
+    o.m = (vb / ngroups) * 64 + (threadIdx.x >> 2);
+    o.c0 = grp * 32 + (threadIdx.x & 3) * 8;
+    return o.m < M && o.c0 < C;          // C % 16 == 0: the 8 channels exist together
+}
+inline long oct_blocks(long M, int C) { return rdo::ceil_div(M, 64L) * rdo::ceil_div(C, 32); }
+inline unsigned oct_grid(long M, int C) {
+    const long g = oct_blocks(M, C);
+    return (unsigned)(g > 8192 ? 8192 : g);
+}
+
+__device__ __forceinline__ void store_p3_oct(u16* planes, long M, int C, const Oct& o, const f32x4& a, const f32x4& b) {
+    const long pstride = M * C;
+    const long e = ((long)(o.c0 >> 4) * M + o.m) * 16 + (o.c0 & 15);
+    const unsigned h0 = cvt_pk(a[0], a[1]), h1 = cvt_pk(a[2], a[3]), h2 = cvt_pk(b[0], b[1]), h3 = cvt_pk(b[2], b[3]);
+    const float r0 = a[0] - lo_f(h0), r1 = a[1] - hi_f(h0), r2 = a[2] - lo_f(h1), r3 = a[3] - hi_f(h1);
+    const float r4 = b[0] - lo_f(h2), r5 = b[1] - hi_f(h2), r6 = b[2] - lo_f(h3), r7 = b[3] - hi_f(h3);
+    const unsigned m0 = cvt_pk(r0, r1), m1 = cvt_pk(r2, r3), m2 = cvt_pk(r4, r5), m3 = cvt_pk(r6, r7);
+    const unsigned l0 = cvt_pk(r0 - lo_f(m0), r1 - hi_f(m0)), l1 = cvt_pk(r2 - lo_f(m1), r3 - hi_f(m1));
+    const unsigned l2 = cvt_pk(r4 - lo_f(m2), r5 - hi_f(m2)), l3 = cvt_pk(r6 - lo_f(m3), r7 - hi_f(m3));
+    *reinterpret_cast<u32x4*>(planes + e) = u32x4{h0, h1, h2, h3};
+    *reinterpret_cast<u32x4*>(planes + pstride + e) = u32x4{m0, m1, m2, m3};
+    *reinterpret_cast<u32x4*>(planes + 2 * pstride + e) = u32x4{l0, l1, l2, l3};
+}
+// exact fp32 values of the thread's 8 channels from planes: (p0 + p1) + p2, both additions exact
+__device__ __forceinline__ void load_p3_oct(const u16* planes, long M, int C, const Oct& o, f32x4& a, f32x4& b) {
+    const long pstride = M * C;
+    const long e = ((long)(o.c0 >> 4) * M + o.m) * 16 + (o.c0 & 15);
+    const u32x4 h = *reinterpret_cast<const u32x4*>(planes + e), m = *reinterpret_cast<const u32x4*>(planes + pstride + e),
+                l = *reinterpret_cast<const u32x4*>(planes + 2 * pstride + e);
+    a = f32x4{(lo_f(h[0]) + lo_f(m[0])) + lo_f(l[0]), (hi_f(h[0]) + hi_f(m[0])) + hi_f(l[0]),
+              (lo_f(h[1]) + lo_f(m[1])) + lo_f(l[1]), (hi_f(h[1]) + hi_f(m[1])) + hi_f(l[1])};
+    b = f32x4{(lo_f(h[2]) + lo_f(m[2])) + lo_f(l[2]), (hi_f(h[2]) + hi_f(m[2])) + hi_f(l[2]),
+              (lo_f(h[3]) + lo_f(m[3])) + lo_f(l[3]), (hi_f(h[3]) + hi_f(m[3])) + hi_f(l[3])};
+}
+
+__device__ __forceinline__ const f32x4& ldq(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void stq(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---- gather + QDrop ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 qdrop_quad(const float* cq, const float* cfp, long src, uint32_t i0, uint32_t key, unsigned long long thr) {
+    const f32x4 q = ldq(cq + src), f = ldq(cfp + src);
+    f32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = ((unsigned long long)lowbias32((i0 + e) ^ key) < thr) ? q[e] : f[e];
+    return o;
+}
+
 __global__ __launch_bounds__(256) void gather_qdrop_p3_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
                                                               const int32_t* iter_ptr, int B, int batch_offset, long per_image, int C,
                                                               unsigned long long thr, uint32_t seed, float* out, u16* planes) {
     const int it = *iter_ptr;
     const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
-    const long quads = per_image / 4;
-    const long total = (long)B * quads;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(t / quads);
-        const long off = (t - (long)b * quads) * 4;
-        const long src = (long)idx_table[(long)it * B + b] * per_image + off;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(cq + src);
-        const f32x4 f = *reinterpret_cast<const f32x4*>(cfp + src);
-        const uint32_t i0 = (uint32_t)((long)(batch_offset + b) * per_image + off);
-        f32x4 o;
+    const long ppi = per_image / C, M = (long)B * ppi;
+    const int ngroups = (C + 31) / 32;
+    const long nvb = ((M + 63) / 64) * ngroups;
+    for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        Oct o;
+        if (!oct_of(vb, ngroups, M, C, o)) continue;
+        const int b = (int)(o.m / ppi);
+        const long row = (long)idx_table[(long)it * B + b] * per_image;
+        f32x4 v[2];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = ((unsigned long long)lowbias32((i0 + e) ^ key) < thr) ? q[e] : f[e];
-        const long dst = (long)b * per_image + off;
-        if (out) *reinterpret_cast<f32x4*>(out + dst) = o;
-        store_p3_at(planes, total * 4 / C, C, dst, o);
+        for (int k = 0; k < 2; ++k) {
+            const int c = o.c0 + k * Q2;
+            const long off = (o.m - (long)b * ppi) * C + c;                           // element offset inside the image
+            const uint32_t i0 = (uint32_t)((long)(batch_offset + b) * per_image + off);   // the element's RNG counter (elementwise.hip)
+            v[k] = qdrop_quad(cq, cfp, row + off, i0, key, thr);
+        }
+        // all loads before any store (the stores may alias the inputs as far as the compiler knows)
+        if (out) {
+            stq(out + o.m * C + o.c0, v[0]);
+            stq(out + o.m * C + o.c0 + Q2, v[1]);
+        }
+        store_p3_oct(planes, M, C, o, v[0], v[1]);
     }
 }
 
-// act: 0 none, 1 LeakyReLU(0.01), 2 ReLU
+// ---- conv activation + loss + gradient + activation backward ------------------------------------------------------------------------
+// act: 0 none, 1 LeakyReLU(0.01), 2 ReLU.  One quad: o = act(p) (+ r); d = o - y; returns sum d^2; g = dL/dout; dp = dL/dpre
+__device__ __forceinline__ float loss_act_quad(const f32x4& p, const f32x4& y, const f32x4* r, int act, float slope, float gs, f32x4& o,
+                                               f32x4& g, f32x4& dp) {
+    o = p;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = p[k] > 0.f ? p[k] : slope * p[k];
+    }
+    if (r) o += *r;
+    const f32x4 dd = o - y;
+    g = dd * gs;
+    dp = g;
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) dp[k] = p[k] > 0.f ? g[k] : slope * g[k];
+    }
+    return (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+}
+
+// fp32 outputs only: channel-major thread order, every access a fully coalesced 16 bytes per lane
 __global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, const float* res, const float* tgt, const int32_t* idx_table,
-                                                           const int32_t* iter_ptr, int B, long per_image, int C, float inv_npix, float coef,
-                                                           int act, float* out, float* gout, float* dpre, u16* dpre_planes,
-                                                           float* loss_out) {
+                                                           const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef,
+                                                           int act, float* out, float* gout, float* dpre, float* loss_out) {
     const int it = *iter_ptr;
     const long quads = per_image / 4;
     const long total = (long)B * quads;
@@ -104,33 +181,77 @@ __global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, con
         const int b = (int)(t / quads);
         const long off = (t - (long)b * quads) * 4;
         const long e = (long)b * per_image + off;
-        const f32x4 p = *reinterpret_cast<const f32x4*>(pre + e);
-        const f32x4 y = *reinterpret_cast<const f32x4*>(tgt + (long)idx_table[(long)it * B + b] * per_image + off);
-        f32x4 o = p;
-        if (act) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) o[k] = p[k] > 0.f ? p[k] : slope * p[k];
-        }
-        if (res) o += *reinterpret_cast<const f32x4*>(res + e);
-        if (out) *reinterpret_cast<f32x4*>(out + e) = o;
-        const f32x4 dd = o - y;
-        acc += (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
-        f32x4 g = dd * gs;
-        if (gout) *reinterpret_cast<f32x4*>(gout + e) = g;
-        if (act) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) g[k] = p[k] > 0.f ? g[k] : slope * g[k];
-        }
-        if (dpre) *reinterpret_cast<f32x4*>(dpre + e) = g;
-        if (dpre_planes) store_p3_at(dpre_planes, total * 4 / C, C, e, g);
+        const f32x4 p = ldq(pre + e), y = ldq(tgt + (long)idx_table[(long)it * B + b] * per_image + off);
+        f32x4 r, o, g, dp;
+        if (res) r = ldq(res + e);
+        acc += loss_act_quad(p, y, res ? &r : nullptr, act, slope, gs, o, g, dp);
+        if (out) stq(out + e, o);
+        if (gout) stq(gout + e, g);
+        if (dpre) stq(dpre + e, dp);
     }
     block_loss_add(acc, inv_npix * coef, loss_out, it);
 }
 
+// with planes on either side (dL/dpre out, residual in): pixel-major
+__global__ __launch_bounds__(256) void loss_act_bwd_pix_kernel(const float* pre, const float* res, const u16* res_planes, const float* tgt,
+                                                               const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
+                                                               int C, float inv_npix, float coef, int act, float* out, float* gout,
+                                                               float* dpre, u16* dpre_planes, float* loss_out) {
+    const int it = *iter_ptr;
+    const long ppi = per_image / C, M = (long)B * ppi;
+    const int ngroups = (C + 31) / 32;
+    const long nvb = ((M + 63) / 64) * ngroups;
+    const float gs = coef * 2.f * inv_npix;
+    const float slope = act == 1 ? 0.01f : 0.f;
+    float acc = 0.f;
+    for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        Oct oc;
+        if (!oct_of(vb, ngroups, M, C, oc)) continue;
+        const int b = (int)(oc.m / ppi);
+        const float* yrow = tgt + ((long)idx_table[(long)it * B + b] - b) * per_image;       // + e = the target of element e
+        f32x4 r[2], d[2], o[2], g[2];
+        const bool has_r = res || res_planes;
+        const long e0 = oc.m * C + oc.c0;
+        if (res_planes && !res) load_p3_oct(res_planes, M, C, oc, r[0], r[1]);
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long e = e0 + k * Q2;
+            if (res) r[k] = ldq(res + e);
+            acc += loss_act_quad(ldq(pre + e), ldq(yrow + e), has_r ? &r[k] : nullptr, act, slope, gs, o[k], g[k], d[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (out) stq(out + e0 + k * Q2, o[k]);
+            if (gout) stq(gout + e0 + k * Q2, g[k]);
+            if (dpre) stq(dpre + e0 + k * Q2, d[k]);
+        }
+        if (dpre_planes) store_p3_oct(dpre_planes, M, C, oc, d[0], d[1]);
+    }
+    block_loss_add(acc, inv_npix * coef, loss_out, it);
+}
+
+// ---- GDN / IGDN epilogue + loss + gradient + dL/dnorm ----------------------------------------------------------------------------------
+__device__ __forceinline__ float loss_gdn_quad(const f32x4& xv, const f32x4& nv, const f32x4& y, const f32x4* r, int inverse, float gs,
+                                               f32x4& o, f32x4& g, f32x4& tv) {
+    f32x4 rs;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        rs[k] = __frsqrt_rn(nv[k]);
+        o[k] = xv[k] * (inverse ? __fsqrt_rn(nv[k]) : rs[k]);       // the GDN / IGDN epilogue of the norm-pool conv
+    }
+    if (r) o += *r;
+    const f32x4 dd = o - y;
+    g = dd * gs;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)       // GDN: y = x n^-1/2 -> dy/dn = -1/2 x n^-3/2 ; IGDN: y = x n^1/2 -> dy/dn = 1/2 x n^-1/2
+        tv[k] = inverse ? (0.5f * g[k] * xv[k]) * rs[k] : (-0.5f * g[k] * xv[k]) * (rs[k] * rs[k] * rs[k]);
+    return (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+}
+
 __global__ __launch_bounds__(256) void loss_gdn_bwd_kernel(const float* x, const float* nrm, const float* res, const float* tgt,
-                                                           const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image, int C,
+                                                           const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
                                                            float inv_npix, float coef, int inverse, float* out, float* gout, float* tbuf,
-                                                           u16* t_planes, float* loss_out) {
+                                                           float* loss_out) {
     const int it = *iter_ptr;
     const long quads = per_image / 4;
     const long total = (long)B * quads;
@@ -140,53 +261,96 @@ __global__ __launch_bounds__(256) void loss_gdn_bwd_kernel(const float* x, const
         const int b = (int)(q / quads);
         const long off = (q - (long)b * quads) * 4;
         const long e = (long)b * per_image + off;
-        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + e);
-        const f32x4 nv = *reinterpret_cast<const f32x4*>(nrm + e);
-        const f32x4 y = *reinterpret_cast<const f32x4*>(tgt + (long)idx_table[(long)it * B + b] * per_image + off);
-        f32x4 r, o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            r[k] = __frsqrt_rn(nv[k]);
-            o[k] = xv[k] * (inverse ? __fsqrt_rn(nv[k]) : r[k]);       // the GDN / IGDN epilogue of the norm-pool conv
-        }
-        if (res) o += *reinterpret_cast<const f32x4*>(res + e);
-        if (out) *reinterpret_cast<f32x4*>(out + e) = o;
-        const f32x4 dd = o - y;
-        acc += (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
-        const f32x4 g = dd * gs;
-        *reinterpret_cast<f32x4*>(gout + e) = g;
-        f32x4 tv;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)       // GDN: y = x n^-1/2 -> dy/dn = -1/2 x n^-3/2 ; IGDN: y = x n^1/2 -> dy/dn = 1/2 x n^-1/2
-            tv[k] = inverse ? (0.5f * g[k] * xv[k]) * r[k] : (-0.5f * g[k] * xv[k]) * (r[k] * r[k] * r[k]);
-        if (tbuf) *reinterpret_cast<f32x4*>(tbuf + e) = tv;
-        if (t_planes) store_p3_at(t_planes, total * 4 / C, C, e, tv);
+        f32x4 r, o, g, tv;
+        if (res) r = ldq(res + e);
+        acc += loss_gdn_quad(ldq(x + e), ldq(nrm + e), ldq(tgt + (long)idx_table[(long)it * B + b] * per_image + off), res ? &r : nullptr,
+                             inverse, gs, o, g, tv);
+        if (out) stq(out + e, o);
+        stq(gout + e, g);
+        stq(tbuf + e, tv);
     }
     block_loss_add(acc, inv_npix * coef, loss_out, it);
 }
 
-__global__ __launch_bounds__(256) void gdn_bwd_dx_p3_kernel(const float* g, const float* x, const float* nrm, const float* acc, long n4,
-                                                            int C, int inverse, float* dx, u16* dx_planes) {
+__global__ __launch_bounds__(256) void loss_gdn_bwd_pix_kernel(const float* x, const float* nrm, const float* res, const float* tgt,
+                                                               const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
+                                                               int C, float inv_npix, float coef, int inverse, float* out, float* gout,
+                                                               float* tbuf, u16* t_planes, float* loss_out) {
+    const int it = *iter_ptr;
+    const long ppi = per_image / C, M = (long)B * ppi;
+    const int ngroups = (C + 31) / 32;
+    const long nvb = ((M + 63) / 64) * ngroups;
+    const float gs = coef * 2.f * inv_npix;
+    float acc = 0.f;
+    for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        Oct oc;
+        if (!oct_of(vb, ngroups, M, C, oc)) continue;
+        const int b = (int)(oc.m / ppi);
+        const float* yrow = tgt + ((long)idx_table[(long)it * B + b] - b) * per_image;
+        f32x4 tv[2], o[2], g[2];
+        const long e0 = oc.m * C + oc.c0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const long e = e0 + k * Q2;
+            f32x4 r;
+            if (res) r = ldq(res + e);
+            acc += loss_gdn_quad(ldq(x + e), ldq(nrm + e), ldq(yrow + e), res ? &r : nullptr, inverse, gs, o[k], g[k], tv[k]);
+        }
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            if (out) stq(out + e0 + k * Q2, o[k]);
+            stq(gout + e0 + k * Q2, g[k]);
+            if (tbuf) stq(tbuf + e0 + k * Q2, tv[k]);
+        }
+        store_p3_oct(t_planes, M, C, oc, tv[0], tv[1]);
+    }
+    block_loss_add(acc, inv_npix * coef, loss_out, it);
+}
+
+// ---- GDN backward: dx -------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 gdn_dx_quad(const f32x4& gv, const f32x4& xv, const f32x4& nv, const f32x4& av, int inverse) {
+    f32x4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float f = inverse ? __fsqrt_rn(nv[k]) : __frsqrt_rn(nv[k]);
+        o[k] = gv[k] * f + 2.f * xv[k] * av[k];
+    }
+    return o;
+}
+
+__global__ __launch_bounds__(256) void gdn_bwd_dx_kernel(const float* g, const float* x, const float* nrm, const float* acc, long n4,
+                                                         int inverse, float* dx) {
     for (long q = (long)blockIdx.x * blockDim.x + threadIdx.x; q < n4; q += (long)gridDim.x * blockDim.x) {
         const long e = q * 4;
-        const f32x4 gv = *reinterpret_cast<const f32x4*>(g + e), xv = *reinterpret_cast<const f32x4*>(x + e);
-        const f32x4 nv = *reinterpret_cast<const f32x4*>(nrm + e), av = *reinterpret_cast<const f32x4*>(acc + e);
-        f32x4 o;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float f = inverse ? __fsqrt_rn(nv[k]) : __frsqrt_rn(nv[k]);
-            o[k] = gv[k] * f + 2.f * xv[k] * av[k];
-        }
-        if (dx) *reinterpret_cast<f32x4*>(dx + e) = o;
-        if (dx_planes) store_p3_at(dx_planes, n4 * 4 / C, C, e, o);
+        stq(dx + e, gdn_dx_quad(ldq(g + e), ldq(x + e), ldq(nrm + e), ldq(acc + e), inverse));
     }
 }
 
-// r = 2 pixel shuffle, one thread per (small pixel, quad of LARGE channels): 16 consecutive channels of the small tensor (four 16-byte
-// loads) hold four large channels x four sub-pixels; a 4 x 4 transpose in registers yields one 16-byte quad for each of the four
-// large pixels (2h+dy, 2w+dx) -- channel c of that pixel is channel 4c + 2dy + dx of the small one -- written as fp32 and as planes
-__global__ __launch_bounds__(256) void pixel_shuffle2_p3_kernel(const float* x, long npix_small, int H, int W, int C, float* out,
-                                                                u16* planes) {
+__global__ __launch_bounds__(256) void gdn_bwd_dx_pix_kernel(const float* g, const float* x, const float* nrm, const float* acc, long M,
+                                                             int C, int inverse, float* dx, u16* dx_planes) {
+    const int ngroups = (C + 31) / 32;
+    const long nvb = ((M + 63) / 64) * ngroups;
+    for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        Oct oc;
+        if (!oct_of(vb, ngroups, M, C, oc)) continue;
+        f32x4 o[2];
+        const long e0 = oc.m * C + oc.c0;
+#pragma unroll
+        for (int k = 0; k < 2; ++k)
+            o[k] = gdn_dx_quad(ldq(g + e0 + k * Q2), ldq(x + e0 + k * Q2), ldq(nrm + e0 + k * Q2), ldq(acc + e0 + k * Q2), inverse);
+        if (dx) {
+            stq(dx + e0, o[0]);
+            stq(dx + e0 + Q2, o[1]);
+        }
+        store_p3_oct(dx_planes, M, C, oc, o[0], o[1]);
+    }
+}
+
+// ---- r = 2 pixel shuffle and its gradient --------------------------------------------------------------------------------------------------
+// Channel c of large pixel (2h + dy, 2w + dx) is channel 4c + 2dy + dx of small pixel (h, w).  fp32-only: one thread per (small
+// pixel, quad of LARGE channels): 16 consecutive channels of the small tensor (four 16-byte loads) hold four large channels x four
+// sub-pixels; a 4 x 4 transpose in registers yields one 16-byte quad for each of the four large pixels.
+__global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float* x, long npix_small, int H, int W, int C, float* out) {
     const int cq = C / 4;
     const long total = npix_small * cq;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -197,23 +361,47 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_p3_kernel(const float* x, 
         const float* src = x + p * (4L * C) + 16 * q;
         f32x4 v[4];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(src + 4 * i);
+        for (int i = 0; i < 4; ++i) v[i] = ldq(src + 4 * i);
         const long big0 = ((bh * 2) * (2L * W) + 2 * w) * C + 4 * q;      // large pixel (b, 2h, 2w)
         const long row = 2L * W * C;
 #pragma unroll
+        for (int j = 0; j < 4; ++j) stq(out + big0 + (j >> 1) * row + (j & 1) * C, f32x4{v[0][j], v[1][j], v[2][j], v[3][j]});
+    }
+}
+
+// with planes: pixel-major over the SMALL pixels; a thread owns 8 large channels = 32 consecutive small channels (128 bytes) and
+// writes 8 channels of each of the four large pixels
+__global__ __launch_bounds__(256) void pixel_shuffle2_pix_kernel(const float* x, long npix_small, int H, int W, int C, float* out,
+                                                                 u16* planes) {
+    const int ngroups = (C + 31) / 32;
+    const long nvb = ((npix_small + 63) / 64) * ngroups;
+    const long ML = npix_small * 4;
+    for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        Oct oc;                                            // (small pixel, first of 8 large channels)
+        if (!oct_of(vb, ngroups, npix_small, C, oc)) continue;
+        const int w = (int)(oc.m % W);
+        const long bh = oc.m / W;
+        const float* src = x + oc.m * (4L * C) + 4 * oc.c0;
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = ldq(src + 4 * k);
+        const long big_pix = (bh * 2) * (2L * W) + 2 * w;
+#pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const f32x4 o = {v[0][j], v[1][j], v[2][j], v[3][j]};
-            const long e = big0 + (j >> 1) * row + (j & 1) * C;
-            if (out) *reinterpret_cast<f32x4*>(out + e) = o;
-            if (planes) store_p3(planes, npix_small * 4, C, e / C, 4 * q, o);
+            const f32x4 a = {v[0][j], v[1][j], v[2][j], v[3][j]}, b = {v[4][j], v[5][j], v[6][j], v[7][j]};
+            const Oct big{big_pix + (j >> 1) * (2L * W) + (j & 1), oc.c0};
+            if (out) {
+                stq(out + big.m * C + oc.c0, a);
+                stq(out + big.m * C + oc.c0 + 4, b);
+            }
+            store_p3_oct(planes, ML, C, big, a, b);
         }
     }
 }
 
-// inverse (the gradient of the r = 2 pixel shuffle): [B,2H,2W,C] -> [B,H,W,4C]; one thread per (small pixel, quad of large channels):
-// four 16-byte loads from the four large pixels, 4 x 4 transpose, four 16-byte stores (16 consecutive channels of the small pixel)
-__global__ __launch_bounds__(256) void pixel_unshuffle2_kernel(const float* x, long npix_small, int H, int W, int C, float* out,
-                                                               u16* planes) {
+// gradient of the shuffle: [B,2H,2W,C] -> [B,H,W,4C]; fp32-only: one thread per (small pixel, quad of large channels): four 16-byte
+// loads from the four large pixels, 4 x 4 transpose, four 16-byte stores (16 consecutive channels of the small pixel)
+__global__ __launch_bounds__(256) void pixel_unshuffle2_kernel(const float* x, long npix_small, int H, int W, int C, float* out) {
     const int cq = C / 4;
     const long total = npix_small * cq;
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
@@ -225,13 +413,40 @@ __global__ __launch_bounds__(256) void pixel_unshuffle2_kernel(const float* x, l
         const long row = 2L * W * C;
         f32x4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v[j] = *reinterpret_cast<const f32x4*>(x + big0 + (j >> 1) * row + (j & 1) * C);
+        for (int j = 0; j < 4; ++j) v[j] = ldq(x + big0 + (j >> 1) * row + (j & 1) * C);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const f32x4 o = {v[0][i], v[1][i], v[2][i], v[3][i]};
-            if (out) *reinterpret_cast<f32x4*>(out + p * (4L * C) + 16 * q + 4 * i) = o;
-            if (planes) store_p3(planes, npix_small, 4 * C, p, 16 * q + 4 * i, o);
+        for (int i = 0; i < 4; ++i) stq(out + p * (4L * C) + 16 * q + 4 * i, f32x4{v[0][i], v[1][i], v[2][i], v[3][i]});
+    }
+}
+
+// with planes: a virtual block covers 32 small pixels x 128 small channels (= 32 large channels, one 128-byte line of each of the
+// four large pixels); a thread owns one 16-channel slice of one small pixel (= 4 large channels): four 16-byte loads, a complete
+// 32-byte record per plane
+__global__ __launch_bounds__(256) void pixel_unshuffle2_pix_kernel(const float* x, long npix_small, int H, int W, int C, float* out,
+                                                                   u16* planes) {
+    const int ngroups = (C + 31) / 32;
+    const long nvb = ((npix_small + 31) / 32) * ngroups;
+    const int C4 = 4 * C;
+    for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
+        const int grp = (int)(vb % ngroups);
+        const long p = (vb / ngroups) * 32 + (threadIdx.x >> 3);
+        const int cl = grp * 32 + (threadIdx.x & 7) * 4;   // first of the 4 large channels
+        if (p >= npix_small || cl >= C) continue;
+        const int w = (int)(p % W);
+        const long bh = p / W;
+        const long big0 = ((bh * 2) * (2L * W) + 2 * w) * C + cl;
+        const long row = 2L * W * C;
+        f32x4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = ldq(x + big0 + (j >> 1) * row + (j & 1) * C);
+        const f32x4 o0 = {v[0][0], v[1][0], v[2][0], v[3][0]}, o1 = {v[0][1], v[1][1], v[2][1], v[3][1]};
+        const f32x4 o2 = {v[0][2], v[1][2], v[2][2], v[3][2]}, o3 = {v[0][3], v[1][3], v[2][3], v[3][3]};
+        if (out) {
+            float* dst = out + p * (long)C4 + 4 * cl;
+            stq(dst, o0); stq(dst + 4, o1); stq(dst + 8, o2); stq(dst + 12, o3);
         }
+        store_p3_oct(planes, npix_small, C4, Oct{p, 4 * cl}, o0, o1);
+        store_p3_oct(planes, npix_small, C4, Oct{p, 4 * cl + 8}, o2, o3);
     }
 }
 
@@ -251,27 +466,33 @@ int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32
     u16* pl = reinterpret_cast<u16*>(out_planes);
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(gather_qdrop_p3_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, cache_q, cache_fp,
+            hipLaunchKernelGGL(gather_qdrop_p3_kernel, dim3(oct_grid((long)B * (per_image / C), C)), dim3(256), 0, s, cache_q, cache_fp,
                                idx_table, iter_ptr, B, batch_offset, (long)per_image, C, thr, seed, out, pl);
             return rdo::check_launch("gather_qdrop_p3");
         },
         stream, "gather_qdrop_p3", 0.0, (8.0 + (out ? 4.0 : 0.0) + 6.0) * B * per_image);
 }
 
-int rdo_loss_act_bwd(const float* pre, const float* residual, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
-                     int32_t B, int64_t per_image, int32_t C, float coef, int32_t act, float* out, float* grad_out, float* dpre,
-                     void* dpre_planes, float* loss_out, void* stream) {
+int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residual_planes, const float* tgt_cache,
+                     const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef, int32_t act,
+                     float* out, float* grad_out, float* dpre, void* dpre_planes, float* loss_out, void* stream) {
     RDO_REQUIRE(pre && tgt_cache && idx_table && iter_ptr && (dpre || dpre_planes || grad_out), "rdo_loss_act_bwd: null pointer");
     RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_loss_act_bwd: bad shape");
-    RDO_REQUIRE(!dpre_planes || C % 16 == 0, "rdo_loss_act_bwd: P3 output needs C % 16 == 0");
+    RDO_REQUIRE((!dpre_planes && !residual_planes) || C % 16 == 0, "rdo_loss_act_bwd: P3 tensors need C % 16 == 0");
+    const u16* rpl = residual ? nullptr : reinterpret_cast<const u16*>(residual_planes);
     RDO_REQUIRE(act >= 0 && act <= 2, "rdo_loss_act_bwd: act %d (0 none, 1 LeakyReLU(0.01), 2 ReLU)", act);
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
     u16* pl = reinterpret_cast<u16*>(dpre_planes);
     const double n = (double)B * per_image;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(loss_act_bwd_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, pre, residual, tgt_cache,
-                               idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, act, out, grad_out, dpre, pl, loss_out);
+            if (pl || rpl)
+                hipLaunchKernelGGL(loss_act_bwd_pix_kernel, dim3(loss_grid(oct_blocks((long)B * (per_image / C), C))), dim3(256), 0, s, pre, residual, rpl,
+                                   tgt_cache, idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, act, out, grad_out, dpre, pl,
+                                   loss_out);
+            else
+                hipLaunchKernelGGL(loss_act_bwd_kernel, dim3(loss_grid(rdo::ceil_div((long)B * per_image / 4, 256L))), dim3(256), 0, s, pre, residual, tgt_cache,
+                                   idx_table, iter_ptr, B, (long)per_image, inv_npix, coef, act, out, grad_out, dpre, loss_out);
             return rdo::check_launch("loss_act_bwd");
         },
         stream, "loss_act_bwd", 0.0,
@@ -289,8 +510,13 @@ int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, c
     const double n = (double)B * per_image;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(loss_gdn_bwd_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, x, norm, residual, tgt_cache,
-                               idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, inverse, out, grad_out, t, pl, loss_out);
+            if (pl)
+                hipLaunchKernelGGL(loss_gdn_bwd_pix_kernel, dim3(loss_grid(oct_blocks((long)B * (per_image / C), C))), dim3(256), 0, s, x, norm, residual,
+                                   tgt_cache, idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, inverse, out, grad_out, t, pl,
+                                   loss_out);
+            else
+                hipLaunchKernelGGL(loss_gdn_bwd_kernel, dim3(loss_grid(rdo::ceil_div((long)B * per_image / 4, 256L))), dim3(256), 0, s, x, norm, residual, tgt_cache,
+                                   idx_table, iter_ptr, B, (long)per_image, inv_npix, coef, inverse, out, grad_out, t, loss_out);
             return rdo::check_launch("loss_gdn_bwd");
         },
         stream, "loss_gdn_bwd", 0.0,
@@ -304,7 +530,11 @@ int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const f
     u16* pl = reinterpret_cast<u16*>(dx_planes);
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(gdn_bwd_dx_p3_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, g, x, norm, acc, (long)(n / 4), C, inverse, dx, pl);
+            if (pl)
+                hipLaunchKernelGGL(gdn_bwd_dx_pix_kernel, dim3(oct_grid(n / C, C)), dim3(256), 0, s, g, x, norm, acc, (long)(n / C), C, inverse,
+                                   dx, pl);
+            else
+                hipLaunchKernelGGL(gdn_bwd_dx_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, g, x, norm, acc, (long)(n / 4), inverse, dx);
             return rdo::check_launch("gdn_bwd_dx_p3");
         },
         stream, "gdn_bwd_dx", 0.0, (double)n * (16.0 + (dx ? 4.0 : 0.0) + (pl ? 6.0 : 0.0)));
@@ -317,7 +547,10 @@ int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_
     const long nps = (long)B * H * W, npl = nps * 4;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(pixel_shuffle2_p3_kernel, dim3(grid_for(nps * C / 4)), dim3(256), 0, s, x, nps, H, W, C, out, pl);
+            if (pl)
+                hipLaunchKernelGGL(pixel_shuffle2_pix_kernel, dim3(oct_grid(nps, C)), dim3(256), 0, s, x, nps, H, W, C, out, pl);
+            else
+                hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for(nps * C / 4)), dim3(256), 0, s, x, nps, H, W, C, out);
             return rdo::check_launch("pixel_shuffle_p3");
         },
         stream, "pixel_shuffle", 0.0, (double)npl * C * (4.0 + (out ? 4.0 : 0.0) + (pl ? 6.0 : 0.0)));
@@ -329,7 +562,12 @@ int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_
     u16* pl = reinterpret_cast<u16*>(out_planes);
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid_for(nps * C / 4)), dim3(256), 0, s, x, nps, H, W, C, out, pl);
+            if (pl) {
+                const long g = rdo::ceil_div(nps, 32L) * rdo::ceil_div(C, 32);
+                hipLaunchKernelGGL(pixel_unshuffle2_pix_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, x, nps, H, W, C, out, pl);
+            } else {
+                hipLaunchKernelGGL(pixel_unshuffle2_kernel, dim3(grid_for(nps * C / 4)), dim3(256), 0, s, x, nps, H, W, C, out);
+            }
             return rdo::check_launch("pixel_unshuffle2");
         },
         stream, "pixel_shuffle", 0.0, (double)nps * C * 32.0);

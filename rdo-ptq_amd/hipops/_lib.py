@@ -95,11 +95,11 @@ _SIGS = {
     "rdo_split_p3": (C.c_int, [P, C.c_int64, C.c_int32, P, P]),
     "rdo_conv2d_fwd_p3_workspace": (C.c_int64, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_fwd_p3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
-    "rdo_conv2d_fwd_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, C.c_int64, P]),
+    "rdo_conv2d_fwd_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, C.c_int64, P]),
     "rdo_conv2d_wgrad_p3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_wgrad_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, C.c_int, P]),
     "rdo_gather_qdrop_p3": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_uint32, P, P, P]),
-    "rdo_loss_act_bwd": (C.c_int, [P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P, P]),
+    "rdo_loss_act_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P, P]),
     "rdo_loss_gdn_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P, P]),
     "rdo_gdn_bwd_dx_p3": (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),
     "rdo_pixel_shuffle_p3": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),

@@ -505,13 +505,13 @@ def conv_p3_supported(x_shape, w_shape, stride, pad, square_input=False):
 
 
 def conv2d_fwd_p3(xp, x_shape, w_shape, wplanes, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, out=None, pre=None,
-                  out_planes=None):
+                  out_planes=None, aux_planes=None):
     """Conv on a P3 input (`xp` = planes of the NHWC tensor of shape `x_shape`) with fragment-ordered weight planes; writes whichever
     of out / pre / out_planes is given."""
     d = conv_desc(x_shape, w_shape, stride, pad, epilogue, False, residual is not None)
     need = int(L.lib().rdo_conv2d_fwd_p3_workspace(C.byref(d)))
     ws = _scratch(xp.device, need) if need else None
-    L.check(L.lib().rdo_conv2d_fwd_p3(C.byref(d), _ptr(xp), _ptr(wplanes), _ptr(bias), _ptr(aux), _ptr(residual), _ptr(out), _ptr(pre),
+    L.check(L.lib().rdo_conv2d_fwd_p3(C.byref(d), _ptr(xp), _ptr(wplanes), _ptr(bias), _ptr(aux), _ptr(aux_planes), _ptr(residual), _ptr(out), _ptr(pre),
                                       _ptr(out_planes), _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "rdo_conv2d_fwd_p3")
     return out
 
@@ -525,9 +525,10 @@ def gather_qdrop_p3(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 
 
-def loss_act_bwd(pre, residual, tgt_cache, idx_table, iter_ptr, coef, act, loss_log, out=None, grad_out=None, dpre=None, dpre_planes=None):
+def loss_act_bwd(pre, residual, tgt_cache, idx_table, iter_ptr, coef, act, loss_log, out=None, grad_out=None, dpre=None, dpre_planes=None,
+                 residual_planes=None):
     B, per_image = pre.shape[0], pre[0].numel()
-    L.check(L.lib().rdo_loss_act_bwd(_ptr(pre), _ptr(residual), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
+    L.check(L.lib().rdo_loss_act_bwd(_ptr(pre), _ptr(residual), _ptr(residual_planes), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
                                      pre.shape[-1], coef, int(act), _ptr(out), _ptr(grad_out), _ptr(dpre), _ptr(dpre_planes),
                                      _ptr(loss_log), _stream()), "rdo_loss_act_bwd")
 

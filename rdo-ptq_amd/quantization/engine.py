@@ -372,6 +372,7 @@ class UnitEngine:
 
     # ------------------------------------------------------------------------------------------------------------------ P3 path
     P3_MIN_OUT = 65536 * 192        # plane-input forward kernel pays off from 4 x 128^2 x 192 output elements (profiles/r02a)
+    p3_lean = os.environ.get("RDO_P3_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fp32
 
     def _p3(self, name, like):
         if name not in self.P:
@@ -393,10 +394,10 @@ class UnitEngine:
         ops.conv2d_fwd_p3(xp, tuple(x_shape), op.w4, op.wq_planes, op.beta if op.is_gdn else op.bias, op.stride, op.pad,
                           epilogue=epilogue, aux=aux, residual=residual, out=out, pre=pre, out_planes=out_planes)
 
-    def _dgrad_p3(self, op, dyp, dy_shape, out=None, out_planes=None, epilogue=L.EPI_NONE, aux=None):
+    def _dgrad_p3(self, op, dyp, dy_shape, out=None, out_planes=None, epilogue=L.EPI_NONE, aux=None, aux_planes=None):
         op.enable_planes(False, True)
         ops.conv2d_fwd_p3(dyp, tuple(dy_shape), tuple(op.wd4().shape), op.wd_planes, None, 1, op.K - 1 - op.pad, epilogue=epilogue,
-                          aux=aux, out=out, out_planes=out_planes)
+                          aux=aux, aux_planes=aux_planes, out=out, out_planes=out_planes)
 
     def _wgrad_p3(self, op, xp, x_shape, dyp):
         if op.slabs is None:
@@ -434,13 +435,19 @@ class UnitEngine:
         c1, c2 = o["conv1"], o["conv2"]
         xp, h1p = self._p3("x", x), self._p3("h1", t["h1"])
         dp2p, dh1p = self._p3("dpre2", t["h1"]), self._p3("dh1", t["h1"])
-        ops.gather_qdrop_p3(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, xp, self.batch_offset)
-        self._conv_p3(c1, xp, x.shape, out=t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
+        lean = self.p3_lean
+        # lean: x and h1 exist as planes only -- the residual add of the tail sums the three planes back (exactly), the LeakyReLU
+        # mask of the dgrad epilogue reads the sign off plane 0
+        ops.gather_qdrop_p3(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, None if lean else x, xp,
+                            self.batch_offset)
+        self._conv_p3(c1, xp, x.shape, out=None if lean else t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
         self._conv_p3(c2, h1p, t["h1"].shape, out=t["pre2"])
         self._task_is_rec = True
-        ops.loss_act_bwd(t["pre2"], x, self.co, self.idx, self.it, 2.0, ops.ACT_LRELU, self.loss_log, dpre_planes=dp2p)
+        ops.loss_act_bwd(t["pre2"], None if lean else x, self.co, self.idx, self.it, 2.0, ops.ACT_LRELU, self.loss_log, dpre_planes=dp2p,
+                         residual_planes=xp if lean else None)
         self._wgrad_p3(c2, h1p, t["h1"].shape, dp2p)
-        self._dgrad_p3(c2, dp2p, t["h1"].shape, out_planes=dh1p, epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+        self._dgrad_p3(c2, dp2p, t["h1"].shape, out_planes=dh1p, epilogue=L.EPI_LRELU_BWD, aux=None if lean else t["h1"],
+                       aux_planes=h1p if lean else None)
         self._split_point()
         self._wgrad_p3(c1, xp, x.shape, dh1p)
 
@@ -471,7 +478,7 @@ class UnitEngine:
             else:
                 self._conv(sp, x, t["sp"], epilogue=L.EPI_LRELU)
                 self._conv(up, x, t["up"])
-            ops.pixel_shuffle_p3(t["sp"], out=t["h1"], out_planes=h1p)
+            ops.pixel_shuffle_p3(t["sp"], out=None if self.p3_lean else t["h1"], out_planes=h1p)
             self._shuffle(t["up"], r, t["ups"])
             res = t["ups"]
         else:
@@ -498,7 +505,9 @@ class UnitEngine:
         self._gdn_backward_p3(g, t["dout"], t[cname], t["norm"], tp, t["acc"], dcp)
         self._wgrad(g, t[cname], t["t"], square=True)
         self._wgrad_p3(cv, h1p, t["h1"].shape, dcp)
-        self._dgrad_p3(cv, dcp, t["h1"].shape, out=t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=t["h1"])
+        lean_aux = rbu and self.p3_lean
+        self._dgrad_p3(cv, dcp, t["h1"].shape, out=t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=None if lean_aux else t["h1"],
+                       aux_planes=h1p if lean_aux else None)
         if rbu:
             if sub_p3:
                 dspp = self._p3("dsp", t["dsp"])

@@ -83,6 +83,12 @@ def test_conv_p3_epilogues(ops, L, H, Cout):
         assert torch.equal(ops.p3_to_float(opl, ref.shape), ref), epi
         if want_pre:
             assert torch.equal(pre, pre_ref)
+        if epi in (L.EPI_LRELU_BWD, L.EPI_RELU_BWD):
+            # activation-backward masks from plane 0 of the aux tensor (same sign as the fp32 value), planes-only output
+            opl2 = ops.p3_empty(ref.shape, "cuda")
+            ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, b, 1, 1, epilogue=epi, aux_planes=ops.split_p3(aux), residual=r,
+                              out_planes=opl2)
+            assert torch.equal(opl2, opl), epi
 
 
 def test_gather_qdrop_p3(ops):
@@ -132,6 +138,12 @@ def test_loss_act_bwd_equals_unfused_chain(ops, act, with_res):
     pl2 = ops.p3_empty(pre.shape, "cuda")
     ops.loss_act_bwd(pre, res, tgt, idx, it, 2.0, act, torch.zeros(1, 32, device="cuda"), dpre_planes=pl2)
     assert torch.equal(pl2, pl)
+    if with_res:
+        # the residual handed over as planes only (exact: the three planes sum back to the fp32 value)
+        pl3, out3 = ops.p3_empty(pre.shape, "cuda"), torch.empty_like(pre)
+        ops.loss_act_bwd(pre, None, tgt, idx, it, 2.0, act, torch.zeros(1, 32, device="cuda"), out=out3, dpre_planes=pl3,
+                         residual_planes=ops.split_p3(res))
+        assert torch.equal(pl3, pl) and torch.equal(out3, o)
 
 
 @pytest.mark.parametrize("inverse", [False, True])

@@ -20,11 +20,20 @@ from quantization.recon import _unit_modules  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=20000)
 ap.add_argument("--images", type=int, default=64)
+ap.add_argument("--units", default="rb,rbu", help="comma list out of rb,rbu")
+ap.add_argument("--tune", default="", help="comma list of key=value for rdo_set_tuning (kernel ablation / variant switches)")
 a = ap.parse_args()
+if a.tune:
+    from hipops import ops as _ops
+    for kv in a.tune.split(","):
+        k, v = kv.split("=")
+        _ops.set_tuning(k, int(v))
 N = 192
 WQ = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
 for name, mk, qcls, shape in (("g_a.1 RB @128^2", lambda: lic.ResidualBlock(N, N), QuantRB, (a.images, 128, 128, N)),
                               ("g_s.5 RBU 64^2->128^2", lambda: lic.ResidualBlockUpsample(N, N, 2), QuantRBU, (a.images, 64, 64, N))):
+    if ("rbu" if qcls is QuantRBU else "rb") not in a.units.split(","):
+        continue
     torch.manual_seed(1)
     blk = mk().cuda()
     for m in blk.modules():
