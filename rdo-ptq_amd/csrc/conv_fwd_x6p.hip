@@ -437,6 +437,252 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Halo variant for 3 x 3, stride 1, pad 1 convs whose H and W are multiples of 16: the 256 output pixels of a workgroup are a
+// 16 x 16 PATCH of one image, and the 18 x 18 halo of that patch (16 channels of one slice, three planes = 30.4 KiB) is fetched ONCE
+// per channel slice and serves all nine taps -- a tap is an offset into the halo tile when the A fragments are read.  The kernel above
+// re-fetches a shifted 256-pixel tile for every tap: 24 KiB x 9 per slice against 30.4 KiB here, i.e. 57 % of its L2 -> LDS bytes
+// overall (weights unchanged).  That matters because this kernel runs at the board's power limit (tools/clock_probe.py: 1.37 kW,
+// clock pulled down to 2.2-2.3 GHz; MFMAs alone 0.94 kW at 2.4 GHz): with the activation DMA of eight taps in nine pointed at the zero
+// page (x6p_ablate bit 64) the same launch took 181 us instead of 204.  LDS: two halo buffers (slice cs and cs + 1) + the three-deep
+// weight ring = 118 KiB.  DMA per wave and stage: three weight pieces for stage s + 2 and, in taps 0-3, one of the wave's four pieces
+// of the next slice's halo; the counted vmcnt at the top of a stage is therefore 4 in taps 1-4 and 3 otherwise (the halo piece is
+// issued before the weight pieces of its stage).
+__global__ __launch_bounds__(512, 2) void conv_fwd_x6h_kernel(X6PArgs a) {
+    constexpr int BN = 192;
+    constexpr int TM = 2, TN = 3;
+    constexpr int PT = 16, HWD = PT + 2, HPIX = HWD * HWD;   // patch edge, halo edge, halo pixels (324)
+    constexpr int APL = HPIX * 32;                           // one plane of the halo tile: 10368 B
+    constexpr int APIECES = 3 * HPIX * 2;                    // 16-byte pieces of the three planes: 1944 (31 wave instructions)
+    constexpr int ABUF = 32768;
+    constexpr int BPLANE = BN * 32, BSTAGE = 3 * BPLANE;     // 18 KiB
+    constexpr int RING = 3;
+    constexpr int BBASE = 2 * ABUF;
+    constexpr int SROW = 196;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][ABUF] halo tiles, [RING][BSTAGE] weights; epilogue: fp32 [128][SROW]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
+    const int li = lane & 31, lh = lane >> 5;
+    const TileId tile = xcd_tile_id(a.xcd_mode);
+    const int n0 = tile.n * BN;
+    const int pw_n = a.W / PT, ph_n = a.H / PT;
+    const int pb = tile.m / (ph_n * pw_n);
+    const int prem = tile.m - pb * (ph_n * pw_n);
+    const int h0 = (prem / pw_n) * PT, w0 = (prem % pw_n) * PT;
+    const int pbase = (pb * a.H + h0) * a.W + w0;            // first pixel of the patch
+    const long Min = (long)a.B * a.H * a.W;
+    const u16* const zero = reinterpret_cast<const u16*>(g_zero_page);
+
+    // ---- A loader: pieces wave, wave + 8, wave + 16, wave + 24 of the [plane][halo pixel][chunk] image
+    int a_off[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int e = (wave + 8 * j) * 64 + lane;
+        const int pl = e / (HPIX * 2);
+        const int r = e - pl * (HPIX * 2);
+        const int q = r >> 1;
+        const int chunk = (r & 1) ^ ((q >> 3) & 1);          // source chunk that belongs at LDS position (q, r & 1)
+        const int hr = q / HWD, hc = q - hr * HWD;
+        const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
+        const bool ok = e < APIECES && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+        a_off[j] = ok ? (int)(pl * a.xplane) + ((pb * a.H + hi) * a.W + wi) * 16 + chunk * 8 : -1;
+    }
+    // ---- B loader: as in conv_fwd_x6p_kernel
+    int dma_src[3], dma_k[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int k = wave + 8 * j < 18 ? wave + 8 * j : wave + 8;
+        dma_k[j] = k;
+        const int e = k * 64 + lane;
+        const int pl = e / (BN * 2);
+        const int r = e - pl * (BN * 2);
+        const int row = r >> 1, ch = (r & 1) ^ ((row >> 3) & 1);
+        const int n = n0 + row < a.Cout ? n0 + row : 0;
+        dma_src[j] = (int)(pl * a.wplane) + n * 16 + 8 * ch;
+    }
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int csteps = a.Cin / 16;
+    const int nstages = 9 * csteps;
+
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    auto dma_a = [&](int j, int cs_next) {                   // piece j of the wave, halo of slice cs_next into buffer cs_next & 1
+        if (a.ablate & 1) return;
+        const int cn = cs_next < csteps ? cs_next : csteps - 1;
+        const u16* src = a_off[j] >= 0 ? a.xp + a_off[j] + (long)cn * Min * 16 : zero;
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(smem + (cs_next & 1) * ABUF + (wave + 8 * j) * 1024), 16, 0, 0);
+    };
+    const u16* wsrc = a.wp;
+    auto dma_b = [&](int j, int nb) {
+        if (a.ablate & 2) return;
+        __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_src[j]), (lds_void*)(smem + BBASE + nb * BSTAGE + dma_k[j] * 1024), 16, 0, 0);
+    };
+    auto set_wsrc = [&](int stage) { wsrc = a.wp + (long)(stage < nstages ? stage : nstages - 1) * a.Cout * 16; };
+
+    int q00[TM], fb_off[3][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int tl = wm0 + i * 32 + li;
+        q00[i] = (tl >> 4) * HWD + (tl & 15);
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) fb_off[p][j] = BBASE + p * BPLANE + chunk_off16(wn0 + j * 32 + li, lh);
+    const bool late = wave >= 4;
+
+    // prologue: halo of slice 0, weights of stages 0 and 1
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dma_a(j, 0);
+    set_wsrc(0);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dma_b(j, 0);
+    set_wsrc(1);
+#pragma unroll
+    for (int j = 0; j < 3; ++j) dma_b(j, 1);
+
+    int buf = 0, s = 0;
+    auto stage = [&](auto tapc, int cs) {
+        constexpr int TAP = decltype(tapc)::value;
+        constexpr int KH = TAP / 3, KW = TAP % 3;
+        // stage s (weights) and, in tap 0, this slice's halo have landed once at most the DMAs issued after them are outstanding
+        if (a.ablate & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if constexpr (TAP >= 1 && TAP <= 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const int nb = buf >= 1 ? buf - 1 : RING - 1;        // (s + 2) % 3
+        const char* stb = smem + buf * BSTAGE;
+        const char* sta = smem + (cs & 1) * ABUF;
+        int fa_off[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int q = q00[i] + KH * HWD + KW;
+            fa_off[i] = q * 32 + (((lh ^ (q >> 3)) & 1) << 4);
+        }
+        bf16x8 fa[3][TM], fb[3][TN];
+        auto rd_a = [&](int p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(sta + p * APL + fa_off[i]);
+        };
+        auto rd_b = [&](int p) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(stb + fb_off[p][j]);
+        };
+        auto mma = [&](int pa, int pb_) {
+            if (a.ablate & 4) return;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[pa][i], fb[pb_][j], acc[i][j], 0, 0, 0);
+        };
+        set_wsrc(s + 2);
+        auto slot = [&](int k) {                             // DMA slot k of this wave's three: halo piece first (taps 0-3), then weight piece k
+            if (k == 0) {
+                if constexpr (TAP < 4) dma_a(TAP, cs + 1);
+            }
+            dma_b(k, nb);
+        };
+        // fragments in the order the products need them: (A2,B0) (A0,B2) (A1,B0) (A1,B1) (A0,B1) (A0,B0), small terms first
+        rd_a(2); rd_b(0);
+        rd_a(0); rd_b(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(2, 0);
+        rd_a(1);
+        if (!late) slot(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 2);
+        rd_b(1);
+        if (!late) slot(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 0);
+        if (!late) slot(2);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(1, 1);
+        if (late) slot(0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 1);
+        if (late) slot(1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(0, 0);
+        if (late) slot(2);
+        __builtin_amdgcn_sched_barrier(0);
+        buf = buf + 1 == RING ? 0 : buf + 1;
+        ++s;
+    };
+    for (int cs = 0; cs < csteps; ++cs) {
+        [&]<int... T>(std::integer_sequence<int, T...>) { (stage(std::integral_constant<int, T>{}, cs), ...); }
+        (std::make_integer_sequence<int, 9>{});
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail DMAs still target LDS: drain before the epilogue reuses it
+    __builtin_amdgcn_s_barrier();
+
+    // ---- epilogue: as in conv_fwd_x6p_kernel, tile row tl = pixel (tl / 16, tl % 16) of the patch
+    float* const stg = reinterpret_cast<float*>(smem);
+    const bool need_planes = a.outp != nullptr;
+#pragma unroll
+    for (int pass = 0; pass < TM; ++pass) {
+        if (pass) __syncthreads();
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                stg[((wave >> 1) * 32 + rr) * SROW + wn0 + j * 32 + li] = acc[pass][j][r];
+            }
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < 12; ++k) {
+            const int q = tid + 512 * k;                     // 128 rows x 48 quads of channels
+            const int row = q / 48, c4 = q - row * 48;
+            const int tl = (row >> 5) * 64 + pass * 32 + (row & 31);
+            const int m = pbase + (tl >> 4) * a.W + (tl & 15);
+            const int n = n0 + c4 * 4;
+            if (n >= a.Cout) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SROW + c4 * 4);
+            const long o = (long)m * a.Cout + n;
+            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+            if (a.pre) *reinterpret_cast<f32x4*>(a.pre + o) = v;
+            if (a.epilogue != RDO_EPI_NONE) {
+                const f32x4 x4 = aux_quad(a, m, n, o);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = activate(a, v[e], x4[e]);
+            }
+            if (a.add_residual) v += *reinterpret_cast<const f32x4*>(a.residual + o);
+            if (a.out) *reinterpret_cast<f32x4*>(a.out + o) = v;
+            if (need_planes) *reinterpret_cast<f32x4*>(stg + row * SROW + c4 * 4) = v;
+        }
+        if (need_planes) {
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int q = tid + 512 * k;                 // 128 rows x 12 slices of 16 channels
+                const int row = q & 127, sl = q >> 7;
+                const int tl = (row >> 5) * 64 + pass * 32 + (row & 31);
+                const int m = pbase + (tl >> 4) * a.W + (tl & 15);
+                const int n = n0 + sl * 16;
+                if (n >= a.Cout) continue;
+                float v[16];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(stg + row * SROW + sl * 16 + 4 * c);
+                    v[4 * c] = t4[0]; v[4 * c + 1] = t4[1]; v[4 * c + 2] = t4[2]; v[4 * c + 3] = t4[3];
+                }
+                store_slice(a, m, n, v);
+            }
+        }
+    }
+}
+
 // split-K second pass: sum the partial accumulators, then the same per-slice finish (planes included); lanes along pixels
 __global__ __launch_bounds__(256) void x6p_splitk_epilogue_kernel(X6PArgs a) {
     const int spr = a.Cout / 16;                             // slices per row
@@ -562,6 +808,25 @@ extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, c
     const double bytes = 6.0 * a.xplane + 6.0 * a.wplane +
                          (double)a.M * a.Cout * (4.0 * ((out != nullptr) + (pre != nullptr) + (aux != nullptr) + (residual != nullptr)) +
                                                  6.0 * (out_planes != nullptr));
+    // 3 x 3 "same" convs on 16 x 16 patches: the halo kernel (no K split: the shapes that qualify for P3 fill the chip with tiles)
+    const bool halo = rdo::tuning(rdo::T_X6P_HALO) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 &&
+                      a.W % 16 == 0 && ks == 1;
+    if (halo)
+        return rdo::dispatch(
+            [a](hipStream_t s) {
+                constexpr size_t lds = (size_t)2 * 32768 + 3 * 3 * 192 * 32;
+                static bool attr = false;
+                if (!attr) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds) != hipSuccess)
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6h) failed");
+                    attr = true;
+                }
+                dim3 grid((unsigned)(a.M / 256), (unsigned)rdo::ceil_div(a.Cout, 192), 1);
+                hipLaunchKernelGGL(conv_fwd_x6h_kernel, grid, dim3(512), lds, s, a);
+                return rdo::check_launch("conv_fwd_x6h");
+            },
+            stream, "conv_fwd_x6_p3_halo", flops, bytes);
     return rdo::dispatch(
         [a](hipStream_t s) {
             constexpr size_t lds = (size_t)3 * 3 * (256 + 192) * 32;

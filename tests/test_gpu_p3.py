@@ -62,6 +62,33 @@ def test_conv_p3_equals_fp32_input_x6(ops, L, H, Cin, Cout, K, s, p):
     assert torch.equal(opl2, opl)
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, N, N), (4, 64, 64, N, 4 * N), (2, 128, 256, 64, N), (1, 256, 256, 32, 2 * N)])
+def test_conv_p3_halo_kernel_equals_per_tap_kernel(ops, L, B, H, W, Cin, Cout):
+    """3x3 / stride 1 / pad 1 on 16 x 16 patches with the halo tile resident in LDS: same K order and accumulation as the per-tap
+    kernel, so the same bits -- borders (zero halo), all epilogue outputs and the P3 planes included."""
+    g = torch.Generator(device="cuda").manual_seed(H + Cin)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    res = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+    wpl, xp = ops.split_bf16x3(w), ops.split_p3(x)
+    got = {}
+    for halo in (0, 1):
+        ops.set_tuning("x6p_halo", halo)
+        try:
+            out, pre = torch.empty(B, H, W, Cout, device="cuda"), torch.empty(B, H, W, Cout, device="cuda")
+            opl = ops.p3_empty(out.shape, "cuda")
+            ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, b, 1, 1, epilogue=L.EPI_LRELU, residual=res, out=out, pre=pre,
+                              out_planes=opl)
+            got[halo] = (out, pre, opl)
+        finally:
+            ops.set_tuning("x6p_halo", 1)
+    for u, v in zip(got[0], got[1]):
+        assert torch.equal(u, v)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    assert (got[1][1].double() - ref).abs().max() <= 2e-6 * ref.abs().max()
+
+
 @pytest.mark.parametrize("H,Cout", [(128, N), (64, N)])
 def test_conv_p3_epilogues(ops, L, H, Cout):
     g = torch.Generator(device="cuda").manual_seed(H)
