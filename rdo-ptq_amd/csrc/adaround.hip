@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
 // every weight tensor of a unit in ONE launch (the AdaRound step of a block unit was 3-5 launches of 6-36 us, each a few hundred
 // workgroups that left most of the chip idle): block ranges [blk_end[t-1], blk_end[t]) belong to tensor t
 constexpr int kMaxBatch = 8;
+constexpr int kManySlabs = 128;
 struct AdaBatch {
     AdaArgs a[kMaxBatch];
     int blk_end[kMaxBatch];
@@ -243,7 +244,10 @@ __global__ __launch_bounds__(256) void ada_step_batch_kernel(AdaBatch b) {
     int t = 0;
     while (t + 1 < b.n && (int)blockIdx.x >= b.blk_end[t]) ++t;
     const int beg = t ? b.blk_end[t - 1] : 0;
-    ada_step_body<4>(b.a[t], (long)blockIdx.x - beg, (long)b.blk_end[t] - beg);
+    // many slabs over a small tensor (the 1x1 GDN gamma gradient, 256 slabs of 36 K elements): one element per thread -- four times
+    // the threads walking the slab chain; same per-element summation order
+    if (b.a[t].nsplit >= kManySlabs && b.a[t].mode != 2) ada_step_body<1>(b.a[t], (long)blockIdx.x - beg, (long)b.blk_end[t] - beg);
+    else ada_step_body<4>(b.a[t], (long)blockIdx.x - beg, (long)b.blk_end[t] - beg);
 }
 
 // wd[ci][KH-1-kh][KW-1-kw][co] = wq[co][kh][kw][ci]: 32x32 tiles through LDS, 128-byte segments on both sides
@@ -499,7 +503,7 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
         a.alpha = it.alpha; a.m = it.adam_m; a.v = it.adam_v; a.wq = it.wq; a.wd = it.wd; a.round_loss_out = round_loss_out; a.mode = mode;
         a.wq_planes = static_cast<unsigned short*>(it.wq_planes);
         a.wd_planes = it.wd ? static_cast<unsigned short*>(it.wd_planes) : nullptr;
-        blocks += (int)grid_for(it.d.numel / 4);
+        blocks += (int)grid_for((it.nsplit >= kManySlabs && mode != 2) ? it.d.numel : it.d.numel / 4);
         b.blk_end[i] = blocks;
         bytes += 4.0 * it.d.numel * ((mode == 2 ? 1 : it.nsplit) + (mode == 1 ? 3.0 : 9.0));
         if (mode != 1 && it.wd && it.d.Cin > 0) {

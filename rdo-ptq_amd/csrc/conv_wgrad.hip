@@ -213,6 +213,11 @@ int g_force_big = -1, g_force_ns = -1;   // tuning overrides (rdo_debug_force_wg
 
 // 192x192 tiles (3x3 MFMA tiles per wave, 96 KiB LDS, one workgroup per CU) need a long pixel reduction per workgroup
 // to pay off; with few output pixels the 64x64 tile (one MFMA tile per wave, 5 workgroups per CU) spreads the work wider.
+inline bool one_tile_many_pixels(const rdo_conv_desc* d) {
+    return d->KH == 1 && d->KW == 1 && d->Cout >= 160 && d->Cout <= 192 && d->Cin >= 160 && d->Cin <= 192 &&
+           (long)d->B * d->Ho * d->Wo >= 16384;
+}
+
 inline bool big_tiles(const rdo_conv_desc* d) {
     if (g_force_big >= 0) return g_force_big != 0;
     const long M = (long)d->B * d->Ho * d->Wo;
@@ -221,7 +226,11 @@ inline bool big_tiles(const rdo_conv_desc* d) {
     const long big_tiles_total = (long)d->KH * d->KW * rdo::ceil_div(d->Cout, 192) * rdo::ceil_div(d->Cin, 192);
     // many tiles (the 768 / 1152-channel sub-pixel convs): few pixel splits fill the chip, so short reductions still pay off
     const long min_m = big_tiles_total >= 32 ? 1024 : 4096;
-    return d->Cout >= 160 && d->Cin >= 160 && M >= min_m && big_tiles_total >= 4;
+    if (d->Cout >= 160 && d->Cin >= 160 && M >= min_m && big_tiles_total >= 4) return true;
+    // ... except over >= 16 K pixels (the GDN gamma gradient of the 64^2 and 128^2 units): there the split-bf16 tile with 256 splits
+    // beats the fp32 small tile even after the AdaRound step has read 256 slabs of 144 KiB (tools/bench_wgrad_1x1.py: 37 + 12 us
+    // against 87 + 9 at 4 x 128^2, 19 + 12 against 27 + 9 at 4 x 64^2)
+    return one_tile_many_pixels(d);
 }
 
 inline int tiles_total(const rdo_conv_desc* d) {
@@ -260,7 +269,8 @@ extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d) {
     const long max_by_m = rdo::ceil_div(M, 128);
     if (ns > max_by_m) ns = max_by_m;
     if (ns < 1) ns = 1;
-    if (ns > 64) ns = 64;
+    const long cap = (g_force_big < 0 && one_tile_many_pixels(d)) ? 256 : 64;
+    if (ns > cap) ns = cap;
     return (int)ns;
 }
 
