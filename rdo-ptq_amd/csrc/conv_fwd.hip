@@ -379,6 +379,8 @@ extern "C" int64_t rdo_conv2d_fwd_workspace(const rdo_conv_desc* d) {
 
 bool rdo_conv_is_thin(const rdo_conv_desc* d, bool forward);                                                            // conv_thin.hip
 int rdo_launch_thin_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, float* out, hipStream_t s);
+bool rdo_conv_is_thincout(const rdo_conv_desc* d, bool forward);                                                        // conv_thincout.hip
+int rdo_launch_thincout_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, float* out, hipStream_t s);
 
 extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
                               const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
@@ -397,6 +399,12 @@ extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const floa
     RDO_REQUIRE(epi == RDO_EPI_NONE || epi == RDO_EPI_LRELU || epi == RDO_EPI_RELU || aux != nullptr,
                 "rdo_conv2d_fwd: epilogue %d needs aux", epi);
     RDO_REQUIRE(!d->add_residual || residual != nullptr, "rdo_conv2d_fwd: add_residual without residual");
+    if (rdo_conv_is_thincout(d, true) && pre == nullptr && true) {
+        const rdo_conv_desc dd = *d;
+        const double M = (double)d->B * d->Ho * d->Wo;
+        return rdo::dispatch([=](hipStream_t s) { return rdo_launch_thincout_fwd(&dd, x, w, bias, out, s); }, stream, "conv_thincout_fwd",
+                             2.0 * M * d->Cout * d->Cin * 9.0, 4.0 * ((double)d->B * d->H * d->W * d->Cin + M * d->Cout));
+    }
     if (rdo_conv_is_thin(d, true) && pre == nullptr) {
         const rdo_conv_desc dd = *d;
         const double M = (double)d->B * d->Ho * d->Wo;

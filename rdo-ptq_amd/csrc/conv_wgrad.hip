@@ -243,6 +243,9 @@ inline int tiles_total(const rdo_conv_desc* d) {
 int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, int mchunk, hipStream_t s);
 bool rdo_conv_is_thin(const rdo_conv_desc* d, bool forward);                                                            // conv_thin.hip
 int rdo_launch_thin_wgrad(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, hipStream_t s);
+bool rdo_conv_is_thincout(const rdo_conv_desc* d, bool forward);                                                        // conv_thincout.hip
+int rdo_thincout_patches(const rdo_conv_desc* d);
+int rdo_launch_thincout_wgrad(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, hipStream_t s);
 
 // 1 when rdo_conv2d_wgrad runs this shape on the split-bf16 MFMA path (conv_wgrad_x6.hip): big-tile problems whose output
 // rows are a multiple of 4 pixels wide and whose channel counts allow 16-byte quads.  RDO_CONV_X6=0 disables it.
@@ -261,8 +264,11 @@ extern "C" void rdo_debug_force_wgrad_choice(int big, int nsplit) {
 
 extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d) {
     if (!d) return 1;
+    if (g_force_big < 0 && rdo_conv_is_thincout(d, false)) return rdo_thincout_patches(d);      // one slab per 16 x 16 patch
     if (g_force_ns >= 1) return g_force_ns;
     const long M = (long)d->B * d->Ho * d->Wo;
+    // few input channels (conv_thin.hip): one workgroup column per 64 output channels, so the pixel splits alone have to fill the chip
+    if (rdo_conv_is_thin(d, false)) return (int)(M >= 65536 ? 128 : (M >= 512 ? M / 512 : 1));
     // big tile: ~1 workgroup per CU; small tile: ~4 per CU.  Chunks of at least 128 pixels (4 reduction steps).
     const long target = big_tiles(d) ? 256 : 1024;
     long ns = target / tiles_total(d);
@@ -292,6 +298,12 @@ extern "C" int rdo_conv2d_wgrad(const rdo_conv_desc* d, const float* x, const fl
     const bool vec = (d->Cin % 4 == 0) && (d->Cout % 4 == 0) &&
                      ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) % 16 == 0);
     const bool big = big_tiles(d);
+    if (g_force_big < 0 && rdo_conv_is_thincout(d, false) && nsplit == rdo_thincout_patches(d)) {
+        const rdo_conv_desc dd = *d;
+        return rdo::dispatch([=](hipStream_t s) { return rdo_launch_thincout_wgrad(&dd, x, dy, slabs, s); }, stream, "conv_thincout_wgrad",
+                             2.0 * a.M * (double)a.Cout * a.Cin * 9.0,
+                             4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout + (double)nsplit * a.Cout * 9.0 * a.Cin));
+    }
     if (rdo_conv_is_thin(d, false)) {
         const rdo_conv_desc dd = *d;
         return rdo::dispatch([=](hipStream_t s) { return rdo_launch_thin_wgrad(&dd, x, dy, slabs, nsplit, s); }, stream,
