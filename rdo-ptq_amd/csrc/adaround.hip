@@ -105,6 +105,13 @@ __device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, 
             // loads (one L2 / fabric round trip each) was the whole kernel time
             const float* sp = a.slabs + e0;
             int s = 0;
+            for (; s + 16 <= a.nsplit; s += 16) {            // long chains (the 28-slab 3x3 convs, the 256-slab 1x1): sixteen in flight
+                vec_t t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const vec_t*>(sp + (long)(s + u) * d.numel);
+                g4 += (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                      (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+            }
             for (; s + 8 <= a.nsplit; s += 8) {
                 vec_t t[8];
 #pragma unroll
