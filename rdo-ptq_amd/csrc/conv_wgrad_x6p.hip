@@ -240,6 +240,198 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Row variant for 3 x 3 / stride 1 / pad 1 with Wo a multiple of 32 and Cin a multiple of 64: a workgroup owns the THREE kw taps of one
+// kh for a block of 64 input channels -- still a 192 x 192 output tile (192 co x [3 taps x 64 ci]) -- and a stage is 32 consecutive
+// pixels of ONE output row.  The three taps read the same input row shifted by one pixel, so the X image of a stage is 34 pixels x 64
+// channels (13 KiB for the three planes) instead of 32 x 192 (36 KiB): 49 KiB of L2 -> LDS traffic per stage instead of 72, for the
+// same 108 MFMAs per wave.  (Why it matters: these kernels sit at the board power limit, tools/clock_probe.py; the forward kernel
+// gained 11 % from the same kind of cut.)  A tap is a row offset when the B fragments are read; everything else -- LDS images, chunk
+// swizzle, transposed reads, k-slot assignment, MFMA order -- is the kernel above.
+constexpr int XROWS = 40;                      // 34 used; five 8-row DMA pieces per plane
+constexpr int XPLANEB = XROWS * 128;
+constexpr int STAGE3B = OPB + 3 * XPLANEB;     // 36 + 15 = 51 KiB
+
+__global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
+    constexpr int T = 192;
+    constexpr int TM = 3, TN = 6;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][STAGE3B]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lc = lane >> 4;
+    const int wco0 = (wave >> 1) * 48;
+
+    // XCD-aware numbering, (kh, ci block, co tile) fastest
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int chunk = lid / gridDim.y;
+    int t = lid - chunk * gridDim.y;
+    const int cib = t % a.tiles_ci; t /= a.tiles_ci;                     // tiles_ci = Cin / 64 here
+    const int tco = t % a.tiles_co; t /= a.tiles_co;
+    const int kh = t;
+    const int co0 = tco * T, ci0 = cib * 64;
+
+    // stages = 32-pixel segments of output rows; this chunk owns segments [sbeg, send)
+    const int segs_row = a.Wo / PK;
+    const int segs_total = a.B * a.Ho * segs_row;
+    const int spc = (segs_total + a.nsplit - 1) / a.nsplit;
+    const int sbeg = chunk * spc;
+    const int send = min(segs_total, sbeg + spc);
+    const int nsteps = send > sbeg ? send - sbeg : 0;
+
+    const u16* const zero = reinterpret_cast<const u16*>(g_zero_page_w);
+    const int prow8 = lane >> 3, cpos = lane & 7;
+    // dY pieces of this wave: k = wave + 8 j of the 36 [plane][sub-tile][8-row group] pieces
+    int yoff[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int k = wave + 8 * j;
+        const int plane = k / 12, sub = (k % 12) >> 2, rg = k & 3;
+        const int row = 8 * rg + prow8;
+        const int ch = co0 + 64 * sub + 8 * (cpos ^ (2 * ((row >> 1) & 3)));
+        yoff[j] = (k < 36 && ch < a.Cout) ? (int)(plane * a.yplane) + ((ch >> 4) * a.M + row) * 16 + (ch & 15) : -1;
+    }
+    // X pieces: k = wave + 8 j of the 15 [plane][8-row group] pieces; row r of the image is input pixel wo0 - 1 + r
+    int xoff[2], xrow[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = wave + 8 * j;
+        const int plane = k / 5, rg = k - plane * 5;
+        const int row = 8 * rg + prow8;
+        const int ch = ci0 + 8 * (cpos ^ (2 * ((row >> 1) & 3)));
+        xrow[j] = row;
+        xoff[j] = (k < 15 && row < PK + 2) ? (int)(plane * a.xplane) + (ch >> 4) * a.Min * 16 + (ch & 15) : -1;
+    }
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef const __attribute__((address_space(1))) void glb_void;
+    int seg = sbeg;
+    auto dma_stage = [&](int buf) {
+        const int sg = seg < send ? seg : send - 1;
+        ++seg;
+        const int b = sg / (a.Ho * segs_row);
+        const int rem = sg - b * (a.Ho * segs_row);
+        const int ho = rem / segs_row;
+        const int wo0 = (rem - ho * segs_row) * PK;
+        const int m0 = (b * a.Ho + ho) * a.Wo + wo0;
+        const int hi = ho + kh - 1;
+        const bool rowok = (unsigned)hi < (unsigned)a.H;
+        const int xbase = (b * a.H + hi) * a.W + wo0 - 1;
+        char* const dst = smem + buf * STAGE3B;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) {
+            const int k = wave + 8 * j;
+            if (k >= 36) break;
+            const u16* src = yoff[j] >= 0 ? a.yp + yoff[j] + (long)m0 * 16 : zero;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + (k / 12) * PLANEB + ((k % 12) >> 2) * SUBB + (k & 3) * 1024), 16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int k = wave + 8 * j;
+            if (k >= 15) break;
+            const int wi = wo0 - 1 + xrow[j];
+            const bool ok = xoff[j] >= 0 && rowok && (unsigned)wi < (unsigned)a.W;
+            const u16* src = ok ? a.xp + xoff[j] + (long)(xbase + xrow[j]) * 16 : zero;
+            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + OPB + (k / 5) * XPLANEB + (k % 5) * 1024), 16, 0, 0);
+        }
+    };
+
+    f32x4acc acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addresses (lane roles as above); column tile jt = 6 (wave & 1) + j of the 12: tap kw = jt / 4, channels 16 (jt % 4)
+    const int fr = 4 * lc + ((lane >> 2) & 3);
+    const int p4 = lane & 3;
+    int fa_off[TM], fb_off[TN];
+    {
+        const int fsw = 2 * ((fr >> 1) & 3);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int c = wco0 + 16 * i;
+            const int chunkpos = (2 * ((c & 63) >> 4) + (p4 >> 1)) ^ fsw;
+            fa_off[i] = (c >> 6) * SUBB + fr * 128 + chunkpos * 16 + (p4 & 1) * 8;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int jt = 6 * (wave & 1) + j;
+        const int row = fr + (jt >> 2);                                  // tap kw: input pixel = output pixel + kw - 1 = image row + kw
+        const int chunkpos = (2 * (jt & 3) + (p4 >> 1)) ^ (2 * ((row >> 1) & 3));
+        fb_off[j] = OPB + row * 128 + chunkpos * 16 + (p4 & 1) * 8;
+    }
+
+    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
+    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+
+    const bool late = wave >= 4;
+    if (nsteps > 0) dma_stage(0);
+    bf16x8 fa[3][TM], fb[2][3][2];
+    auto read_b = [&](auto setc, const char* st, int third) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[S][p][j] = tr_pair(st + p * XPLANEB + fb_off[2 * third + j]);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    for (int s = 0; s < nsteps; ++s) {
+        const int buf = s & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more = s + 1 < nsteps;
+        if (more && !late) dma_stage(buf ^ 1);
+        const char* st = smem + buf * STAGE3B;
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
+        read_b(S0{}, st, 0);
+        [&]<int... SL>(std::integer_sequence<int, SL...>) {
+            (([&] {
+                 constexpr int T3 = SL / 6, Q = SL % 6, SET = T3 & 1;
+                 if constexpr (Q == 0 && T3 < 2) {
+                     if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
+                     else read_b(S0{}, st, T3 + 1);
+                 }
+#pragma unroll
+                 for (int i = 0; i < TM; ++i)
+#pragma unroll
+                     for (int j = 0; j < 2; ++j)
+                         acc[i][2 * T3 + j] =
+                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 if constexpr (SL == 5) {
+                     if (more && late) dma_stage(buf ^ 1);
+                 }
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
+        }
+        (std::make_integer_sequence<int, 18>{});
+    }
+
+    const long wsize = (long)a.Cout * 9 * a.Cin;
+    float* slab = a.slabs + (long)chunk * wsize;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int jt = 6 * (wave & 1) + j;
+        const int tap = kh * 3 + (jt >> 2);
+        const int ci = ci0 + (jt & 3) * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wco0 + i * 16 + 4 * lc + r;
+                if (co < a.Cout) slab[((long)co * 9 + tap) * a.Cin + ci] = acc[i][j][r];
+            }
+    }
+}
+
 }  // namespace
 
 extern "C" int rdo_conv2d_wgrad_uses_bf16x6(const rdo_conv_desc* d);
@@ -275,6 +467,27 @@ extern "C" int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes,
     a.tiles_ci = (int)rdo::ceil_div(a.Cin, T);
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
     const double bytes = 6.0 * (a.xplane + a.yplane) + 4.0 * nsplit * (double)a.Cout * a.KH * a.KW * a.Cin;
+    // 3 x 3 / stride 1 / pad 1 over whole 32-pixel row segments, Cin in blocks of 64: the three kw taps share one input image
+    if (rdo::tuning(rdo::T_WGRAD_P3_ROW) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Wo % 32 == 0 && a.Cin % 64 == 0 &&
+        a.Wo == a.W && a.Ho == a.H && (long)(a.M / 32) >= nsplit) {
+        WgPArgs b = a;
+        b.tiles_ci = a.Cin / 64;
+        return rdo::dispatch(
+            [b](hipStream_t s) {
+                constexpr size_t lds = (size_t)2 * STAGE3B;
+                static bool attr = false;
+                if (!attr) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6p3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                            (int)lds) != hipSuccess)
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6p3) failed");
+                    attr = true;
+                }
+                dim3 grid((unsigned)b.nsplit, (unsigned)(3 * b.tiles_co * b.tiles_ci));
+                hipLaunchKernelGGL(conv_wgrad_x6p3_kernel, grid, dim3(512), lds, s, b);
+                return rdo::check_launch("conv_wgrad_x6p3");
+            },
+            stream, "conv_wgrad_x6_p3_rows", flops, bytes);
+    }
     return rdo::dispatch(
         [a](hipStream_t s) {
             constexpr size_t lds = (size_t)2 * STAGEB;

@@ -245,3 +245,24 @@ def test_wgrad_p3_matches_fp64_and_fp32_input_kernel(ops, B, H, Cin, Cout, K, s,
     e = float((dw.double() - ref).abs().max()) / scale
     e6 = float((ref6.double() - ref).abs().max()) / scale
     assert e < 1e-5 and e < 2.0 * e6 + 2e-7, (e, e6)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, 192, 192), (4, 64, 64, 192, 768), (1, 32, 64, 64, 48), (2, 32, 32, 128, 320), (4, 64, 64, 192, 192)])
+def test_wgrad_p3_row_kernel_equals_per_tap_kernel(ops, B, H, W, Cin, Cout):
+    """3x3 / stride 1 / pad 1: three kw taps on one 34-pixel input row image.  Same pixel chunks, same order of sums per output element
+    as the per-tap kernel, so the same slabs bit for bit (row ends and image top / bottom included)."""
+    g = torch.Generator(device="cuda").manual_seed(H + W + Cout)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    dy = torch.randn(B, H, W, Cout, device="cuda", generator=g) * 0.1
+    wshape = (Cout, 3, 3, Cin)
+    if not ops.wgrad_p3_supported(tuple(x.shape), wshape, 1, 1):
+        pytest.skip("shape not on the plane path")
+    xp, dyp = ops.split_p3(x), ops.split_p3(dy)
+    got = {}
+    for row in (0, 1):
+        ops.set_tuning("wgrad_p3_row", row)
+        try:
+            got[row] = ops.conv2d_wgrad_p3(xp, tuple(x.shape), dyp, wshape, 1, 1)
+        finally:
+            ops.set_tuning("wgrad_p3_row", 1)
+    assert torch.equal(got[0], got[1])
