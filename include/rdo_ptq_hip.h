@@ -151,6 +151,7 @@ typedef struct rdo_ada_step_item {
 } rdo_ada_step_item;
 int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
                             const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
+                            int32_t* iter_shadow /* nullable alternative to advance_iter: receives *iter_ptr + 1 (hand-over above) */,
                             void* stream);
 
 /* only the data-gradient half (slab reduce + chain rule -> dalpha_data), for the all-reduce bucket of the DP path */
@@ -180,7 +181,13 @@ int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, int32_t n_b
  * i = element index in the GLOBAL mini-batch: (batch_offset + b) * per_image + offset.  A data-parallel rank that holds rows
  * [batch_offset, batch_offset + B) of the global mini-batch draws exactly the mask slice a single process would (same seed). */
 int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr,
-                     int32_t B, int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out, void* stream);
+                     int32_t B, int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out,
+                     int32_t* iter_publish /* nullable, see "iteration-counter hand-over" */, void* stream);
+/* Iteration-counter hand-over (saves the one-thread "counter += 1" launch per iteration): every kernel of an iteration reads the
+ * device counter *iter_ptr; instead of incrementing it after the last kernel, the AdaRound step (the LAST kernel, which only reads
+ * *iter_ptr) leaves *iter_ptr + 1 in a second word `iter_shadow`, and the gather (the FIRST kernel of the next iteration) is handed
+ * iter_ptr = that shadow word and iter_publish = the real counter, which its first thread stores while every thread uses the value
+ * read from the shadow.  No kernel reads a word that another thread of the same launch writes.  Both words start equal. */
 
 /* ---- K8: lp_loss(pred, tgt[idx]) forward + gradient, p = 2: loss = sum((pred-tgt)^2)/(npix), sum over channels
  * grad = coef * 2 (pred - tgt) / npix ; `coef` = 2 reproduces rec_loss + (degenerate) task_loss of SURVEY 3.4.
@@ -290,7 +297,7 @@ int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes, const void
 /* rdo_gather_qdrop writing the mini-batch as P3 planes (and as fp32 when `out` != NULL) */
 int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
                         int32_t batch_offset, int64_t per_image, int32_t C, float prob, uint32_t seed, float* out, void* out_planes,
-                        void* stream);
+                        int32_t* iter_publish, void* stream);
 /* Tail of a unit whose last op is a conv (+ activation) (+ residual):   out = act(pre) + residual ; d = out - tgt[idx]
  *   loss_out[*iter][slot] += coef * sum d^2 / npix ; grad_out = coef * 2 d / npix ; dpre = grad_out * act'(pre)
  * i.e. the activation epilogue of the conv, rdo_lp2_loss_grad and rdo_lrelu_bwd / rdo_relu_bwd in one pass (layer_opt.py:133,150,

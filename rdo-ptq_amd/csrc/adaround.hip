@@ -243,11 +243,13 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
 constexpr int kMaxBatch = 8;
 constexpr int kManySlabs = 128;
 struct AdaBatch {
+    int32_t* iter_shadow;   // nullable: block 0 leaves *iter_ptr + 1 here (iteration-counter hand-over, rdo_ptq_hip.h)
     AdaArgs a[kMaxBatch];
     int blk_end[kMaxBatch];
     int n;
 };
 __global__ __launch_bounds__(256) void ada_step_batch_kernel(AdaBatch b) {
+    if (b.iter_shadow && blockIdx.x == 0 && threadIdx.x == 0) *b.iter_shadow = *b.a[0].iter_ptr + 1;
     int t = 0;
     while (t + 1 < b.n && (int)blockIdx.x >= b.blk_end[t]) ++t;
     const int beg = t ? b.blk_end[t - 1] : 0;
@@ -488,10 +490,12 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
 
 int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
                             const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
-                            void* stream) {
+                            int32_t* iter_shadow, void* stream) {
     RDO_REQUIRE(items && n >= 1 && n <= kMaxBatch, "rdo_adaround_step_batch: bad argument (1 <= n <= %d)", kMaxBatch);
     RDO_REQUIRE(mode >= 0 && mode <= 2, "rdo_adaround_step_batch: mode %d (0 fused step, 1 gradient only, 2 apply)", mode);
     RDO_REQUIRE(mode == 1 || (sched && iter_ptr), "rdo_adaround_step_batch: schedule / iteration counter missing");
+    RDO_REQUIRE(!(advance_iter && iter_shadow), "rdo_adaround_step_batch: advance_iter and iter_shadow are alternatives");
+    RDO_REQUIRE(!iter_shadow || iter_ptr, "rdo_adaround_step_batch: iter_shadow needs iter_ptr");
     AdaBatch b{}, bw{};
     int blocks = 0, wblocks = 0;
     double bytes = 0.0;
@@ -520,6 +524,7 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
         }
     }
     b.n = n;
+    b.iter_shadow = iter_shadow;
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(ada_step_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);

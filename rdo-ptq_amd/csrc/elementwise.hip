@@ -20,8 +20,9 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
 // ---- K7: gather + QDrop (layer_opt.py:289-292).  keep = u32(seed, iter, i) < floor(p * 2^32) takes the quantised-prefix input.
 __global__ __launch_bounds__(256) void gather_qdrop_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
                                                            const int32_t* iter_ptr, int B, int batch_offset, long per_image,
-                                                           unsigned long long thr, uint32_t seed, float* out) {
+                                                           unsigned long long thr, uint32_t seed, float* out, int32_t* iter_publish) {
     const int it = *iter_ptr;
+    if (iter_publish && blockIdx.x == 0 && threadIdx.x == 0) *iter_publish = it;      // rdo_ptq_hip.h: iteration-counter hand-over
     const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
     const long quads = per_image / 4;
     const long total = (long)B * quads;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(256) void aq_apply_kernel(const float* x, long n, i
 extern "C" {
 
 int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
-                     int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out, void* stream) {
+                     int32_t batch_offset, int64_t per_image, float prob, uint32_t seed, float* out, int32_t* iter_publish, void* stream) {
     RDO_REQUIRE(cache_q && cache_fp && idx_table && iter_ptr && out, "rdo_gather_qdrop: null pointer");
     RDO_REQUIRE(batch_offset >= 0, "rdo_gather_qdrop: negative batch_offset");
     RDO_REQUIRE(B > 0 && per_image > 0 && per_image % 4 == 0, "rdo_gather_qdrop: per_image (%ld) must be a multiple of 4",
@@ -316,7 +317,7 @@ int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t*
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(gather_qdrop_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, cache_q, cache_fp,
-                               idx_table, iter_ptr, B, batch_offset, (long)per_image, thr, seed, out);
+                               idx_table, iter_ptr, B, batch_offset, (long)per_image, thr, seed, out, iter_publish);
             return rdo::check_launch("gather_qdrop");
         },
         stream, "gather_qdrop", 0.0, 12.0 * B * per_image);

@@ -119,8 +119,10 @@ __device__ __forceinline__ f32x4 qdrop_quad(const float* cq, const float* cfp, l
 
 __global__ __launch_bounds__(256) void gather_qdrop_p3_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
                                                               const int32_t* iter_ptr, int B, int batch_offset, long per_image, int C,
-                                                              unsigned long long thr, uint32_t seed, float* out, u16* planes) {
+                                                              unsigned long long thr, uint32_t seed, float* out, u16* planes,
+                                                              int32_t* iter_publish) {
     const int it = *iter_ptr;
+    if (iter_publish && blockIdx.x == 0 && threadIdx.x == 0) *iter_publish = it;
     const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
     const long ppi = per_image / C, M = (long)B * ppi;
     const int ngroups = (C + 31) / 32;
@@ -456,7 +458,7 @@ extern "C" {
 
 int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
                         int32_t batch_offset, int64_t per_image, int32_t C, float prob, uint32_t seed, float* out, void* out_planes,
-                        void* stream) {
+                        int32_t* iter_publish, void* stream) {
     RDO_REQUIRE(cache_q && cache_fp && idx_table && iter_ptr && out_planes, "rdo_gather_qdrop_p3: null pointer");
     RDO_REQUIRE(B > 0 && batch_offset >= 0 && per_image > 0 && C > 0 && C % 16 == 0 && per_image % C == 0, "rdo_gather_qdrop_p3: bad shape");
     RDO_REQUIRE((long)(batch_offset + B) * per_image < (1L << 32), "rdo_gather_qdrop_p3: batch tensor exceeds the 32-bit RNG counter");
@@ -467,7 +469,7 @@ int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(gather_qdrop_p3_kernel, dim3(oct_grid((long)B * (per_image / C), C)), dim3(256), 0, s, cache_q, cache_fp,
-                               idx_table, iter_ptr, B, batch_offset, (long)per_image, C, thr, seed, out, pl);
+                               idx_table, iter_ptr, B, batch_offset, (long)per_image, C, thr, seed, out, pl, iter_publish);
             return rdo::check_launch("gather_qdrop_p3");
         },
         stream, "gather_qdrop_p3", 0.0, (8.0 + (out ? 4.0 : 0.0) + 6.0) * B * per_image);

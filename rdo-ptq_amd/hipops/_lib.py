@@ -57,13 +57,13 @@ _SIGS = {
     "rdo_adaround_init_alpha": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P]),
     "rdo_adaround_fwd": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, P, P, P]),
     "rdo_adaround_step": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
-    "rdo_adaround_step_batch": (C.c_int, [C.POINTER(AdaStepItem), C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, P, P, P]),
+    "rdo_adaround_step_batch": (C.c_int, [C.POINTER(AdaStepItem), C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, P, P, P, P]),
     "rdo_adaround_grad": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, C.c_int, P, P]),
     "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
     "rdo_uaq_fakequant": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, P]),
     "rdo_uaq_init_minmax": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, P, P, P]),
     "rdo_actquant_perchannel": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),
-    "rdo_gather_qdrop": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_uint32, P, P]),
+    "rdo_gather_qdrop": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_uint32, P, P, P]),
     "rdo_lp2_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, P, P, P]),
     "rdo_lp_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, P, P, P, P]),
     "rdo_lrelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
@@ -98,7 +98,7 @@ _SIGS = {
     "rdo_conv2d_fwd_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, C.c_int64, P]),
     "rdo_conv2d_wgrad_p3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_wgrad_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, C.c_int, P]),
-    "rdo_gather_qdrop_p3": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_uint32, P, P, P]),
+    "rdo_gather_qdrop_p3": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_uint32, P, P, P, P]),
     "rdo_loss_act_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P, P]),
     "rdo_loss_gdn_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P, P]),
     "rdo_gdn_bwd_dx_p3": (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),

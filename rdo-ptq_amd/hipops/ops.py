@@ -160,7 +160,7 @@ def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_
                                       _ptr(wd), _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _stream()), "rdo_adaround_step")
 
 
-def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None, mode=0):
+def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None, mode=0, iter_shadow=None):
     """items: list of dicts(d, w, delta, zp, slabs, alpha, m, v, wq, wd, wq_planes, wd_planes[, dalpha]) -- one launch for every
     weight tensor of a unit (<= 8, numel % 4 == 0): mode 0 the fused AdaRound step, 1 the data gradient into `dalpha`, 2 the update
     from an (all-reduced) `dalpha`; `advance_iter`: the device iteration counter to increment afterwards."""
@@ -175,7 +175,7 @@ def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_
         a.wq_planes, a.wd_planes = dp(it.get("wq_planes")), dp(it.get("wd_planes"))
         a.dalpha = dp(it.get("dalpha"))
     L.check(L.lib().rdo_adaround_step_batch(arr, len(items), int(mode), grad_scale, round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(round_log),
-                                            _ptr(advance_iter), _stream()), "rdo_adaround_step_batch")
+                                            _ptr(advance_iter), _ptr(iter_shadow), _stream()), "rdo_adaround_step_batch")
 
 
 def adaround_grad(d, w, alpha, delta, zp, slabs, dalpha):
@@ -207,13 +207,13 @@ def actquant_perchannel(x, out=None, ws=None, n_bits=8):
     return out
 
 
-def gather_qdrop(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, batch_offset=0):
+def gather_qdrop(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, batch_offset=0, iter_publish=None):
     """`batch_offset`: row of the global mini-batch this (data-parallel) rank's first row is -- the QDrop counter runs over the
     global batch, so N ranks with one seed draw the mask a single process would."""
     per_image = cache_q[0].numel()
     L.check(L.lib().rdo_gather_qdrop(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,
                                      prob, seed,
-                                     _ptr(out), _stream()), "rdo_gather_qdrop")
+                                     _ptr(out), _ptr(iter_publish), _stream()), "rdo_gather_qdrop")
     return out
 
 
@@ -516,10 +516,11 @@ def conv2d_fwd_p3(xp, x_shape, w_shape, wplanes, bias=None, stride=1, pad=0, epi
     return out
 
 
-def gather_qdrop_p3(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, out_planes, batch_offset=0):
+def gather_qdrop_p3(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, out_planes, batch_offset=0, iter_publish=None):
     per_image = cache_q[0].numel()
     L.check(L.lib().rdo_gather_qdrop_p3(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,
-                                        cache_q.shape[-1], prob, seed, _ptr(out), _ptr(out_planes), _stream()), "rdo_gather_qdrop_p3")
+                                        cache_q.shape[-1], prob, seed, _ptr(out), _ptr(out_planes), _ptr(iter_publish), _stream()),
+            "rdo_gather_qdrop_p3")
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2

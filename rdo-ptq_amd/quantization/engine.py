@@ -159,6 +159,7 @@ class UnitEngine:
         self.use_p3 = bool(use_p3)             # big units on P3 tensors (plane-input LDS-DMA GEMM kernels); False: fp32 activations only
         self.P = {}                            # name -> planes of the P3 form of an activation buffer
         self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
+        self.fold_iter = os.environ.get("RDO_FOLD_ITER", "1") != "0"     # iteration-counter hand-over instead of an increment launch
         # opt-in R + lambda*D task loss (loss_mode='rd'): dict(model=QuantModel, unit=module, cali=calibration images NCHW on the GPU,
         # lmbda=float).  The unit output of every iteration is pushed through the REST of the wrapped model on torch's tape
         # (hipops.autograd) and losses.RateDistortionLoss is differentiated back to it; rec_loss stays the lp term.
@@ -182,7 +183,10 @@ class UnitEngine:
             raise ValueError("idx_table refers to images outside the cache")
         self.idx = idx_table.to(self.dev).contiguous()
         self.sched = ops.make_sched(self.iters, warmup, b_range, lr, self.dev)
-        self.it = torch.zeros(1, dtype=torch.int32, device=self.dev)
+        # iteration counter and its shadow (rdo_ptq_hip.h, "iteration-counter hand-over"): when the unit's AdaRound step is one batched
+        # launch it leaves it + 1 in the shadow and the next gather publishes it -- no separate increment launch
+        self._it2 = torch.zeros(2, dtype=torch.int32, device=self.dev)
+        self.it, self.it_shadow = self._it2[0:1], self._it2[1:2]
         self.loss_log = torch.zeros(self.iters, L.LOG_SLOTS, device=self.dev)      # kernels spread atomics over the slots
         self.task_log = torch.zeros(self.iters, L.LOG_SLOTS, device=self.dev)      # task term where it is a separate quantity
         self._task_is_rec = False              # True: task == rec on the same tensors, both logged as 2 * rec in loss_log
@@ -438,8 +442,8 @@ class UnitEngine:
         lean = self.p3_lean
         # lean: x and h1 exist as planes only -- the residual add of the tail sums the three planes back (exactly), the LeakyReLU
         # mask of the dgrad epilogue reads the sign off plane 0
-        ops.gather_qdrop_p3(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, None if lean else x, xp,
-                            self.batch_offset)
+        ops.gather_qdrop_p3(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None if lean else x, xp,
+                            self.batch_offset, iter_publish=self._it_pub())
         self._conv_p3(c1, xp, x.shape, out=None if lean else t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
         self._conv_p3(c2, h1p, t["h1"].shape, out=t["pre2"])
         self._task_is_rec = True
@@ -456,7 +460,8 @@ class UnitEngine:
         gamma'^T GEMM of the GDN backward on P3 tensors; the (cheap or thin) first convs stay on fp32 activations."""
         o, t, x = self.ops, self.t, self.x_in
         rbu = self.kind == "rbu"
-        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, self.batch_offset)
+        ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
+                         iter_publish=self._it_pub())
         if rbu:
             sp, cv, g, up = o["subpel_conv"], o["conv"], o["igdn"], o["upsample"]
             cname, dname = "c", "dc"
@@ -529,7 +534,8 @@ class UnitEngine:
             return self._fb_rb_p3()
         if self.p3_plan in ("rbws", "rbu"):
             return self._fb_gdn_block_p3()
-        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, self.batch_offset)
+        ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
+                         iter_publish=self._it_pub())
         if self.kind == "layer" and o["layer"].is_gdn:
             # a GDN / IGDN that is its own unit (sequential Minnen2018-style coders): only gamma is trained, no dx needed
             op = o["layer"]
@@ -646,6 +652,17 @@ class UnitEngine:
     def _batchable(self, opl):
         return self.batch_step and 1 <= len(opl) <= 8 and all(op.numel() % 4 == 0 for op in opl)
 
+    @property
+    def _handover(self):
+        """The counter hand-over needs the step of the whole unit in one batched launch (it is that launch that fills the shadow)."""
+        return self.fold_iter and self._batchable(list(self.ops.values()))
+
+    def _it_src(self):
+        return self.it_shadow if self._handover else self.it
+
+    def _it_pub(self):
+        return self.it if self._handover else None
+
     def _grad_ops(self, names):
         opl = [self.ops[n] for n in names]
         if self._batchable(opl):
@@ -659,7 +676,10 @@ class UnitEngine:
         tensors allow it, else one launch per op.  The bf16 planes of the new weights are written by the same launches."""
         opl = list(self.ops.values())
         if self._batchable(opl):
-            ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, advance_iter=self.it)
+            if self._handover:
+                ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, iter_shadow=self.it_shadow)
+            else:
+                ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, advance_iter=self.it)
             return
         for op in opl:
             ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
@@ -702,7 +722,8 @@ class UnitEngine:
                 opl = list(self.ops.values())
                 if self._batchable(opl):
                     ops.adaround_step_batch(self._items(opl), 1.0 / self.world, self.weight, self.sched, self.it, self.round_log,
-                                            advance_iter=self.it, mode=2)
+                                            advance_iter=None if self._handover else self.it, mode=2,
+                                            iter_shadow=self.it_shadow if self._handover else None)
                 else:
                     for op in opl:
                         ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, 1.0 / self.world, self.weight, self.sched,

@@ -372,7 +372,8 @@ class TapeEngine(UnitEngine):
         from .quant_block import QuantRSTB
         self.tape, self.G, self._aliased = [], {}, set()
         x = self.x_in
-        ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, x, self.batch_offset)
+        ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
+                         iter_publish=self._it_pub())
         y = self._unit_forward(x)
         n_unit = len(self.tape)
         plain = not self.tail and not self.tail_round                 # fp_out is the identity: task == rec (coef 2)
