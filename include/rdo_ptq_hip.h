@@ -74,6 +74,12 @@ int rdo_get_tuning(const char* key);
 int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
                    const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
                    const void* wplanes /* nullable: 3 x Cout*KH*KW*Cin bf16 from rdo_split_bf16x3_conv(w) */, void* stream);
+/* Split factor rdo_conv2d_fwd uses for this shape (1: no K split); `has_planes`: the caller passes bf16 weight planes. */
+int rdo_conv2d_fwd_ksplit(const rdo_conv_desc* d, int has_planes, int64_t workspace_floats);
+/* Only the K-split accumulation of rdo_conv2d_fwd: partial sums [ksplit][B*Ho*Wo][Cout] stay in `workspace` (ksplit =
+ * rdo_conv2d_fwd_ksplit(...) must be >= 2) for rdo_loss_act_bwd_splitk.  No bias, no epilogue. */
+int rdo_conv2d_fwd_partials(const rdo_conv_desc* d, const float* x, const float* w, const void* wplanes /* nullable */,
+                            float* workspace, int64_t workspace_floats, void* stream);
 /* Large problems can run on the bf16 MFMA at fp32-level accuracy: every fp32 operand is split EXACTLY into three bf16
  * planes (x = x1 + x2 + x3) and the six significant cross products are accumulated in fp32 (dropped terms <= 3*2^-24 |x w|).
  * Activations are split in the kernel's loader; the caller supplies the weight planes.  rdo_conv2d_fwd takes this path when
@@ -305,6 +311,13 @@ int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32
 int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residual_planes /* nullable: the residual as P3 planes */,
                      const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C,
                      float coef, int32_t act, float* out, float* grad_out, float* dpre, void* dpre_planes, float* loss_out, void* stream);
+/* The same tail taking the conv's output as the K-split partial sums rdo_conv2d_fwd_partials left in the workspace
+ * ([ksplit][B*per_image]): pre = sum of the slabs in slab order + bias -- the conv's own second pass folded into the first load, so
+ * conv epilogue, loss and activation backward are ONE pass and `pre` never exists in memory.  Bit-identical to rdo_conv2d_fwd
+ * followed by rdo_loss_act_bwd. */
+int rdo_loss_act_bwd_splitk(const float* partial, int32_t ksplit, const float* bias /* nullable */, const float* residual,
+                            const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, int64_t per_image,
+                            int32_t C, float coef, int32_t act, float* out, float* grad_out, float* dpre, float* loss_out, void* stream);
 /* Tail of a unit that ends in GDN / IGDN (+ residual):  out = x * norm^(-1/2 | +1/2) + residual ; loss and grad_out as above ;
  *   t = dL/dnorm = -1/2 g x norm^-3/2 (GDN) | 1/2 g x norm^-1/2 (IGDN)      = GDN epilogue + rdo_lp2_loss_grad + rdo_gdn_bwd_t */
 int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, const float* tgt_cache, const int32_t* idx_table,

@@ -38,6 +38,7 @@ struct FwdArgs {
     int epilogue, square_input, add_residual;
     float* partial;  // split-K: raw accumulators [ksplit][M][Cout]; nullptr when the kernel writes the final output
     int ksplit;
+    int partial_only;  // split-K: leave the slabs in the workspace, no epilogue launch (rdo_conv2d_fwd_partials)
 };
 
 #define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
@@ -278,7 +279,7 @@ int launch(const FwdArgs& a, hipStream_t s) {
     dim3 grid((unsigned)rdo::ceil_div(a.M, BM), (unsigned)rdo::ceil_div(a.Cout, BN), (unsigned)a.ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
     if (int rc = rdo::check_launch("conv_fwd")) return rc;
-    if (a.ksplit > 1) {
+    if (a.ksplit > 1 && !a.partial_only) {
         long g = rdo::ceil_div((long)a.M * a.Cout, 256);
         hipLaunchKernelGGL(conv_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
         return rdo::check_launch("conv_splitk_epilogue");
@@ -381,6 +382,49 @@ bool rdo_conv_is_thin(const rdo_conv_desc* d, bool forward);                    
 int rdo_launch_thin_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, float* out, hipStream_t s);
 bool rdo_conv_is_thincout(const rdo_conv_desc* d, bool forward);                                                        // conv_thincout.hip
 int rdo_launch_thincout_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, float* out, hipStream_t s);
+
+int rdo_conv2d_fwd_bf16x6_partials(const rdo_conv_desc* d, const float* x, const void* wplanes, float* workspace,
+                                   int64_t workspace_floats, void* stream);                                               // conv_fwd_x6.hip
+
+// Split factor rdo_conv2d_fwd would use for this shape (1: no split-K pass, e.g. the thin kernels or enough tiles without it)
+extern "C" int rdo_conv2d_fwd_ksplit(const rdo_conv_desc* d, int has_planes, int64_t workspace_floats) {
+    if (!d) return 1;
+    if (rdo_conv_is_thincout(d, true) || rdo_conv_is_thin(d, true)) return 1;
+    const long M = (long)d->B * d->Ho * d->Wo;
+    if (has_planes && rdo_conv2d_fwd_uses_bf16x6(d)) {
+        const int ks = rdo_conv2d_fwd_bf16x6_ksplit(d);
+        return (ks > 1 && (long)ks * M * d->Cout <= workspace_floats) ? ks : 1;
+    }
+    FwdArgs a = make_args(d);
+    return choose(a, workspace_floats).ksplit;
+}
+
+// The K-split accumulation of rdo_conv2d_fwd WITHOUT its second pass: the raw partial sums stay in `workspace` as
+// [ksplit][B*Ho*Wo][Cout] (ksplit = rdo_conv2d_fwd_ksplit(...) >= 2, else an error) for a consumer that folds "sum the slabs, add
+// the bias" into its own first load -- rdo_loss_act_bwd_splitk, which is then conv epilogue, loss and activation backward in one pass.
+extern "C" int rdo_conv2d_fwd_partials(const rdo_conv_desc* d, const float* x, const float* w, const void* wplanes, float* workspace,
+                                       int64_t workspace_floats, void* stream) {
+    RDO_REQUIRE(d && x && w && workspace, "rdo_conv2d_fwd_partials: null argument");
+    const int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
+    RDO_REQUIRE(ho == d->Ho && wo == d->Wo, "rdo_conv2d_fwd_partials: Ho/Wo do not match geometry");
+    RDO_REQUIRE((long)d->B * d->H * d->W * d->Cin < (1L << 31) && (long)d->Cout * d->KH * d->KW * d->Cin < (1L << 31) &&
+                    (long)d->B * d->Ho * d->Wo < (1L << 31), "rdo_conv2d_fwd_partials: tensor too large");
+    const int ks = rdo_conv2d_fwd_ksplit(d, wplanes != nullptr, workspace_floats);
+    RDO_REQUIRE(ks >= 2, "rdo_conv2d_fwd_partials: this shape is not split over K (rdo_conv2d_fwd_ksplit = %d)", ks);
+    if (wplanes && rdo_conv2d_fwd_uses_bf16x6(d)) return rdo_conv2d_fwd_bf16x6_partials(d, x, wplanes, workspace, workspace_floats, stream);
+    FwdArgs a = make_args(d);
+    a.x = x; a.w = w;
+    const Choice c = choose(a, workspace_floats);
+    a.ksplit = c.ksplit;
+    a.partial = workspace;
+    a.partial_only = 1;
+    const int tile = c.tile;
+    const bool vec = (d->Cin % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(w)) % 16 == 0);
+    const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
+    const double bytes = 4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout * c.ksplit + (double)a.Cout * a.KH * a.KW * a.Cin);
+    return rdo::dispatch([a, vec, tile](hipStream_t s) { return vec ? launch_choice<true>(a, tile, s) : launch_choice<false>(a, tile, s); },
+                         stream, kTiles[tile].tag, flops, bytes);
+}
 
 extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const float* w, const float* bias, const float* aux,
                               const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,

@@ -40,6 +40,7 @@ struct X6Args {
     int xcd_mode;         // 1: XCD-aware tile numbering
     float* partial;       // split-K (v3): raw accumulators [ksplit][M][Cout]; nullptr -> final output
     int ksplit;
+    int partial_only;     // split-K: no epilogue launch, the slabs stay in the workspace (rdo_conv2d_fwd_partials)
 };
 
 // exact three-way split through the hardware RNE conversion (a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950)
@@ -878,10 +879,10 @@ extern "C" int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d) {
     return best;
 }
 
-extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, const void* wplanes, const float* bias, const float* aux,
-                                     const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
-                                     void* stream) {
-    RDO_REQUIRE(d && x && wplanes && out, "rdo_conv2d_fwd_bf16x6: null argument");
+static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* wplanes, const float* bias, const float* aux,
+                           const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats, void* stream,
+                           bool partial_only) {
+    RDO_REQUIRE(d && x && wplanes && (out || partial_only), "rdo_conv2d_fwd_bf16x6: null argument");
     RDO_REQUIRE(d->Cin % 16 == 0, "rdo_conv2d_fwd_bf16x6: Cin must be a multiple of 16");
     X6Args a{};
     a.x = x; a.wp = reinterpret_cast<const u16*>(wplanes); a.bias = bias; a.aux = aux; a.residual = residual; a.out = out; a.pre = pre;
@@ -897,6 +898,8 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
     if (ks > 1 && (!workspace || (long)ks * a.M * a.Cout > workspace_floats)) ks = 1;
     a.ksplit = ks;
     a.partial = ks > 1 ? workspace : nullptr;
+    a.partial_only = partial_only ? 1 : 0;
+    RDO_REQUIRE(!partial_only || ks > 1, "rdo_conv2d_fwd_bf16x6: partial sums requested for a shape that is not split over K");
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
     return rdo::dispatch(
         [a](hipStream_t s) {
@@ -921,7 +924,7 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
                 dim3 grid6((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
                 hipLaunchKernelGGL(conv_fwd_x6v6_kernel, grid6, dim3(256), lds6, s, a);
                 if (int rc = rdo::check_launch("conv_fwd_x6v6")) return rc;
-                if (a.ksplit > 1) {
+                if (a.ksplit > 1 && !a.partial_only) {
                     long g = rdo::ceil_div((long)a.M * a.Cout, 256);
                     hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
                     return rdo::check_launch("x6_splitk_epilogue");
@@ -943,7 +946,7 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
             else if (ver == 4) hipLaunchKernelGGL(conv_fwd_x6v3_kernel<true>, grid, dim3(256), lds, s, a);
             else hipLaunchKernelGGL(conv_fwd_x6v5_kernel, grid, dim3(256), lds, s, a);
             if (int rc = rdo::check_launch("conv_fwd_x6")) return rc;
-            if (a.ksplit > 1) {
+            if (a.ksplit > 1 && !a.partial_only) {
                 long g = rdo::ceil_div((long)a.M * a.Cout, 256);
                 hipLaunchKernelGGL(x6_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, a);
                 return rdo::check_launch("x6_splitk_epilogue");
@@ -952,4 +955,15 @@ extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, con
         },
         stream, "conv_fwd_x6_128x192", flops,
         4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout) + 6.0 * a.wplane);
+}
+
+extern "C" int rdo_conv2d_fwd_bf16x6(const rdo_conv_desc* d, const float* x, const void* wplanes, const float* bias, const float* aux,
+                                     const float* residual, float* out, float* pre, float* workspace, int64_t workspace_floats,
+                                     void* stream) {
+    return fwd_bf16x6_impl(d, x, wplanes, bias, aux, residual, out, pre, workspace, workspace_floats, stream, false);
+}
+
+int rdo_conv2d_fwd_bf16x6_partials(const rdo_conv_desc* d, const float* x, const void* wplanes, float* workspace, int64_t workspace_floats,
+                                   void* stream) {
+    return fwd_bf16x6_impl(d, x, wplanes, nullptr, nullptr, nullptr, nullptr, nullptr, workspace, workspace_floats, stream, true);
 }

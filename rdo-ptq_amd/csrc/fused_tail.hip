@@ -170,7 +170,10 @@ __device__ __forceinline__ float loss_act_quad(const f32x4& p, const f32x4& y, c
 }
 
 // fp32 outputs only: channel-major thread order, every access a fully coalesced 16 bytes per lane
-__global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, const float* res, const float* tgt, const int32_t* idx_table,
+// `partial` != nullptr: the pre-activation is still the K-split partial sums of the conv (rdo_conv2d_fwd_partials): pre = (0 + slab 0
+// + slab 1 + ...) + bias, the sum order of the conv's own second pass
+__global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, const float* partial, int ks, long slab, const float* bias,
+                                                           int C, const float* res, const float* tgt, const int32_t* idx_table,
                                                            const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef,
                                                            int act, float* out, float* gout, float* dpre, float* loss_out) {
     const int it = *iter_ptr;
@@ -183,7 +186,15 @@ __global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, con
         const int b = (int)(t / quads);
         const long off = (t - (long)b * quads) * 4;
         const long e = (long)b * per_image + off;
-        const f32x4 p = ldq(pre + e), y = ldq(tgt + (long)idx_table[(long)it * B + b] * per_image + off);
+        const f32x4 y = ldq(tgt + (long)idx_table[(long)it * B + b] * per_image + off);
+        f32x4 p;
+        if (partial) {
+            p = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int z = 0; z < ks; ++z) p += ldq(partial + z * slab + e);
+            if (bias) p += ldq(bias + (int)(e % C));
+        } else {
+            p = ldq(pre + e);
+        }
         f32x4 r, o, g, dp;
         if (res) r = ldq(res + e);
         acc += loss_act_quad(p, y, res ? &r : nullptr, act, slope, gs, o, g, dp);
@@ -493,12 +504,33 @@ int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residu
                                    tgt_cache, idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, act, out, grad_out, dpre, pl,
                                    loss_out);
             else
-                hipLaunchKernelGGL(loss_act_bwd_kernel, dim3(loss_grid(rdo::ceil_div((long)B * per_image / 4, 256L))), dim3(256), 0, s, pre, residual, tgt_cache,
-                                   idx_table, iter_ptr, B, (long)per_image, inv_npix, coef, act, out, grad_out, dpre, loss_out);
+                hipLaunchKernelGGL(loss_act_bwd_kernel, dim3(loss_grid(rdo::ceil_div((long)B * per_image / 4, 256L))), dim3(256), 0, s, pre,
+                                   (const float*)nullptr, 0, 0L, (const float*)nullptr, C, residual, tgt_cache, idx_table, iter_ptr, B,
+                                   (long)per_image, inv_npix, coef, act, out, grad_out, dpre, loss_out);
             return rdo::check_launch("loss_act_bwd");
         },
         stream, "loss_act_bwd", 0.0,
         n * (8.0 + 4.0 * ((residual != nullptr) + (out != nullptr) + (grad_out != nullptr) + (dpre != nullptr)) + (pl ? 6.0 : 0.0)));
+}
+
+int rdo_loss_act_bwd_splitk(const float* partial, int32_t ksplit, const float* bias, const float* residual, const float* tgt_cache,
+                            const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef,
+                            int32_t act, float* out, float* grad_out, float* dpre, float* loss_out, void* stream) {
+    RDO_REQUIRE(partial && ksplit >= 2 && tgt_cache && idx_table && iter_ptr && (dpre || grad_out), "rdo_loss_act_bwd_splitk: bad argument");
+    RDO_REQUIRE(B > 0 && C > 0 && C % 4 == 0 && per_image > 0 && per_image % C == 0, "rdo_loss_act_bwd_splitk: bad shape");
+    RDO_REQUIRE(act >= 0 && act <= 2, "rdo_loss_act_bwd_splitk: act %d (0 none, 1 LeakyReLU(0.01), 2 ReLU)", act);
+    const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
+    const long slab = (long)B * per_image;
+    const double n = (double)B * per_image;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(loss_act_bwd_kernel, dim3(loss_grid(rdo::ceil_div((long)B * per_image / 4, 256L))), dim3(256), 0, s,
+                               (const float*)nullptr, partial, ksplit, slab, bias, C, residual, tgt_cache, idx_table, iter_ptr, B,
+                               (long)per_image, inv_npix, coef, act, out, grad_out, dpre, loss_out);
+            return rdo::check_launch("loss_act_bwd_splitk");
+        },
+        stream, "loss_act_bwd", 0.0,
+        n * (4.0 + 4.0 * ksplit + 4.0 * ((residual != nullptr) + (out != nullptr) + (grad_out != nullptr) + (dpre != nullptr))));
 }
 
 int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, const float* tgt_cache, const int32_t* idx_table,

@@ -82,6 +82,38 @@ def conv2d_fwd(x, w, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, 
     return out
 
 
+SCRATCH_FLOATS = 1 << 22     # smallest split-K workspace _scratch hands out
+
+
+def conv_fwd_ksplit(x_shape, w_shape, stride, pad, has_planes, device):
+    """Split factor conv2d_fwd uses for this shape with the workspace it would get (1: no split-K pass)."""
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    need = int(L.lib().rdo_conv2d_fwd_workspace(C.byref(d)))
+    return int(L.lib().rdo_conv2d_fwd_ksplit(C.byref(d), int(bool(has_planes)), max(need, SCRATCH_FLOATS))), need
+
+
+def conv2d_fwd_partials(x, w, stride=1, pad=0, wplanes=None):
+    """K-split accumulation only: returns (workspace tensor holding [ksplit][M][Cout] partial sums, ksplit).  The workspace is the
+    shared split-K scratch of the device: consume it with the next launch (loss_act_bwd_splitk)."""
+    d = conv_desc(x.shape, w.shape, stride, pad)
+    ks, need = conv_fwd_ksplit(tuple(x.shape), tuple(w.shape), stride, pad, wplanes is not None, x.device)
+    ws = _scratch(x.device, need)
+    L.check(L.lib().rdo_conv2d_fwd_partials(C.byref(d), _ptr(x), _ptr(w), _ptr(wplanes), _ptr(ws), ws.numel(), _stream()),
+            "rdo_conv2d_fwd_partials")
+    return ws, ks
+
+
+def loss_act_bwd_splitk(partial, ksplit, bias, out_shape, residual, tgt_cache, idx_table, iter_ptr, coef, act, loss_log, out=None, grad_out=None,
+                        dpre=None):
+    B = out_shape[0]
+    per_image = 1
+    for v in out_shape[1:]:
+        per_image *= int(v)
+    L.check(L.lib().rdo_loss_act_bwd_splitk(_ptr(partial), int(ksplit), _ptr(bias), _ptr(residual), _ptr(tgt_cache), _ptr(idx_table),
+                                            _ptr(iter_ptr), B, per_image, int(out_shape[-1]), coef, int(act), _ptr(out), _ptr(grad_out),
+                                            _ptr(dpre), _ptr(loss_log), _stream()), "rdo_loss_act_bwd_splitk")
+
+
 def wgrad_nsplit(x_shape, w_shape, stride, pad):
     d = conv_desc(x_shape, w_shape, stride, pad)
     return int(L.lib().rdo_conv2d_wgrad_nsplit(C.byref(d)))

@@ -159,6 +159,7 @@ class UnitEngine:
         self.use_p3 = bool(use_p3)             # big units on P3 tensors (plane-input LDS-DMA GEMM kernels); False: fp32 activations only
         self.P = {}                            # name -> planes of the P3 form of an activation buffer
         self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
+        self.fuse_splitk = os.environ.get("RDO_FUSE_SPLITK", "1") != "0"   # split-K conv + unit tail: the conv's second pass inside the tail
         self.fold_iter = os.environ.get("RDO_FOLD_ITER", "1") != "0"     # iteration-counter hand-over instead of an increment launch
         # opt-in R + lambda*D task loss (loss_mode='rd'): dict(model=QuantModel, unit=module, cali=calibration images NCHW on the GPU,
         # lmbda=float).  The unit output of every iteration is pushed through the REST of the wrapped model on torch's tape
@@ -370,6 +371,21 @@ class UnitEngine:
         self._task_is_rec = True
         ops.loss_act_bwd(pre, res, self.co, self.idx, self.it, 2.0, act, self.loss_log, grad_out=gout, dpre=dpre)
 
+    def _conv_tail(self, op, x, pre, res, act, dpre, gout=None):
+        """Last conv of a unit + its fused tail.  When the conv is split over K, its second pass (sum the partial slabs, add the
+        bias) moves into the tail's first load: one launch and one round trip of the pre-activation tensor less."""
+        if ops.uses_bf16x6(tuple(x.shape), op.w4, op.stride, op.pad):
+            op.enable_planes(True, False)
+        ks, _ = ops.conv_fwd_ksplit(tuple(x.shape), op.w4, op.stride, op.pad, op.wq_planes is not None, self.dev)
+        if self.fuse_splitk and ks >= 2 and not op.is_gdn:
+            ws, ks = ops.conv2d_fwd_partials(x, op.wq4(), op.stride, op.pad, wplanes=op.wq_planes)
+            self._task_is_rec = True
+            ops.loss_act_bwd_splitk(ws, ks, op.bias, tuple(pre.shape), res, self.co, self.idx, self.it, 2.0, act, self.loss_log,
+                                    grad_out=gout, dpre=dpre)
+            return
+        self._conv(op, x, pre)
+        self._tail_act(pre, res, act, dpre, gout=gout)
+
     def _tail_gdn(self, x, norm, res, inverse, gout, tbuf):
         self._task_is_rec = True
         ops.loss_gdn_bwd(x, norm, res, self.co, self.idx, self.it, 2.0, inverse, self.loss_log, gout, t=tbuf)
@@ -556,9 +572,8 @@ class UnitEngine:
             if epi is None and self.include_act and type(op.qm.activation_function).__name__ != "StraightThrough":
                 raise NotImplementedError("calibration engine: only LeakyReLU(0.01) or ReLU may be fused into a layer unit")
             if self.fused:
-                self._conv(op, x, t["y"])                                                         # pre-activation
                 act = {None: ops.ACT_NONE, L.EPI_LRELU: ops.ACT_LRELU, L.EPI_RELU: ops.ACT_RELU}[epi]
-                self._tail_act(t["y"], None, act, t["dpre"])
+                self._conv_tail(op, x, t["y"], None, act, t["dpre"])                              # t["y"]: pre-activation, if it is stored
                 self._wgrad(op, x, t["dpre"])
             elif epi is not None:
                 self._conv(op, x, t["y"], epilogue=epi)
@@ -577,8 +592,7 @@ class UnitEngine:
                 self._conv(o["skip"], x, t["sk"])
                 res = t["sk"]
             if self.fused:
-                self._conv(c2, t["h1"], t["pre2"])
-                self._tail_act(t["pre2"], res, ops.ACT_LRELU, t["dpre2"], gout=t["dout"] if "skip" in o else None)
+                self._conv_tail(c2, t["h1"], t["pre2"], res, ops.ACT_LRELU, t["dpre2"], gout=t["dout"] if "skip" in o else None)
             else:
                 self._conv(c2, t["h1"], t["out"], epilogue=L.EPI_LRELU, residual=res, pre=t["pre2"])
                 self._loss(t["out"], t["dout"])

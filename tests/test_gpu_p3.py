@@ -266,3 +266,36 @@ def test_wgrad_p3_row_kernel_equals_per_tap_kernel(ops, B, H, W, Cin, Cout):
         finally:
             ops.set_tuning("wgrad_p3_row", 1)
     assert torch.equal(got[0], got[1])
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,K,s,p,x6", [(4, 64, N, N, 3, 1, 1, True), (4, 32, N, N, 3, 1, 1, True), (4, 16, N, N, 3, 1, 1, False),
+                                                   (4, 16, 320, N, 5, 2, 2, False), (4, 32, N, N, 3, 2, 1, False)])
+@pytest.mark.parametrize("act", [0, 1])
+def test_splitk_conv_with_tail_doing_its_second_pass(ops, L, B, H, Cin, Cout, K, s, p, x6, act):
+    """rdo_conv2d_fwd_partials + rdo_loss_act_bwd_splitk (the conv's slab sum and bias inside the tail's first load) against
+    rdo_conv2d_fwd + rdo_loss_act_bwd: the same bits for the pre-activation-derived outputs, the same loss up to summation order."""
+    g = torch.Generator(device="cuda").manual_seed(H * K + Cin + act)
+    x = torch.randn(B, H, H, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, K, K, Cin, device="cuda", generator=g) / (K * K * Cin) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    wpl = ops.split_bf16x3(w) if x6 else None
+    ks, _ = ops.conv_fwd_ksplit(tuple(x.shape), tuple(w.shape), s, p, x6, "cuda")
+    assert ks >= 2
+    Ho = (H + 2 * p - K) // s + 1
+    n = 6
+    res = torch.randn(B, Ho, Ho, Cout, device="cuda", generator=g)
+    tgt = torch.randn(n, Ho, Ho, Cout, device="cuda", generator=g)
+    idx = torch.tensor([[5, 0, 3, 3]], dtype=torch.int32, device="cuda")
+    it = torch.zeros(1, dtype=torch.int32, device="cuda")
+    pre = ops.conv2d_fwd(x, w, b, s, p, wplanes=wpl)
+    ref = [torch.empty_like(pre) for _ in range(3)]
+    log_ref = torch.zeros(1, 32, device="cuda")
+    ops.loss_act_bwd(pre, res, tgt, idx, it, 2.0, act, log_ref, out=ref[0], grad_out=ref[1], dpre=ref[2])
+    ws, ks2 = ops.conv2d_fwd_partials(x, w, s, p, wplanes=wpl)
+    assert ks2 == ks
+    got = [torch.empty_like(pre) for _ in range(3)]
+    log = torch.zeros(1, 32, device="cuda")
+    ops.loss_act_bwd_splitk(ws, ks, b, tuple(pre.shape), res, tgt, idx, it, 2.0, act, log, out=got[0], grad_out=got[1], dpre=got[2])
+    for u, v in zip(got, ref):
+        assert torch.equal(u, v)
+    torch.testing.assert_close(log.sum(), log_ref.sum(), rtol=1e-5, atol=0)
