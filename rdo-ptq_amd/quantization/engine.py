@@ -139,7 +139,7 @@ class _Op:
 class UnitEngine:
     def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
                  warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
-                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=True, fuse_tail=True, batch_step=True, use_p3=True, rd=None):
+                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=None, fuse_tail=True, batch_step=True, use_p3=True, rd=None):
         if kind not in UNIT_KINDS:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
@@ -153,7 +153,7 @@ class UnitEngine:
         self.include_act = include_act_func
         self.use_graph = use_graph
         self.batch_offset = int(batch_offset)  # first row of this rank's share of the global mini-batch (QDrop counter)
-        self.dp_overlap = bool(dp_overlap)
+        self.dp_overlap = None if dp_overlap is None else bool(dp_overlap)
         if os.environ.get("RDO_USE_P3") is not None:
             use_p3 = os.environ["RDO_USE_P3"] != "0"      # A/B switch for whole runs (bench.py)
         self.use_p3 = bool(use_p3)             # big units on P3 tensors (plane-input LDS-DMA GEMM kernels); False: fp32 activations only
@@ -233,7 +233,12 @@ class UnitEngine:
         # Data parallel: one flat bucket of d(rec+task)/d(alpha) per unit.  The op whose weight gradient is the LAST kernel of the
         # backward pass (the block's first conv) sits at the end of the bucket: everything in front of it is complete before that
         # wgrad starts, so its all-reduce overlaps the wgrad (two recorded plans, `_split_point`).
-        self._late = {"rb": "conv1", "rbws": "conv1", "rbu": "subpel_conv"}.get(k) if (self.split and self.dp_overlap) else None
+        # Only where that last wgrad is long enough to hide a collective behind (>= 64^2 activations at batch 4): on the small units
+        # the second all-reduce and the second gradient launch cost more than the overlap saves.
+        overlap = self.dp_overlap
+        if overlap is None:                    # default: by size; True / False force it (tests, A/B)
+            overlap = self.B * self.cq.shape[1] * self.cq.shape[2] >= self.DP_OVERLAP_MIN_PIXELS
+        self._late = {"rb": "conv1", "rbws": "conv1", "rbu": "subpel_conv"}.get(k) if (self.split and overlap) else None
         if self.split:
             total = sum(op.numel() for op in o.values())
             self.bucket = torch.zeros(total, device=self.dev)
@@ -391,6 +396,7 @@ class UnitEngine:
         ops.loss_gdn_bwd(x, norm, res, self.co, self.idx, self.it, 2.0, inverse, self.loss_log, gout, t=tbuf)
 
     # ------------------------------------------------------------------------------------------------------------------ P3 path
+    DP_OVERLAP_MIN_PIXELS = 16384   # mini-batch input pixels from which the bucket all-reduce is split in two (see _build_ops)
     P3_MIN_OUT = 65536 * 192        # plane-input forward kernel pays off from 4 x 128^2 x 192 output elements (profiles/r02a)
     p3_lean = os.environ.get("RDO_P3_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fp32
 
