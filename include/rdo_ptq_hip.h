@@ -61,6 +61,7 @@ const char* rdo_last_error(void);
  *   "graph_unroll" iterations per replayed graph in rdo_plan_run for long runs (default 8; 1: one graph launch per iteration)
  *   "x6p_halo"     1 (default): 3x3 stride-1 pad-1 plane-input convs with H, W multiples of 16 run the halo-tile kernel; 0: the per-tap kernel
  *   "wgrad_p3_row" 1 (default): 3x3 stride-1 plane-input weight gradients share one input row image between the three kw taps
+ *   "thin_mfma"    1 (default): weight gradients with <= 4 input channels and a patch of 5..32 values run the gather-operand MFMA kernel
  *   "tail_grid"    most workgroups of a fused loss kernel (each ends with one atomic add into the 32-slot loss log)
  *   "x6p_ablate"   diagnostic bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
  *                  8 no fragment reads, 16 rotate the K order per tile (results stay right)

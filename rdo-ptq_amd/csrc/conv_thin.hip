@@ -128,6 +128,90 @@ __global__ __launch_bounds__(64 * G) void thin_wgrad_kernel(ThinArgs a) {
     }
 }
 
+// ---- MFMA weight gradient for 4 < patch <= 32 values (3x3x3): no LDS staging, no im2col ---------------------------------------------------
+// The im2col matrix [pixels][patch] is never materialised: a lane GATHERS its element straight from the (L2-resident, 3 MB) input
+// image as the MFMA operand.  v_mfma_f32_32x32x2_f32 (true fp32): D[co][j] with A = dY^T (lane = co, k = pixel: one coalesced 128-byte
+// row segment per k) and B = patch values (lane = patch index j -- its tap offset is a per-lane constant --, k = pixel).
+// 26 us for the RGB stem at 4 x 128^2 x 192 with 256 pixel splits (stream kernel: 52 us with 128, 115 with the old 37).  The same
+// construction for the FORWARD (A = gathered patch values, B = weights in registers) was measured at 38 - 49 us against 40 for the
+// stream kernel and dropped; for 1x1 kernels (patch <= 4) the stream kernels win both ways (12 / 15 us against 21 / 25).
+typedef float f32x16t __attribute__((ext_vector_type(16)));
+
+// element offset and validity of patch value j of the output pixel whose input origin is (hi0, wi0) in image b
+struct PatchIdx { int dh, dw, c; };
+__device__ __forceinline__ PatchIdx patch_idx(const ThinArgs& a, int j) {
+    const int tap = j / a.Cin;
+    PatchIdx p;
+    p.c = j - tap * a.Cin;
+    p.dh = tap / a.KW;
+    p.dw = tap - p.dh * a.KW;
+    return p;
+}
+
+// grid (nsplit); the four waves of a workgroup take quarters of the chunk's pixels, fold through LDS in wave order
+template <int CT>
+__global__ __launch_bounds__(256) void thin_wgrad_mfma_kernel(ThinArgs a) {
+    __shared__ float fold[CT * 32 * 32];
+    const int lane = threadIdx.x & 63, li = lane & 31, lh = lane >> 5, wave = threadIdx.x >> 6;
+    const int mbeg = blockIdx.x * a.mchunk, mend = min(a.M, mbeg + a.mchunk);
+    const int per_wave = ((mend - mbeg + 3) / 4 + 1) & ~1;   // even: a k-step is two pixels
+    const int wbeg = mbeg + wave * per_wave, wend = min(mend, wbeg + per_wave);
+    const PatchIdx pj = patch_idx(a, li < a.patch ? li : 0);
+    const bool jok = li < a.patch;
+    const int HoWo = a.Ho * a.Wo;
+    f32x16t acc[CT];
+#pragma unroll
+    for (int t = 0; t < CT; ++t)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[t][q] = 0.f;
+    constexpr int U = 4;                                     // k-steps per trip: their loads are issued together
+    for (int m0 = wbeg; m0 < wend; m0 += 2 * U) {
+        float bv[U], av[U][CT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int m = m0 + 2 * u + lh;
+            const bool okm = m < wend;
+            const int mm = okm ? m : 0;
+            const int b = mm / HoWo, r = mm - b * HoWo;
+            const int ho = r / a.Wo, wo = r - ho * a.Wo;
+            const int hi = ho * a.stride - a.pad + pj.dh, wi = wo * a.stride - a.pad + pj.dw;
+            const bool ok = okm && jok && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
+            bv[u] = ok ? a.x[((long)(b * a.H + hi) * a.W + wi) * a.Cin + pj.c] : 0.f;
+#pragma unroll
+            for (int t = 0; t < CT; ++t) {
+                const int co = 32 * t + li;
+                av[u][t] = (okm && co < a.Cout) ? a.dy[(long)mm * a.Cout + co] : 0.f;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int t = 0; t < CT; ++t) acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[u][t], bv[u], acc[t], 0, 0, 0);
+    }
+    // D[co = 32 t + row][j = li], row = (q & 3) + 8 (q >> 2) + 4 lh
+    for (int w = 0; w < 4; ++w) {
+        __syncthreads();
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < CT; ++t)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) {
+                    float* f = &fold[(t * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh) * 32 + li];
+                    *f = (w == 0 ? 0.f : *f) + acc[t][q];
+                }
+        }
+    }
+    __syncthreads();
+    float* dst = a.out + (long)blockIdx.x * a.Cout * a.patch;
+    for (int e = threadIdx.x; e < CT * 32 * 32; e += 256) {
+        const int co = e >> 5, j = e & 31;
+        if (co < a.Cout && j < a.patch) dst[(long)co * a.patch + j] = fold[e];
+    }
+}
+
+// instances: Cout <= 128 / 192 / 256
+inline int thin_ct(int Cout) { return Cout <= 128 ? 4 : (Cout <= 192 ? 6 : (Cout <= 256 ? 8 : 0)); }
+
 ThinArgs make(const rdo_conv_desc* d) {
     ThinArgs a{};
     a.B = d->B; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
@@ -169,6 +253,14 @@ int rdo_launch_thin_wgrad(const rdo_conv_desc* d, const float* x, const float* d
     ThinArgs a = make(d);
     a.x = x; a.dy = dy; a.out = slabs;
     a.mchunk = (int)(rdo::ceil_div(rdo::ceil_div(a.M, nsplit), PB) * PB);
+    if (thin_ct(a.Cout) && a.patch > 4 && a.patch <= 32 && rdo::tuning(rdo::T_THIN_MFMA)) {
+        a.mchunk = (int)(rdo::ceil_div(rdo::ceil_div(a.M, nsplit), 8) * 8);
+        const int ct = thin_ct(a.Cout);
+        if (ct == 4) hipLaunchKernelGGL(thin_wgrad_mfma_kernel<4>, dim3((unsigned)nsplit), dim3(256), 0, s, a);
+        else if (ct == 6) hipLaunchKernelGGL(thin_wgrad_mfma_kernel<6>, dim3((unsigned)nsplit), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL(thin_wgrad_mfma_kernel<8>, dim3((unsigned)nsplit), dim3(256), 0, s, a);
+        return rdo::check_launch("conv_thin_wgrad_mfma");
+    }
     dim3 grid((unsigned)nsplit, (unsigned)rdo::ceil_div(a.Cout, 64));
     if (a.patch <= 4) hipLaunchKernelGGL((thin_wgrad_kernel<4, 8>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((thin_wgrad_kernel<32, 8>), grid, dim3(512), 0, s, a);

@@ -268,7 +268,12 @@ extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d) {
     if (g_force_ns >= 1) return g_force_ns;
     const long M = (long)d->B * d->Ho * d->Wo;
     // few input channels (conv_thin.hip): one workgroup column per 64 output channels, so the pixel splits alone have to fill the chip
-    if (rdo_conv_is_thin(d, false)) return (int)(M >= 65536 ? 128 : (M >= 512 ? M / 512 : 1));
+    if (rdo_conv_is_thin(d, false)) {
+        const long per = d->KH * d->KW * d->Cin > 4 ? 256 : 512;      // pixels per split: the MFMA form (patch > 4) wants 256 workgroups
+        const long cap = d->KH * d->KW * d->Cin > 4 ? 256 : 128;
+        const long ns = M / per;
+        return (int)(ns < 1 ? 1 : (ns > cap ? cap : ns));
+    }
     // big tile: ~1 workgroup per CU; small tile: ~4 per CU.  Chunks of at least 128 pixels (4 reduction steps).
     const long target = big_tiles(d) ? 256 : 1024;
     long ns = target / tiles_total(d);
