@@ -299,6 +299,14 @@ int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* 
                       void* stream);
 /* rdo_conv2d_wgrad with both operands as P3 planes (x: [B*H*W][Cin], dy: [B*Ho*Wo][Cout]); same slabs, same nsplit rule
  * (rdo_conv2d_wgrad_nsplit).  Supported for the shapes of rdo_conv2d_wgrad_uses_bf16x6 with Cin % 16 == Cout % 16 == 0, no square_input. */
+/* Last conv of a unit + its tail in ONE launch: rdo_conv2d_fwd_p3 followed by rdo_loss_act_bwd (residual as planes, dL/dpre as planes)
+ * with the pre-activation never written: the halo kernel's epilogue forms out = act(conv + bias) + residual, the loss against
+ * tgt_cache[idx] and dL/dpre.  3x3 / stride 1 / pad 1 shapes of the halo kernel only (rdo_conv2d_fwd_p3_tail_supported);
+ * same bits as the two-call form (tests/test_gpu_p3.py). */
+int rdo_conv2d_fwd_p3_tail_supported(const rdo_conv_desc* d);
+int rdo_conv2d_fwd_p3_tail(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias,
+                           const void* residual_planes /* nullable */, const float* tgt_cache, const int32_t* idx_table,
+                           const int32_t* iter_ptr, int32_t B, float coef, int32_t act, void* dpre_planes, float* loss_out, void* stream);
 int rdo_conv2d_wgrad_p3_supported(const rdo_conv_desc* d);
 int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes, const void* dy_planes, float* slabs, int nsplit, void* stream);
 /* rdo_gather_qdrop writing the mini-batch as P3 planes (and as fp32 when `out` != NULL) */

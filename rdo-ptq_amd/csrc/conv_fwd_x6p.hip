@@ -55,6 +55,16 @@ struct X6PArgs {
     int xcd_mode;
     float* partial;       // split-K: raw accumulators [ksplit][M][Cout]
     int ksplit;
+    // unit tail folded into the halo kernel's epilogue (rdo_conv2d_fwd_p3_tail): out = act(conv + bias) + residual, loss against the
+    // cached target rows, dL/dpre written as the result planes -- rdo_loss_act_bwd without the pre-activation round trip
+    const float* tail_tgt;    // nullptr: no tail
+    const int32_t* tail_idx;
+    const int32_t* tail_iter;
+    const u16* tail_resp;     // residual as P3 planes of [M][Cout] (nullable)
+    float* tail_loss;
+    long tail_per_image;
+    int tail_B, tail_act;
+    float tail_coef, tail_inv_npix;
     int ablate;           // diagnostic bit mask (tuning key "x6p_ablate"): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads
 };
 
@@ -168,6 +178,50 @@ __device__ __forceinline__ void finish16(const X6PArgs& a, int m, int n, float (
         for (int c = 0; c < 4; ++c) *reinterpret_cast<f32x4*>(a.out + o + 4 * c) = f32x4{v[4 * c], v[4 * c + 1], v[4 * c + 2], v[4 * c + 3]};
     }
     if (a.outp) store_slice(a, m, n, v);
+}
+
+// Unit tail on the 16 finished channels [n, n+16) of pixel m (v = conv + bias, the pre-activation): v becomes dL/dpre, the return value
+// is sum d^2.  The arithmetic of loss_act_quad (fused_tail.hip), operation for operation.
+__device__ __forceinline__ float tail16(const X6PArgs& a, int m, int n, float (&v)[16]) {
+    const int b = (int)(((long)m * a.Cout) / a.tail_per_image);
+    const int it = *a.tail_iter;
+    const float* y = a.tail_tgt + (long)a.tail_idx[(long)it * a.tail_B + b] * a.tail_per_image + ((long)m * a.Cout - (long)b * a.tail_per_image) + n;
+    const float slope = a.tail_act == 1 ? 0.01f : 0.f;
+    const float gs = a.tail_coef * 2.f * a.tail_inv_npix;
+    float r[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[k] = 0.f;
+    if (a.tail_resp) {                                       // exact fp32 residual from its planes: (p0 + p1) + p2
+        const u16* rp = a.tail_resp + ((long)(n >> 4) * a.M + m) * 16;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const u32x4 p0 = *reinterpret_cast<const u32x4*>(rp + 8 * h), p1 = *reinterpret_cast<const u32x4*>(rp + a.oplane + 8 * h),
+                        p2 = *reinterpret_cast<const u32x4*>(rp + 2 * a.oplane + 8 * h);
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                r[8 * h + 2 * k] = (lo_f(p0[k]) + lo_f(p1[k])) + lo_f(p2[k]);
+                r[8 * h + 2 * k + 1] = (hi_f(p0[k]) + hi_f(p1[k])) + hi_f(p2[k]);
+            }
+        }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const f32x4 y4 = *reinterpret_cast<const f32x4*>(y + 4 * c);
+        float dd[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float p = v[4 * c + k];
+            float o = p;
+            if (a.tail_act) o = p > 0.f ? p : slope * p;
+            if (a.tail_resp) o += r[4 * c + k];
+            dd[k] = o - y4[k];
+            const float g = dd[k] * gs;
+            v[4 * c + k] = a.tail_act ? (p > 0.f ? g : slope * g) : g;
+        }
+        acc += (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+    }
+    return acc;
 }
 
 __global__ __launch_bounds__(512, 2) void conv_fwd_x6p_kernel(X6PArgs a) {
@@ -629,6 +683,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6h_kernel(X6PArgs a) {
     // ---- epilogue: as in conv_fwd_x6p_kernel, tile row tl = pixel (tl / 16, tl % 16) of the patch
     float* const stg = reinterpret_cast<float*>(smem);
     const bool need_planes = a.outp != nullptr;
+    float tail_loss = 0.f;
 #pragma unroll
     for (int pass = 0; pass < TM; ++pass) {
         if (pass) __syncthreads();
@@ -677,9 +732,19 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6h_kernel(X6PArgs a) {
                     const f32x4 t4 = *reinterpret_cast<const f32x4*>(stg + row * SROW + sl * 16 + 4 * c);
                     v[4 * c] = t4[0]; v[4 * c + 1] = t4[1]; v[4 * c + 2] = t4[2]; v[4 * c + 3] = t4[3];
                 }
+                if (a.tail_tgt) tail_loss += tail16(a, m, n, v);
                 store_slice(a, m, n, v);
             }
         }
+    }
+    if (a.tail_tgt) {                                        // one atomic per workgroup (256 of them, 8 per log slot)
+        __shared__ float red[8];
+        for (int o = 32; o > 0; o >>= 1) tail_loss += __shfl_down(tail_loss, o, 64);
+        if (lane == 0) red[wave] = tail_loss;
+        __syncthreads();
+        if (tid == 0 && a.tail_loss)
+            atomicAdd(a.tail_loss + (long)(*a.tail_iter) * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)),
+                      (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) * (a.tail_inv_npix * a.tail_coef));
     }
 }
 
@@ -772,9 +837,14 @@ extern "C" int64_t rdo_conv2d_fwd_p3_workspace(const rdo_conv_desc* d) {
     return ks > 1 ? (int64_t)ks * d->B * d->Ho * d->Wo * d->Cout : 0;
 }
 
-extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
-                                 const void* aux_planes, const float* residual, float* out, float* pre, void* out_planes,
-                                 float* workspace, int64_t workspace_floats, void* stream) {
+static bool p3_halo_shape(const rdo_conv_desc* d) {
+    return rdo::tuning(rdo::T_X6P_HALO) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H % 16 == 0 && d->W % 16 == 0 &&
+           p3_ksplit(d) == 1;
+}
+
+static int conv2d_fwd_p3_impl(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
+                              const void* aux_planes, const float* residual, float* out, float* pre, void* out_planes,
+                              float* workspace, int64_t workspace_floats, void* stream, const X6PArgs* tail) {
     RDO_REQUIRE(d && x_planes && wplanes && (out || out_planes || pre), "rdo_conv2d_fwd_p3: null argument");
     RDO_REQUIRE(rdo_conv2d_fwd_p3_supported(d), "rdo_conv2d_fwd_p3: shape not on the split-bf16 plane path (rdo_conv2d_fwd_p3_supported)");
     const int ho = (d->H + 2 * d->pad - d->KH) / d->stride + 1, wo = (d->W + 2 * d->pad - d->KW) / d->stride + 1;
@@ -799,6 +869,11 @@ extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, c
     a.epilogue = d->epilogue; a.add_residual = d->add_residual;
     a.xcd_mode = rdo::tuning(rdo::T_XCD);
     a.ablate = rdo::tuning(rdo::T_X6P_ABLATE);
+    if (tail) {
+        a.tail_tgt = tail->tail_tgt; a.tail_idx = tail->tail_idx; a.tail_iter = tail->tail_iter; a.tail_resp = tail->tail_resp;
+        a.tail_loss = tail->tail_loss; a.tail_per_image = tail->tail_per_image; a.tail_B = tail->tail_B; a.tail_act = tail->tail_act;
+        a.tail_coef = tail->tail_coef; a.tail_inv_npix = tail->tail_inv_npix;
+    }
     int ks = p3_ksplit(d);
     if (ks < 1) ks = 1;
     if (ks > 1 && (!workspace || (long)ks * a.M * a.Cout > workspace_floats)) ks = 1;
@@ -809,8 +884,8 @@ extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, c
                          (double)a.M * a.Cout * (4.0 * ((out != nullptr) + (pre != nullptr) + (aux != nullptr) + (residual != nullptr)) +
                                                  6.0 * (out_planes != nullptr));
     // 3 x 3 "same" convs on 16 x 16 patches: the halo kernel (no K split: the shapes that qualify for P3 fill the chip with tiles)
-    const bool halo = rdo::tuning(rdo::T_X6P_HALO) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 &&
-                      a.W % 16 == 0 && ks == 1;
+    const bool halo = p3_halo_shape(d) && ks == 1;
+    RDO_REQUIRE(!tail || halo, "rdo_conv2d_fwd_p3_tail: shape not on the halo kernel (rdo_conv2d_fwd_p3_tail_supported)");
     if (halo)
         return rdo::dispatch(
             [a](hipStream_t s) {
@@ -848,4 +923,31 @@ extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, c
             return RDO_OK;
         },
         stream, "conv_fwd_x6_p3_256x192", flops, bytes);
+}
+
+extern "C" int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
+                                 const void* aux_planes, const float* residual, float* out, float* pre, void* out_planes,
+                                 float* workspace, int64_t workspace_floats, void* stream) {
+    return conv2d_fwd_p3_impl(d, x_planes, wplanes, bias, aux, aux_planes, residual, out, pre, out_planes, workspace, workspace_floats, stream,
+                              nullptr);
+}
+
+extern "C" int rdo_conv2d_fwd_p3_tail_supported(const rdo_conv_desc* d) {
+    return d && rdo_conv2d_fwd_p3_supported(d) && p3_halo_shape(d) && d->epilogue == RDO_EPI_NONE && !d->add_residual;
+}
+
+// Last conv of a unit + its tail in ONE launch (halo kernel): the epilogue forms out = act(conv + bias) + residual, the loss against
+// the cached target rows and dL/dpre, and writes only the planes of dL/dpre -- rdo_conv2d_fwd_p3 + rdo_loss_act_bwd without the
+// pre-activation tensor ever reaching memory.
+extern "C" int rdo_conv2d_fwd_p3_tail(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias,
+                                      const void* residual_planes, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr,
+                                      int32_t B, float coef, int32_t act, void* dpre_planes, float* loss_out, void* stream) {
+    RDO_REQUIRE(d && tgt_cache && idx_table && iter_ptr && dpre_planes, "rdo_conv2d_fwd_p3_tail: null argument");
+    RDO_REQUIRE(rdo_conv2d_fwd_p3_tail_supported(d), "rdo_conv2d_fwd_p3_tail: shape / epilogue not supported (rdo_conv2d_fwd_p3_tail_supported)");
+    RDO_REQUIRE(B == d->B && act >= 0 && act <= 2, "rdo_conv2d_fwd_p3_tail: B must be the conv's batch, act in 0..2");
+    X6PArgs t{};
+    t.tail_tgt = tgt_cache; t.tail_idx = idx_table; t.tail_iter = iter_ptr; t.tail_resp = reinterpret_cast<const u16*>(residual_planes);
+    t.tail_loss = loss_out; t.tail_per_image = (long)d->Ho * d->Wo * d->Cout; t.tail_B = B; t.tail_act = act; t.tail_coef = coef;
+    t.tail_inv_npix = (float)(1.0 / ((double)B * d->Ho * d->Wo));
+    return conv2d_fwd_p3_impl(d, x_planes, wplanes, bias, nullptr, nullptr, nullptr, nullptr, nullptr, dpre_planes, nullptr, 0, stream, &t);
 }

@@ -98,6 +98,8 @@ _SIGS = {
     "rdo_conv2d_fwd_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, C.c_int64, P]),
     "rdo_conv2d_wgrad_p3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_wgrad_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, C.c_int, P]),
+    "rdo_conv2d_fwd_p3_tail_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rdo_conv2d_fwd_p3_tail": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_int32, P, P, P]),
     "rdo_conv2d_fwd_ksplit": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int64]),
     "rdo_conv2d_fwd_partials": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, C.c_int64, P]),
     "rdo_loss_act_bwd_splitk": (C.c_int, [P, C.c_int32, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P]),

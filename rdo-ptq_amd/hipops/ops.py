@@ -548,6 +548,20 @@ def conv2d_fwd_p3(xp, x_shape, w_shape, wplanes, bias=None, stride=1, pad=0, epi
     return out
 
 
+def conv_p3_tail_supported(x_shape, w_shape, stride, pad):
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    return bool(L.lib().rdo_conv2d_fwd_p3_tail_supported(C.byref(d)))
+
+
+def conv2d_fwd_p3_tail(xp, x_shape, w_shape, wplanes, bias, stride, pad, residual_planes, tgt_cache, idx_table, iter_ptr, coef, act, dpre_planes,
+                       loss_log):
+    """Plane-input conv + unit tail in one launch: dpre_planes <- dL/dpre of out = act(conv + bias) + residual against tgt_cache[idx]."""
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    L.check(L.lib().rdo_conv2d_fwd_p3_tail(C.byref(d), _ptr(xp), _ptr(wplanes), _ptr(bias), _ptr(residual_planes), _ptr(tgt_cache),
+                                           _ptr(idx_table), _ptr(iter_ptr), x_shape[0], coef, int(act), _ptr(dpre_planes), _ptr(loss_log),
+                                           _stream()), "rdo_conv2d_fwd_p3_tail")
+
+
 def gather_qdrop_p3(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, out_planes, batch_offset=0, iter_publish=None):
     per_image = cache_q[0].numel()
     L.check(L.lib().rdo_gather_qdrop_p3(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,

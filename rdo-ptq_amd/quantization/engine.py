@@ -160,6 +160,7 @@ class UnitEngine:
         self.P = {}                            # name -> planes of the P3 form of an activation buffer
         self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
         self.fuse_splitk = os.environ.get("RDO_FUSE_SPLITK", "1") != "0"   # split-K conv + unit tail: the conv's second pass inside the tail
+        self.fuse_p3_tail = os.environ.get("RDO_P3_TAIL", "1") != "0"       # last conv of a P3 ResidualBlock unit + its tail in one launch
         self.fold_iter = os.environ.get("RDO_FOLD_ITER", "1") != "0"     # iteration-counter hand-over instead of an increment launch
         # opt-in R + lambda*D task loss (loss_mode='rd'): dict(model=QuantModel, unit=module, cali=calibration images NCHW on the GPU,
         # lmbda=float).  The unit output of every iteration is pushed through the REST of the wrapped model on torch's tape
@@ -467,10 +468,16 @@ class UnitEngine:
         ops.gather_qdrop_p3(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None if lean else x, xp,
                             self.batch_offset, iter_publish=self._it_pub())
         self._conv_p3(c1, xp, x.shape, out=None if lean else t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
-        self._conv_p3(c2, h1p, t["h1"].shape, out=t["pre2"])
         self._task_is_rec = True
-        ops.loss_act_bwd(t["pre2"], None if lean else x, self.co, self.idx, self.it, 2.0, ops.ACT_LRELU, self.loss_log, dpre_planes=dp2p,
-                         residual_planes=xp if lean else None)
+        if self.fuse_p3_tail and ops.conv_p3_tail_supported(tuple(t["h1"].shape), c2.w4, c2.stride, c2.pad):
+            # conv2 + tail in one launch: the pre-activation never reaches memory
+            c2.enable_planes(True, False)
+            ops.conv2d_fwd_p3_tail(h1p, tuple(t["h1"].shape), c2.w4, c2.wq_planes, c2.bias, c2.stride, c2.pad, xp, self.co, self.idx, self.it,
+                                   2.0, ops.ACT_LRELU, dp2p, self.loss_log)
+        else:
+            self._conv_p3(c2, h1p, t["h1"].shape, out=t["pre2"])
+            ops.loss_act_bwd(t["pre2"], None if lean else x, self.co, self.idx, self.it, 2.0, ops.ACT_LRELU, self.loss_log, dpre_planes=dp2p,
+                             residual_planes=xp if lean else None)
         self._wgrad_p3(c2, h1p, t["h1"].shape, dp2p)
         self._dgrad_p3(c2, dp2p, t["h1"].shape, out_planes=dh1p, epilogue=L.EPI_LRELU_BWD, aux=None if lean else t["h1"],
                        aux_planes=h1p if lean else None)

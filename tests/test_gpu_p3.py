@@ -299,3 +299,32 @@ def test_splitk_conv_with_tail_doing_its_second_pass(ops, L, B, H, Cin, Cout, K,
     for u, v in zip(got, ref):
         assert torch.equal(u, v)
     torch.testing.assert_close(log.sum(), log_ref.sum(), rtol=1e-5, atol=0)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,with_res", [(4, 128, 128, N, N, 1, True), (2, 128, 256, 64, N, 0, True), (4, 128, 128, N, N, 2, False)])
+def test_conv_p3_with_tail_in_its_epilogue(ops, L, B, H, W, Cin, Cout, act, with_res):
+    """rdo_conv2d_fwd_p3_tail (halo kernel whose epilogue forms the loss and dL/dpre) against rdo_conv2d_fwd_p3 + rdo_loss_act_bwd:
+    identical dL/dpre planes, the same loss up to summation order."""
+    g = torch.Generator(device="cuda").manual_seed(H + W + Cin + act)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    n = B + 2
+    res = torch.randn(B, H, W, Cout, device="cuda", generator=g) if with_res else None
+    tgt = torch.randn(n, H, W, Cout, device="cuda", generator=g)
+    idx = torch.tensor([[(3 * i + 1) % n for i in range(B)], [(5 * i) % n for i in range(B)]], dtype=torch.int32, device="cuda")
+    it = torch.ones(1, dtype=torch.int32, device="cuda")
+    wpl, xp = ops.split_bf16x3(w), ops.split_p3(x)
+    resp = ops.split_p3(res) if with_res else None
+    assert ops.conv_p3_tail_supported(tuple(x.shape), tuple(w.shape), 1, 1)
+    pre = torch.empty(B, H, W, Cout, device="cuda")
+    ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, b, 1, 1, out=pre)
+    ref = ops.p3_empty(pre.shape, "cuda")
+    log_ref = torch.zeros(2, 32, device="cuda")
+    ops.loss_act_bwd(pre, None, tgt, idx, it, 2.0, act, log_ref, dpre_planes=ref, residual_planes=resp)
+    got = ops.p3_empty(pre.shape, "cuda")
+    log = torch.zeros(2, 32, device="cuda")
+    ops.conv2d_fwd_p3_tail(xp, tuple(x.shape), tuple(w.shape), wpl, b, 1, 1, resp, tgt, idx, it, 2.0, act, got, log)
+    assert torch.equal(got, ref)
+    assert float(log[0].abs().sum()) == 0.0
+    torch.testing.assert_close(log[1].sum(), log_ref[1].sum(), rtol=1e-5, atol=0)
