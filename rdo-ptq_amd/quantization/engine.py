@@ -383,7 +383,7 @@ class UnitEngine:
         if ops.uses_bf16x6(tuple(x.shape), op.w4, op.stride, op.pad):
             op.enable_planes(True, False)
         ks, _ = ops.conv_fwd_ksplit(tuple(x.shape), op.w4, op.stride, op.pad, op.wq_planes is not None, self.dev)
-        if self.fuse_splitk and ks >= 2 and not op.is_gdn:
+        if self.fuse_splitk and ks >= 2 and not op.is_gdn and pre.shape[-1] % 4 == 0:      # quads of channels (bias, partial sums)
             ws, ks = ops.conv2d_fwd_partials(x, op.wq4(), op.stride, op.pad, wplanes=op.wq_planes)
             self._task_is_rec = True
             ops.loss_act_bwd_splitk(ws, ks, op.bias, tuple(pre.shape), res, self.co, self.idx, self.it, 2.0, act, self.loss_log,
