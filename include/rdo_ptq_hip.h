@@ -64,7 +64,8 @@ const char* rdo_last_error(void);
  *   "thin_mfma"    1 (default): weight gradients with <= 4 input channels and a patch of 5..32 values run the gather-operand MFMA kernel
  *   "tail_grid"    most workgroups of a fused loss kernel (each ends with one atomic add into the 32-slot loss log)
  *   "x6p_ablate"   diagnostic bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
- *                  8 no fragment reads, 16 rotate the K order per tile (results stay right)
+ *                  8 no fragment reads, 16 rotate the K order per tile (results stay right), 32 the weight-gradient kernel's DMA issue
+ *                  schedule, 64 activation tile fetched for tap (0,0) only (per-tap kernel; the traffic of the halo kernel)
  * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */
 int rdo_set_tuning(const char* key, int32_t value);
 int rdo_get_tuning(const char* key);
