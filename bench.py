@@ -81,10 +81,10 @@ def parse():
 
 
 # ----------------------------------------------------------------------------- product side
-def seeded_model(N, seed, device):
+def seeded_model(N, seed, device, arch="anchor"):
     import lic
     torch.manual_seed(seed)
-    model = lic.Cheng2020Anchor(N=N)
+    model = lic.Cheng2020Attention(N=N) if arch == "attn" else lic.Cheng2020Anchor(N=N)
     g = torch.Generator().manual_seed(seed)
     with torch.no_grad():                       # non-degenerate GDN parameters (default init has gamma = 0.1*I)
         for name, p in model.named_parameters():

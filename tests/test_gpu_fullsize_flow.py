@@ -84,6 +84,104 @@ def test_small_layer_units_n192_match_oracle(cheng192, name):
     assert float((a_gpu - a_ref).abs().max()) <= 2.5e-2          # 12 steps of lr 1e-3, both directions
 
 
+@pytest.fixture(scope="module")
+def attn192():
+    """Oracle Cheng2020-attn N=192 (seeded, variance-preserving weights) with the (input, output) of the convs inside two attention
+    blocks -- g_a.3 at 64^2 and g_a.8 at 16^2 for 256 x 256 crops -- captured by forward hooks."""
+    from oracle import lic_oracle as L
+    torch.manual_seed(SEED)
+    model = L.Cheng2020Attention(N=192).eval()
+    g = torch.Generator().manual_seed(SEED)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() == 4 and "entropy_bottleneck" not in name:
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 2 * (3.0 / p[0].numel()) ** 0.5)
+    names = ["g_a.3.conv_a.0.conv.0", "g_a.3.conv_a.0.conv.2", "g_a.3.conv_a.0.conv.4", "g_a.3.conv_b.3", "g_a.8.conv_a.1.conv.2",
+             "g_a.8.conv_b.2.conv.0"]
+    mods = dict(model.named_modules())
+    io, hooks = {}, []
+    for n in names:
+        hooks.append(mods[n].register_forward_hook(lambda m, i, o, n=n: io.__setitem__(n, (i[0].detach().clone(), o.detach().clone()))))
+    with torch.no_grad():
+        model(torch.rand(4, 3, 256, 256, generator=g))
+    for h in hooks:
+        h.remove()
+    return mods, io
+
+
+# (unit, fused activation): QuantModel surgery fuses the ReLU that follows a conv inside the attention blocks' residual units
+ATTN_UNITS = [("g_a.3.conv_a.0.conv.0", "relu"), ("g_a.3.conv_a.0.conv.2", "relu"), ("g_a.3.conv_a.0.conv.4", None), ("g_a.3.conv_b.3", None),
+              ("g_a.8.conv_a.1.conv.2", "relu"), ("g_a.8.conv_b.2.conv.0", "relu")]
+
+
+@pytest.mark.parametrize("name,act", ATTN_UNITS)
+def test_attention_block_layer_units_n192_w10_match_oracle(attn192, name, act):
+    """BASELINE config 3 at full width, unit level: the 1x1 (192 -> 96 -> 192) and 3x3 (96 -> 96) convs of the attention blocks as
+    ReLU-fused layer units with 10-bit channel-wise weights, HIP engine against oracle.reconstruct_unit on the same caches, index
+    stream and QDrop masks."""
+    from helpers import AQ
+    from oracle import rdo_oracle as O
+    from oracle.rdo_oracle import QOp
+    from quantization.engine import UnitEngine
+    from quantization.quant_layer import QuantModule
+    mods, io = attn192
+    mod = mods[name]
+    inp, out = io[name]
+    if act == "relu":
+        out = torch.relu(out)
+    g = torch.Generator().manual_seed(11)
+    inp_q = inp + 1e-3 * torch.randn(inp.shape, generator=g)
+    iters, B = 10, 4
+    idx = np.stack([np.random.RandomState(i).permutation(4) for i in range(iters)])
+    wq10 = {"n_bits": 10, "channel_wise": True, "scale_method": "max"}
+    op = QOp("conv", mod.weight.detach().clone(), mod.bias.detach().clone(), stride=mod.stride[0], padding=mod.padding[0], act=act, n_bits=10)
+    op.init_scale()
+    log = O.reconstruct_unit("layer", {"layer": op}, inp_q, inp, out, iters=iters, batch_size=B, idx_stream=idx,
+                             mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(SEED, i, shape, 0.5), input_prob=0.5,
+                             weight=0.01, b_range=(20, 2), warmup=0.2)
+    conv = nn.Conv2d(mod.in_channels, mod.out_channels, mod.kernel_size, stride=mod.stride, padding=mod.padding)
+    with torch.no_grad():
+        conv.weight.copy_(mod.weight)
+        conv.bias.copy_(mod.bias)
+    qm = QuantModule(conv.cuda(), wq10, AQ).cuda()
+    if act == "relu":
+        qm.activation_function = nn.ReLU(inplace=True)
+    nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
+    eng = UnitEngine("layer", {"layer": qm}, nh(inp_q), nh(inp), nh(out), batch_size=B, iters=iters, weight=0.01, b_range=(20, 2),
+                     warmup=0.2, input_prob=0.5, seed=SEED, idx_table=torch.from_numpy(idx))
+    e = eng.ops["layer"]
+    np.testing.assert_array_equal(e.delta.cpu().numpy(), op.delta.reshape(-1).numpy())
+    np.testing.assert_array_equal(e.zp.cpu().numpy(), op.zp.reshape(-1).numpy())
+    eng.run()
+    torch.cuda.synchronize()
+    total, rt, rd = eng.logs()
+    np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=3e-4, atol=1e-7)
+    np.testing.assert_allclose(rd.numpy(), np.array(log.round), rtol=2e-4, atol=1e-7)
+    a_gpu, a_ref = eng.alpha_of("layer").cpu(), op.alpha
+    far = ((a_gpu - a_ref).abs() > 2e-3).float().mean()
+    flips = ((a_gpu >= 0) != (a_ref >= 0)).float().mean()
+    assert float(far) < 2e-3 and float(flips) < 5e-3, (float(far), float(flips))
+    assert float((a_gpu - a_ref).abs().max()) <= 2.5e-2
+
+
+def test_full_size_main2_flow_cheng2020_attn_w10a10():
+    """BASELINE config 3 at full width through the public API: Cheng2020-attn N=192, 10-bit channel-wise weights (first / last layer
+    8-bit), all 108 calibration units (13 block units, 4 x 19 attention-block convs, the stem conv and the hyper / entropy-parameter
+    layers), then W10 and W10A10 (dynamic 10-bit activation grids) evaluation."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import e2e_fullsize
+    r = e2e_fullsize.run_flow(images=8, iters=12, batch=4, eval_hw=(256, 384), n_eval=1, log=lambda *_: None, arch="attn", w_bits=10, a_bits=10)
+    assert r["n_units"] == 13 + 4 * 19 + 1 + 5 + 5 + 3 + 1 + 1
+    for k in ("psnr_fp", "bpp_fp", "psnr_w8_rtn", "bpp_w8_rtn", "psnr_w8", "bpp_w8", "psnr_w8a8", "bpp_w8a8", "fid_rtn", "fid_w8", "fid_w8a8"):
+        assert np.isfinite(r[k]), k
+    assert r["fid_w8"] >= r["fid_rtn"] - 1.0          # 10-bit weights: nearest rounding is already close; calibration must not hurt
+    assert r["fid_w8a8"] >= 25.0
+    from quantization import QuantModule
+    mods = [m for m in r["qnn"].modules() if isinstance(m, QuantModule) and m.org_weight is not None]
+    assert all(m.trained for m in mods)
+    assert mods[0].weight_quantizer.n_bits == 8 and mods[1].weight_quantizer.n_bits == 10
+
+
 def test_full_size_main2_flow():
     """recon_model over the 29 units of Cheng2020-anchor N=192 through layer_/block_reconstruction, then W8 and W8A8 evaluation:
     unit count, finite metrics, and the calibrated model no further from the FP32 model than nearest rounding was (with a few

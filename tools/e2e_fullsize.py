@@ -24,11 +24,12 @@ from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstr
 from test_datasets import evaluate_images  # noqa: E402
 
 
-def run_flow(images=64, iters=200, batch=4, eval_hw=(512, 768), n_eval=2, log=print):
-    """The whole flow once; returns the numbers it prints (dict)."""
+def run_flow(images=64, iters=200, batch=4, eval_hw=(512, 768), n_eval=2, log=print, arch="anchor", w_bits=8, a_bits=8):
+    """The whole flow once; returns the numbers it prints (dict).  arch: "anchor" | "attn" (Cheng2020-attn, BASELINE config 3);
+    w_bits / a_bits: weight grid and (dynamic) activation grid (10 / 10 = the W10A10 configuration)."""
     import math
     dev = torch.device("cuda:0")
-    model = bench.seeded_model(192, 1005, dev)
+    model = bench.seeded_model(192, 1005, dev, arch=arch)
     g = torch.Generator().manual_seed(1005)
     with torch.no_grad():      # variance-preserving conv weights, so that the signal (and quantisation error) reaches the output
         for name, p_ in model.named_parameters():
@@ -49,8 +50,10 @@ def run_flow(images=64, iters=200, batch=4, eval_hw=(512, 768), n_eval=2, log=pr
         mse = float(((out - ref_out) ** 2).mean())
         peak = float(ref_out.max() - ref_out.min())
         return 10 * math.log10(peak * peak / max(mse, 1e-30))
-    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
-    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    wq = {"n_bits": w_bits, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": a_bits, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    if a_bits != 8:
+        aq["dynamic_bits"] = a_bits           # the reference's dynamic activation quantiser hard-wires 8 bits (quantizer.py:81)
     qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True).to(dev).eval()
     qnn.set_first_last_layer_to_8bit()
     qnn.disable_network_output_quantization()
