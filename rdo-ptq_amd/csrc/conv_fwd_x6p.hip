@@ -625,10 +625,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_x6h_kernel(X6PArgs a) {
         }
         bf16x8 fa[3][TM], fb[3][TN];
         auto rd_a = [&](int p) {
+            if (a.ablate & 8) return;                        // diagnostic: no fragment reads (stale registers multiplied)
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const bf16x8*>(sta + p * APL + fa_off[i]);
         };
         auto rd_b = [&](int p) {
+            if (a.ablate & 8) return;
 #pragma unroll
             for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const bf16x8*>(stb + fb_off[p][j]);
         };

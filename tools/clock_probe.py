@@ -58,8 +58,8 @@ th.start()
 time.sleep(1.5)
 phases = [("idle", None)]
 conv = lambda: ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, None, 1, 1, out=out)
-for name, abl in (("conv x6p", 0), ("conv x6p, no DMA (MFMA only)", 3), ("conv x6p, no MFMA (DMA only)", 4),
-                  ("conv x6p, activation DMA for 1 tap in 9 (halo-reuse traffic)", 64), ("same, no MFMA", 68)):
+for name, abl in (("plane-input conv (halo kernel)", 0), ("same, no fragment reads", 8), ("same, no DMA (MFMAs + fragment reads)", 3),
+                  ("same, no DMA, no fragment reads (MFMAs only)", 11), ("same, no MFMA (DMA + fragment reads)", 4)):
     ops.set_tuning("x6p_ablate", abl)
     phases.append((name, run_for(conv, 4.0)))
 ops.set_tuning("x6p_ablate", 0)
