@@ -275,3 +275,41 @@ def test_rbws_stem_unit_on_p3_tensors_matches_fp32_activations():
         _seed_gdn(blk.gdn, torch.Generator().manual_seed(6))
         return blk.cuda()
     _p3_vs_fp32(mk, QuantRBWS, (4, 256, 256, 3), 33, "rbws")
+
+
+@pytest.mark.parametrize("kind", ["rb", "rbu"])
+def test_full_size_p3_units_data_parallel_sequence_equals_fused_step(kind):
+    """The 128^2 units on P3 tensors (halo / row kernels, conv2 + tail in one launch) through the data-parallel op sequence on one rank
+    (gradient -> bucket -> apply, all-reduce split in two around the last weight gradient) against the fused single-launch step:
+    bit-identical alphas."""
+    import lic
+    from quantization.engine import UnitEngine
+    from quantization.quant_block import QuantRB, QuantRBU
+    from quantization.recon import _unit_modules
+    WQ = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    res = []
+    for split in (False, True):
+        torch.manual_seed(41)
+        if kind == "rb":
+            blk, qcls, shape = lic.ResidualBlock(N, N).cuda(), QuantRB, (4, 128, 128, N)
+        else:
+            blk = lic.ResidualBlockUpsample(N, N, 2)
+            _seed_gdn(blk.igdn, torch.Generator().manual_seed(5))
+            blk, qcls, shape = blk.cuda(), QuantRBU, (4, 64, 64, N)
+        unit = qcls(blk, WQ, dict(WQ, leaf_param=False)).cuda()
+        k, mods = _unit_modules(unit)
+        g = torch.Generator(device="cuda").manual_seed(41)
+        cq = torch.randn(*shape, device="cuda", generator=g)
+        cf = cq + 0.01 * torch.randn(cq.shape, device="cuda", generator=g)
+        with torch.no_grad():
+            co = blk(cf.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        idx = torch.stack([torch.arange(4, dtype=torch.int32)] * 4)
+        eng = UnitEngine(k, mods, cq, cf, co, batch_size=4, iters=4, warmup=0.0, input_prob=0.5, seed=3, idx_table=idx, force_dp_split=split)
+        assert eng.p3_plan == kind and (eng.plan_a2 is not None) == split
+        eng.run()
+        torch.cuda.synchronize()
+        res.append(({n: eng.alpha_of(n).clone() for n in eng.ops}, eng.logs()[0]))
+        del eng
+    for n in res[0][0]:
+        assert torch.equal(res[0][0][n], res[1][0][n]), n
+    torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=0)
