@@ -236,10 +236,13 @@ class UnitEngine:
         # wgrad starts, so its all-reduce overlaps the wgrad (two recorded plans, `_split_point`).
         # Only where that last wgrad is long enough to hide a collective behind (>= 64^2 activations at batch 4): on the small units
         # the second all-reduce and the second gradient launch cost more than the overlap saves.
+        late = {"rb": "conv1", "rbws": "conv1", "rbu": "subpel_conv"}.get(k)
         overlap = self.dp_overlap
-        if overlap is None:                    # default: by size; True / False force it (tests, A/B)
-            overlap = self.B * self.cq.shape[1] * self.cq.shape[2] >= self.DP_OVERLAP_MIN_PIXELS
-        self._late = {"rb": "conv1", "rbws": "conv1", "rbu": "subpel_conv"}.get(k) if (self.split and overlap) else None
+        if overlap is None and late is not None:   # default: by the size of that last weight gradient; True / False force it (tests, A/B)
+            lo = o[late]
+            ho, wo = self._out_hw(lo, self.cq.shape[1], self.cq.shape[2])
+            overlap = 2.0 * self.B * ho * wo * lo.numel() >= self.DP_OVERLAP_MIN_FLOP
+        self._late = late if (self.split and overlap) else None
         if self.split:
             total = sum(op.numel() for op in o.values())
             self.bucket = torch.zeros(total, device=self.dev)
@@ -397,7 +400,10 @@ class UnitEngine:
         ops.loss_gdn_bwd(x, norm, res, self.co, self.idx, self.it, 2.0, inverse, self.loss_log, gout, t=tbuf)
 
     # ------------------------------------------------------------------------------------------------------------------ P3 path
-    DP_OVERLAP_MIN_PIXELS = 16384   # mini-batch input pixels from which the bucket all-reduce is split in two (see _build_ops)
+    # FLOPs of the unit's last weight gradient from which the bucket all-reduce is split in two (see _build_ops): 43.5 GFLOP (~200 us)
+    # for the 3x3 convs of the 128^2 units hides a collective; 10.9 GFLOP (~45 us, the 64^2 units) is about the latency of the second
+    # all-reduce the split adds, and the 3 -> 192 stem of g_a.0 is 26 us
+    DP_OVERLAP_MIN_FLOP = 30e9
     P3_MIN_OUT = 65536 * 192        # plane-input forward kernel pays off from 4 x 128^2 x 192 output elements (profiles/r02a)
     p3_lean = os.environ.get("RDO_P3_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fp32
 

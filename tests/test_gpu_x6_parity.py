@@ -305,7 +305,7 @@ def test_full_size_p3_units_data_parallel_sequence_equals_fused_step(kind):
             co = blk(cf.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
         idx = torch.stack([torch.arange(4, dtype=torch.int32)] * 4)
         eng = UnitEngine(k, mods, cq, cf, co, batch_size=4, iters=4, warmup=0.0, input_prob=0.5, seed=3, idx_table=idx, force_dp_split=split)
-        assert eng.p3_plan == kind and (eng.plan_a2 is not None) == split
+        assert eng.p3_plan == kind and (eng.plan_a2 is not None) == split          # 43.5-GFLOP last wgrad: the all-reduce is split
         eng.run()
         torch.cuda.synchronize()
         res.append(({n: eng.alpha_of(n).clone() for n in eng.ops}, eng.logs()[0]))
