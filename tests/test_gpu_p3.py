@@ -62,7 +62,8 @@ def test_conv_p3_equals_fp32_input_x6(ops, L, H, Cin, Cout, K, s, p):
     assert torch.equal(opl2, opl)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, N, N), (4, 64, 64, N, 4 * N), (2, 128, 256, 64, N), (1, 256, 256, 32, 2 * N)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, N, N), (4, 64, 64, N, 4 * N), (2, 128, 256, 64, N), (1, 256, 256, 32, 2 * N),
+                                            (1, 256, 256, 32, 48), (8, 96, 96, 48, 208), (2, 176, 208, 32, 16), (3, 112, 240, 80, 320)])
 def test_conv_p3_halo_kernel_equals_per_tap_kernel(ops, L, B, H, W, Cin, Cout):
     """3x3 / stride 1 / pad 1 on 16 x 16 patches with the halo tile resident in LDS: same K order and accumulation as the per-tap
     kernel, so the same bits -- borders (zero halo), all epilogue outputs and the P3 planes included."""
@@ -247,7 +248,8 @@ def test_wgrad_p3_matches_fp64_and_fp32_input_kernel(ops, B, H, Cin, Cout, K, s,
     assert e < 1e-5 and e < 2.0 * e6 + 2e-7, (e, e6)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, 192, 192), (4, 64, 64, 192, 768), (1, 32, 64, 64, 48), (2, 32, 32, 128, 320), (4, 64, 64, 192, 192)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, 192, 192), (4, 64, 64, 192, 768), (1, 32, 64, 64, 48), (2, 32, 32, 128, 320), (4, 64, 64, 192, 192),
+                                            (2, 96, 64, 256, 160), (1, 48, 160, 192, 208), (3, 16, 32, 320, 192)])
 def test_wgrad_p3_row_kernel_equals_per_tap_kernel(ops, B, H, W, Cin, Cout):
     """3x3 / stride 1 / pad 1: three kw taps on one 34-pixel input row image.  Same pixel chunks, same order of sums per output element
     as the per-tap kernel, so the same slabs bit for bit (row ends and image top / bottom included)."""
