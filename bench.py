@@ -11,9 +11,11 @@ wall time.  Caches (cached_inps / cached_outs of every unit) are res
 
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--images n] [--no-cpu-baseline]
 
-N > 1 is launched by `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...`: one rank per GPU, each
-with its own calibration shard and mini-batch (weak scaling), the per-unit alpha-gradient bucket all-reduced over RCCL
-every iteration.  Rank 0 prints ONE JSON line.
+N > 1: one rank per GPU, each with its own calibration shard and mini-batch (weak scaling), the per-unit alpha-gradient bucket
+all-reduced over RCCL every iteration; rank 0 prints ONE JSON line.  Either launched by `python -m torch.distributed.run
+--nproc-per-node N bench.py --gpus N ...` (RANK / LOCAL_RANK / WORLD_SIZE in the environment), or plainly as `python bench.py --gpus N`:
+this process then starts the N ranks itself as fresh child processes BEFORE it touches a GPU (it never initialises HIP) and exits
+with their status.  `--gpus N` with fewer than N visible GPUs, or a WORLD_SIZE that contradicts it, is refused.
 """
 import argparse
 import json
@@ -249,7 +251,9 @@ def gpu_leg(a, rank, world, device):
         if not torch.isfinite(tot[:a.warmup + a.steps + sustain]).all():
             raise RuntimeError(f"non-finite loss in unit {name}")
     p3_units = [n for n, e in engines if getattr(e, "p3_plan", None)]
-    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, p3_units=p3_units)
+    # which data-parallel loop ran: "graph" (iteration + collectives replayed from one graph) or "host" (plan / all-reduce / plan)
+    dp_paths = sorted({e.dp_path for _, e in engines if e.dp_path is not None})
+    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, p3_units=p3_units, dp_paths=dp_paths)
 
 
 # ----------------------------------------------------------------------------- CPU baseline (oracle = "port")
@@ -290,13 +294,58 @@ def cpu_leg(a):
                        f"iteration(s) after 1 warm-up, B={n}, {a.crop}x{a.crop}, {cores} threads")
 
 
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (one per GPU, rendezvous on 127.0.0.1)
+    and return the worst exit status.  The parent only COUNTS devices -- it must not initialise HIP (a process that has may neither
+    fork GPU children safely nor be replaced by exec)."""
+    import socket
+    import subprocess
+    have = torch.cuda.device_count()
+    if have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible on this box -- refusing to run a smaller world "
+                         f"under the label n_gpus={a.gpus}")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(a.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for p in list(procs):
+                c = p.poll()
+                if c is None:
+                    continue
+                procs.remove(p)
+                if c != 0:
+                    rc = rc or c
+                    for q in procs:          # one rank failed: the others would wait in a collective for ever
+                        q.terminate()
+            time.sleep(0.2)
+    finally:
+        for p in procs:
+            p.kill()
+    return rc
+
+
 def main():
     a = parse()
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        raise SystemExit(f"bench.py: --gpus {a.gpus} contradicts WORLD_SIZE={world} (launch with --nproc-per-node {a.gpus})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
+    if torch.cuda.device_count() <= local:
+        raise SystemExit(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} GPU(s) are visible")
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1 or os.environ.get("RDO_BENCH_FORCE_DP"):
@@ -354,6 +403,9 @@ def main():
             out["sustained_value"] = round(n_units * a.batch * world / (sum(w) / len(w) * 1e-3), 2)
             out["sustained_window_ms"] = {"min": round(min(w), 3), "max": round(max(w), 3), "windows_of": 100}
         out["config"]["p3_units"] = res["p3_units"]
+        if res["dp_paths"]:
+            out["dp_graph"] = res["dp_paths"] == ["graph"]
+            out["config"]["dp_loop"] = "+".join(res["dp_paths"])
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_leg(a)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)

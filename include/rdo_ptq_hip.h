@@ -63,7 +63,8 @@ const char* rdo_last_error(void);
  *   "wgrad_p3_row" 1 (default): 3x3 stride-1 plane-input weight gradients share one input row image between the three kw taps
  *   "thin_mfma"    1 (default): weight gradients with <= 4 input channels and a patch of 5..32 values run the gather-operand MFMA kernel
  *   "tail_grid"    most workgroups of a fused loss kernel (each ends with one atomic add into the 32-slot loss log)
- *   "x6p_ablate"   diagnostic bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
+ *   "x6p_ablate"   ONLY in a diagnostic build (`make DIAG=1`, -DRDO_DIAG; the shipped library rejects a non-zero value and ignores
+ *                  RDO_X6P_ABLATE): bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
  *                  8 no fragment reads, 16 rotate the K order per tile (results stay right), 32 the weight-gradient kernel's DMA issue
  *                  schedule, 64 activation tile fetched for tap (0,0) only (per-tap kernel; the traffic of the halo kernel)
  * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */

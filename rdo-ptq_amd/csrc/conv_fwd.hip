@@ -269,12 +269,12 @@ template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC>
 int launch(const FwdArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
     auto kern = conv_fwd_kernel<BM, BN, WAVES_M, WAVES_N, VEC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static rdo::PerDevice attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd, %zu B LDS) failed", lds);
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid((unsigned)rdo::ceil_div(a.M, BM), (unsigned)rdo::ceil_div(a.Cout, BN), (unsigned)a.ksplit);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, a);
@@ -443,7 +443,7 @@ extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const floa
     RDO_REQUIRE(epi == RDO_EPI_NONE || epi == RDO_EPI_LRELU || epi == RDO_EPI_RELU || aux != nullptr,
                 "rdo_conv2d_fwd: epilogue %d needs aux", epi);
     RDO_REQUIRE(!d->add_residual || residual != nullptr, "rdo_conv2d_fwd: add_residual without residual");
-    if (rdo_conv_is_thincout(d, true) && pre == nullptr && true) {
+    if (rdo_conv_is_thincout(d, true) && pre == nullptr) {
         const rdo_conv_desc dd = *d;
         const double M = (double)d->B * d->Ho * d->Wo;
         return rdo::dispatch([=](hipStream_t s) { return rdo_launch_thincout_fwd(&dd, x, w, bias, out, s); }, stream, "conv_thincout_fwd",

@@ -914,12 +914,12 @@ static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* w
                                a.ksplit <= (a.Cin / 16) * a.KH;
             if (ver_env >= 6 && v6_ok && 3 * a.wplane < (1L << 31)) {
                 constexpr size_t lds6 = (size_t)2 * 3 * 144 * 32 + (size_t)2 * 3 * 192 * 32;
-                static bool attr6 = false;
-                if (!attr6) {
+                static rdo::PerDevice attr6;
+                if (!attr6.done()) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v6_kernel),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds6) != hipSuccess)
                         return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6 v6) failed");
-                    attr6 = true;
+                    attr6.mark();
                 }
                 dim3 grid6((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
                 hipLaunchKernelGGL(conv_fwd_x6v6_kernel, grid6, dim3(256), lds6, s, a);
@@ -935,11 +935,11 @@ static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* w
                              : ver == 4 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<true>)
                                         : reinterpret_cast<const void*>(conv_fwd_x6v5_kernel);
             const size_t lds = (size_t)2 * 3 * (128 + 192) * 32 + (ver == 5 ? 0 : 4096);
-            static bool attr[3] = {false, false, false};
-            if (!attr[ver - 3]) {
+            static rdo::PerDevice attr[3];
+            if (!attr[ver - 3].done()) {
                 if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6 v%d) failed", ver);
-                attr[ver - 3] = true;
+                attr[ver - 3].mark();
             }
             dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
             if (ver == 3) hipLaunchKernelGGL(conv_fwd_x6v3_kernel<false>, grid, dim3(256), lds, s, a);

@@ -65,7 +65,13 @@ struct X6PArgs {
     long tail_per_image;
     int tail_B, tail_act;
     float tail_coef, tail_inv_npix;
-    int ablate;           // diagnostic bit mask (tuning key "x6p_ablate"): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads
+    // diagnostic bit mask (tuning key "x6p_ablate"): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads -- results are WRONG when
+    // non-zero, so the masks exist only in a `make DIAG=1` build (-DRDO_DIAG); the shipped library folds every test away
+#ifdef RDO_DIAG
+    int ablate;
+#else
+    static constexpr int ablate = 0;
+#endif
 };
 
 __device__ __forceinline__ unsigned cvt_pk(float a, float b) {
@@ -870,7 +876,9 @@ static int conv2d_fwd_p3_impl(const rdo_conv_desc* d, const void* x_planes, cons
     a.oplane = (long)a.M * a.Cout;
     a.epilogue = d->epilogue; a.add_residual = d->add_residual;
     a.xcd_mode = rdo::tuning(rdo::T_XCD);
+#ifdef RDO_DIAG
     a.ablate = rdo::tuning(rdo::T_X6P_ABLATE);
+#endif
     if (tail) {
         a.tail_tgt = tail->tail_tgt; a.tail_idx = tail->tail_idx; a.tail_iter = tail->tail_iter; a.tail_resp = tail->tail_resp;
         a.tail_loss = tail->tail_loss; a.tail_per_image = tail->tail_per_image; a.tail_B = tail->tail_B; a.tail_act = tail->tail_act;
@@ -892,12 +900,12 @@ static int conv2d_fwd_p3_impl(const rdo_conv_desc* d, const void* x_planes, cons
         return rdo::dispatch(
             [a](hipStream_t s) {
                 constexpr size_t lds = (size_t)2 * 32768 + 3 * 3 * 192 * 32;
-                static bool attr = false;
-                if (!attr) {
+                static rdo::PerDevice attr;
+                if (!attr.done()) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds) != hipSuccess)
                         return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6h) failed");
-                    attr = true;
+                    attr.mark();
                 }
                 dim3 grid((unsigned)(a.M / 256), (unsigned)rdo::ceil_div(a.Cout, 192), 1);
                 hipLaunchKernelGGL(conv_fwd_x6h_kernel, grid, dim3(512), lds, s, a);
@@ -907,12 +915,12 @@ static int conv2d_fwd_p3_impl(const rdo_conv_desc* d, const void* x_planes, cons
     return rdo::dispatch(
         [a](hipStream_t s) {
             constexpr size_t lds = (size_t)3 * 3 * (256 + 192) * 32;
-            static bool attr = false;
-            if (!attr) {
+            static rdo::PerDevice attr;
+            if (!attr.done()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) != hipSuccess)
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6p) failed");
-                attr = true;
+                attr.mark();
             }
             dim3 grid((unsigned)rdo::ceil_div(a.M, 256), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
             hipLaunchKernelGGL(conv_fwd_x6p_kernel, grid, dim3(512), lds, s, a);

@@ -265,12 +265,12 @@ int rdo_launch_thincout_wgrad(const rdo_conv_desc* d, const float* x, const floa
     auto go = [&](auto ntc) {
         constexpr int NT = decltype(ntc)::value;
         constexpr size_t lds = (size_t)(HPIX * 16 * NT + 256 * 16) * sizeof(float);
-        static bool attr = false;
-        if (!attr) {
+        static rdo::PerDevice attr;
+        if (!attr.done()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(thincout_wgrad_kernel<NT>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)lds) != hipSuccess)
                 return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(thincout_wgrad) failed");
-            attr = true;
+            attr.mark();
         }
         hipLaunchKernelGGL(thincout_wgrad_kernel<NT>, dim3(patches, (unsigned)(slices / NT)), dim3(256), lds, s, a);
         return rdo::check_launch("conv_thincout_wgrad");

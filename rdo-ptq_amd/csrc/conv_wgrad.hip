@@ -194,12 +194,12 @@ template <int TCO, int TCI, bool VEC>
 int launch(WgArgs a, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * PK * (TCO + TCI) * sizeof(float);
     auto kern = conv_wgrad_kernel<TCO, TCI, VEC>;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static rdo::PerDevice attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
             hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad, %zu B LDS) failed", lds);
-        attr_set = true;
+        attr_set.mark();
     }
     a.tiles_co = (int)rdo::ceil_div(a.Cout, TCO);
     a.tiles_ci = (int)rdo::ceil_div(a.Cin, TCI);

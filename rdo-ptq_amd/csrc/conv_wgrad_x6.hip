@@ -602,27 +602,27 @@ int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy,
     a.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * sizeof(float));     // < 2^32: checked by uses_bf16x6
     a.dy_bytes = (unsigned)((size_t)a.M * d->Cout * sizeof(float));
     constexpr size_t lds = (size_t)2 * 3 * (T + T) / 4 * (4 * 64 + 16);
-    static bool attr_set = false;
-    if (!attr_set) {
+    static rdo::PerDevice attr_set;
+    if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<T, T, false>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<T, T, true>),
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6, %zu B LDS) failed", lds);
-        attr_set = true;
+        attr_set.mark();
     }
     dim3 grid((unsigned)nsplit, (unsigned)(a.KH * a.KW * a.tiles_co * a.tiles_ci));
     // default: the eight-wave kernel (two waves per SIMD); RDO_WGX6_W8=0 selects the four-wave one (A/B: tools/wgrad_x6_check.py)
     const int w8 = rdo::tuning(rdo::T_WGRAD_X6_W8);
     if (w8) {
-        static bool attr8 = false;
-        if (!attr8) {
+        static rdo::PerDevice attr8;
+        if (!attr8.done()) {
             if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6w8_kernel<false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
                 hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6w8_kernel<true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                 return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6w8, %zu B LDS) failed", lds);
-            attr8 = true;
+            attr8.mark();
         }
         if (a.square_input) hipLaunchKernelGGL((conv_wgrad_x6w8_kernel<true>), grid, dim3(512), lds, s, a);
         else hipLaunchKernelGGL((conv_wgrad_x6w8_kernel<false>), grid, dim3(512), lds, s, a);

@@ -475,12 +475,12 @@ extern "C" int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes,
         return rdo::dispatch(
             [b](hipStream_t s) {
                 constexpr size_t lds = (size_t)2 * STAGE3B;
-                static bool attr = false;
-                if (!attr) {
+                static rdo::PerDevice attr;
+                if (!attr.done()) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6p3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds) != hipSuccess)
                         return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6p3) failed");
-                    attr = true;
+                    attr.mark();
                 }
                 dim3 grid((unsigned)b.nsplit, (unsigned)(3 * b.tiles_co * b.tiles_ci));
                 hipLaunchKernelGGL(conv_wgrad_x6p3_kernel, grid, dim3(512), lds, s, b);
@@ -491,12 +491,12 @@ extern "C" int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes,
     return rdo::dispatch(
         [a](hipStream_t s) {
             constexpr size_t lds = (size_t)2 * STAGEB;
-            static bool attr = false;
-            if (!attr) {
+            static rdo::PerDevice attr;
+            if (!attr.done()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) != hipSuccess)
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6p) failed");
-                attr = true;
+                attr.mark();
             }
             dim3 grid((unsigned)a.nsplit, (unsigned)(a.KH * a.KW * a.tiles_co * a.tiles_ci));
             hipLaunchKernelGGL(conv_wgrad_x6p_kernel, grid, dim3(512), lds, s, a);

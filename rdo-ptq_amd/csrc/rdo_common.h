@@ -2,7 +2,9 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <functional>
 #include <string>
@@ -49,6 +51,19 @@ inline int check_launch(const char* what) {
     } while (0)
 
 constexpr int kWave = 64;
+
+// "Has this once-per-device set-up been done on the CURRENT device?" -- hipFuncSetAttribute (the > 64 KiB dynamic-LDS limit of the big
+// tiles) applies to the device that is current when it is called, so a process that drives a second GPU must repeat it there.
+struct PerDevice {
+    std::atomic<uint64_t> bits{0};
+    static uint64_t bit() {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        return 1ull << (d & 63);
+    }
+    bool done() const { return (bits.load(std::memory_order_acquire) & bit()) != 0; }
+    void mark() { bits.fetch_or(bit(), std::memory_order_release); }
+};
 
 // Process-wide kernel-variant switches (rdo_set_tuning / rdo_get_tuning; initialised once from the RDO_* environment variables
 // of the same meaning so that command-line A/B runs keep working).

@@ -61,6 +61,7 @@ struct rdo_plan {
     hipGraphExec_t exec = nullptr;
     hipGraph_t graph_k = nullptr;        // kUnroll iterations in one graph: no inter-graph gap between them
     hipGraphExec_t exec_k = nullptr;
+    int unroll_k = 0;                    // iterations inside exec_k (the tuning value at ITS capture, not the current one)
     hipStream_t cap_stream = nullptr;
     bool recording = false;
 };
@@ -73,6 +74,9 @@ const char* rdo_last_error(void) { return rdo::g_err.c_str(); }
 int rdo_set_tuning(const char* key, int32_t value) {
     const int i = rdo::tune_index(key);
     RDO_REQUIRE(i >= 0, "rdo_set_tuning: unknown key '%s'", key ? key : "(null)");
+#ifndef RDO_DIAG
+    RDO_REQUIRE(i != rdo::T_X6P_ABLATE || value == 0, "rdo_set_tuning: 'x6p_ablate' exists only in a diagnostic build (make DIAG=1)");
+#endif
     rdo::tune_init();
     rdo::g_tune[i].store(value);
     return RDO_OK;
@@ -162,8 +166,16 @@ int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream) {
     const int unroll = rdo::tuning(rdo::T_GRAPH_UNROLL);
     int i = 0;
     if (unroll > 1 && n_iters >= 2 * unroll) {
-        if (!p->exec_k)
+        if (p->exec_k && p->unroll_k != unroll) {      // "graph_unroll" changed since the capture: the old graph holds the old count
+            (void)hipGraphExecDestroy(p->exec_k);
+            (void)hipGraphDestroy(p->graph_k);
+            p->exec_k = nullptr;
+            p->graph_k = nullptr;
+        }
+        if (!p->exec_k) {
             if (int rc = capture(unroll, &p->graph_k, &p->exec_k)) return rc;
+            p->unroll_k = unroll;
+        }
         for (; i + unroll <= n_iters; i += unroll) {
             hipError_t e = hipGraphLaunch(p->exec_k, s);
             if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));

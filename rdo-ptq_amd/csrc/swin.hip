@@ -345,12 +345,12 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
     const int no_pv = out == nullptr;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            static bool attr = false;
-            if (!attr) {
+            static rdo::PerDevice attr;
+            if (!attr.done()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_fwd_mfma_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_fwd_mfma) failed");
-                attr = true;
+                attr.mark();
             }
             hipLaunchKernelGGL(win_attn_fwd_mfma_kernel, dim3(windows, g.heads), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv);
             return rdo::check_launch("window_attention_fwd");
@@ -381,12 +381,12 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
     const size_t lds = ((size_t)4 * 64 * g.hs + (size_t)2 * 64 * SS) * sizeof(float);
     return rdo::dispatch(
         [=](hipStream_t s) {
-            static bool attr = false;
-            if (!attr) {
+            static rdo::PerDevice attr;
+            if (!attr.done()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_bwd_mfma_kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess)
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_bwd_mfma) failed");
-                attr = true;
+                attr.mark();
             }
             hipLaunchKernelGGL(win_attn_bwd_mfma_kernel, dim3(windows, g.heads), dim3(256), lds, s, qkv, bias, dout, g, dqkv);
             return rdo::check_launch("window_attention_bwd");

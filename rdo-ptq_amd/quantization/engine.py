@@ -199,6 +199,8 @@ class UnitEngine:
             self.world = torch.distributed.get_world_size(group)
         # the data-parallel op sequence (grad -> all-reduce -> apply) can be forced on a single rank to test it
         self.split = self.world > 1 or force_dp_split
+        self.dp_path = None                    # "graph" | "host" once a data-parallel run has started (_run_dp)
+        self._dp_graph, self._dp_graph_failed = None, False
         self._build_ops()
         self._alloc()
         self._record()
@@ -801,31 +803,50 @@ class UnitEngine:
         self.plan_b.run(1, graph=graph)
 
     def _run_dp(self, n):
-        """n data-parallel iterations.  With the RCCL backend the whole iteration -- the recorded kernels of the three plans AND the
-        collectives -- is captured once into ONE graph (torch.cuda.graph: RCCL collectives are capturable) and replayed n times
-        with no host work in between; otherwise (gloo in the tests, capture refused) the host drives plan / collective / plan."""
+        """n data-parallel iterations.  Default: the HOST drives plan A -> all-reduce -> plan B (each plan a graph replay, the
+        collective enqueued by torch.distributed in between).  Opt-in `RDO_DP_GRAPH=1` with the RCCL backend: the whole iteration --
+        the recorded kernels of the three plans AND the collectives -- is captured once into ONE graph (torch.cuda.graph) and
+        replayed with no host work in between.  The ranks AGREE on the outcome of the capture (MIN all-reduce of an "ok" flag) before
+        anyone replays: a rank never replays a graph with collectives while another runs the host loop.  `self.dp_path` says
+        which loop ran ("graph" / "host"); every rank logs it."""
+        import logging
         dist = torch.distributed
         comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
-        want = self.use_graph and os.environ.get("RDO_DP_GRAPH", "1") != "0" and (not comm or dist.get_backend(self.group) == "nccl")
-        if want and getattr(self, "_dp_graph", None) is None and not getattr(self, "_dp_graph_failed", False) and n > 1:
+        want = self.use_graph and os.environ.get("RDO_DP_GRAPH", "0") == "1" and (not comm or dist.get_backend(self.group) == "nccl")
+        if want and self._dp_graph is None and not self._dp_graph_failed and n > 1:
+            ok = 1
             try:
                 self._dp_iteration(False)                           # one eager iteration: warms RCCL and every lazy initialisation
                 n -= 1
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._dp_iteration(False)
-                self._dp_graph = g
             except Exception as e:      # pragma: no cover - depends on the RCCL / driver stack
-                import logging
-                logging.warning("data-parallel iteration could not be captured into a graph (%s): host-driven loop", e)
-                self._dp_graph_failed = True
+                logging.warning("rank %s: data-parallel iteration could not be captured into a graph (%s)", self._rank(), e)
+                ok = 0
                 torch.cuda.synchronize()
-        if getattr(self, "_dp_graph", None) is not None:
+            if comm:
+                flag = torch.tensor([ok], device=self.dev, dtype=torch.int32)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+                ok = int(flag.item())
+            if ok:
+                self._dp_graph = g
+            else:
+                self._dp_graph_failed = True
+        path = "graph" if self._dp_graph is not None else "host"
+        if self.dp_path != path:
+            self.dp_path = path
+            logging.getLogger("rdo_ptq.dp").info("rank %s: data-parallel loop = %s (world %d)", self._rank(), path, self.world)
+        if self._dp_graph is not None:
             for _ in range(n):
                 self._dp_graph.replay()
             return
         for _ in range(n):
             self._dp_iteration(self.use_graph)
+
+    def _rank(self):
+        dist = torch.distributed
+        return dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
 
     def _rd_tail(self, i):
         """Iteration i's task loss: the images of the mini-batch through the wrapped model with this unit's output replaced by the
