@@ -245,6 +245,7 @@ def gpu_leg(a, rank, world, device):
         for (tag, fl, by), m in zip(info, ms):
             d = per_tag.setdefault(tag, [0, 0.0, 0.0, 0.0])
             d[0] += 1; d[1] += m; d[2] += fl; d[3] += by
+    log("roofline probe done")
     # sanity: losses finite
     for name, e in engines:
         tot, _, _ = e.logs()
@@ -342,6 +343,11 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} contradicts WORLD_SIZE={world} (launch with --nproc-per-node {a.gpus})")
+    # The ONE JSON line goes to the real stdout; everything else that lands on fd 1 -- RCCL prints a version banner there when the
+    # first communicator is created -- is sent to stderr.
+    json_out = os.fdopen(os.dup(1), "w")
+    sys.stdout.flush()
+    os.dup2(2, 1)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the product path has no CPU fallback")
     if torch.cuda.device_count() <= local:
@@ -353,6 +359,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         torch.distributed.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
     res = gpu_leg(a, rank, world, device)
+    log("gpu leg done")
     n_units, dt = res["n_units"], res["dt"]
     value = n_units * a.batch * a.steps * world / dt
     if rank == 0:
@@ -409,7 +416,7 @@ def main():
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_leg(a)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)
-        print(json.dumps(out))
+        print(json.dumps(out), file=json_out, flush=True)
     if torch.distributed.is_initialized():
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
