@@ -271,37 +271,41 @@ def _maybe_aq(x, aq):
     return act_quant(x) if aq else x
 
 
-def rbws_forward(ops: Dict[str, QOp], x, aq=False):
-    """QuantRBWS.forward, quant_block.py:235-248.  `aq` == (use_act_quant and trained)."""
+def rbws_forward(ops: Dict[str, QOp], x, aq=False, inner_aq=False):
+    """QuantRBWS.forward, quant_block.py:235-248.  `aq` == (block.use_act_quant and block.trained).  `inner_aq`: the inner
+    QuantModules built WITHOUT disable_act_quant (conv2, gdn, skip: quant_block.py:227-232) quantise their own outputs once they
+    are trained and activation quantisation is on (quant_layer.py:130-133) -- the state of a calibrated block in the W8A8 evaluation."""
     out = F.leaky_relu(ops["conv1"](x), 0.01)
     out = _maybe_aq(out, aq)
-    out = ops["gdn"](ops["conv2"](out))
-    identity = ops["skip"](x) if "skip" in ops else x
+    out = _maybe_aq(ops["conv2"](out), inner_aq)
+    out = _maybe_aq(ops["gdn"](out), inner_aq)
+    identity = _maybe_aq(ops["skip"](x), inner_aq) if "skip" in ops else x
     out = out + identity
     return _maybe_aq(out, aq)
 
 
-def rbu_forward(ops: Dict[str, QOp], x, aq=False, r=2):
-    """QuantRBU.forward, quant_block.py:270-282."""
+def rbu_forward(ops: Dict[str, QOp], x, aq=False, r=2, inner_aq=False):
+    """QuantRBU.forward, quant_block.py:270-282; inner quantisers: conv, igdn, upsample[0] (quant_block.py:257-268)."""
     out = F.leaky_relu(F.pixel_shuffle(ops["subpel_conv"](x), r), 0.01)
     out = _maybe_aq(out, aq)
-    out = ops["igdn"](ops["conv"](out))
-    out = out + F.pixel_shuffle(ops["upsample"](x), r)
+    out = _maybe_aq(ops["conv"](out), inner_aq)
+    out = _maybe_aq(ops["igdn"](out), inner_aq)
+    out = out + F.pixel_shuffle(_maybe_aq(ops["upsample"](x), inner_aq), r)
     return _maybe_aq(out, aq)
 
 
-def rb_forward(ops: Dict[str, QOp], x, aq=False):
-    """QuantRB.forward, quant_block.py:298-313."""
+def rb_forward(ops: Dict[str, QOp], x, aq=False, inner_aq=False):
+    """QuantRB.forward, quant_block.py:298-313; inner quantiser: skip only (conv1 / conv2 are built with disable_act_quant)."""
     out = F.leaky_relu(ops["conv1"](x), 0.01)
     out = _maybe_aq(out, aq)
     out = F.leaky_relu(ops["conv2"](out), 0.01)
     out = _maybe_aq(out, aq)
-    identity = ops["skip"](x) if "skip" in ops else x
+    identity = _maybe_aq(ops["skip"](x), inner_aq) if "skip" in ops else x
     out = out + identity
     return _maybe_aq(out, aq)
 
 
-def layer_forward(ops: Dict[str, QOp], x, aq=False):
+def layer_forward(ops: Dict[str, QOp], x, aq=False, inner_aq=False):
     """A bare QuantModule unit (quant_layer.py:107-134)."""
     return _maybe_aq(ops["layer"](x), aq)
 

@@ -12,5 +12,7 @@ def layer_reconstruction(model: QuantModel, layer: QuantModule, layer_name: str,
                          asym: bool = False, include_act_func: bool = True, b_range: tuple = (20, 2), warmup: float = 0.0,
                          input_prob: float = 1.0, act_quant: bool = False, lr: float = 4e-5, p: float = 2.0, config=None,
                          args=None):
-    reconstruct(model, layer, layer_name, cali_data, batch_size, iters, weight, opt_mode, asym, include_act_func, b_range,
-                warmup, input_prob, act_quant, lr, p, config, args, is_block=False)
+    """Returns the calibration engine of the unit (the reference returns None): its per-iteration loss logs and the mini-batch index
+    table stay readable after the run; None for a PixelShuffle pseudo-unit."""
+    return reconstruct(model, layer, layer_name, cali_data, batch_size, iters, weight, opt_mode, asym, include_act_func, b_range,
+                       warmup, input_prob, act_quant, lr, p, config, args, is_block=False)

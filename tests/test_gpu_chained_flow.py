@@ -1,0 +1,146 @@
+"""Chained end-to-end parity: the WHOLE calibration flow of main2.py:214-282 -- every unit
+calibrated on caches produced by the already calibrated prefix, then the W8 and the W8A8 evaluation -- on the product (HIP, public
+`layer_reconstruction` / `block_reconstruction` API) against `oracle.flow_oracle.FlowOracle` running the same flow on the CPU from
+the same weights, calibration images, mini-batch index streams (recorded from the product's engines: inputs, not expected values)
+and counter-RNG QDrop masks.
+
+Compared: the hard rounding decision of EVERY weight of every layer, W8 and W8A8 bpp / PSNR on held-out images.  Tolerances (fp32
+summation order only; a decision flips where an alpha ends within Adam noise of zero; in W8A8 a value within float noise of a boundary
+of one of the cascaded dynamic 8-bit grids moves one level): per layer at least 99.5 % identical decisions (layers of fewer than 400
+weights: at most 2 differing), over the model >= 99.8 %; W8 bpp 1e-3 relative, PSNR 0.02 dB; W8A8 bpp 2e-3 relative, PSNR 0.05 dB."""
+import math
+import types
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+pytestmark = pytest.mark.gpu
+SEED = 1005
+
+
+def _seed_model(ref, g):
+    from oracle import lic_oracle as L
+    with torch.no_grad():
+        # variance-preserving conv weights: with torch's default init the activations shrink layer by layer and the latents of a
+        # random model collapse to zero (bpp and x_hat would not respond to the weights at all)
+        for name, p in ref.named_parameters():
+            if p.dim() == 4 and "entropy_bottleneck" not in name:
+                p.copy_((torch.rand(p.shape, generator=g) - 0.5) * 2 * (3.0 / p[0].numel()) ** 0.5)
+        for m in ref.modules():
+            if isinstance(m, L.GDN):
+                c = m.gamma.shape[0]
+                m.gamma.copy_(torch.sqrt(0.1 * torch.eye(c) + 0.01 * torch.rand(c, c, generator=g) + 2.0 ** -36))
+                m.beta.copy_(torch.sqrt(0.5 + torch.rand(c, generator=g) + 2.0 ** -36))
+        cp = getattr(ref, "context_prediction", None)
+        if cp is not None:
+            cp.weight.data *= cp.mask          # a trained checkpoint carries the masked weight; the wrapper never re-applies the mask
+
+
+def _sync_state(dst, src):
+    sd = src.state_dict()
+    with torch.no_grad():
+        for k, v in dst.state_dict().items():
+            v.copy_(sd[k])
+
+
+def _product_flow(qnn, cali, B, iters, last_layer):
+    """main2.py:214-263 on the drop-in package; -> {dotted unit name: engine} in recon_model order."""
+    from quantization import BaseQuantBlock, QuantModule, block_reconstruction, layer_reconstruction
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020")
+    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
+                  warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    engines = {}
+
+    def recon_model(m: nn.Module, prefix):
+        for name, module in m.named_children():
+            if isinstance(module, QuantModule):
+                eng = layer_reconstruction(qnn, module, name, **kwargs)
+                if eng is not None:
+                    engines[prefix + name] = eng
+            elif isinstance(module, BaseQuantBlock):
+                engines[prefix + name] = block_reconstruction(qnn, module, name, **kwargs)
+            else:
+                recon_model(module, prefix + name + ".")
+    qnn.set_quant_state(weight_quant=True, act_quant=False)
+    last_layer(qnn).set_quant_state(True, False)
+    recon_model(qnn.model, "")
+    return engines
+
+
+def _compare(engines, flow, qnn, last_layer, test_imgs):
+    from test_datasets import evaluate_images
+    assert list(engines) == [u.name for u in flow.units]
+    same = total = 0
+    for u in flow.units:
+        eng = engines[u.name]
+        for n, op in u.ops.items():
+            a_gpu, a_ref = eng.alpha_of(n).cpu(), op.alpha
+            assert a_gpu.shape == a_ref.shape, (u.name, n)
+            diff = int(((a_gpu >= 0) != (a_ref >= 0)).sum())
+            numel = a_ref.numel()
+            assert diff <= max(2, 0.005 * numel), (u.name, n, diff, numel)
+            same += numel - diff
+            total += numel
+    assert same >= 0.998 * total, (same, total)
+    res = {}
+    for act, (tol_bpp, tol_psnr) in ((False, (1e-3, 0.02)), (True, (2e-3, 0.05))):
+        qnn.set_quant_state(weight_quant=True, act_quant=act)
+        last_layer(qnn).set_quant_state(True, False)
+        psnr, bpp = evaluate_images(qnn.eval(), test_imgs, p=64)
+        psnr_o, bpp_o = flow.evaluate(test_imgs, p=64, act_quant=act)
+        assert math.isfinite(psnr) and bpp > 0
+        assert abs(bpp - bpp_o) <= tol_bpp * bpp_o, (act, bpp, bpp_o)
+        assert abs(psnr - psnr_o) <= tol_psnr, (act, psnr, psnr_o)
+        res[act] = (psnr, bpp, psnr_o, bpp_o)
+    return same / total, res
+
+
+def _run(arch, N, iters):
+    import lic
+    from oracle import lic_oracle as L
+    from oracle.flow_oracle import FlowOracle
+    from quantization import QuantModel
+    torch.manual_seed(SEED)
+    g = torch.Generator().manual_seed(SEED)
+    if arch == "cheng":
+        ref, prod = L.Cheng2020Anchor(N=N).eval(), lic.Cheng2020Anchor(N=N).eval()
+        last_layer = lambda q: q.model.g_s[-1][0]
+    else:
+        ref, prod = L.MeanScaleHyperprior(N=N, M=N * 3 // 2).eval(), lic.MeanScaleHyperprior(N=N, M=N * 3 // 2).eval()
+        last_layer = lambda q: q.model.g_s[-1]
+    _seed_model(ref, g)
+    _sync_state(prod, ref)
+    n_img, B = 8, 4
+    cali = torch.rand(n_img, 3, 64, 64, generator=g)
+    test_imgs = [torch.rand(1, 3, 96, 80, generator=g) for _ in range(2)]
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    qnn = QuantModel(model=prod.cuda(), weight_quant_params=wq, act_quant_params=dict(wq, leaf_param=False), is_cheng=arch == "cheng").cuda().eval()
+    qnn.set_first_last_layer_to_8bit()
+    qnn.disable_network_output_quantization()
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:B].cuda())
+    torch.manual_seed(SEED)            # main2.py seed_all: unit seeds and the randperm stream start here
+    engines = _product_flow(qnn, cali.cuda(), B, iters, last_layer)
+    flow = FlowOracle(ref)
+    idx = {name: e.idx.cpu().numpy() for name, e in engines.items()}
+    for u in flow.units:               # the two sides derive the same QDrop key for every unit
+        assert engines[u.name].seed == FlowOracle.unit_seed(SEED, u.local), u.name
+    logs = flow.recon_model(cali, idx, SEED, iters=iters, batch_size=B)
+    # first and last iteration's loss of every unit, product vs oracle: the chain has not drifted apart
+    for u in flow.units:
+        tot = engines[u.name].logs()[0].numpy()
+        np.testing.assert_allclose(tot[[0, -1]], np.array(logs[u.name].total)[[0, -1]], rtol=5e-3, atol=1e-6, err_msg=u.name)
+    return _compare(engines, flow, qnn, last_layer, test_imgs)
+
+
+def test_chained_flow_toy_cheng2020_matches_oracle_flow():
+    agree, res = _run("cheng", 16, 120)
+    print("cheng2020 toy: identical rounding decisions", agree, "W8", res[False], "W8A8", res[True])
+
+
+def test_chained_flow_toy_minnen2018_matches_oracle_flow():
+    agree, res = _run("minnen", 16, 120)
+    print("minnen2018 toy: identical rounding decisions", agree, "W8", res[False], "W8A8", res[True])

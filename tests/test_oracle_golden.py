@@ -151,20 +151,8 @@ def test_block_forward(golden_dir, tag):
 
 
 def _block_forward_w8a8(kind, ops, x):
-    import torch.nn.functional as F
-    aq = O.act_quant
     with torch.no_grad():
-        if kind == "rbws":
-            out = aq(F.leaky_relu(ops["conv1"](x), 0.01))
-            out = aq(ops["gdn"](aq(ops["conv2"](out))))
-            return aq(out + aq(ops["skip"](x)))
-        if kind == "rbu":
-            out = aq(F.leaky_relu(F.pixel_shuffle(ops["subpel_conv"](x), 2), 0.01))
-            out = aq(ops["igdn"](aq(ops["conv"](out))))
-            return aq(out + F.pixel_shuffle(aq(ops["upsample"](x)), 2))
-        out = aq(F.leaky_relu(ops["conv1"](x), 0.01))
-        out = aq(F.leaky_relu(ops["conv2"](out), 0.01))
-        return aq(out + x)
+        return O.UNIT_FORWARD[kind](ops, x, aq=True, inner_aq=True)
 
 
 # ----------------------------------------------------------------------------- the reconstruction loop
