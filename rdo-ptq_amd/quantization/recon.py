@@ -141,11 +141,20 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
                              f"{world_size} ranks (uneven shards would weight samples unequally)")
         cali_data = dp.shard(cali_data)
         batch_size = batch_size // world_size
-    t0 = time.time()
+    # args.timing (optional list): the caller wants this unit's wall split -- cache building / plan recording / loop -- which costs
+    # three device synchronisations (tools/full_schedule.py, bench.py's recon_model_wall_s)
+    timing = getattr(args, "timing", None) if args is not None else None
+
+    def _mark():
+        if timing is not None:
+            torch.cuda.synchronize()
+        return time.time()
+    t0 = _mark()
     # dynamic activation quantisation makes cached values depend on the caching batch: keep the reference's batch of 1 then
     cache_bs = 1 if act_quant else max(1, min(32, cali_data.size(0)))
     (inp_q, inp_fp), out_fp = save_inp_oup_data(model, unit, cali_data, asym, act_quant, batch_size=cache_bs, input_prob=True)
-    logging.info("Cached init time: {}".format(time.time() - t0))
+    t1 = _mark()
+    logging.info("Cached init time: {}".format(t1 - t0))
     module_list, name_list = find_unquantized_module(model, unit_name, [], [])
     logging.info(name_list)
     # Lu2022 naming (g_a0 ... g_s7): the task term runs through the untrained rest of the sub-coder, and through round_ste for
@@ -186,7 +195,11 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
                          task_cache=task_cache, **common)
     else:
         eng = UnitEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), **common)
+    t2 = _mark()
     eng.run()
+    t3 = _mark()
+    if timing is not None:
+        timing.append(dict(unit=unit_name, kind=kind, cache_s=t1 - t0, record_s=t2 - t1, loop_s=t3 - t2))
     if logging.getLogger().isEnabledFor(logging.INFO) and iters >= 500:
         rec, task, rd, b = eng.logs_terms()
         for c in range(500, iters + 1, 500):
