@@ -36,7 +36,10 @@ PEAK_HBM_GBS = 8000.0
 
 def kernel_peak(tag):
     """Dense MFMA peak for the arithmetic a conv kernel family executes, in ALGORITHMIC (fp32-equivalent) TFLOP/s:
-    the *_x6_* kernels issue 6 bf16 MFMA products per fp32 product (exact 3-way operand split)."""
+    the *_x6_* kernels issue 6 bf16 MFMA products per fp32 product (exact 3-way operand split), the *_h2_* kernels 3 fp16 products
+    (two-way fp16 split of the power-of-two-scaled operands, include/rdo_ptq_hip.h)."""
+    if "_h2_" in tag:
+        return PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent MAC"
     if "_x6_" in tag:
         return PEAK_BF16_MFMA_TFLOPS / 6.0, "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent MAC"
     return PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak"
@@ -251,10 +254,10 @@ def gpu_leg(a, rank, world, device):
         tot, _, _ = e.logs()
         if not torch.isfinite(tot[:a.warmup + a.steps + sustain]).all():
             raise RuntimeError(f"non-finite loss in unit {name}")
-    p3_units = [n for n, e in engines if getattr(e, "p3_plan", None)]
+    h2_units = [n for n, e in engines if getattr(e, "h2_plan", None)]
     # which data-parallel loop ran: "graph" (iteration + collectives replayed from one graph) or "host" (plan / all-reduce / plan)
     dp_paths = sorted({e.dp_path for _, e in engines if e.dp_path is not None})
-    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, p3_units=p3_units, dp_paths=dp_paths)
+    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, h2_units=h2_units, dp_paths=dp_paths)
 
 
 # ----------------------------------------------------------------------------- CPU baseline (oracle = "port")
@@ -392,9 +395,9 @@ def main():
                                    f"{a.images} calib images {a.crop}x{a.crop} per GPU, batch {a.batch} per GPU",
                        "units": n_units, "batch_per_gpu": a.batch, "images_per_gpu": a.images,
                        "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
-                       "gemm_arithmetic": "fp32-accurate: large convs on bf16 MFMA with exact 3-way operand split (6 products, "
-                                          "fp32 accumulate; operands of the 128^2 units pre-split by their producers = P3 tensors), "
-                                          "all others on fp32 MFMA",
+                       "gemm_arithmetic": "fp32-accurate: convs of the 128^2 units on fp16 MFMA with a two-way fp16 split of the power-of-two-"
+                                          "scaled operands (3 products, fp32 accumulate; operands pre-split by their producers = H2 tensors), "
+                                          "other large convs on bf16 MFMA with the exact 3-way split (6 products), all others on fp32 MFMA",
                        "cache_build_s": round(res["t_cache"], 2)},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": round(peak, 1),
                          "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
@@ -409,7 +412,7 @@ def main():
             out["sustained_steps"] = 100 * len(w)
             out["sustained_value"] = round(n_units * a.batch * world / (sum(w) / len(w) * 1e-3), 2)
             out["sustained_window_ms"] = {"min": round(min(w), 3), "max": round(max(w), 3), "windows_of": 100}
-        out["config"]["p3_units"] = res["p3_units"]
+        out["config"]["h2_units"] = res["h2_units"]
         if res["dp_paths"]:
             out["dp_graph"] = res["dp_paths"] == ["graph"]
             out["config"]["dp_loop"] = "+".join(res["dp_paths"])

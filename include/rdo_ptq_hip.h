@@ -142,10 +142,12 @@ typedef struct rdo_sched_row {
 int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* slabs,
                       int nsplit, float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr,
                       float* alpha, float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out,
-                      void* wq_planes, void* wd_planes, void* stream);
-/* wq_planes / wd_planes (nullable): 3 x numel bf16 -- the exact three-way split of the new wq / wd in fragment order (what
- * rdo_split_bf16x3_conv would produce for wq [rows][KH][KW][Cin] and for wd [Cin][KH][KW][rows]), written in the same pass so that
- * the split-precision conv path needs no separate refresh launch. */
+                      void* wq_planes, void* wd_planes, float wq_plane_scale, float wd_plane_scale, void* stream);
+/* wq_planes / wd_planes (nullable): the planes of the new wq / wd in fragment order, written in the same pass so that the
+ * split-precision conv paths need no separate refresh launch.  plane scale == 0: 3 x numel bf16, the exact three-way split (what
+ * rdo_split_bf16x3_conv would produce for wq [rows][KH][KW][Cin] and for wd [Cin][KH][KW][rows]; operand of the fp32-input kernels
+ * rdo_conv2d_fwd / rdo_conv2d_fwd_bf16x6); plane scale > 0 (a power of two): 2 x numel fp16, the two-way split of w * scale
+ * (rdo_split_h2_conv; operand of rdo_conv2d_fwd_h2). */
 
 /* rdo_adaround_step (mode 0), rdo_adaround_grad (mode 1: slabs -> dalpha) or rdo_adaround_apply (mode 2: dalpha -> update) for all
  * (<= 8) weight tensors of a unit in one launch (plus one launch for their dgrad layouts), numel % 4 == 0.
@@ -157,6 +159,7 @@ typedef struct rdo_ada_step_item {
     float *alpha, *adam_m, *adam_v, *wq, *wd /* nullable */;
     void *wq_planes /* nullable */, *wd_planes /* nullable */;
     float* dalpha;      /* modes 1 (out) and 2 (in): this tensor's slice of the data-parallel gradient bucket */
+    float wq_plane_scale, wd_plane_scale;   /* 0: bf16 three-way planes, > 0: fp16 two-way planes of w * scale (see rdo_adaround_step) */
 } rdo_ada_step_item;
 int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
                             const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
@@ -170,7 +173,7 @@ int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha,
 int rdo_adaround_apply(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* dalpha,
                        float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr,
                        float* alpha, float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out,
-                       void* wq_planes, void* wd_planes, void* stream);
+                       void* wq_planes, void* wd_planes, float wq_plane_scale, float wd_plane_scale, void* stream);
 
 /* ---- K5: nearest fake-quant of a weight (UniformAffineQuantizer.forward)                  quantizer.py:175-177 */
 int rdo_uaq_fakequant(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, float* wq, float* wd,
@@ -279,49 +282,64 @@ int rdo_neg_log2_sum(const float* lik, int64_t n, float scale, float* out /* += 
 int rdo_sq_diff_sum(const float* a, const float* b, int64_t n, float scale, int32_t clamp01_a, float* out /* += */,
                     void* stream);                                                                    /* MSE numerator */
 
-/* ---- "P3" tensors and fused unit tails (round 2) ----------------------------------------------------------------------------
- * A P3 tensor is an fp32 NHWC activation [M pixels][C channels] (C % 16 == 0) stored as its EXACT three-way bf16 split
- * x = p0 + p1 + p2 (p0 = bf16(x), p1 = bf16(x - p0), p2 = bf16(x - p0 - p1)), in "slice-major" planes [3][C/16][M][16]:
+/* ---- "H2" tensors and fused unit tails -------------------------------------------------------------------------------------------
+ * An H2 tensor is an fp32 NHWC activation [M pixels][C channels] (C % 16 == 0) stored as the exact two-way fp16 split of its
+ * power-of-two-scaled self:  x * s = h1 + h2 (+ <= 2^-24 |x s|),  h1 = fp16(x s), h2 = fp16(x s - h1), in "slice-major" planes
+ * [2][C/16][M][16]:
  *     element (m, c) of plane p  at   p * M * C + ((c / 16) * M + m) * 16 + c % 16
- * The split-bf16 GEMM kernels read it by LDS-DMA -- a K stage is the 16 channels of one slice for a run of pixels, i.e. contiguous
- * 32-byte records -- so the conversion work is done once per element by the PRODUCER instead of once per use inside the K loops.
- * Producers: rdo_conv2d_fwd_p3 (epilogue), rdo_gather_qdrop_p3, rdo_loss_act_bwd, rdo_loss_gdn_bwd, rdo_gdn_bwd_dx_p3,
- * rdo_pixel_shuffle_p3, rdo_split_p3 (from an fp32 tensor). */
-int rdo_split_p3(const float* x, int64_t npix, int32_t C, void* planes /* 3*npix*C bf16 */, void* stream);
-/* 1: rdo_conv2d_fwd_p3 accepts this shape (a large problem of rdo_conv2d_fwd_uses_bf16x6 with Cin % 16 == 0, Cout % 16 == 0, no
- * square_input) */
-int rdo_conv2d_fwd_p3_supported(const rdo_conv_desc* d);
-int64_t rdo_conv2d_fwd_p3_workspace(const rdo_conv_desc* d);   /* floats of split-K scratch rdo_conv2d_fwd_p3 wants (0: none) */
-/* rdo_conv2d_fwd (same epilogues, same results to fp32 accumulation order) with the activation given as P3 planes and the weight as
- * fragment-ordered planes (rdo_split_bf16x3_conv / rdo_adaround_step).  Any of out / pre / out_planes may be NULL (at least one is
- * required); out_planes receives the P3 form of `out`. */
-int rdo_conv2d_fwd_p3(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias, const float* aux,
-                      const void* aux_planes /* nullable: P3 form of aux, enough for RDO_EPI_LRELU_BWD / _RELU_BWD (sign only) */,
-                      const float* residual, float* out, float* pre, void* out_planes, float* workspace, int64_t workspace_floats,
+ * The split-precision GEMM kernels read it by LDS-DMA -- a K stage is the 16 channels of one slice for a run of pixels, i.e.
+ * contiguous 32-byte records -- so the conversion work is done once per element by the PRODUCER instead of once per use inside the K
+ * loops, and a product of two such operands takes THREE fp16 MFMA products (h1 g1 + h1 g2 + h2 g1) at the accuracy of an fp32 fma
+ * chain (tools/f16_probe.hip) where the exact three-way bf16 split of rounds 1-2 took six.  `s` is chosen per tensor by the caller (a
+ * power of two; the engine takes it from a probe iteration so that max |x s| ~ 2^7; anything in [2^-2, 2^15] keeps fp32 accuracy, and
+ * fp16 denormals are honoured by the MFMA).  A value with |x s| > 65504 cannot be stored: producers raise the sticky device flag read
+ * by rdo_h2_overflow() -- the engine checks it after every run and fails loudly.
+ * Producers: rdo_conv2d_fwd_h2 (epilogue), rdo_gather_qdrop_h2, rdo_loss_act_bwd, rdo_loss_gdn_bwd, rdo_gdn_bwd_dx_h2,
+ * rdo_pixel_shuffle_h2, rdo_pixel_unshuffle2, rdo_split_h2 (from an fp32 tensor); weights: rdo_adaround_step* (plane scale > 0),
+ * rdo_split_h2_conv. */
+int rdo_h2_overflow(int reset);   /* 1: some producer met a value outside fp16 range since the last reset (synchronises); -1: error */
+int rdo_split_h2(const float* x, int64_t npix, int32_t C, float scale, void* planes /* 2*npix*C fp16 */, void* stream);
+/* conv weight [Cout][KH][KW][Cin] -> two fp16 planes of w * scale in fragment order (see rdo_split_bf16x3_conv for the order) */
+int rdo_split_h2_conv(const float* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, float scale, void* planes /* 2*numel fp16 */,
                       void* stream);
-/* rdo_conv2d_wgrad with both operands as P3 planes (x: [B*H*W][Cin], dy: [B*Ho*Wo][Cout]); same slabs, same nsplit rule
- * (rdo_conv2d_wgrad_nsplit).  Supported for the shapes of rdo_conv2d_wgrad_uses_bf16x6 with Cin % 16 == Cout % 16 == 0, no square_input. */
-/* Last conv of a unit + its tail in ONE launch: rdo_conv2d_fwd_p3 followed by rdo_loss_act_bwd (residual as planes, dL/dpre as planes)
+/* 1: rdo_conv2d_fwd_h2 accepts this shape (a large problem of rdo_conv2d_fwd_uses_bf16x6 with Cin % 16 == 0, Cout % 16 == 0, no
+ * square_input) */
+int rdo_conv2d_fwd_h2_supported(const rdo_conv_desc* d);
+int64_t rdo_conv2d_fwd_h2_workspace(const rdo_conv_desc* d);   /* floats of split-K scratch rdo_conv2d_fwd_h2 wants (0: none) */
+/* rdo_conv2d_fwd (same epilogues, same results to fp32 accumulation order) with the activation given as H2 planes (scale x_scale) and
+ * the weight as fragment-ordered fp16 planes (scale w_scale; rdo_split_h2_conv / rdo_adaround_step).  Any of out / pre / out_planes
+ * may be NULL (at least one is required); out_planes receives the H2 form of `out` with scale out_scale. */
+int rdo_conv2d_fwd_h2(const rdo_conv_desc* d, const void* x_planes, float x_scale, const void* wplanes, float w_scale, const float* bias,
+                      const float* aux,
+                      const void* aux_planes /* nullable: H2 form of aux, enough for RDO_EPI_LRELU_BWD / _RELU_BWD (sign only) */,
+                      const float* residual, float* out, float* pre, void* out_planes, float out_scale, float* workspace,
+                      int64_t workspace_floats, void* stream);
+/* Last conv of a unit + its tail in ONE launch: rdo_conv2d_fwd_h2 followed by rdo_loss_act_bwd (residual as planes, dL/dpre as planes)
  * with the pre-activation never written: the halo kernel's epilogue forms out = act(conv + bias) + residual, the loss against
- * tgt_cache[idx] and dL/dpre.  3x3 / stride 1 / pad 1 shapes of the halo kernel only (rdo_conv2d_fwd_p3_tail_supported);
- * same bits as the two-call form (tests/test_gpu_p3.py). */
-int rdo_conv2d_fwd_p3_tail_supported(const rdo_conv_desc* d);
-int rdo_conv2d_fwd_p3_tail(const rdo_conv_desc* d, const void* x_planes, const void* wplanes, const float* bias,
-                           const void* residual_planes /* nullable */, const float* tgt_cache, const int32_t* idx_table,
-                           const int32_t* iter_ptr, int32_t B, float coef, int32_t act, void* dpre_planes, float* loss_out, void* stream);
-int rdo_conv2d_wgrad_p3_supported(const rdo_conv_desc* d);
-int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes, const void* dy_planes, float* slabs, int nsplit, void* stream);
-/* rdo_gather_qdrop writing the mini-batch as P3 planes (and as fp32 when `out` != NULL) */
-int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
+ * tgt_cache[idx] and dL/dpre.  3x3 / stride 1 / pad 1 shapes of the halo kernel only (rdo_conv2d_fwd_h2_tail_supported);
+ * same bits as the two-call form (tests/test_gpu_h2.py). */
+int rdo_conv2d_fwd_h2_tail_supported(const rdo_conv_desc* d);
+int rdo_conv2d_fwd_h2_tail(const rdo_conv_desc* d, const void* x_planes, float x_scale, const void* wplanes, float w_scale,
+                           const float* bias, const void* residual_planes /* nullable */, float residual_scale, const float* tgt_cache,
+                           const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, float coef, int32_t act, void* dpre_planes,
+                           float dpre_scale, float* loss_out, void* stream);
+/* rdo_conv2d_wgrad with both operands as H2 planes (x: [B*H*W][Cin], dy: [B*Ho*Wo][Cout]); same slabs, same nsplit rule
+ * (rdo_conv2d_wgrad_nsplit).  Supported for the shapes of rdo_conv2d_wgrad_uses_bf16x6 with Cin % 16 == Cout % 16 == 0, no square_input. */
+int rdo_conv2d_wgrad_h2_supported(const rdo_conv_desc* d);
+int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes, float x_scale, const void* dy_planes, float dy_scale, float* slabs,
+                        int nsplit, void* stream);
+/* rdo_gather_qdrop writing the mini-batch as H2 planes (and as fp32 when `out` != NULL) */
+int rdo_gather_qdrop_h2(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
                         int32_t batch_offset, int64_t per_image, int32_t C, float prob, uint32_t seed, float* out, void* out_planes,
-                        int32_t* iter_publish, void* stream);
+                        float out_scale, int32_t* iter_publish, void* stream);
 /* Tail of a unit whose last op is a conv (+ activation) (+ residual):   out = act(pre) + residual ; d = out - tgt[idx]
  *   loss_out[*iter][slot] += coef * sum d^2 / npix ; grad_out = coef * 2 d / npix ; dpre = grad_out * act'(pre)
  * i.e. the activation epilogue of the conv, rdo_lp2_loss_grad and rdo_lrelu_bwd / rdo_relu_bwd in one pass (layer_opt.py:133,150,
  * 303-306).  act: 0 none, 1 LeakyReLU(0.01), 2 ReLU.  out / grad_out / dpre / dpre_planes are optional outputs. */
-int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residual_planes /* nullable: the residual as P3 planes */,
-                     const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C,
-                     float coef, int32_t act, float* out, float* grad_out, float* dpre, void* dpre_planes, float* loss_out, void* stream);
+int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residual_planes /* nullable: the residual as H2 planes */,
+                     float residual_scale, const float* tgt_cache, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
+                     int64_t per_image, int32_t C, float coef, int32_t act, float* out, float* grad_out, float* dpre, void* dpre_planes,
+                     float dpre_scale, float* loss_out, void* stream);
 /* The same tail taking the conv's output as the K-split partial sums rdo_conv2d_fwd_partials left in the workspace
  * ([ksplit][B*per_image]): pre = sum of the slabs in slab order + bias -- the conv's own second pass folded into the first load, so
  * conv epilogue, loss and activation backward are ONE pass and `pre` never exists in memory.  Bit-identical to rdo_conv2d_fwd
@@ -333,14 +351,16 @@ int rdo_loss_act_bwd_splitk(const float* partial, int32_t ksplit, const float* b
  *   t = dL/dnorm = -1/2 g x norm^-3/2 (GDN) | 1/2 g x norm^-1/2 (IGDN)      = GDN epilogue + rdo_lp2_loss_grad + rdo_gdn_bwd_t */
 int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, const float* tgt_cache, const int32_t* idx_table,
                      const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef, int32_t inverse, float* out,
-                     float* grad_out, float* t, void* t_planes, float* loss_out, void* stream);
-int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t C, int32_t inverse,
-                      float* dx, void* dx_planes, void* stream);            /* rdo_gdn_bwd_dx with fp32 and / or P3 output */
-/* F.pixel_shuffle(x, 2) on NHWC: [B,H,W,4C] -> [B,2H,2W,C] as fp32 and / or P3 planes */
-int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream);
+                     float* grad_out, float* t, void* t_planes, float t_scale, float* loss_out, void* stream);
+int rdo_gdn_bwd_dx_h2(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t C, int32_t inverse,
+                      float* dx, void* dx_planes, float dx_scale, void* stream);   /* rdo_gdn_bwd_dx with fp32 and / or H2 output */
+/* F.pixel_shuffle(x, 2) on NHWC: [B,H,W,4C] -> [B,2H,2W,C] as fp32 and / or H2 planes */
+int rdo_pixel_shuffle_h2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, float out_scale,
+                         void* stream);
 /* its gradient: [B,2H,2W,C] -> [B,H,W,4C] (= rdo_pixel_shuffle(..., inverse = 1) for r = 2, 16-byte accesses on both sides), as fp32
- * and / or P3 planes */
-int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream);
+ * and / or H2 planes */
+int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, float out_scale,
+                         void* stream);
 
 /* ---- unit executor: a recorded sequence of the calls above, replayed per calibration iteration with no host work.
  * Python records the per-iteration op list once per unit (layer_reconstruction / block_reconstruction, layer_opt.py:287-309);

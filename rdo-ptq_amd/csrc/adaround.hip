@@ -39,8 +39,11 @@ struct AdaArgs {
     float* wd;
     float* round_loss_out;
     int mode;               // 0 fused step, 1 grad only, 2 apply
-    unsigned short* wq_planes;   // optional: exact bf16 three-way split of the new wq, [3][numel] (conv_fwd_x6.hip operand)
+    unsigned short* wq_planes;   // optional: planes of the new wq in fragment order -- exact bf16 three-way split [3][numel] (conv_fwd_x6.hip
+                                 // operand) when wq_pscale == 0, else the fp16 two-way split of wq * wq_pscale [2][numel] (conv_fwd_h2.hip)
     unsigned short* wd_planes;   // optional: the same for the dgrad layout wd
+    float wq_pscale, wd_pscale;
+    int* ovf;                    // sticky fp16 overflow flag (rdo_h2_overflow)
 };
 
 // exact three-way bf16 split (hardware RNE conversions), as rdo_split_bf16x3
@@ -193,7 +196,25 @@ __device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, 
             *reinterpret_cast<vec_t*>(a.v + e0) = v4;
             *reinterpret_cast<vec_t*>(a.alpha + e0) = al4;
             *reinterpret_cast<vec_t*>(a.wq + e0) = o4;
-            if (a.wq_planes) {
+            if (a.wq_planes && a.wq_pscale > 0.f) {            // fp16 two-way split of wq * scale, fragment order
+                int bad = 0;
+                if constexpr (W == 4) {
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    u32x2 ph, pl;
+                    unsigned h, l;
+                    rdo::h2_split_pk(o4[0], o4[1], a.wq_pscale, h, l, bad); ph[0] = h; pl[0] = l;
+                    rdo::h2_split_pk(o4[2], o4[3], a.wq_pscale, h, l, bad); ph[1] = h; pl[1] = l;
+                    const long f0 = d.Cin > 0 ? rdo::frag_index(e0, d.rows, d.KH, d.KW, d.Cin) : e0;
+                    *reinterpret_cast<u32x2*>(a.wq_planes + f0) = ph;
+                    *reinterpret_cast<u32x2*>(a.wq_planes + d.numel + f0) = pl;
+                } else {
+#pragma unroll
+                    for (int k = 0; k < W; ++k)
+                        rdo::h2_split_store(o4[k], a.wq_pscale, a.wq_planes, d.numel,
+                                            d.Cin > 0 ? rdo::frag_index(e0 + k, d.rows, d.KH, d.KW, d.Cin) : e0 + k, bad);
+                }
+                rdo::h2_report(bad, a.ovf);
+            } else if (a.wq_planes) {
                 if constexpr (W == 4) {                        // one 8-byte store per plane
                     typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
                     u16x4 ph, pm, pl;
@@ -260,7 +281,8 @@ __global__ __launch_bounds__(256) void ada_step_batch_kernel(AdaBatch b) {
 }
 
 // wd[ci][KH-1-kh][KW-1-kw][co] = wq[co][kh][kw][ci]: 32x32 tiles through LDS, 128-byte segments on both sides
-__device__ __forceinline__ void wd_transpose_body(const rdo_ada_desc& d, const float* wq, float* wd, unsigned short* wd_planes, int bid) {
+__device__ __forceinline__ void wd_transpose_body(const rdo_ada_desc& d, const float* wq, float* wd, unsigned short* wd_planes, float pscale,
+                                                  int* ovf, int bid) {
     const int taps = d.KH * d.KW, cdim = d.Cin;
     const int ctiles = (cdim + 31) / 32;
     const int ct = bid % ctiles; bid /= ctiles;
@@ -283,12 +305,19 @@ __device__ __forceinline__ void wd_transpose_body(const rdo_ada_desc& d, const f
             const long o = ((long)ci * taps + tapf) * d.rows + co;
             wd[o] = tile[tx][ty + 8 * k];
             // wd is the weight [Cin][KH][KW][Cout] of the dgrad conv: its planes go in that conv's fragment order
-            if (wd_planes) split3_store(tile[tx][ty + 8 * k], wd_planes, d.numel, rdo::frag_index(o, d.Cin, d.KH, d.KW, d.rows));
+            if (wd_planes && pscale > 0.f) {
+                int bad = 0;
+                rdo::h2_split_store(tile[tx][ty + 8 * k], pscale, wd_planes, d.numel, rdo::frag_index(o, d.Cin, d.KH, d.KW, d.rows), bad);
+                rdo::h2_report(bad, ovf);
+            } else if (wd_planes) {
+                split3_store(tile[tx][ty + 8 * k], wd_planes, d.numel, rdo::frag_index(o, d.Cin, d.KH, d.KW, d.rows));
+            }
         }
     }
 }
-__global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const float* wq, float* wd, unsigned short* wd_planes) {
-    wd_transpose_body(d, wq, wd, wd_planes, blockIdx.x);
+__global__ __launch_bounds__(256) void wd_transpose_kernel(rdo_ada_desc d, const float* wq, float* wd, unsigned short* wd_planes, float pscale,
+                                                           int* ovf) {
+    wd_transpose_body(d, wq, wd, wd_planes, pscale, ovf, blockIdx.x);
 }
 // batched form; also advances the device iteration counter when asked to (the launch does not read it, and every kernel of the
 // iteration that does has completed before this one starts: stream order)
@@ -296,7 +325,7 @@ __global__ __launch_bounds__(256) void wd_transpose_batch_kernel(AdaBatch b, int
     int t = 0;
     while (t + 1 < b.n && (int)blockIdx.x >= b.blk_end[t]) ++t;
     const int beg = t ? b.blk_end[t - 1] : 0;
-    wd_transpose_body(b.a[t].d, b.a[t].wq, b.a[t].wd, b.a[t].wd_planes, (int)blockIdx.x - beg);
+    wd_transpose_body(b.a[t].d, b.a[t].wq, b.a[t].wd, b.a[t].wd_planes, b.a[t].wd_pscale, b.a[t].ovf, (int)blockIdx.x - beg);
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
 }
 
@@ -401,7 +430,8 @@ int run_step(AdaArgs a, void* stream) {
                 hipLaunchKernelGGL(ada_step_kernel<1>, dim3(grid_for(a.d.numel)), dim3(256), 0, s, a);
             if (a.mode != 1 && a.wd && a.d.Cin > 0) {
                 const long blocks = rdo::ceil_div(a.d.rows, 32) * a.d.KH * a.d.KW * rdo::ceil_div(a.d.Cin, 32);
-                hipLaunchKernelGGL(wd_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.d, (const float*)a.wq, a.wd, a.wd_planes);
+                hipLaunchKernelGGL(wd_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a.d, (const float*)a.wq, a.wd, a.wd_planes, a.wd_pscale,
+                                   a.ovf);
             }
             return rdo::check_launch("ada_step");
         },
@@ -475,7 +505,7 @@ int rdo_reduce_slabs(const float* slabs, int nsplit, int64_t numel, float* out, 
 int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* slabs, int nsplit,
                       float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr, float* alpha,
                       float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out, void* wq_planes, void* wd_planes,
-                      void* stream) {
+                      float wq_plane_scale, float wd_plane_scale, void* stream) {
     if (int rc = check_desc(d, "rdo_adaround_step")) return rc;
     RDO_REQUIRE(w && delta && zp && slabs && nsplit >= 1 && sched && iter_ptr && alpha && adam_m && adam_v && wq,
                 "rdo_adaround_step: null pointer");
@@ -485,6 +515,7 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
     a.wq = wq; a.wd = wd; a.round_loss_out = round_loss_out; a.mode = 0;
     a.wq_planes = static_cast<unsigned short*>(wq_planes);
     a.wd_planes = wd ? static_cast<unsigned short*>(wd_planes) : nullptr;
+    a.wq_pscale = wq_plane_scale; a.wd_pscale = wd_plane_scale; a.ovf = rdo::h2_overflow_flag();
     return run_step(a, stream);
 }
 
@@ -514,6 +545,7 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
         a.alpha = it.alpha; a.m = it.adam_m; a.v = it.adam_v; a.wq = it.wq; a.wd = it.wd; a.round_loss_out = round_loss_out; a.mode = mode;
         a.wq_planes = static_cast<unsigned short*>(it.wq_planes);
         a.wd_planes = it.wd ? static_cast<unsigned short*>(it.wd_planes) : nullptr;
+        a.wq_pscale = it.wq_plane_scale; a.wd_pscale = it.wd_plane_scale; a.ovf = rdo::h2_overflow_flag();
         blocks += (int)grid_for((it.nsplit >= kManySlabs && mode != 2) ? it.d.numel : it.d.numel / 4);
         b.blk_end[i] = blocks;
         bytes += 4.0 * it.d.numel * ((mode == 2 ? 1 : it.nsplit) + (mode == 1 ? 3.0 : 9.0));
@@ -550,7 +582,7 @@ int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha,
 int rdo_adaround_apply(const rdo_ada_desc* d, const float* w, const float* delta, const float* zp, const float* dalpha,
                        float grad_scale, float round_weight, const rdo_sched_row* sched, const int32_t* iter_ptr, float* alpha,
                        float* adam_m, float* adam_v, float* wq, float* wd, float* round_loss_out, void* wq_planes, void* wd_planes,
-                       void* stream) {
+                       float wq_plane_scale, float wd_plane_scale, void* stream) {
     if (int rc = check_desc(d, "rdo_adaround_apply")) return rc;
     RDO_REQUIRE(w && delta && zp && dalpha && sched && iter_ptr && alpha && adam_m && adam_v && wq,
                 "rdo_adaround_apply: null pointer");
@@ -560,6 +592,7 @@ int rdo_adaround_apply(const rdo_ada_desc* d, const float* w, const float* delta
     a.wq = wq; a.wd = wd; a.round_loss_out = round_loss_out; a.mode = 2;
     a.wq_planes = static_cast<unsigned short*>(wq_planes);
     a.wd_planes = wd ? static_cast<unsigned short*>(wd_planes) : nullptr;
+    a.wq_pscale = wq_plane_scale; a.wd_pscale = wd_plane_scale; a.ovf = rdo::h2_overflow_flag();
     return run_step(a, stream);
 }
 

@@ -1,5 +1,6 @@
-// Weight gradient of the LARGE problems on "P3" tensors (exact three-way bf16 splits in slice-major planes, rdo_ptq_hip.h):
-//   dw[co][tap][ci] = sum_m dy[m][co] * x[pix(m, tap)][ci]      on v_mfma_f32_16x16x32_bf16, six products, fp32 accumulate.
+// Weight gradient of the LARGE problems on "H2" tensors (exact two-way fp16 splits of the scaled values in slice-major planes,
+// rdo_common.h / rdo_ptq_hip.h):
+//   dw[co][tap][ci] = sum_m dy[m][co] * x[pix(m, tap)][ci]      on v_mfma_f32_16x16x32_f16, three products, fp32 accumulate.
 //
 // The fp32-input kernel (conv_wgrad_x6.hip) spends 4.6 vector instructions per MFMA in its loader: it splits both operands for
 // every tap workgroup again and transposes them in registers, because the MFMA wants 8 consecutive PIXELS per lane while NHWC memory
@@ -8,10 +9,10 @@
 // of its channel.  The K loop contains no conversion and no permutation arithmetic.
 //
 // Tile 192 (co) x 192 (ci) per tap, 512 threads: wave (w >> 1, w & 1) owns 48 x 96 as 3 x 6 MFMA tiles, 32 pixels per stage.
-// LDS image of a stage, per operand and plane: [3 channel sub-tiles of 64][32 pixels][8 chunks of 16 B] = 12 KiB, i.e. 72 KiB per
+// LDS image of a stage, per operand and plane: [3 channel sub-tiles of 64][32 pixels][8 chunks of 16 B] = 12 KiB, i.e. 48 KiB per
 // stage, double buffered.  A DMA piece is 8 pixels x 128 bytes of one sub-tile (1 KiB, lane l -> pixel l >> 3, chunk l & 7); waves
-// 0-3 fetch dY, waves 4-7 fetch X, nine pieces each per stage, all for ONE pixel row per lane.  The DMA of stage s+1 is issued at
-// the top of stage s: a full stage (216 MFMAs per SIMD) to land.
+// 0-3 fetch dY, waves 4-7 fetch X, six pieces each per stage, all for ONE pixel row per lane.  The DMA of stage s+1 is issued at
+// the top of stage s: a full stage to land.
 // Bank conflicts: chunk position c' = c ^ 2 ((pixel >> 1) & 3) (applied on the per-lane SOURCE address); a transposed read of a
 // 32-lane half covers 8 consecutive pixels x 32 bytes and then touches all 64 banks once.
 // K slots: the MFMA sums over 32 k values and both operands may use ANY common assignment of pixels to k slots.  Lane group g
@@ -23,8 +24,10 @@
 namespace {
 
 typedef float f32x4acc __attribute__((ext_vector_type(4)));
-typedef short bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 typedef short s16x4 __attribute__((ext_vector_type(4)));
+constexpr int NP = 2;                          // planes of an H2 tensor
 typedef unsigned short u16;
 
 __device__ __attribute__((aligned(64))) unsigned g_zero_page_w[16];
@@ -32,8 +35,8 @@ __device__ __attribute__((aligned(64))) unsigned g_zero_page_w[16];
 constexpr int PK = 32;
 constexpr int SUBB = 32 * 128;                 // bytes of one [32 pixels][64 channels] sub-tile image
 constexpr int PLANEB = 3 * SUBB;               // 192 channels of one plane
-constexpr int OPB = 3 * PLANEB;                // one operand (three planes)
-constexpr int STAGEB = 2 * OPB;                // 72 KiB
+constexpr int OPB = NP * PLANEB;               // one operand (two planes)
+constexpr int STAGEB = 2 * OPB;                // 48 KiB
 
 struct WgPArgs {
     const u16* xp;
@@ -43,16 +46,17 @@ struct WgPArgs {
     int B, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad;
     int M, Min, mchunk, nsplit;
     int tiles_co, tiles_ci;
+    float inv_scale;           // 1 / (s_x * s_dy): the accumulators hold s_x s_dy times the gradient sums
 };
 
-__device__ __forceinline__ bf16x8 tr_pair(const char* p) {
+__device__ __forceinline__ f16x8 tr_pair(const char* p) {
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
     const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p));
     const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 16 * 128));      // pixels + 16
-    return bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(f16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
 }
 
-__global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
+__global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(WgPArgs a) {
     constexpr int T = 192;
     constexpr int TM = 3, TN = 6;
 
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
             const u16* src = okc ? opbase + ((long)(ch >> 4) * Mop + pix) * 16 + (ch & 15) : zero;
             const long ps = okc ? pstride : 0;
 #pragma unroll
-            for (int p = 0; p < 3; ++p)
+            for (int p = 0; p < NP; ++p)
                 __builtin_amdgcn_global_load_lds((glb_void*)(src + p * ps), (lds_void*)(dst + p * PLANEB + sub * SUBB), 16, 0, 0);
         }
         advance();
@@ -171,15 +175,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
     }
     (void)l16;
 
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int PA[3] = {1, 0, 0};             // (dy2, x1) (dy1, x2) (dy1, x1): small terms first
+    constexpr int PB[3] = {0, 1, 0};
 
     if (nsteps > 0) dma_stage(0);
-    bf16x8 fa[3][TM], fb[2][3][2];
+    f16x8 fa[NP][TM], fb[2][NP][2];
     auto read_b = [&](auto setc, const char* st, int third) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[S][p][j] = tr_pair(st + p * PLANEB + fb_off[2 * third + j]);
     };
@@ -190,19 +194,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // this wave's pieces of stage s have landed
         __builtin_amdgcn_s_barrier();                                    // ... everybody's have, and nobody reads buffer buf ^ 1 any more
         // The two waves of a SIMD (w and w + 4) run this loop in lock-step: if both issued their nine DMAs here, the matrix pipe would
-        // idle for the whole issue phase.  Waves 0-3 (dY) issue now, waves 4-7 (X) after their first six MFMA slots -- while one wave
+        // idle for the whole issue phase.  Waves 0-3 (dY) issue now, waves 4-7 (X) after their first three MFMA slots -- while one wave
         // of a SIMD is held up issuing, its partner multiplies.  X still has two thirds of a stage to land.
         const bool more = s + 1 < nsteps;
         if (more && !ldx) dma_stage(buf ^ 1);
         const char* st = smem + buf * STAGEB;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
         read_b(S0{}, st, 0);
         [&]<int... SL>(std::integer_sequence<int, SL...>) {
             (([&] {
-                 constexpr int T3 = SL / 6, Q = SL % 6, SET = T3 & 1;
+                 constexpr int T3 = SL / 3, Q = SL % 3, SET = T3 & 1;
                  if constexpr (Q == 0 && T3 < 2) {
                      if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
                      else read_b(S0{}, st, T3 + 1);
@@ -212,15 +216,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
 #pragma unroll
                      for (int j = 0; j < 2; ++j)
                          acc[i][2 * T3 + j] =
-                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
-                 if constexpr (SL == 5) {
+                             __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 if constexpr (SL == 2) {
                      if (more && ldx) dma_stage(buf ^ 1);
                  }
                  __builtin_amdgcn_sched_barrier(0);
              }()),
              ...);
         }
-        (std::make_integer_sequence<int, 18>{});
+        (std::make_integer_sequence<int, 9>{});
     }
 
     const long wsize = (long)a.Cout * a.KH * a.KW * a.Cin;
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wco0 + i * 16 + 4 * lc + r;
-                if (co < a.Cout) slab[((long)co * taps + tap) * a.Cin + ci] = acc[i][j][r];
+                if (co < a.Cout) slab[((long)co * taps + tap) * a.Cin + ci] = acc[i][j][r] * a.inv_scale;
             }
     }
 }
@@ -244,15 +248,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p_kernel(WgPArgs a) {
 // Row variant for 3 x 3 / stride 1 / pad 1 with Wo a multiple of 32 and Cin a multiple of 64: a workgroup owns the THREE kw taps of one
 // kh for a block of 64 input channels -- still a 192 x 192 output tile (192 co x [3 taps x 64 ci]) -- and a stage is 32 consecutive
 // pixels of ONE output row.  The three taps read the same input row shifted by one pixel, so the X image of a stage is 34 pixels x 64
-// channels (13 KiB for the three planes) instead of 32 x 192 (36 KiB): 49 KiB of L2 -> LDS traffic per stage instead of 72, for the
-// same 108 MFMAs per wave.  (Why it matters: these kernels sit at the board power limit, tools/clock_probe.py; the forward kernel
+// channels (8.5 KiB for the two planes) instead of 32 x 192 (24 KiB): 33 KiB of L2 -> LDS traffic per stage instead of 48, for the
+// same 54 MFMAs per wave.  (Why it matters: these kernels sit at the board power limit, tools/clock_probe.py; the forward kernel
 // gained 11 % from the same kind of cut.)  A tap is a row offset when the B fragments are read; everything else -- LDS images, chunk
 // swizzle, transposed reads, k-slot assignment, MFMA order -- is the kernel above.
 constexpr int XROWS = 40;                      // 34 used; five 8-row DMA pieces per plane
 constexpr int XPLANEB = XROWS * 128;
-constexpr int STAGE3B = OPB + 3 * XPLANEB;     // 36 + 15 = 51 KiB
+constexpr int STAGE3B = OPB + NP * XPLANEB;    // 24 + 10 = 34 KiB
 
-__global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
+__global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     constexpr int T = 192;
     constexpr int TM = 3, TN = 6;
 
@@ -284,17 +288,18 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
 
     const u16* const zero = reinterpret_cast<const u16*>(g_zero_page_w);
     const int prow8 = lane >> 3, cpos = lane & 7;
-    // dY pieces of this wave: k = wave + 8 j of the 36 [plane][sub-tile][8-row group] pieces
-    int yoff[5];
+    // dY pieces of this wave: k = wave + 8 j of the 24 [plane][sub-tile][8-row group] pieces
+    constexpr int YP = NP * 12, XP = NP * 5;
+    int yoff[3];
 #pragma unroll
-    for (int j = 0; j < 5; ++j) {
+    for (int j = 0; j < 3; ++j) {
         const int k = wave + 8 * j;
         const int plane = k / 12, sub = (k % 12) >> 2, rg = k & 3;
         const int row = 8 * rg + prow8;
         const int ch = co0 + 64 * sub + 8 * (cpos ^ (2 * ((row >> 1) & 3)));
-        yoff[j] = (k < 36 && ch < a.Cout) ? (int)(plane * a.yplane) + ((ch >> 4) * a.M + row) * 16 + (ch & 15) : -1;
+        yoff[j] = (k < YP && ch < a.Cout) ? (int)(plane * a.yplane) + ((ch >> 4) * a.M + row) * 16 + (ch & 15) : -1;
     }
-    // X pieces: k = wave + 8 j of the 15 [plane][8-row group] pieces; row r of the image is input pixel wo0 - 1 + r
+    // X pieces: k = wave + 8 j of the 10 [plane][8-row group] pieces; row r of the image is input pixel wo0 - 1 + r
     int xoff[2], xrow[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -303,7 +308,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
         const int row = 8 * rg + prow8;
         const int ch = ci0 + 8 * (cpos ^ (2 * ((row >> 1) & 3)));
         xrow[j] = row;
-        xoff[j] = (k < 15 && row < PK + 2) ? (int)(plane * a.xplane) + (ch >> 4) * a.Min * 16 + (ch & 15) : -1;
+        xoff[j] = (k < XP && row < PK + 2) ? (int)(plane * a.xplane) + (ch >> 4) * a.Min * 16 + (ch & 15) : -1;
     }
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
@@ -321,16 +326,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
         const int xbase = (b * a.H + hi) * a.W + wo0 - 1;
         char* const dst = smem + buf * STAGE3B;
 #pragma unroll
-        for (int j = 0; j < 5; ++j) {
+        for (int j = 0; j < 3; ++j) {
             const int k = wave + 8 * j;
-            if (k >= 36) break;
+            if (k >= YP) break;
             const u16* src = yoff[j] >= 0 ? a.yp + yoff[j] + (long)m0 * 16 : zero;
             __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + (k / 12) * PLANEB + ((k % 12) >> 2) * SUBB + (k & 3) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int k = wave + 8 * j;
-            if (k >= 15) break;
+            if (k >= XP) break;
             const int wi = wo0 - 1 + xrow[j];
             const bool ok = xoff[j] >= 0 && rowok && (unsigned)wi < (unsigned)a.W;
             const u16* src = ok ? a.xp + xoff[j] + (long)(xbase + xrow[j]) * 16 : zero;
@@ -365,16 +370,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
         fb_off[j] = OPB + row * 128 + chunkpos * 16 + (p4 & 1) * 8;
     }
 
-    constexpr int PA[6] = {2, 1, 0, 1, 0, 0};
-    constexpr int PB[6] = {0, 1, 2, 0, 1, 0};
+    constexpr int PA[3] = {1, 0, 0};             // (dy2, x1) (dy1, x2) (dy1, x1): small terms first
+    constexpr int PB[3] = {0, 1, 0};
 
     const bool late = wave >= 4;
     if (nsteps > 0) dma_stage(0);
-    bf16x8 fa[3][TM], fb[2][3][2];
+    f16x8 fa[NP][TM], fb[2][NP][2];
     auto read_b = [&](auto setc, const char* st, int third) {
         constexpr int S = decltype(setc)::value;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int j = 0; j < 2; ++j) fb[S][p][j] = tr_pair(st + p * XPLANEB + fb_off[2 * third + j]);
     };
@@ -388,13 +393,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
         if (more && !late) dma_stage(buf ^ 1);
         const char* st = smem + buf * STAGE3B;
 #pragma unroll
-        for (int p = 0; p < 3; ++p)
+        for (int p = 0; p < NP; ++p)
 #pragma unroll
             for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
         read_b(S0{}, st, 0);
         [&]<int... SL>(std::integer_sequence<int, SL...>) {
             (([&] {
-                 constexpr int T3 = SL / 6, Q = SL % 6, SET = T3 & 1;
+                 constexpr int T3 = SL / 3, Q = SL % 3, SET = T3 & 1;
                  if constexpr (Q == 0 && T3 < 2) {
                      if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
                      else read_b(S0{}, st, T3 + 1);
@@ -404,15 +409,15 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
 #pragma unroll
                      for (int j = 0; j < 2; ++j)
                          acc[i][2 * T3 + j] =
-                             __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
-                 if constexpr (SL == 5) {
+                             __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 if constexpr (SL == 2) {
                      if (more && late) dma_stage(buf ^ 1);
                  }
                  __builtin_amdgcn_sched_barrier(0);
              }()),
              ...);
         }
-        (std::make_integer_sequence<int, 18>{});
+        (std::make_integer_sequence<int, 9>{});
     }
 
     const long wsize = (long)a.Cout * 9 * a.Cin;
@@ -427,7 +432,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wco0 + i * 16 + 4 * lc + r;
-                if (co < a.Cout) slab[((long)co * 9 + tap) * a.Cin + ci] = acc[i][j][r];
+                if (co < a.Cout) slab[((long)co * 9 + tap) * a.Cin + ci] = acc[i][j][r] * a.inv_scale;
             }
     }
 }
@@ -437,16 +442,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_x6p3_kernel(WgPArgs a) {
 extern "C" int rdo_conv2d_wgrad_uses_bf16x6(const rdo_conv_desc* d);
 extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d);
 
-extern "C" int rdo_conv2d_wgrad_p3_supported(const rdo_conv_desc* d) {
+extern "C" int rdo_conv2d_wgrad_h2_supported(const rdo_conv_desc* d) {
     if (!d || d->square_input || d->Cin % 16 != 0 || d->Cout % 16 != 0) return 0;
     if ((double)d->B * d->H * d->W * d->Cin >= 2147483648.0 || (double)d->B * d->Ho * d->Wo * d->Cout >= 2147483648.0) return 0;
     return rdo_conv2d_wgrad_uses_bf16x6(d);
 }
 
-extern "C" int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes, const void* dy_planes, float* slabs, int nsplit,
-                                   void* stream) {
-    RDO_REQUIRE(d && x_planes && dy_planes && slabs && nsplit >= 1, "rdo_conv2d_wgrad_p3: bad argument");
-    RDO_REQUIRE(rdo_conv2d_wgrad_p3_supported(d), "rdo_conv2d_wgrad_p3: shape not on the split-bf16 plane path (rdo_conv2d_wgrad_p3_supported)");
+extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes, float x_scale, const void* dy_planes, float dy_scale,
+                                   float* slabs, int nsplit, void* stream) {
+    RDO_REQUIRE(d && x_planes && dy_planes && slabs && nsplit >= 1, "rdo_conv2d_wgrad_h2: bad argument");
+    RDO_REQUIRE(rdo_conv2d_wgrad_h2_supported(d), "rdo_conv2d_wgrad_h2: shape not on the split-precision plane path (rdo_conv2d_wgrad_h2_supported)");
     constexpr int T = 192;
     WgPArgs a{};
     a.xp = reinterpret_cast<const u16*>(x_planes);
@@ -459,14 +464,16 @@ extern "C" int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes,
     a.xplane = (long)a.Min * a.Cin;
     a.yplane = (long)a.M * a.Cout;
     a.nsplit = nsplit;
+    RDO_REQUIRE(x_scale > 0.f && dy_scale > 0.f, "rdo_conv2d_wgrad_h2: scales must be positive powers of two");
+    a.inv_scale = 1.f / (x_scale * dy_scale);
     // same chunking as rdo_conv2d_wgrad: whole 32-pixel steps per chunk
     long mchunk = rdo::ceil_div(rdo::ceil_div((long)a.M, nsplit), 32) * 32;
     a.mchunk = (int)mchunk;
-    RDO_REQUIRE((long)nsplit * mchunk >= a.M, "rdo_conv2d_wgrad_p3: nsplit too small");
+    RDO_REQUIRE((long)nsplit * mchunk >= a.M, "rdo_conv2d_wgrad_h2: nsplit too small");
     a.tiles_co = (int)rdo::ceil_div(a.Cout, T);
     a.tiles_ci = (int)rdo::ceil_div(a.Cin, T);
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
-    const double bytes = 6.0 * (a.xplane + a.yplane) + 4.0 * nsplit * (double)a.Cout * a.KH * a.KW * a.Cin;
+    const double bytes = 4.0 * (a.xplane + a.yplane) + 4.0 * nsplit * (double)a.Cout * a.KH * a.KW * a.Cin;
     // 3 x 3 / stride 1 / pad 1 over whole 32-pixel row segments, Cin in blocks of 64: the three kw taps share one input image
     if (rdo::tuning(rdo::T_WGRAD_P3_ROW) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Wo % 32 == 0 && a.Cin % 64 == 0 &&
         a.Wo == a.W && a.Ho == a.H && (long)(a.M / 32) >= nsplit) {
@@ -477,30 +484,30 @@ extern "C" int rdo_conv2d_wgrad_p3(const rdo_conv_desc* d, const void* x_planes,
                 constexpr size_t lds = (size_t)2 * STAGE3B;
                 static rdo::PerDevice attr;
                 if (!attr.done()) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6p3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                             (int)lds) != hipSuccess)
-                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6p3) failed");
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_h2r) failed");
                     attr.mark();
                 }
                 dim3 grid((unsigned)b.nsplit, (unsigned)(3 * b.tiles_co * b.tiles_ci));
-                hipLaunchKernelGGL(conv_wgrad_x6p3_kernel, grid, dim3(512), lds, s, b);
-                return rdo::check_launch("conv_wgrad_x6p3");
+                hipLaunchKernelGGL(conv_wgrad_h2r_kernel, grid, dim3(512), lds, s, b);
+                return rdo::check_launch("conv_wgrad_h2r");
             },
-            stream, "conv_wgrad_x6_p3_rows", flops, bytes);
+            stream, "conv_wgrad_h2_rows", flops, bytes);
     }
     return rdo::dispatch(
         [a](hipStream_t s) {
             constexpr size_t lds = (size_t)2 * STAGEB;
             static rdo::PerDevice attr;
             if (!attr.done()) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6p_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)lds) != hipSuccess)
-                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6p) failed");
+                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_h2) failed");
                 attr.mark();
             }
             dim3 grid((unsigned)a.nsplit, (unsigned)(a.KH * a.KW * a.tiles_co * a.tiles_ci));
-            hipLaunchKernelGGL(conv_wgrad_x6p_kernel, grid, dim3(512), lds, s, a);
-            return rdo::check_launch("conv_wgrad_x6p");
+            hipLaunchKernelGGL(conv_wgrad_h2_kernel, grid, dim3(512), lds, s, a);
+            return rdo::check_launch("conv_wgrad_h2");
         },
-        stream, "conv_wgrad_x6_p3_192x192", flops, bytes);
+        stream, "conv_wgrad_h2_192x192", flops, bytes);
 }

@@ -1,13 +1,13 @@
 // Fused "unit tail" kernels: everything between the last forward conv of a reconstruction unit and the first backward GEMM, in one
-// HBM pass, plus the producers of "P3" tensors (exact three-way bf16 splits, planes [3][n]) that the split-bf16 GEMM kernels
-// read by LDS-DMA (conv_fwd_x6p.hip).
+// HBM pass, plus the producers of "H2" tensors (exact two-way fp16 splits of the power-of-two-scaled values, planes [2][n],
+// rdo_common.h) that the split-precision GEMM kernels read by LDS-DMA (conv_fwd_h2.hip).
 //
-//   rdo_gather_qdrop_p3   cached rows -> QDrop mix -> mini-batch as fp32 AND as planes                   (layer_opt.py:289-292)
+//   rdo_gather_qdrop_h2   cached rows -> QDrop mix -> mini-batch as fp32 AND as planes                   (layer_opt.py:289-292)
 //   rdo_loss_act_bwd      out = act(pre) + res ; d = out - tgt[idx] ; loss ; dL/dout ; dL/dpre (fp32 / planes)
 //                         = conv epilogue activation + lp_loss forward/backward + activation backward     (layer_opt.py:133,150,303-306)
 //   rdo_loss_gdn_bwd      out = x * norm^(-+1/2) + res ; loss ; dL/dout ; t = dL/dnorm (fp32 / planes)        (quant_layer.py:142-154)
-//   rdo_gdn_bwd_dx_p3     dx = g * norm^(-+1/2) + 2 x acc as fp32 and planes
-//   rdo_pixel_shuffle_p3  F.pixel_shuffle(r = 2) writing fp32 and planes
+//   rdo_gdn_bwd_dx_h2     dx = g * norm^(-+1/2) + 2 x acc as fp32 and planes
+//   rdo_pixel_shuffle_h2  F.pixel_shuffle(r = 2) writing fp32 and planes
 //
 // The arithmetic of each stage is the one of the separate kernels it replaces (elementwise.hip, the conv epilogues), op for op,
 // and the file is built with -ffp-contract=off like them: fused and unfused paths produce the same bits except for the order in
@@ -18,8 +18,6 @@ namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned short u16;
-typedef __bf16 bf16v2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 // loss kernels: every workgroup ends with one float atomic into one of the 32 log slots; same-address atomics serialise in L2, so the
@@ -39,11 +37,15 @@ __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
     return x;
 }
 
-__device__ __forceinline__ unsigned cvt_pk(float a, float b) {
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2{a, b}, bf16v2));
-}
-__device__ __forceinline__ float lo_f(unsigned pk) { return __builtin_bit_cast(float, pk << 16); }
-__device__ __forceinline__ float hi_f(unsigned pk) { return __builtin_bit_cast(float, pk & 0xffff0000u); }
+struct H2Out {          // planes of an H2 tensor being written: [2][M*C] fp16, values times `s`
+    unsigned short* p;
+    float s;
+    int* ovf;           // sticky overflow flag (rdo_h2_overflow)
+};
+struct H2In {           // planes being read back as fp32: (h1 + h2) * inv
+    const unsigned short* p;
+    float inv;
+};
 
 __device__ __forceinline__ void block_loss_add(float acc, float scale, float* loss_out, int it) {
     __shared__ float red[4];
@@ -80,29 +82,29 @@ inline unsigned oct_grid(long M, int C) {
     return (unsigned)(g > 8192 ? 8192 : g);
 }
 
-__device__ __forceinline__ void store_p3_oct(u16* planes, long M, int C, const Oct& o, const f32x4& a, const f32x4& b) {
+__device__ __forceinline__ void store_h2_oct(const H2Out& pl, long M, int C, const Oct& o, const f32x4& a, const f32x4& b, int& bad) {
     const long pstride = M * C;
     const long e = ((long)(o.c0 >> 4) * M + o.m) * 16 + (o.c0 & 15);
-    const unsigned h0 = cvt_pk(a[0], a[1]), h1 = cvt_pk(a[2], a[3]), h2 = cvt_pk(b[0], b[1]), h3 = cvt_pk(b[2], b[3]);
-    const float r0 = a[0] - lo_f(h0), r1 = a[1] - hi_f(h0), r2 = a[2] - lo_f(h1), r3 = a[3] - hi_f(h1);
-    const float r4 = b[0] - lo_f(h2), r5 = b[1] - hi_f(h2), r6 = b[2] - lo_f(h3), r7 = b[3] - hi_f(h3);
-    const unsigned m0 = cvt_pk(r0, r1), m1 = cvt_pk(r2, r3), m2 = cvt_pk(r4, r5), m3 = cvt_pk(r6, r7);
-    const unsigned l0 = cvt_pk(r0 - lo_f(m0), r1 - hi_f(m0)), l1 = cvt_pk(r2 - lo_f(m1), r3 - hi_f(m1));
-    const unsigned l2 = cvt_pk(r4 - lo_f(m2), r5 - hi_f(m2)), l3 = cvt_pk(r6 - lo_f(m3), r7 - hi_f(m3));
-    *reinterpret_cast<u32x4*>(planes + e) = u32x4{h0, h1, h2, h3};
-    *reinterpret_cast<u32x4*>(planes + pstride + e) = u32x4{m0, m1, m2, m3};
-    *reinterpret_cast<u32x4*>(planes + 2 * pstride + e) = u32x4{l0, l1, l2, l3};
+    u32x4 hi, lo;
+    unsigned h, l;
+    rdo::h2_split_pk(a[0], a[1], pl.s, h, l, bad); hi[0] = h; lo[0] = l;
+    rdo::h2_split_pk(a[2], a[3], pl.s, h, l, bad); hi[1] = h; lo[1] = l;
+    rdo::h2_split_pk(b[0], b[1], pl.s, h, l, bad); hi[2] = h; lo[2] = l;
+    rdo::h2_split_pk(b[2], b[3], pl.s, h, l, bad); hi[3] = h; lo[3] = l;
+    *reinterpret_cast<u32x4*>(pl.p + e) = hi;
+    *reinterpret_cast<u32x4*>(pl.p + pstride + e) = lo;
 }
-// exact fp32 values of the thread's 8 channels from planes: (p0 + p1) + p2, both additions exact
-__device__ __forceinline__ void load_p3_oct(const u16* planes, long M, int C, const Oct& o, f32x4& a, f32x4& b) {
+// fp32 values of the thread's 8 channels from planes: (h1 + h2) / s -- the sum is exact in fp32, the value is the original to 2^-24
+__device__ __forceinline__ void load_h2_oct(const H2In& pl, long M, int C, const Oct& o, f32x4& a, f32x4& b) {
     const long pstride = M * C;
     const long e = ((long)(o.c0 >> 4) * M + o.m) * 16 + (o.c0 & 15);
-    const u32x4 h = *reinterpret_cast<const u32x4*>(planes + e), m = *reinterpret_cast<const u32x4*>(planes + pstride + e),
-                l = *reinterpret_cast<const u32x4*>(planes + 2 * pstride + e);
-    a = f32x4{(lo_f(h[0]) + lo_f(m[0])) + lo_f(l[0]), (hi_f(h[0]) + hi_f(m[0])) + hi_f(l[0]),
-              (lo_f(h[1]) + lo_f(m[1])) + lo_f(l[1]), (hi_f(h[1]) + hi_f(m[1])) + hi_f(l[1])};
-    b = f32x4{(lo_f(h[2]) + lo_f(m[2])) + lo_f(l[2]), (hi_f(h[2]) + hi_f(m[2])) + hi_f(l[2]),
-              (lo_f(h[3]) + lo_f(m[3])) + lo_f(l[3]), (hi_f(h[3]) + hi_f(m[3])) + hi_f(l[3])};
+    const u32x4 h = *reinterpret_cast<const u32x4*>(pl.p + e), l = *reinterpret_cast<const u32x4*>(pl.p + pstride + e);
+    using rdo::h2_hi;
+    using rdo::h2_lo;
+    a = f32x4{(h2_lo(h[0]) + h2_lo(l[0])) * pl.inv, (h2_hi(h[0]) + h2_hi(l[0])) * pl.inv, (h2_lo(h[1]) + h2_lo(l[1])) * pl.inv,
+              (h2_hi(h[1]) + h2_hi(l[1])) * pl.inv};
+    b = f32x4{(h2_lo(h[2]) + h2_lo(l[2])) * pl.inv, (h2_hi(h[2]) + h2_hi(l[2])) * pl.inv, (h2_lo(h[3]) + h2_lo(l[3])) * pl.inv,
+              (h2_hi(h[3]) + h2_hi(l[3])) * pl.inv};
 }
 
 __device__ __forceinline__ const f32x4& ldq(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -117,10 +119,11 @@ __device__ __forceinline__ f32x4 qdrop_quad(const float* cq, const float* cfp, l
     return o;
 }
 
-__global__ __launch_bounds__(256) void gather_qdrop_p3_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
+__global__ __launch_bounds__(256) void gather_qdrop_h2_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
                                                               const int32_t* iter_ptr, int B, int batch_offset, long per_image, int C,
-                                                              unsigned long long thr, uint32_t seed, float* out, u16* planes,
+                                                              unsigned long long thr, uint32_t seed, float* out, H2Out planes,
                                                               int32_t* iter_publish) {
+    int bad = 0;
     const int it = *iter_ptr;
     if (iter_publish && blockIdx.x == 0 && threadIdx.x == 0) *iter_publish = it;
     const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
@@ -145,8 +148,9 @@ __global__ __launch_bounds__(256) void gather_qdrop_p3_kernel(const float* cq, c
             stq(out + o.m * C + o.c0, v[0]);
             stq(out + o.m * C + o.c0 + Q2, v[1]);
         }
-        store_p3_oct(planes, M, C, o, v[0], v[1]);
+        store_h2_oct(planes, M, C, o, v[0], v[1], bad);
     }
+    rdo::h2_report(bad, planes.ovf);
 }
 
 // ---- conv activation + loss + gradient + activation backward ------------------------------------------------------------------------
@@ -206,10 +210,11 @@ __global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, con
 }
 
 // with planes on either side (dL/dpre out, residual in): pixel-major
-__global__ __launch_bounds__(256) void loss_act_bwd_pix_kernel(const float* pre, const float* res, const u16* res_planes, const float* tgt,
+__global__ __launch_bounds__(256) void loss_act_bwd_pix_kernel(const float* pre, const float* res, H2In res_planes, const float* tgt,
                                                                const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
                                                                int C, float inv_npix, float coef, int act, float* out, float* gout,
-                                                               float* dpre, u16* dpre_planes, float* loss_out) {
+                                                               float* dpre, H2Out dpre_planes, float* loss_out) {
+    int bad = 0;
     const int it = *iter_ptr;
     const long ppi = per_image / C, M = (long)B * ppi;
     const int ngroups = (C + 31) / 32;
@@ -223,9 +228,9 @@ __global__ __launch_bounds__(256) void loss_act_bwd_pix_kernel(const float* pre,
         const int b = (int)(oc.m / ppi);
         const float* yrow = tgt + ((long)idx_table[(long)it * B + b] - b) * per_image;       // + e = the target of element e
         f32x4 r[2], d[2], o[2], g[2];
-        const bool has_r = res || res_planes;
+        const bool has_r = res || res_planes.p;
         const long e0 = oc.m * C + oc.c0;
-        if (res_planes && !res) load_p3_oct(res_planes, M, C, oc, r[0], r[1]);
+        if (res_planes.p && !res) load_h2_oct(res_planes, M, C, oc, r[0], r[1]);
 #pragma unroll
         for (int k = 0; k < 2; ++k) {
             const long e = e0 + k * Q2;
@@ -238,8 +243,9 @@ __global__ __launch_bounds__(256) void loss_act_bwd_pix_kernel(const float* pre,
             if (gout) stq(gout + e0 + k * Q2, g[k]);
             if (dpre) stq(dpre + e0 + k * Q2, d[k]);
         }
-        if (dpre_planes) store_p3_oct(dpre_planes, M, C, oc, d[0], d[1]);
+        if (dpre_planes.p) store_h2_oct(dpre_planes, M, C, oc, d[0], d[1], bad);
     }
+    if (dpre_planes.p) rdo::h2_report(bad, dpre_planes.ovf);
     block_loss_add(acc, inv_npix * coef, loss_out, it);
 }
 
@@ -288,7 +294,8 @@ __global__ __launch_bounds__(256) void loss_gdn_bwd_kernel(const float* x, const
 __global__ __launch_bounds__(256) void loss_gdn_bwd_pix_kernel(const float* x, const float* nrm, const float* res, const float* tgt,
                                                                const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
                                                                int C, float inv_npix, float coef, int inverse, float* out, float* gout,
-                                                               float* tbuf, u16* t_planes, float* loss_out) {
+                                                               float* tbuf, H2Out t_planes, float* loss_out) {
+    int bad = 0;
     const int it = *iter_ptr;
     const long ppi = per_image / C, M = (long)B * ppi;
     const int ngroups = (C + 31) / 32;
@@ -315,8 +322,9 @@ __global__ __launch_bounds__(256) void loss_gdn_bwd_pix_kernel(const float* x, c
             stq(gout + e0 + k * Q2, g[k]);
             if (tbuf) stq(tbuf + e0 + k * Q2, tv[k]);
         }
-        store_p3_oct(t_planes, M, C, oc, tv[0], tv[1]);
+        store_h2_oct(t_planes, M, C, oc, tv[0], tv[1], bad);
     }
+    rdo::h2_report(bad, t_planes.ovf);
     block_loss_add(acc, inv_npix * coef, loss_out, it);
 }
 
@@ -340,7 +348,8 @@ __global__ __launch_bounds__(256) void gdn_bwd_dx_kernel(const float* g, const f
 }
 
 __global__ __launch_bounds__(256) void gdn_bwd_dx_pix_kernel(const float* g, const float* x, const float* nrm, const float* acc, long M,
-                                                             int C, int inverse, float* dx, u16* dx_planes) {
+                                                             int C, int inverse, float* dx, H2Out dx_planes) {
+    int bad = 0;
     const int ngroups = (C + 31) / 32;
     const long nvb = ((M + 63) / 64) * ngroups;
     for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
@@ -355,8 +364,9 @@ __global__ __launch_bounds__(256) void gdn_bwd_dx_pix_kernel(const float* g, con
             stq(dx + e0, o[0]);
             stq(dx + e0 + Q2, o[1]);
         }
-        store_p3_oct(dx_planes, M, C, oc, o[0], o[1]);
+        store_h2_oct(dx_planes, M, C, oc, o[0], o[1], bad);
     }
+    rdo::h2_report(bad, dx_planes.ovf);
 }
 
 // ---- r = 2 pixel shuffle and its gradient --------------------------------------------------------------------------------------------------
@@ -385,7 +395,8 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_kernel(const float* x, lon
 // with planes: pixel-major over the SMALL pixels; a thread owns 8 large channels = 32 consecutive small channels (128 bytes) and
 // writes 8 channels of each of the four large pixels
 __global__ __launch_bounds__(256) void pixel_shuffle2_pix_kernel(const float* x, long npix_small, int H, int W, int C, float* out,
-                                                                 u16* planes) {
+                                                                 H2Out planes) {
+    int bad = 0;
     const int ngroups = (C + 31) / 32;
     const long nvb = ((npix_small + 63) / 64) * ngroups;
     const long ML = npix_small * 4;
@@ -407,9 +418,10 @@ __global__ __launch_bounds__(256) void pixel_shuffle2_pix_kernel(const float* x,
                 stq(out + big.m * C + oc.c0, a);
                 stq(out + big.m * C + oc.c0 + 4, b);
             }
-            store_p3_oct(planes, ML, C, big, a, b);
+            store_h2_oct(planes, ML, C, big, a, b, bad);
         }
     }
+    rdo::h2_report(bad, planes.ovf);
 }
 
 // gradient of the shuffle: [B,2H,2W,C] -> [B,H,W,4C]; fp32-only: one thread per (small pixel, quad of large channels): four 16-byte
@@ -436,7 +448,8 @@ __global__ __launch_bounds__(256) void pixel_unshuffle2_kernel(const float* x, l
 // four large pixels); a thread owns one 16-channel slice of one small pixel (= 4 large channels): four 16-byte loads, a complete
 // 32-byte record per plane
 __global__ __launch_bounds__(256) void pixel_unshuffle2_pix_kernel(const float* x, long npix_small, int H, int W, int C, float* out,
-                                                                   u16* planes) {
+                                                                   H2Out planes) {
+    int bad = 0;
     const int ngroups = (C + 31) / 32;
     const long nvb = ((npix_small + 31) / 32) * ngroups;
     const int C4 = 4 * C;
@@ -458,48 +471,51 @@ __global__ __launch_bounds__(256) void pixel_unshuffle2_pix_kernel(const float* 
             float* dst = out + p * (long)C4 + 4 * cl;
             stq(dst, o0); stq(dst + 4, o1); stq(dst + 8, o2); stq(dst + 12, o3);
         }
-        store_p3_oct(planes, npix_small, C4, Oct{p, 4 * cl}, o0, o1);
-        store_p3_oct(planes, npix_small, C4, Oct{p, 4 * cl + 8}, o2, o3);
+        store_h2_oct(planes, npix_small, C4, Oct{p, 4 * cl}, o0, o1, bad);
+        store_h2_oct(planes, npix_small, C4, Oct{p, 4 * cl + 8}, o2, o3, bad);
     }
+    rdo::h2_report(bad, planes.ovf);
 }
 
 }  // namespace
 
 extern "C" {
 
-int rdo_gather_qdrop_p3(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
+int rdo_gather_qdrop_h2(const float* cache_q, const float* cache_fp, const int32_t* idx_table, const int32_t* iter_ptr, int32_t B,
                         int32_t batch_offset, int64_t per_image, int32_t C, float prob, uint32_t seed, float* out, void* out_planes,
-                        int32_t* iter_publish, void* stream) {
-    RDO_REQUIRE(cache_q && cache_fp && idx_table && iter_ptr && out_planes, "rdo_gather_qdrop_p3: null pointer");
-    RDO_REQUIRE(B > 0 && batch_offset >= 0 && per_image > 0 && C > 0 && C % 16 == 0 && per_image % C == 0, "rdo_gather_qdrop_p3: bad shape");
-    RDO_REQUIRE((long)(batch_offset + B) * per_image < (1L << 32), "rdo_gather_qdrop_p3: batch tensor exceeds the 32-bit RNG counter");
-    RDO_REQUIRE(prob >= 0.f && prob <= 1.f, "rdo_gather_qdrop_p3: prob out of [0,1]");
+                        float out_scale, int32_t* iter_publish, void* stream) {
+    RDO_REQUIRE(cache_q && cache_fp && idx_table && iter_ptr && out_planes, "rdo_gather_qdrop_h2: null pointer");
+    RDO_REQUIRE(B > 0 && batch_offset >= 0 && per_image > 0 && C > 0 && C % 16 == 0 && per_image % C == 0, "rdo_gather_qdrop_h2: bad shape");
+    RDO_REQUIRE((long)(batch_offset + B) * per_image < (1L << 32), "rdo_gather_qdrop_h2: batch tensor exceeds the 32-bit RNG counter");
+    RDO_REQUIRE(prob >= 0.f && prob <= 1.f, "rdo_gather_qdrop_h2: prob out of [0,1]");
     double t = floor((double)prob * 4294967296.0);
     const unsigned long long thr = (unsigned long long)(t > 4294967296.0 ? 4294967296.0 : t);
-    u16* pl = reinterpret_cast<u16*>(out_planes);
+    RDO_REQUIRE(out_scale > 0.f, "rdo_gather_qdrop_h2: out_scale must be a positive power of two");
+    const H2Out pl{reinterpret_cast<u16*>(out_planes), out_scale, rdo::h2_overflow_flag()};
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(gather_qdrop_p3_kernel, dim3(oct_grid((long)B * (per_image / C), C)), dim3(256), 0, s, cache_q, cache_fp,
+            hipLaunchKernelGGL(gather_qdrop_h2_kernel, dim3(oct_grid((long)B * (per_image / C), C)), dim3(256), 0, s, cache_q, cache_fp,
                                idx_table, iter_ptr, B, batch_offset, (long)per_image, C, thr, seed, out, pl, iter_publish);
-            return rdo::check_launch("gather_qdrop_p3");
+            return rdo::check_launch("gather_qdrop_h2");
         },
-        stream, "gather_qdrop_p3", 0.0, (8.0 + (out ? 4.0 : 0.0) + 6.0) * B * per_image);
+        stream, "gather_qdrop_h2", 0.0, (8.0 + (out ? 4.0 : 0.0) + 4.0) * B * per_image);
 }
 
-int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residual_planes, const float* tgt_cache,
+int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residual_planes, float residual_scale, const float* tgt_cache,
                      const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef, int32_t act,
-                     float* out, float* grad_out, float* dpre, void* dpre_planes, float* loss_out, void* stream) {
+                     float* out, float* grad_out, float* dpre, void* dpre_planes, float dpre_scale, float* loss_out, void* stream) {
     RDO_REQUIRE(pre && tgt_cache && idx_table && iter_ptr && (dpre || dpre_planes || grad_out), "rdo_loss_act_bwd: null pointer");
     RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_loss_act_bwd: bad shape");
-    RDO_REQUIRE((!dpre_planes && !residual_planes) || C % 16 == 0, "rdo_loss_act_bwd: P3 tensors need C % 16 == 0");
-    const u16* rpl = residual ? nullptr : reinterpret_cast<const u16*>(residual_planes);
+    RDO_REQUIRE((!dpre_planes && !residual_planes) || C % 16 == 0, "rdo_loss_act_bwd: H2 tensors need C % 16 == 0");
+    RDO_REQUIRE((!dpre_planes || dpre_scale > 0.f) && (!residual_planes || residual_scale > 0.f), "rdo_loss_act_bwd: plane scales must be positive powers of two");
+    const H2In rpl{residual ? nullptr : reinterpret_cast<const u16*>(residual_planes), residual_planes ? 1.f / residual_scale : 1.f};
     RDO_REQUIRE(act >= 0 && act <= 2, "rdo_loss_act_bwd: act %d (0 none, 1 LeakyReLU(0.01), 2 ReLU)", act);
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
-    u16* pl = reinterpret_cast<u16*>(dpre_planes);
+    const H2Out pl{reinterpret_cast<u16*>(dpre_planes), dpre_scale, rdo::h2_overflow_flag()};
     const double n = (double)B * per_image;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            if (pl || rpl)
+            if (pl.p || rpl.p)
                 hipLaunchKernelGGL(loss_act_bwd_pix_kernel, dim3(loss_grid(oct_blocks((long)B * (per_image / C), C))), dim3(256), 0, s, pre, residual, rpl,
                                    tgt_cache, idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, act, out, grad_out, dpre, pl,
                                    loss_out);
@@ -510,7 +526,7 @@ int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residu
             return rdo::check_launch("loss_act_bwd");
         },
         stream, "loss_act_bwd", 0.0,
-        n * (8.0 + 4.0 * ((residual != nullptr) + (out != nullptr) + (grad_out != nullptr) + (dpre != nullptr)) + (pl ? 6.0 : 0.0)));
+        n * (8.0 + 4.0 * ((residual != nullptr) + (out != nullptr) + (grad_out != nullptr) + (dpre != nullptr)) + (pl.p ? 4.0 : 0.0)));
 }
 
 int rdo_loss_act_bwd_splitk(const float* partial, int32_t ksplit, const float* bias, const float* residual, const float* tgt_cache,
@@ -535,16 +551,17 @@ int rdo_loss_act_bwd_splitk(const float* partial, int32_t ksplit, const float* b
 
 int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, const float* tgt_cache, const int32_t* idx_table,
                      const int32_t* iter_ptr, int32_t B, int64_t per_image, int32_t C, float coef, int32_t inverse, float* out,
-                     float* grad_out, float* t, void* t_planes, float* loss_out, void* stream) {
+                     float* grad_out, float* t, void* t_planes, float t_scale, float* loss_out, void* stream) {
     RDO_REQUIRE(x && norm && tgt_cache && idx_table && iter_ptr && grad_out && (t || t_planes), "rdo_loss_gdn_bwd: null pointer");
     RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_loss_gdn_bwd: bad shape");
-    RDO_REQUIRE(!t_planes || C % 16 == 0, "rdo_loss_gdn_bwd: P3 output needs C % 16 == 0");
+    RDO_REQUIRE(!t_planes || C % 16 == 0, "rdo_loss_gdn_bwd: H2 output needs C % 16 == 0");
+    RDO_REQUIRE(!t_planes || t_scale > 0.f, "rdo_loss_gdn_bwd: t_scale must be a positive power of two");
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
-    u16* pl = reinterpret_cast<u16*>(t_planes);
+    const H2Out pl{reinterpret_cast<u16*>(t_planes), t_scale, rdo::h2_overflow_flag()};
     const double n = (double)B * per_image;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            if (pl)
+            if (pl.p)
                 hipLaunchKernelGGL(loss_gdn_bwd_pix_kernel, dim3(loss_grid(oct_blocks((long)B * (per_image / C), C))), dim3(256), 0, s, x, norm, residual,
                                    tgt_cache, idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, inverse, out, grad_out, t, pl,
                                    loss_out);
@@ -554,49 +571,54 @@ int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, c
             return rdo::check_launch("loss_gdn_bwd");
         },
         stream, "loss_gdn_bwd", 0.0,
-        n * (16.0 + 4.0 * ((residual != nullptr) + (out != nullptr) + (t != nullptr)) + (pl ? 6.0 : 0.0)));
+        n * (16.0 + 4.0 * ((residual != nullptr) + (out != nullptr) + (t != nullptr)) + (pl.p ? 4.0 : 0.0)));
 }
 
-int rdo_gdn_bwd_dx_p3(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t C, int32_t inverse,
-                      float* dx, void* dx_planes, void* stream) {
-    RDO_REQUIRE(g && x && norm && acc && (dx || dx_planes) && n > 0 && n % 4 == 0 && C > 0 && n % C == 0, "rdo_gdn_bwd_dx_p3: bad argument");
-    RDO_REQUIRE(!dx_planes || C % 16 == 0, "rdo_gdn_bwd_dx_p3: P3 output needs C % 16 == 0");
-    u16* pl = reinterpret_cast<u16*>(dx_planes);
+int rdo_gdn_bwd_dx_h2(const float* g, const float* x, const float* norm, const float* acc, int64_t n, int32_t C, int32_t inverse,
+                      float* dx, void* dx_planes, float dx_scale, void* stream) {
+    RDO_REQUIRE(g && x && norm && acc && (dx || dx_planes) && n > 0 && n % 4 == 0 && C > 0 && n % C == 0, "rdo_gdn_bwd_dx_h2: bad argument");
+    RDO_REQUIRE(!dx_planes || C % 16 == 0, "rdo_gdn_bwd_dx_h2: H2 output needs C % 16 == 0");
+    RDO_REQUIRE(!dx_planes || dx_scale > 0.f, "rdo_gdn_bwd_dx_h2: dx_scale must be a positive power of two");
+    const H2Out pl{reinterpret_cast<u16*>(dx_planes), dx_scale, rdo::h2_overflow_flag()};
     return rdo::dispatch(
         [=](hipStream_t s) {
-            if (pl)
+            if (pl.p)
                 hipLaunchKernelGGL(gdn_bwd_dx_pix_kernel, dim3(oct_grid(n / C, C)), dim3(256), 0, s, g, x, norm, acc, (long)(n / C), C, inverse,
                                    dx, pl);
             else
                 hipLaunchKernelGGL(gdn_bwd_dx_kernel, dim3(grid_for(n / 4)), dim3(256), 0, s, g, x, norm, acc, (long)(n / 4), inverse, dx);
-            return rdo::check_launch("gdn_bwd_dx_p3");
+            return rdo::check_launch("gdn_bwd_dx_h2");
         },
-        stream, "gdn_bwd_dx", 0.0, (double)n * (16.0 + (dx ? 4.0 : 0.0) + (pl ? 6.0 : 0.0)));
+        stream, "gdn_bwd_dx", 0.0, (double)n * (16.0 + (dx ? 4.0 : 0.0) + (pl.p ? 4.0 : 0.0)));
 }
 
-int rdo_pixel_shuffle_p3(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream) {
-    RDO_REQUIRE(x && (out || out_planes) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "rdo_pixel_shuffle_p3: bad argument");
-    RDO_REQUIRE(!out_planes || C % 16 == 0, "rdo_pixel_shuffle_p3: P3 output needs C % 16 == 0");
-    u16* pl = reinterpret_cast<u16*>(out_planes);
+int rdo_pixel_shuffle_h2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, float out_scale,
+                         void* stream) {
+    RDO_REQUIRE(x && (out || out_planes) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "rdo_pixel_shuffle_h2: bad argument");
+    RDO_REQUIRE(!out_planes || C % 16 == 0, "rdo_pixel_shuffle_h2: H2 output needs C % 16 == 0");
+    RDO_REQUIRE(!out_planes || out_scale > 0.f, "rdo_pixel_shuffle_h2: out_scale must be a positive power of two");
+    const H2Out pl{reinterpret_cast<u16*>(out_planes), out_scale, rdo::h2_overflow_flag()};
     const long nps = (long)B * H * W, npl = nps * 4;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            if (pl)
+            if (pl.p)
                 hipLaunchKernelGGL(pixel_shuffle2_pix_kernel, dim3(oct_grid(nps, C)), dim3(256), 0, s, x, nps, H, W, C, out, pl);
             else
                 hipLaunchKernelGGL(pixel_shuffle2_kernel, dim3(grid_for(nps * C / 4)), dim3(256), 0, s, x, nps, H, W, C, out);
-            return rdo::check_launch("pixel_shuffle_p3");
+            return rdo::check_launch("pixel_shuffle_h2");
         },
-        stream, "pixel_shuffle", 0.0, (double)npl * C * (4.0 + (out ? 4.0 : 0.0) + (pl ? 6.0 : 0.0)));
+        stream, "pixel_shuffle", 0.0, (double)npl * C * (4.0 + (out ? 4.0 : 0.0) + (pl.p ? 4.0 : 0.0)));
 }
 
-int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, void* stream) {
+int rdo_pixel_unshuffle2(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, float* out, void* out_planes, float out_scale,
+                         void* stream) {
     RDO_REQUIRE(x && (out || out_planes) && B > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0, "rdo_pixel_unshuffle2: bad argument");
+    RDO_REQUIRE(!out_planes || out_scale > 0.f, "rdo_pixel_unshuffle2: out_scale must be a positive power of two");
     const long nps = (long)B * H * W;
-    u16* pl = reinterpret_cast<u16*>(out_planes);
+    const H2Out pl{reinterpret_cast<u16*>(out_planes), out_scale, rdo::h2_overflow_flag()};
     return rdo::dispatch(
         [=](hipStream_t s) {
-            if (pl) {
+            if (pl.p) {
                 const long g = rdo::ceil_div(nps, 32L) * rdo::ceil_div(C, 32);
                 hipLaunchKernelGGL(pixel_unshuffle2_pix_kernel, dim3((unsigned)(g > 8192 ? 8192 : g)), dim3(256), 0, s, x, nps, H, W, C, out, pl);
             } else {

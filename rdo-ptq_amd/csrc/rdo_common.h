@@ -87,4 +87,43 @@ __host__ __device__ inline long frag_index(long e, int Cout, int KH, int KW, int
 }
 inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// ---- H2 tensors: an fp32 value as an exact two-way fp16 split of its power-of-two-scaled self ---------------------------------------
+//   x * s = h1 + h2 (+ at most 2^-24 |x s|),  h1 = fp16_rne(x s),  h2 = fp16_rne(x s - h1)         (x s - h1 is exact in fp32)
+// A product of two such values needs THREE fp16 MFMA products (h1 g1 + h1 g2 + h2 g1; h2 g2 <= 2^-22 of the product) where the
+// three-way bf16 split needed six, and the operands take 4 bytes per element instead of 6.  fp16 has 5 exponent bits, hence the
+// per-tensor scale s (a power of two: exact): the engine picks it from a probe iteration so that max |x s| ~ 2^7; results stay at
+// fp32-chain accuracy for max |x s| anywhere in [2^-2, 2^15] (tools/f16_probe.hip: rms error 1.1e-7 of max |C| against 1.5e-7 for the
+// bf16 six-product form and 1.8e-7 for an fp32 fma chain; MFMA honours fp16 denormals).  |x s| > 65504 cannot be represented: the
+// producers raise a sticky device flag (rdo_h2_overflow) instead of failing silently.
+int* h2_overflow_flag();                   // device pointer of the sticky flag on the current device (allocated on first use)
+
+#if defined(__HIPCC__)
+typedef _Float16 h2_f16x2 __attribute__((ext_vector_type(2)));
+typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
+// two values -> packed h1 pair, packed h2 pair; `bad` is OR-ed with 1 when a value does not fit fp16
+__device__ __forceinline__ void h2_split_pk(float a, float b, float s, unsigned& hi, unsigned& lo, int& bad) {
+    const float xa = a * s, xb = b * s;
+    const h2_f16x2 h = __builtin_convertvector(h2_f32x2{xa, xb}, h2_f16x2);
+    const h2_f32x2 hf = __builtin_convertvector(h, h2_f32x2);
+    const h2_f16x2 l = __builtin_convertvector(h2_f32x2{xa - hf[0], xb - hf[1]}, h2_f16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    lo = __builtin_bit_cast(unsigned, l);
+    bad |= (int)(!(__builtin_fabsf(xa) <= 65504.f) | !(__builtin_fabsf(xb) <= 65504.f));
+}
+__device__ __forceinline__ float h2_lo(unsigned pk) { return (float)__builtin_bit_cast(h2_f16x2, pk)[0]; }
+__device__ __forceinline__ float h2_hi(unsigned pk) { return (float)__builtin_bit_cast(h2_f16x2, pk)[1]; }
+// scalar form: element i of planes [2][n]
+__device__ __forceinline__ void h2_split_store(float v, float s, unsigned short* planes, long n, long i, int& bad) {
+    const float x = v * s;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    planes[i] = __builtin_bit_cast(unsigned short, h);
+    planes[n + i] = __builtin_bit_cast(unsigned short, l);
+    bad |= (int)!(__builtin_fabsf(x) <= 65504.f);
+}
+__device__ __forceinline__ void h2_report(int bad, int* flag) {
+    if (bad) atomicOr(flag, 1);
+}
+#endif
+
 }  // namespace rdo

@@ -53,6 +53,20 @@ int tuning(Tune t) {
     return g_tune[t].load(std::memory_order_relaxed);
 }
 
+int* h2_overflow_flag() {
+    static std::mutex mu;
+    static int* ptr[64] = {};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(mu);
+    int*& p = ptr[dev & 63];
+    if (!p) {
+        if (hipMalloc(reinterpret_cast<void**>(&p), 64) != hipSuccess) { p = nullptr; return nullptr; }
+        (void)hipMemset(p, 0, 64);
+    }
+    return p;
+}
+
 }  // namespace rdo
 
 struct rdo_plan {
@@ -87,6 +101,15 @@ int rdo_get_tuning(const char* key) {
     if (i < 0) return -1;
     rdo::tune_init();
     return rdo::g_tune[i].load();
+}
+
+int rdo_h2_overflow(int reset) {
+    int* p = rdo::h2_overflow_flag();
+    if (!p) return -1;
+    int v = 0;
+    if (hipMemcpy(&v, p, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset && v) (void)hipMemset(p, 0, sizeof v);
+    return v;
 }
 
 rdo_plan* rdo_plan_create(void) { return new rdo_plan(); }

@@ -26,7 +26,8 @@ class AdaDesc(C.Structure):
 class AdaStepItem(C.Structure):
     _fields_ = [("d", AdaDesc), ("w", C.c_void_p), ("delta", C.c_void_p), ("zp", C.c_void_p), ("slabs", C.c_void_p),
                 ("nsplit", C.c_int32), ("alpha", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("wq", C.c_void_p),
-                ("wd", C.c_void_p), ("wq_planes", C.c_void_p), ("wd_planes", C.c_void_p), ("dalpha", C.c_void_p)]
+                ("wd", C.c_void_p), ("wq_planes", C.c_void_p), ("wd_planes", C.c_void_p), ("dalpha", C.c_void_p),
+                ("wq_plane_scale", C.c_float), ("wd_plane_scale", C.c_float)]
 
 
 class AttnDesc(C.Structure):
@@ -56,10 +57,10 @@ _SIGS = {
     "rdo_reduce_slabs": (C.c_int, [P, C.c_int, C.c_int64, P, P]),
     "rdo_adaround_init_alpha": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P]),
     "rdo_adaround_fwd": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, P, P, P]),
-    "rdo_adaround_step": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
+    "rdo_adaround_step": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, C.c_float, C.c_float, P]),
     "rdo_adaround_step_batch": (C.c_int, [C.POINTER(AdaStepItem), C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, P, P, P, P]),
     "rdo_adaround_grad": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, C.c_int, P, P]),
-    "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, P]),
+    "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, C.c_float, C.c_float, P]),
     "rdo_uaq_fakequant": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, P]),
     "rdo_uaq_init_minmax": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, P, P, P]),
     "rdo_actquant_perchannel": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),
@@ -92,23 +93,26 @@ _SIGS = {
     "rdo_gaussian_likelihood_bwd": (C.c_int, [P, P, P, C.c_int64, C.c_float, C.c_float, P, P, P]),
     "rdo_neg_log2_sum": (C.c_int, [P, C.c_int64, C.c_float, P, P]),
     "rdo_sq_diff_sum": (C.c_int, [P, P, C.c_int64, C.c_float, C.c_int32, P, P]),
-    "rdo_split_p3": (C.c_int, [P, C.c_int64, C.c_int32, P, P]),
-    "rdo_conv2d_fwd_p3_workspace": (C.c_int64, [C.POINTER(ConvDesc)]),
-    "rdo_conv2d_fwd_p3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
-    "rdo_conv2d_fwd_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, P, P, P, C.c_int64, P]),
-    "rdo_conv2d_wgrad_p3_supported": (C.c_int, [C.POINTER(ConvDesc)]),
-    "rdo_conv2d_wgrad_p3": (C.c_int, [C.POINTER(ConvDesc), P, P, P, C.c_int, P]),
-    "rdo_conv2d_fwd_p3_tail_supported": (C.c_int, [C.POINTER(ConvDesc)]),
-    "rdo_conv2d_fwd_p3_tail": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, P, P, P, C.c_int32, C.c_float, C.c_int32, P, P, P]),
+    "rdo_h2_overflow": (C.c_int, [C.c_int]),
+    "rdo_split_h2": (C.c_int, [P, C.c_int64, C.c_int32, C.c_float, P, P]),
+    "rdo_split_h2_conv": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, P, P]),
+    "rdo_conv2d_fwd_h2_workspace": (C.c_int64, [C.POINTER(ConvDesc)]),
+    "rdo_conv2d_fwd_h2_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rdo_conv2d_fwd_h2": (C.c_int, [C.POINTER(ConvDesc), P, C.c_float, P, C.c_float, P, P, P, P, P, P, P, C.c_float, P, C.c_int64, P]),
+    "rdo_conv2d_wgrad_h2_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rdo_conv2d_wgrad_h2": (C.c_int, [C.POINTER(ConvDesc), P, C.c_float, P, C.c_float, P, C.c_int, P]),
+    "rdo_conv2d_fwd_h2_tail_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rdo_conv2d_fwd_h2_tail": (C.c_int, [C.POINTER(ConvDesc), P, C.c_float, P, C.c_float, P, P, C.c_float, P, P, P, C.c_int32, C.c_float, C.c_int32, P,
+                                         C.c_float, P, P]),
     "rdo_conv2d_fwd_ksplit": (C.c_int, [C.POINTER(ConvDesc), C.c_int, C.c_int64]),
     "rdo_conv2d_fwd_partials": (C.c_int, [C.POINTER(ConvDesc), P, P, P, P, C.c_int64, P]),
     "rdo_loss_act_bwd_splitk": (C.c_int, [P, C.c_int32, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P]),
-    "rdo_gather_qdrop_p3": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_uint32, P, P, P, P]),
-    "rdo_loss_act_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P, P]),
-    "rdo_loss_gdn_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, P, P]),
-    "rdo_gdn_bwd_dx_p3": (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),
-    "rdo_pixel_shuffle_p3": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
-    "rdo_pixel_unshuffle2": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, P]),
+    "rdo_gather_qdrop_h2": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_uint32, P, P, C.c_float, P, P]),
+    "rdo_loss_act_bwd": (C.c_int, [P, P, P, C.c_float, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, C.c_float, P, P]),
+    "rdo_loss_gdn_bwd": (C.c_int, [P, P, P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_int32, P, P, P, P, C.c_float, P, P]),
+    "rdo_gdn_bwd_dx_h2": (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, C.c_int32, P, P, C.c_float, P]),
+    "rdo_pixel_shuffle_h2": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, C.c_float, P]),
+    "rdo_pixel_unshuffle2": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P, C.c_float, P]),
     "rdo_plan_create": (P, []),
     "rdo_plan_destroy": (None, [P]),
     "rdo_plan_begin_record": (C.c_int, [P]),

@@ -4,20 +4,44 @@ Conventions: every tensor is a contiguous fp32 CUDA tensor; activations are NHWC
 `[Cout,KH,KW,Cin]` (the memory image of torch's channels_last OIHW weight).  Calls are enqueued on torch's current stream.
 When a plan is being recorded (hipops.plan.Plan.record()), the same calls are captured instead of launched."""
 import ctypes as C
+import math
 
 import torch
 
 from . import _lib as L
 
 
+class H2:
+    """Planes of an H2 tensor (include/rdo_ptq_hip.h): `.t` int16 [2, ...] holding fp16 bit patterns -- the two-way split of the values
+    times `.scale` (a power of two) -- for activations in slice-major order [2, C/16, pixels, 16], for conv weights in fragment order."""
+    __slots__ = ("t", "scale")
+
+    def __init__(self, t, scale):
+        self.t, self.scale = t, float(scale)
+        m, e = math.frexp(self.scale)
+        if not (self.scale > 0 and m == 0.5):
+            raise ValueError(f"H2 scale must be a positive power of two, got {scale}")
+
+    @property
+    def device(self):
+        return self.t.device
+
+
 def _ptr(t):
     if t is None:
         return None
+    if isinstance(t, H2):
+        t = t.t
     if not t.is_cuda:
         raise RuntimeError(f"librdoptq_hip has no CPU path: tensor is on {t.device}")
     if t.dtype not in (torch.float32, torch.int32, torch.int16) or not t.is_contiguous():
         raise RuntimeError(f"librdoptq_hip needs contiguous fp32/int32 tensors, got {t.dtype} contiguous={t.is_contiguous()}")
     return C.c_void_p(t.data_ptr())
+
+
+def _pscale(planes):
+    """plane scale argument of the AdaRound entries: 0 = bf16 three-way planes (or none), > 0 = fp16 two-way planes of w * scale"""
+    return planes.scale if isinstance(planes, H2) else 0.0
 
 
 def _stream():
@@ -186,10 +210,12 @@ def uaq_init_minmax(w, n_levels):
 
 def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_ptr, alpha, m, v, wq, wd, round_log,
                   wq_planes=None, wd_planes=None):
-    """`wq_planes` / `wd_planes`: optional int16 [3, numel] tensors that receive the bf16 three-way split of the new weights."""
+    """`wq_planes` / `wd_planes`: optional planes of the new weights in fragment order -- an int16 [3, numel] tensor receives the bf16
+    three-way split, an `H2` object the fp16 two-way split of w * scale."""
     L.check(L.lib().rdo_adaround_step(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(slabs), slabs.shape[0], grad_scale,
                                       round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(alpha), _ptr(m), _ptr(v), _ptr(wq),
-                                      _ptr(wd), _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _stream()), "rdo_adaround_step")
+                                      _ptr(wd), _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _pscale(wq_planes), _pscale(wd_planes),
+                                      _stream()), "rdo_adaround_step")
 
 
 def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None, mode=0, iter_shadow=None):
@@ -205,6 +231,7 @@ def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_
         a.nsplit = it["slabs"].shape[0] if it.get("slabs") is not None else 0
         a.alpha, a.adam_m, a.adam_v, a.wq, a.wd = dp(it["alpha"]), dp(it["m"]), dp(it["v"]), dp(it["wq"]), dp(it.get("wd"))
         a.wq_planes, a.wd_planes = dp(it.get("wq_planes")), dp(it.get("wd_planes"))
+        a.wq_plane_scale, a.wd_plane_scale = _pscale(it.get("wq_planes")), _pscale(it.get("wd_planes"))
         a.dalpha = dp(it.get("dalpha"))
     L.check(L.lib().rdo_adaround_step_batch(arr, len(items), int(mode), grad_scale, round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(round_log),
                                             _ptr(advance_iter), _ptr(iter_shadow), _stream()), "rdo_adaround_step_batch")
@@ -219,7 +246,8 @@ def adaround_apply(d, w, delta, zp, dalpha, grad_scale, round_weight, sched, ite
                    wq_planes=None, wd_planes=None):
     L.check(L.lib().rdo_adaround_apply(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(dalpha), grad_scale, round_weight,
                                        _ptr(sched), _ptr(iter_ptr), _ptr(alpha), _ptr(m), _ptr(v), _ptr(wq), _ptr(wd),
-                                       _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _stream()), "rdo_adaround_apply")
+                                       _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _pscale(wq_planes), _pscale(wd_planes), _stream()),
+            "rdo_adaround_apply")
 
 
 def set_tuning(key, value):
@@ -505,68 +533,112 @@ def make_sched(iters, warmup, b_range, lr=1e-3, device="cuda"):
     return rows.to(device)
 
 
-# ----------------------------------------------------------------------------- P3 tensors and fused unit tails
-def p3_empty(shape, device):
-    """Planes of a P3 tensor for an fp32 NHWC tensor of `shape` [..., C] (C % 16 == 0): int16 [3, C/16, pixels, 16] -- slice-major
+# ----------------------------------------------------------------------------- H2 tensors and fused unit tails
+H2_TARGET = 128.0      # a tensor's scale puts its largest magnitude (as probed) near 2^7: x512 head-room to fp16's 65504, fp32-chain
+                       # accuracy down to max |x s| = 2^-2 (tools/f16_probe.hip)
+
+
+def pow2_scale(amax, target=H2_TARGET):
+    """The power of two s with target / 2 < amax * s <= target (1.0 for an all-zero tensor)."""
+    amax = float(amax)
+    if not math.isfinite(amax):
+        raise ValueError("pow2_scale: non-finite magnitude")
+    if amax <= 0.0:
+        return 1.0
+    return 2.0 ** min(60, max(-60, math.floor(math.log2(target / amax))))
+
+
+def h2_empty(shape, device, scale=1.0):
+    """Planes of an H2 tensor for an fp32 NHWC tensor of `shape` [..., C] (C % 16 == 0): int16 [2, C/16, pixels, 16] -- slice-major
     planes, include/rdo_ptq_hip.h."""
     Cc = shape[-1]
     if Cc % 16:
-        raise ValueError(f"P3 tensors need a channel count that is a multiple of 16, got {Cc}")
+        raise ValueError(f"H2 tensors need a channel count that is a multiple of 16, got {Cc}")
     npix = 1
     for d in shape[:-1]:
         npix *= int(d)
-    return torch.empty((3, Cc // 16, npix, 16), device=device, dtype=torch.int16)
+    return H2(torch.empty((2, Cc // 16, npix, 16), device=device, dtype=torch.int16), scale)
 
 
-def p3_to_float(planes, shape):
-    """p0 + p1 + p2 as an fp32 tensor of `shape` (exact)."""
-    x = sum((planes[i].to(torch.int32) << 16).view(torch.float32) for i in range(3))      # [C/16, pixels, 16]
+def h2_to_float(planes, shape):
+    """(h1 + h2) / scale as an fp32 tensor of `shape` (the original values to 2^-24 relative)."""
+    x = (planes.t[0].view(torch.float16).float() + planes.t[1].view(torch.float16).float()) / planes.scale      # [C/16, pixels, 16]
     return x.permute(1, 0, 2).reshape(shape).contiguous()
 
 
-def split_p3(x, planes=None):
-    planes = p3_empty(x.shape, x.device) if planes is None else planes
+def h2_overflow(reset=True):
+    """True when a producer of H2 planes met a value outside fp16's range since the last reset (synchronises the device)."""
+    rc = int(L.lib().rdo_h2_overflow(int(bool(reset))))
+    if rc < 0:
+        raise RuntimeError("rdo_h2_overflow failed")
+    return bool(rc)
+
+
+def split_h2(x, planes=None, scale=None):
+    """fp32 NHWC tensor -> H2 planes; without `planes` / `scale` the scale comes from the tensor's own largest magnitude (a device
+    synchronisation: set-up and tests only)."""
+    if planes is None:
+        planes = h2_empty(x.shape, x.device, pow2_scale(x.abs().max()) if scale is None else scale)
     Cc = x.shape[-1]
-    L.check(L.lib().rdo_split_p3(_ptr(x), x.numel() // Cc, Cc, _ptr(planes), _stream()), "rdo_split_p3")
+    L.check(L.lib().rdo_split_h2(_ptr(x), x.numel() // Cc, Cc, planes.scale, _ptr(planes), _stream()), "rdo_split_h2")
     return planes
 
 
-def conv_p3_supported(x_shape, w_shape, stride, pad, square_input=False):
+def split_h2_conv(w, planes=None, scale=None):
+    """Conv weight in kernel layout [Cout,KH,KW,Cin] (or [C,C] = 1x1) -> H2 weight planes int16 [2, Cout,KH,KW,Cin] in the fragment
+    order the split-precision kernels read ([Cin/16][KH][KW][Cout][16])."""
+    if w.dim() == 2:
+        w = w.reshape(w.shape[0], 1, 1, w.shape[1])
+    if w.dim() != 4:
+        raise ValueError("split_h2_conv: expected a conv weight [Cout,KH,KW,Cin]")
+    if planes is None:
+        planes = H2(torch.empty((2,) + tuple(w.shape), device=w.device, dtype=torch.int16), pow2_scale(w.abs().max()) if scale is None else scale)
+    co, kh, kw, ci = w.shape
+    L.check(L.lib().rdo_split_h2_conv(_ptr(w), co, kh, kw, ci, planes.scale, _ptr(planes), _stream()), "rdo_split_h2_conv")
+    return planes
+
+
+def conv_h2_supported(x_shape, w_shape, stride, pad, square_input=False):
     d = conv_desc(x_shape, w_shape, stride, pad, square_input=square_input)
-    return bool(L.lib().rdo_conv2d_fwd_p3_supported(C.byref(d)))
+    return bool(L.lib().rdo_conv2d_fwd_h2_supported(C.byref(d)))
 
 
-def conv2d_fwd_p3(xp, x_shape, w_shape, wplanes, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, out=None, pre=None,
+def _oscale(p):
+    return p.scale if p is not None else 1.0
+
+
+def conv2d_fwd_h2(xp, x_shape, w_shape, wplanes, bias=None, stride=1, pad=0, epilogue=L.EPI_NONE, aux=None, residual=None, out=None, pre=None,
                   out_planes=None, aux_planes=None):
-    """Conv on a P3 input (`xp` = planes of the NHWC tensor of shape `x_shape`) with fragment-ordered weight planes; writes whichever
+    """Conv on an H2 input (`xp` = planes of the NHWC tensor of shape `x_shape`) with fragment-ordered H2 weight planes; writes whichever
     of out / pre / out_planes is given."""
     d = conv_desc(x_shape, w_shape, stride, pad, epilogue, False, residual is not None)
-    need = int(L.lib().rdo_conv2d_fwd_p3_workspace(C.byref(d)))
+    need = int(L.lib().rdo_conv2d_fwd_h2_workspace(C.byref(d)))
     ws = _scratch(xp.device, need) if need else None
-    L.check(L.lib().rdo_conv2d_fwd_p3(C.byref(d), _ptr(xp), _ptr(wplanes), _ptr(bias), _ptr(aux), _ptr(aux_planes), _ptr(residual), _ptr(out), _ptr(pre),
-                                      _ptr(out_planes), _ptr(ws), ws.numel() if ws is not None else 0, _stream()), "rdo_conv2d_fwd_p3")
+    L.check(L.lib().rdo_conv2d_fwd_h2(C.byref(d), _ptr(xp), xp.scale, _ptr(wplanes), wplanes.scale, _ptr(bias), _ptr(aux), _ptr(aux_planes),
+                                      _ptr(residual), _ptr(out), _ptr(pre), _ptr(out_planes), _oscale(out_planes), _ptr(ws),
+                                      ws.numel() if ws is not None else 0, _stream()), "rdo_conv2d_fwd_h2")
     return out
 
 
-def conv_p3_tail_supported(x_shape, w_shape, stride, pad):
+def conv_h2_tail_supported(x_shape, w_shape, stride, pad):
     d = conv_desc(x_shape, w_shape, stride, pad)
-    return bool(L.lib().rdo_conv2d_fwd_p3_tail_supported(C.byref(d)))
+    return bool(L.lib().rdo_conv2d_fwd_h2_tail_supported(C.byref(d)))
 
 
-def conv2d_fwd_p3_tail(xp, x_shape, w_shape, wplanes, bias, stride, pad, residual_planes, tgt_cache, idx_table, iter_ptr, coef, act, dpre_planes,
+def conv2d_fwd_h2_tail(xp, x_shape, w_shape, wplanes, bias, stride, pad, residual_planes, tgt_cache, idx_table, iter_ptr, coef, act, dpre_planes,
                        loss_log):
     """Plane-input conv + unit tail in one launch: dpre_planes <- dL/dpre of out = act(conv + bias) + residual against tgt_cache[idx]."""
     d = conv_desc(x_shape, w_shape, stride, pad)
-    L.check(L.lib().rdo_conv2d_fwd_p3_tail(C.byref(d), _ptr(xp), _ptr(wplanes), _ptr(bias), _ptr(residual_planes), _ptr(tgt_cache),
-                                           _ptr(idx_table), _ptr(iter_ptr), x_shape[0], coef, int(act), _ptr(dpre_planes), _ptr(loss_log),
-                                           _stream()), "rdo_conv2d_fwd_p3_tail")
+    L.check(L.lib().rdo_conv2d_fwd_h2_tail(C.byref(d), _ptr(xp), xp.scale, _ptr(wplanes), wplanes.scale, _ptr(bias), _ptr(residual_planes),
+                                           _oscale(residual_planes), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), x_shape[0], coef, int(act),
+                                           _ptr(dpre_planes), dpre_planes.scale, _ptr(loss_log), _stream()), "rdo_conv2d_fwd_h2_tail")
 
 
-def gather_qdrop_p3(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, out_planes, batch_offset=0, iter_publish=None):
+def gather_qdrop_h2(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, out_planes, batch_offset=0, iter_publish=None):
     per_image = cache_q[0].numel()
-    L.check(L.lib().rdo_gather_qdrop_p3(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,
-                                        cache_q.shape[-1], prob, seed, _ptr(out), _ptr(out_planes), _ptr(iter_publish), _stream()),
-            "rdo_gather_qdrop_p3")
+    L.check(L.lib().rdo_gather_qdrop_h2(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,
+                                        cache_q.shape[-1], prob, seed, _ptr(out), _ptr(out_planes), out_planes.scale, _ptr(iter_publish),
+                                        _stream()), "rdo_gather_qdrop_h2")
 
 
 ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
@@ -575,48 +647,50 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 def loss_act_bwd(pre, residual, tgt_cache, idx_table, iter_ptr, coef, act, loss_log, out=None, grad_out=None, dpre=None, dpre_planes=None,
                  residual_planes=None):
     B, per_image = pre.shape[0], pre[0].numel()
-    L.check(L.lib().rdo_loss_act_bwd(_ptr(pre), _ptr(residual), _ptr(residual_planes), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
-                                     pre.shape[-1], coef, int(act), _ptr(out), _ptr(grad_out), _ptr(dpre), _ptr(dpre_planes),
-                                     _ptr(loss_log), _stream()), "rdo_loss_act_bwd")
+    L.check(L.lib().rdo_loss_act_bwd(_ptr(pre), _ptr(residual), _ptr(residual_planes), _oscale(residual_planes), _ptr(tgt_cache), _ptr(idx_table),
+                                     _ptr(iter_ptr), B, per_image, pre.shape[-1], coef, int(act), _ptr(out), _ptr(grad_out), _ptr(dpre),
+                                     _ptr(dpre_planes), _oscale(dpre_planes), _ptr(loss_log), _stream()), "rdo_loss_act_bwd")
 
 
 def loss_gdn_bwd(x, norm, residual, tgt_cache, idx_table, iter_ptr, coef, inverse, loss_log, grad_out, t=None, t_planes=None, out=None):
     B, per_image = x.shape[0], x[0].numel()
     L.check(L.lib().rdo_loss_gdn_bwd(_ptr(x), _ptr(norm), _ptr(residual), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
-                                     x.shape[-1], coef, int(inverse), _ptr(out), _ptr(grad_out), _ptr(t), _ptr(t_planes), _ptr(loss_log),
-                                     _stream()), "rdo_loss_gdn_bwd")
+                                     x.shape[-1], coef, int(inverse), _ptr(out), _ptr(grad_out), _ptr(t), _ptr(t_planes), _oscale(t_planes),
+                                     _ptr(loss_log), _stream()), "rdo_loss_gdn_bwd")
 
 
-def gdn_bwd_dx_p3(g, x, norm, acc, inverse, dx=None, dx_planes=None):
-    L.check(L.lib().rdo_gdn_bwd_dx_p3(_ptr(g), _ptr(x), _ptr(norm), _ptr(acc), g.numel(), g.shape[-1], int(inverse), _ptr(dx),
-                                      _ptr(dx_planes), _stream()), "rdo_gdn_bwd_dx_p3")
+def gdn_bwd_dx_h2(g, x, norm, acc, inverse, dx=None, dx_planes=None):
+    L.check(L.lib().rdo_gdn_bwd_dx_h2(_ptr(g), _ptr(x), _ptr(norm), _ptr(acc), g.numel(), g.shape[-1], int(inverse), _ptr(dx),
+                                      _ptr(dx_planes), _oscale(dx_planes), _stream()), "rdo_gdn_bwd_dx_h2")
 
 
-def pixel_shuffle_p3(x, out=None, out_planes=None):
+def pixel_shuffle_h2(x, out=None, out_planes=None):
     """[B,H,W,4C] -> [B,2H,2W,C] (r = 2) as fp32 and / or planes."""
     B, H, W, CC = x.shape
-    L.check(L.lib().rdo_pixel_shuffle_p3(_ptr(x), B, H, W, CC // 4, _ptr(out), _ptr(out_planes), _stream()), "rdo_pixel_shuffle_p3")
+    L.check(L.lib().rdo_pixel_shuffle_h2(_ptr(x), B, H, W, CC // 4, _ptr(out), _ptr(out_planes), _oscale(out_planes), _stream()),
+            "rdo_pixel_shuffle_h2")
 
 
 def pixel_unshuffle2(x, out=None, out_planes=None):
-    """[B,2H,2W,C] -> [B,H,W,4C]: gradient of the r = 2 pixel shuffle (16-byte accesses on both sides), as fp32 and / or P3 planes."""
+    """[B,2H,2W,C] -> [B,H,W,4C]: gradient of the r = 2 pixel shuffle (16-byte accesses on both sides), as fp32 and / or H2 planes."""
     B, Hr, Wr, Cc = x.shape
     if out is None and out_planes is None:
         out = torch.empty((B, Hr // 2, Wr // 2, 4 * Cc), device=x.device, dtype=torch.float32)
-    L.check(L.lib().rdo_pixel_unshuffle2(_ptr(x), B, Hr // 2, Wr // 2, Cc, _ptr(out), _ptr(out_planes), _stream()), "rdo_pixel_unshuffle2")
+    L.check(L.lib().rdo_pixel_unshuffle2(_ptr(x), B, Hr // 2, Wr // 2, Cc, _ptr(out), _ptr(out_planes), _oscale(out_planes), _stream()),
+            "rdo_pixel_unshuffle2")
     return out
 
 
-def wgrad_p3_supported(x_shape, w_shape, stride, pad):
+def wgrad_h2_supported(x_shape, w_shape, stride, pad):
     d = conv_desc(x_shape, w_shape, stride, pad)
-    return bool(L.lib().rdo_conv2d_wgrad_p3_supported(C.byref(d)))
+    return bool(L.lib().rdo_conv2d_wgrad_h2_supported(C.byref(d)))
 
 
-def conv2d_wgrad_p3(xp, x_shape, dyp, w_shape, stride=1, pad=0, slabs=None):
-    """Weight-gradient slabs from P3 operands (planes of x [B,H,W,Cin] and of dy [B,Ho,Wo,Cout])."""
+def conv2d_wgrad_h2(xp, x_shape, dyp, w_shape, stride=1, pad=0, slabs=None):
+    """Weight-gradient slabs from H2 operands (planes of x [B,H,W,Cin] and of dy [B,Ho,Wo,Cout])."""
     d = conv_desc(x_shape, w_shape, stride, pad)
     ns = int(L.lib().rdo_conv2d_wgrad_nsplit(C.byref(d))) if slabs is None else slabs.shape[0]
     if slabs is None:
         slabs = torch.empty((ns,) + tuple(w_shape), device=xp.device, dtype=torch.float32)
-    L.check(L.lib().rdo_conv2d_wgrad_p3(C.byref(d), _ptr(xp), _ptr(dyp), _ptr(slabs), ns, _stream()), "rdo_conv2d_wgrad_p3")
+    L.check(L.lib().rdo_conv2d_wgrad_h2(C.byref(d), _ptr(xp), xp.scale, _ptr(dyp), dyp.scale, _ptr(slabs), ns, _stream()), "rdo_conv2d_wgrad_h2")
     return slabs

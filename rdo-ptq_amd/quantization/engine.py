@@ -97,6 +97,13 @@ class _Op:
             self.desc = ops.ada_desc(self.w, self.n_levels)
             self.w4 = tuple(self.w.shape)
             self.bias = None if qm.bias is None else qm.bias.detach().contiguous()
+        # bound of |soft-quantised weight| over the whole run (every level of every row's grid; through the GDN re-parametrisation
+        # where there is one) -> the power-of-two scale of this op's fp16 weight planes
+        lv = torch.maximum(self.zp.abs(), (self.n_levels - 1 - self.zp).abs()) * self.delta
+        wb = float(lv.max())
+        if self.is_gdn:
+            wb = max(wb, float(self.desc.reparam_bound)) ** 2
+        self.wscale = ops.pow2_scale(wb)
         self.alpha = torch.empty_like(self.w)
         self.m = torch.zeros_like(self.w)
         self.v = torch.zeros_like(self.w)
@@ -110,19 +117,29 @@ class _Op:
         # the split-bf16 MFMA path (large problems only; decided by the library from the activation shape)
         self.wq_planes = self.wd_planes = None
 
-    def enable_planes(self, fwd: bool, dgrad: bool):
+    def enable_planes(self, fwd: bool, dgrad: bool, h2: bool = False):
         """Allocate the plane buffers (called while the plan is being recorded: no kernel may run here; the engine fills them
-        once eagerly after recording and re-fills them inside the plan after every AdaRound step)."""
-        if fwd and self.wq_planes is None:
-            self.wq_planes = torch.empty((3,) + tuple(self.wq.shape), device=self.wq.device, dtype=torch.int16)
-        if dgrad and self.wd is not None and self.wd_planes is None:
-            self.wd_planes = torch.empty((3,) + tuple(self.wd.shape), device=self.wd.device, dtype=torch.int16)
+        once eagerly after recording and re-fills them inside the plan after every AdaRound step).  h2: fp16 two-way planes of
+        w * wscale for the plane-input kernels (conv_fwd_h2.hip); else the bf16 three-way planes of the fh22-input kernels."""
+        def alloc(like, cur):
+            if cur is not None:
+                if isinstance(cur, ops.H2) != h2:
+                    raise RuntimeError(f"calibration engine: op '{self.name}' needs its weight planes in two formats")
+                return cur
+            if h2:
+                return ops.H2(torch.empty((2,) + tuple(like.shape), device=like.device, dtype=torch.int16), self.wscale)
+            return torch.empty((3,) + tuple(like.shape), device=like.device, dtype=torch.int16)
+        if fwd:
+            self.wq_planes = alloc(self.wq, self.wq_planes)
+        if dgrad and self.wd is not None:
+            self.wd_planes = alloc(self.wd, self.wd_planes)
 
     def refresh_planes(self):
-        if self.wq_planes is not None:
-            ops.split_bf16x3(self.wq4(), self.wq_planes)
-        if self.wd_planes is not None:
-            ops.split_bf16x3(self.wd4(), self.wd_planes)
+        for planes, w4 in ((self.wq_planes, self.wq4), (self.wd_planes, self.wd4)):
+            if isinstance(planes, ops.H2):
+                ops.split_h2_conv(w4(), planes=planes)
+            elif planes is not None:
+                ops.split_bf16x3(w4(), planes)
 
     def wq4(self):
         return self.wq.reshape(self.w4)
@@ -139,12 +156,12 @@ class _Op:
 class UnitEngine:
     def __init__(self, kind, modules, cache_q, cache_fp, cache_out, *, batch_size, iters, weight=0.01, b_range=(20, 2),
                  warmup=0.2, input_prob=0.5, lr=1e-3, seed=0, idx_table=None, include_act_func=True, group=None,
-                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=None, fuse_tail=True, batch_step=True, use_p3=True, rd=None):
+                 use_graph=True, force_dp_split=False, task_p=2.0, batch_offset=0, dp_overlap=None, fuse_tail=True, batch_step=True, use_h2=True, rd=None):
         if kind not in UNIT_KINDS:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4):
-                raise RuntimeError("calibration engine: caches must be contiguous fp32 NHWC CUDA tensors")
+                raise RuntimeError("calibration engine: caches must be contiguous fh22 NHWC CUDA tensors")
         self.kind, self.mods = kind, modules
         self.cq, self.cf, self.co = cache_q, cache_fp, cache_out
         self.B, self.iters = int(batch_size), int(iters)
@@ -154,21 +171,21 @@ class UnitEngine:
         self.use_graph = use_graph
         self.batch_offset = int(batch_offset)  # first row of this rank's share of the global mini-batch (QDrop counter)
         self.dp_overlap = None if dp_overlap is None else bool(dp_overlap)
-        if os.environ.get("RDO_USE_P3") is not None:
-            use_p3 = os.environ["RDO_USE_P3"] != "0"      # A/B switch for whole runs (bench.py)
-        self.use_p3 = bool(use_p3)             # big units on P3 tensors (plane-input LDS-DMA GEMM kernels); False: fp32 activations only
-        self.P = {}                            # name -> planes of the P3 form of an activation buffer
+        if os.environ.get("RDO_USE_H2") is not None:
+            use_h2 = os.environ["RDO_USE_H2"] != "0"      # A/B switch for whole runs (bench.py)
+        self.use_h2 = bool(use_h2)             # big units on H2 tensors (plane-input LDS-DMA GEMM kernels); False: fh22 activations only
+        self.P = {}                            # name -> planes of the H2 form of an activation buffer
         self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
         self.fuse_splitk = os.environ.get("RDO_FUSE_SPLITK", "1") != "0"   # split-K conv + unit tail: the conv's second pass inside the tail
-        self.fuse_p3_tail = os.environ.get("RDO_P3_TAIL", "1") != "0"       # last conv of a P3 ResidualBlock unit + its tail in one launch
+        self.fuse_h2_tail = os.environ.get("RDO_H2_TAIL", "1") != "0"       # last conv of a H2 ResidualBlock unit + its tail in one launch
         self.fold_iter = os.environ.get("RDO_FOLD_ITER", "1") != "0"     # iteration-counter hand-over instead of an increment launch
         # opt-in R + lambda*D task loss (loss_mode='rd'): dict(model=QuantModel, unit=module, cali=calibration images NCHW on the GPU,
         # lmbda=float).  The unit output of every iteration is pushed through the REST of the wrapped model on torch's tape
         # (hipops.autograd) and losses.RateDistortionLoss is differentiated back to it; rec_loss stays the lp term.
         self.rd = rd
         if rd is not None:
-            fuse_tail = use_p3 = False
-            self.use_p3 = False
+            fuse_tail = use_h2 = False
+            self.use_h2 = False
         self.fuse_tail = bool(fuse_tail)       # False: the separate epilogue / loss / activation-backward kernels (A/B, tests)
         self.dev = cache_q.device
         n = cache_q.shape[0]
@@ -203,6 +220,9 @@ class UnitEngine:
         self._dp_graph, self._dp_graph_failed = None, False
         self._build_ops()
         self._alloc()
+        self.scales = {}                       # activation buffer name -> power-of-two scale of its H2 planes
+        self._probing = False
+        self._probe_scales()
         self._record()
         for op in self.ops.values():
             op.refresh_planes()          # initial soft weights -> bf16 planes (eager, before the first iteration)
@@ -369,7 +389,7 @@ class UnitEngine:
 
     def _shuffle(self, x, r, out):
         if r == 2 and x.shape[-1] % 16 == 0:
-            return ops.pixel_shuffle_p3(x, out=out)
+            return ops.pixel_shuffle_h2(x, out=out)
         return ops.pixel_shuffle(x, r, out)
 
     def _unshuffle(self, x, r, out):
@@ -401,100 +421,101 @@ class UnitEngine:
         self._task_is_rec = True
         ops.loss_gdn_bwd(x, norm, res, self.co, self.idx, self.it, 2.0, inverse, self.loss_log, gout, t=tbuf)
 
-    # ------------------------------------------------------------------------------------------------------------------ P3 path
+    # ------------------------------------------------------------------------------------------------------------------ H2 path
     # FLOPs of the unit's last weight gradient from which the bucket all-reduce is split in two (see _build_ops): 43.5 GFLOP (~200 us)
     # for the 3x3 convs of the 128^2 units hides a collective; 10.9 GFLOP (~45 us, the 64^2 units) is about the latency of the second
     # all-reduce the split adds, and the 3 -> 192 stem of g_a.0 is 26 us
     DP_OVERLAP_MIN_FLOP = 30e9
-    P3_MIN_OUT = 65536 * 192        # plane-input forward kernel pays off from 4 x 128^2 x 192 output elements (profiles/r02a)
-    p3_lean = os.environ.get("RDO_P3_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fp32
+    H2_MIN_OUT = 65536 * 192        # plane-input forward kernel pays off from 4 x 128^2 x 192 output elements (profiles/r02a)
+    h2_lean = os.environ.get("RDO_H2_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fh22
 
-    def _p3(self, name, like):
+    def _h2(self, name, like):
+        """Planes of activation buffer `name` (H2 form, scale from the probe iteration)."""
         if name not in self.P:
-            self.P[name] = ops.p3_empty(like.shape, self.dev)
+            self.P[name] = ops.h2_empty(like.shape, self.dev, self.scales[name])
         return self.P[name]
 
-    def _conv_ok_p3(self, op, x_shape, dgrad=False):
+    def _conv_ok_h2(self, op, x_shape, dgrad=False):
         if dgrad:
             w4, stride, pad = tuple(op.wd4().shape), 1, op.K - 1 - op.pad
         else:
             w4, stride, pad = op.w4, op.stride, op.pad
-        if not ops.conv_p3_supported(tuple(x_shape), w4, stride, pad):
+        if not ops.conv_h2_supported(tuple(x_shape), w4, stride, pad):
             return False
         d = ops.conv_desc(tuple(x_shape), w4, stride, pad)
-        return d.B * d.Ho * d.Wo * d.Cout >= self.P3_MIN_OUT
+        return d.B * d.Ho * d.Wo * d.Cout >= self.H2_MIN_OUT
 
-    def _conv_p3(self, op, xp, x_shape, out=None, out_planes=None, epilogue=L.EPI_NONE, aux=None, residual=None, pre=None):
-        op.enable_planes(True, False)
-        ops.conv2d_fwd_p3(xp, tuple(x_shape), op.w4, op.wq_planes, op.beta if op.is_gdn else op.bias, op.stride, op.pad,
+    def _conv_h2(self, op, xp, x_shape, out=None, out_planes=None, epilogue=L.EPI_NONE, aux=None, residual=None, pre=None):
+        op.enable_planes(True, False, h2=True)
+        ops.conv2d_fwd_h2(xp, tuple(x_shape), op.w4, op.wq_planes, op.beta if op.is_gdn else op.bias, op.stride, op.pad,
                           epilogue=epilogue, aux=aux, residual=residual, out=out, pre=pre, out_planes=out_planes)
 
-    def _dgrad_p3(self, op, dyp, dy_shape, out=None, out_planes=None, epilogue=L.EPI_NONE, aux=None, aux_planes=None):
-        op.enable_planes(False, True)
-        ops.conv2d_fwd_p3(dyp, tuple(dy_shape), tuple(op.wd4().shape), op.wd_planes, None, 1, op.K - 1 - op.pad, epilogue=epilogue,
+    def _dgrad_h2(self, op, dyp, dy_shape, out=None, out_planes=None, epilogue=L.EPI_NONE, aux=None, aux_planes=None):
+        op.enable_planes(False, True, h2=True)
+        ops.conv2d_fwd_h2(dyp, tuple(dy_shape), tuple(op.wd4().shape), op.wd_planes, None, 1, op.K - 1 - op.pad, epilogue=epilogue,
                           aux=aux, aux_planes=aux_planes, out=out, out_planes=out_planes)
 
-    def _wgrad_p3(self, op, xp, x_shape, dyp):
+    def _wgrad_h2(self, op, xp, x_shape, dyp):
         if op.slabs is None:
             self._slabs(op, x_shape)
-        ops.conv2d_wgrad_p3(xp, tuple(x_shape), dyp, op.w4, op.stride, op.pad, slabs=op.slabs)
+        ops.conv2d_wgrad_h2(xp, tuple(x_shape), dyp, op.w4, op.stride, op.pad, slabs=op.slabs)
 
-    def _gdn_backward_p3(self, g, dout, xin, norm, tp, acc, dxp):
+    def _gdn_backward_h2(self, g, dout, xin, norm, tp, acc, dxp):
         """GDN / IGDN backward with t given as planes `tp` (written by the fused tail): acc = t . gamma' on the plane kernel, then
         dx as planes only (its consumers are the plane-input weight gradient and dgrad)."""
-        self._dgrad_p3(g, tp, xin.shape, out=acc)
-        ops.gdn_bwd_dx_p3(dout, xin, norm, acc, g.inverse, dx_planes=dxp)
+        self._dgrad_h2(g, tp, xin.shape, out=acc)
+        ops.gdn_bwd_dx_h2(dout, xin, norm, acc, g.inverse, dx_planes=dxp)
 
-    def _plan_p3(self):
-        """Which big convs of this unit run on P3 tensors (decided once, at record time)."""
+    def _plan_h2(self):
+        """Which big convs of this unit run on H2 tensors (decided once, at record time)."""
         o, k = self.ops, self.kind
-        if not (self.use_p3 and self.fused):
+        if not (self.use_h2 and self.fused):
             return None
         xs = tuple(self.x_in.shape)
         if k == "rb" and "skip" not in o:
             c1, c2 = o["conv1"], o["conv2"]
             hs = tuple(self.t["h1"].shape)
-            if (self._conv_ok_p3(c1, xs) and self._conv_ok_p3(c2, hs) and self._conv_ok_p3(c2, hs, dgrad=True)
-                    and ops.wgrad_p3_supported(xs, c1.w4, c1.stride, c1.pad) and ops.wgrad_p3_supported(hs, c2.w4, 1, c2.pad)):
+            if (self._conv_ok_h2(c1, xs) and self._conv_ok_h2(c2, hs) and self._conv_ok_h2(c2, hs, dgrad=True)
+                    and ops.wgrad_h2_supported(xs, c1.w4, c1.stride, c1.pad) and ops.wgrad_h2_supported(hs, c2.w4, 1, c2.pad)):
                 return "rb"
         if k in ("rbws", "rbu"):
             cv, g = (o["conv2"], o["gdn"]) if k == "rbws" else (o["conv"], o["igdn"])
             hs = tuple(self.t["h1"].shape)
-            if (hs[-1] % 16 == 0 and (k != "rbu" or self.r == 2) and self._conv_ok_p3(cv, hs) and self._conv_ok_p3(cv, hs, dgrad=True)
-                    and ops.wgrad_p3_supported(hs, cv.w4, 1, cv.pad) and self._conv_ok_p3(g, hs, dgrad=True)):
+            if (hs[-1] % 16 == 0 and (k != "rbu" or self.r == 2) and self._conv_ok_h2(cv, hs) and self._conv_ok_h2(cv, hs, dgrad=True)
+                    and ops.wgrad_h2_supported(hs, cv.w4, 1, cv.pad) and self._conv_ok_h2(g, hs, dgrad=True)):
                 return k
         return None
 
-    def _fb_rb_p3(self):
+    def _fb_rb_h2(self):
         o, t, x = self.ops, self.t, self.x_in
         c1, c2 = o["conv1"], o["conv2"]
-        xp, h1p = self._p3("x", x), self._p3("h1", t["h1"])
-        dp2p, dh1p = self._p3("dpre2", t["h1"]), self._p3("dh1", t["h1"])
-        lean = self.p3_lean
+        xp, h1p = self._h2("x", x), self._h2("h1", t["h1"])
+        dp2p, dh1p = self._h2("dpre2", t["h1"]), self._h2("dh1", t["h1"])
+        lean = self.h2_lean
         # lean: x and h1 exist as planes only -- the residual add of the tail sums the three planes back (exactly), the LeakyReLU
         # mask of the dgrad epilogue reads the sign off plane 0
-        ops.gather_qdrop_p3(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None if lean else x, xp,
+        ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None if lean else x, xp,
                             self.batch_offset, iter_publish=self._it_pub())
-        self._conv_p3(c1, xp, x.shape, out=None if lean else t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
+        self._conv_h2(c1, xp, x.shape, out=None if lean else t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
         self._task_is_rec = True
-        if self.fuse_p3_tail and ops.conv_p3_tail_supported(tuple(t["h1"].shape), c2.w4, c2.stride, c2.pad):
+        if self.fuse_h2_tail and ops.conv_h2_tail_supported(tuple(t["h1"].shape), c2.w4, c2.stride, c2.pad):
             # conv2 + tail in one launch: the pre-activation never reaches memory
-            c2.enable_planes(True, False)
-            ops.conv2d_fwd_p3_tail(h1p, tuple(t["h1"].shape), c2.w4, c2.wq_planes, c2.bias, c2.stride, c2.pad, xp, self.co, self.idx, self.it,
+            c2.enable_planes(True, False, h2=True)
+            ops.conv2d_fwd_h2_tail(h1p, tuple(t["h1"].shape), c2.w4, c2.wq_planes, c2.bias, c2.stride, c2.pad, xp, self.co, self.idx, self.it,
                                    2.0, ops.ACT_LRELU, dp2p, self.loss_log)
         else:
-            self._conv_p3(c2, h1p, t["h1"].shape, out=t["pre2"])
+            self._conv_h2(c2, h1p, t["h1"].shape, out=t["pre2"])
             ops.loss_act_bwd(t["pre2"], None if lean else x, self.co, self.idx, self.it, 2.0, ops.ACT_LRELU, self.loss_log, dpre_planes=dp2p,
                              residual_planes=xp if lean else None)
-        self._wgrad_p3(c2, h1p, t["h1"].shape, dp2p)
-        self._dgrad_p3(c2, dp2p, t["h1"].shape, out_planes=dh1p, epilogue=L.EPI_LRELU_BWD, aux=None if lean else t["h1"],
+        self._wgrad_h2(c2, h1p, t["h1"].shape, dp2p)
+        self._dgrad_h2(c2, dp2p, t["h1"].shape, out_planes=dh1p, epilogue=L.EPI_LRELU_BWD, aux=None if lean else t["h1"],
                        aux_planes=h1p if lean else None)
         self._split_point()
-        self._wgrad_p3(c1, xp, x.shape, dh1p)
+        self._wgrad_h2(c1, xp, x.shape, dh1p)
 
-    def _fb_gdn_block_p3(self):
+    def _fb_gdn_block_h2(self):
         """RBWS / RBU whose second conv and GDN run at >= 4 x 128^2 x 192: that conv, its weight gradient and dgrad, and the
-        gamma'^T GEMM of the GDN backward on P3 tensors; the (cheap or thin) first convs stay on fp32 activations."""
+        gamma'^T GEMM of the GDN backward on H2 tensors; the (cheap or thin) first convs stay on fh22 activations."""
         o, t, x = self.ops, self.t, self.x_in
         rbu = self.kind == "rbu"
         ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
@@ -505,57 +526,57 @@ class UnitEngine:
         else:
             c1, cv, g = o["conv1"], o["conv2"], o["gdn"]
             cname, dname = "c2", "dc2"
-        h1p, tp, dcp = self._p3("h1", t["h1"]), self._p3("t", t["h1"]), self._p3(dname, t["h1"])
+        h1p, tp, dcp = self._h2("h1", t["h1"]), self._h2("t", t["h1"]), self._h2(dname, t["h1"])
         if rbu:
             r = self.r
             # the two 192 -> 768 sub-pixel convs and their weight gradients on planes as well when the shapes qualify
             xs = tuple(x.shape)
-            sub_p3 = (x.shape[-1] % 16 == 0 and self._conv_ok_p3(sp, xs) and self._conv_ok_p3(up, xs)
-                      and ops.wgrad_p3_supported(xs, sp.w4, sp.stride, sp.pad) and ops.wgrad_p3_supported(xs, up.w4, up.stride, up.pad))
-            if sub_p3:
-                xp = self._p3("x", x)
-                ops.split_p3(x, xp)
-                self._conv_p3(sp, xp, xs, out=t["sp"], epilogue=L.EPI_LRELU)
-                self._conv_p3(up, xp, xs, out=t["up"])
+            sub_h2 = (x.shape[-1] % 16 == 0 and self._conv_ok_h2(sp, xs) and self._conv_ok_h2(up, xs)
+                      and ops.wgrad_h2_supported(xs, sp.w4, sp.stride, sp.pad) and ops.wgrad_h2_supported(xs, up.w4, up.stride, up.pad))
+            if sub_h2:
+                xp = self._h2("x", x)
+                ops.split_h2(x, xp)
+                self._conv_h2(sp, xp, xs, out=t["sp"], epilogue=L.EPI_LRELU)
+                self._conv_h2(up, xp, xs, out=t["up"])
             else:
                 self._conv(sp, x, t["sp"], epilogue=L.EPI_LRELU)
                 self._conv(up, x, t["up"])
-            ops.pixel_shuffle_p3(t["sp"], out=None if self.p3_lean else t["h1"], out_planes=h1p)
+            ops.pixel_shuffle_h2(t["sp"], out=None if self.h2_lean else t["h1"], out_planes=h1p)
             self._shuffle(t["up"], r, t["ups"])
             res = t["ups"]
         else:
             self._conv(c1, x, t["h1"], epilogue=L.EPI_LRELU)
-            ops.split_p3(t["h1"], h1p)
+            ops.split_h2(t["h1"], h1p)
             res = x
             if "skip" in o:
                 self._conv(o["skip"], x, t["sk"])
                 res = t["sk"]
-        self._conv_p3(cv, h1p, t["h1"].shape, out=t[cname])
+        self._conv_h2(cv, h1p, t["h1"].shape, out=t[cname])
         self._conv(g, t[cname], t["norm"], square=True)
         self._task_is_rec = True
         ops.loss_gdn_bwd(t[cname], t["norm"], res, self.co, self.idx, self.it, 2.0, rbu, self.loss_log, t["dout"], t=t["t"], t_planes=tp)
         if rbu:
-            if sub_p3:
-                dupp = self._p3("dup", t["dup"])
+            if sub_h2:
+                dupp = self._h2("dup", t["dup"])
                 ops.pixel_unshuffle2(t["dout"], out_planes=dupp)
-                self._wgrad_p3(up, xp, xs, dupp)
+                self._wgrad_h2(up, xp, xs, dupp)
             else:
                 self._unshuffle(t["dout"], r, t["dup"])
                 self._wgrad(up, x, t["dup"])
         elif "skip" in o:
             self._wgrad(o["skip"], x, t["dout"])
-        self._gdn_backward_p3(g, t["dout"], t[cname], t["norm"], tp, t["acc"], dcp)
+        self._gdn_backward_h2(g, t["dout"], t[cname], t["norm"], tp, t["acc"], dcp)
         self._wgrad(g, t[cname], t["t"], square=True)
-        self._wgrad_p3(cv, h1p, t["h1"].shape, dcp)
-        lean_aux = rbu and self.p3_lean
-        self._dgrad_p3(cv, dcp, t["h1"].shape, out=t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=None if lean_aux else t["h1"],
+        self._wgrad_h2(cv, h1p, t["h1"].shape, dcp)
+        lean_aux = rbu and self.h2_lean
+        self._dgrad_h2(cv, dcp, t["h1"].shape, out=t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=None if lean_aux else t["h1"],
                        aux_planes=h1p if lean_aux else None)
         if rbu:
-            if sub_p3:
-                dspp = self._p3("dsp", t["dsp"])
+            if sub_h2:
+                dspp = self._h2("dsp", t["dsp"])
                 ops.pixel_unshuffle2(t["dh1"], out_planes=dspp)
                 self._split_point()
-                self._wgrad_p3(sp, xp, xs, dspp)
+                self._wgrad_h2(sp, xp, xs, dspp)
             else:
                 self._unshuffle(t["dh1"], r, t["dsp"])
                 self._split_point()
@@ -564,13 +585,46 @@ class UnitEngine:
             self._split_point()
             self._wgrad(c1, x, t["dh1"])
 
+    H2_PROBED = {"rb": ("x", "h1", "dpre2", "dh1"), "rbws": ("h1", "t", "dc2"), "rbu": ("x", "h1", "t", "dc", "dup", "dsp")}
+
+    def _probe_scales(self):
+        """fp16 planes need a per-tensor power-of-two scale (include/rdo_ptq_hip.h, "H2 tensors").  One PROBE iteration of the unit on
+        fp32 activations and the plain fp32 kernels (no planes, no AdaRound step), run eagerly before the plan is recorded, gives the
+        magnitude of every tensor the plan will keep as planes; the scale puts that magnitude at 2^7 -- a x512 margin before fp16
+        overflows (which the producers flag, see `_check_overflow`) and x512 down before accuracy would start to degrade.  The
+        reconstruction error, hence the gradients, changes by far less than that over a run (profiles/r03_full_schedule.log)."""
+        plan = self._plan_h2()
+        if plan is None:
+            return
+        saved = ops.set_tuning("conv_x6", 0)
+        self._probing = True
+        try:
+            self._forward_backward()
+        finally:
+            self._probing = False
+            ops.set_tuning("conv_x6", saved)
+        names = self.H2_PROBED[plan]
+        amax = torch.stack([(self.x_in if n == "x" else self.t[n]).abs().max() for n in names]).cpu()
+        if not torch.isfinite(amax).all():
+            raise RuntimeError("calibration engine: non-finite activations in the probe iteration")
+        self.scales = {n: ops.pow2_scale(float(a)) for n, a in zip(names, amax)}
+        # the probe leaves no trace: logs of iteration 0, counters, gradient slabs (the recorded kernels may want another split count)
+        self.loss_log.zero_(); self.task_log.zero_(); self.round_log.zero_(); self._it2.zero_()
+        for op in self.ops.values():
+            op.slabs = None
+
+    def _check_overflow(self):
+        if self.P and ops.h2_overflow(reset=True):
+            raise RuntimeError("calibration engine: a value left the fp16 range of its H2 planes (scales from the probe iteration: "
+                               f"{self.scales}); results of this run are invalid")
+
     def _forward_backward(self):
         o, t, x = self.ops, self.t, self.x_in
-        self.p3_plan = self._plan_p3()
-        if self.p3_plan == "rb":
-            return self._fb_rb_p3()
-        if self.p3_plan in ("rbws", "rbu"):
-            return self._fb_gdn_block_p3()
+        self.h2_plan = None if self._probing else self._plan_h2()
+        if self.h2_plan == "rb":
+            return self._fb_rb_h2()
+        if self.h2_plan in ("rbws", "rbu"):
+            return self._fb_gdn_block_h2()
         ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
                          iter_publish=self._it_pub())
         if self.kind == "layer" and o["layer"].is_gdn:
@@ -675,7 +729,7 @@ class UnitEngine:
             g.enable_planes(False, True)
         ops.conv2d_fwd(tbuf, g.wd4(), None, 1, 0, out=acc, wplanes=g.wd_planes)   # t . gamma'  (wd = gamma'^T as [C][1][1][C])
         if xin.numel() % 4 == 0:
-            ops.gdn_bwd_dx_p3(dout, xin, norm, acc, inverse, dx=dx)   # 16-byte accesses
+            ops.gdn_bwd_dx_h2(dout, xin, norm, acc, inverse, dx=dx)   # 16-byte accesses
         else:
             ops.gdn_bwd_dx(dout, xin, norm, acc, inverse, dx)
         self._wgrad(g, xin, tbuf, square=True)                        # dgamma'[k][i] = sum_m t_k x_i^2
@@ -725,7 +779,7 @@ class UnitEngine:
         """Called by the backward pass right before its last weight-gradient kernel.  Data-parallel recording only: the gradients
         of every other op are final here -> chain them into the front of the bucket, close plan A and continue in plan A2, so
         that `run` can start the all-reduce of the front while the last wgrad computes."""
-        if self._late is None or self.plan_a2 is not None:
+        if self._probing or self._late is None or self.plan_a2 is not None:
             return
         self._grad_ops([n for n in self.ops if n != self._late])
         self._rec_ctx.__exit__(None, None, None)
@@ -888,6 +942,7 @@ class UnitEngine:
     def logs(self):
         """(total, rec+task, round) per iteration as CPU tensors (synchronises)."""
         rec, task = self._data_terms()
+        self._check_overflow()
         rt = (rec + task).cpu()
         rd = self.round_log.sum(1).cpu()
         return rt + rd, rt, rd
@@ -910,6 +965,7 @@ class UnitEngine:
     def finish(self):
         """Hand the trained rounding back to the modules: AdaRoundQuantizer with hard targets, `trained` flags
         (layer_opt.py:313-316 / block_opt.py:316-321)."""
+        self._check_overflow()
         for name, op in self.ops.items():
             qm = op.qm
             rows = op.alpha.flip(1, 2).contiguous() if op.tconv is not None else op.alpha

@@ -97,7 +97,7 @@ def test_block_units_n192_match_oracle_trajectory(cheng192_blocks, name):
     eng = UnitEngine(kind, mods, nh(inp_q), nh(inp), nh(out), batch_size=B, iters=ITERS, weight=0.01, b_range=(20, 2),
                      warmup=0.2, input_prob=0.5, seed=SEED, idx_table=torch.from_numpy(idx))
     if kind != "layer" and out.shape[1] * out.shape[2] * out.shape[3] * B >= 65536 * 192:
-        assert eng.p3_plan == kind, "the 128^2 units must run on the plane-input (P3) kernels in this test"
+        assert eng.h2_plan == kind, "the 128^2 units must run on the plane-input (H2) kernels in this test"
     for n, op in ops_o.items():
         e = eng.ops[n]
         np.testing.assert_array_equal(e.delta.cpu().numpy(), op.delta.reshape(-1).numpy())

@@ -216,15 +216,15 @@ def test_full_size_rbu_unit_step_matches_torch_autograd():
     _step_vs_autograd(eng, forward, cq, co, ["subpel_conv", "conv", "igdn", "upsample"])
 
 
-# ---- the same units on P3 tensors (plane-input kernels) and on fp32 activations ---------------------------------------------------
-def _p3_vs_fp32(make_blk, qcls, cq_shape, seed, plan):
-    """Three iterations of one full-size unit with use_p3 on / off: same losses (summation order aside), same alphas except where
+# ---- the same units on H2 tensors (plane-input kernels) and on fp32 activations ---------------------------------------------------
+def _h2_vs_fp32(make_blk, qcls, cq_shape, seed, plan):
+    """Three iterations of one full-size unit with use_h2 on / off: same losses (summation order aside), same alphas except where
     Adam amplifies a gradient at the fp32 noise level."""
     from quantization.engine import UnitEngine
     from quantization.recon import _unit_modules
     WQ = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
     res = []
-    for use_p3 in (True, False):
+    for use_h2 in (True, False):
         torch.manual_seed(seed)
         blk = make_blk()
         unit = qcls(blk, WQ, dict(WQ, leaf_param=False)).cuda()
@@ -236,8 +236,8 @@ def _p3_vs_fp32(make_blk, qcls, cq_shape, seed, plan):
         with torch.no_grad():
             co = blk(cf.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
         idx = torch.stack([torch.arange(n, dtype=torch.int32)] * 3)
-        eng = UnitEngine(kind, mods, cq, cf, co, batch_size=n, iters=3, warmup=0.0, input_prob=0.5, seed=3, idx_table=idx, use_p3=use_p3)
-        assert eng.p3_plan == (plan if use_p3 else None)
+        eng = UnitEngine(kind, mods, cq, cf, co, batch_size=n, iters=3, warmup=0.0, input_prob=0.5, seed=3, idx_table=idx, use_h2=use_h2)
+        assert eng.h2_plan == (plan if use_h2 else None)
         eng.run()
         torch.cuda.synchronize()
         res.append(({k: eng.alpha_of(k).clone() for k in eng.ops}, eng.logs()[0]))
@@ -248,13 +248,13 @@ def _p3_vs_fp32(make_blk, qcls, cq_shape, seed, plan):
         assert float(bad.float().mean()) < 2e-3, (k, float(bad.float().mean()))
 
 
-def test_rb_unit_on_p3_tensors_matches_fp32_activations():
+def test_rb_unit_on_h2_tensors_matches_fp32_activations():
     import lic
     from quantization.quant_block import QuantRB
-    _p3_vs_fp32(lambda: lic.ResidualBlock(N, N).cuda(), QuantRB, (4, 128, 128, N), 31, "rb")
+    _h2_vs_fp32(lambda: lic.ResidualBlock(N, N).cuda(), QuantRB, (4, 128, 128, N), 31, "rb")
 
 
-def test_rbu_unit_on_p3_tensors_matches_fp32_activations():
+def test_rbu_unit_on_h2_tensors_matches_fp32_activations():
     import lic
     from quantization.quant_block import QuantRBU
 
@@ -262,10 +262,10 @@ def test_rbu_unit_on_p3_tensors_matches_fp32_activations():
         blk = lic.ResidualBlockUpsample(N, N, 2)
         _seed_gdn(blk.igdn, torch.Generator().manual_seed(5))
         return blk.cuda()
-    _p3_vs_fp32(mk, QuantRBU, (4, 64, 64, N), 32, "rbu")
+    _h2_vs_fp32(mk, QuantRBU, (4, 64, 64, N), 32, "rbu")
 
 
-def test_rbws_stem_unit_on_p3_tensors_matches_fp32_activations():
+def test_rbws_stem_unit_on_h2_tensors_matches_fp32_activations():
     """g_a.0 of Cheng2020-anchor: 3 -> 192 at 256^2 -> 128^2 (thin RGB stem kernels feeding a P3 second conv and GDN backward)."""
     import lic
     from quantization.quant_block import QuantRBWS
@@ -274,12 +274,12 @@ def test_rbws_stem_unit_on_p3_tensors_matches_fp32_activations():
         blk = lic.ResidualBlockWithStride(3, N, stride=2)
         _seed_gdn(blk.gdn, torch.Generator().manual_seed(6))
         return blk.cuda()
-    _p3_vs_fp32(mk, QuantRBWS, (4, 256, 256, 3), 33, "rbws")
+    _h2_vs_fp32(mk, QuantRBWS, (4, 256, 256, 3), 33, "rbws")
 
 
 @pytest.mark.parametrize("kind", ["rb", "rbu"])
-def test_full_size_p3_units_data_parallel_sequence_equals_fused_step(kind):
-    """The 128^2 units on P3 tensors (halo / row kernels, conv2 + tail in one launch) through the data-parallel op sequence on one rank
+def test_full_size_h2_units_data_parallel_sequence_equals_fused_step(kind):
+    """The 128^2 units on H2 tensors (halo / row kernels, conv2 + tail in one launch) through the data-parallel op sequence on one rank
     (gradient -> bucket -> apply, all-reduce split in two around the last weight gradient) against the fused single-launch step:
     bit-identical alphas."""
     import lic
@@ -305,7 +305,7 @@ def test_full_size_p3_units_data_parallel_sequence_equals_fused_step(kind):
             co = blk(cf.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
         idx = torch.stack([torch.arange(4, dtype=torch.int32)] * 4)
         eng = UnitEngine(k, mods, cq, cf, co, batch_size=4, iters=4, warmup=0.0, input_prob=0.5, seed=3, idx_table=idx, force_dp_split=split)
-        assert eng.p3_plan == kind and (eng.plan_a2 is not None) == split          # 43.5-GFLOP last wgrad: the all-reduce is split
+        assert eng.h2_plan == kind and (eng.plan_a2 is not None) == split          # 43.5-GFLOP last wgrad: the all-reduce is split
         eng.run()
         torch.cuda.synchronize()
         res.append(({n: eng.alpha_of(n).clone() for n in eng.ops}, eng.logs()[0]))

@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/ab_unit
 mkdir -p $OUT
-export RDO_USE_P3=1
+export RDO_USE_H2=1
 for k in 0 3 4 11 32; do
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/t -o t --output-format csv -- python3 $R/tools/long_run_units.py --iters 220 --images 16 --units rb --tune x6p_ablate=$k > $OUT/log_abl_$k.txt 2>&1
   echo "abl=$k rc=$?"

@@ -6,7 +6,7 @@ OUT=$R/gpurun_out/ab_unit
 mkdir -p $OUT
 for u in rb rbu; do
 for p in 0 1; do
-  export RDO_USE_P3=$p
+  export RDO_USE_H2=$p
   timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/t -o t --output-format csv -- python3 $R/tools/long_run_units.py --iters 320 --images 16 --units $u > $OUT/log_${u}_$p.txt 2>&1
   echo "$u p3=$p rc=$?"
   cp $(find $OUT/t -name "*kernel_stats.csv" | head -1) $OUT/${u}_p3_${p}_stats.csv

@@ -32,16 +32,16 @@ def main():
     it = torch.zeros(1, dtype=torch.int32, device=dev)
     x, nrm, acc, gg = r(B, H, H, C), r(B, H, H, C).abs() + 1, r(B, H, H, C), r(B, H, H, C)
     out, gout, t = torch.empty_like(x), torch.empty_like(x), torch.empty_like(x)
-    pl, pl2 = ops.p3_empty(x.shape, dev), ops.p3_empty(x.shape, dev)
+    pl, pl2 = ops.h2_empty(x.shape, dev, 16.0), ops.h2_empty(x.shape, dev, 16.0)
     log = torch.zeros(4, 32, device=dev)
     small = r(B, H // 2, H // 2, 4 * C)
-    spl = ops.p3_empty(small.shape, dev)
+    spl = ops.h2_empty(small.shape, dev, 16.0)
     mb = x.numel() / 1e6
     rows = [
         ("gather_qdrop (fp32)", lambda: ops.gather_qdrop(cq, cf, idx, it, B, 0.5, 1, out), 12),
-        ("gather_qdrop_p3 (fp32 + planes)", lambda: ops.gather_qdrop_p3(cq, cf, idx, it, B, 0.5, 1, out, pl), 18),
-        ("gather_qdrop_p3 (planes)", lambda: ops.gather_qdrop_p3(cq, cf, idx, it, B, 0.5, 1, None, pl), 14),
-        ("split_p3", lambda: ops.split_p3(x, pl), 10),
+        ("gather_qdrop_h2 (fp32 + planes)", lambda: ops.gather_qdrop_h2(cq, cf, idx, it, B, 0.5, 1, out, pl), 18),
+        ("gather_qdrop_h2 (planes)", lambda: ops.gather_qdrop_h2(cq, cf, idx, it, B, 0.5, 1, None, pl), 14),
+        ("split_h2", lambda: ops.split_h2(x, pl), 10),
         ("loss_act_bwd (res, dpre fp32)", lambda: ops.loss_act_bwd(x, acc, tgt, idx, it, 2.0, 1, log, dpre=t), 16),
         ("loss_act_bwd (res, dpre planes)", lambda: ops.loss_act_bwd(x, acc, tgt, idx, it, 2.0, 1, log, dpre_planes=pl), 18),
         ("loss_act_bwd (res planes, dpre planes)",
@@ -49,11 +49,11 @@ def main():
         ("loss_gdn_bwd (res, gout, t fp32)", lambda: ops.loss_gdn_bwd(x, nrm, acc, tgt, idx, it, 2.0, False, log, gout, t=t), 24),
         ("loss_gdn_bwd (res, gout, t fp32 + planes)",
          lambda: ops.loss_gdn_bwd(x, nrm, acc, tgt, idx, it, 2.0, False, log, gout, t=t, t_planes=pl), 30),
-        ("gdn_bwd_dx (fp32)", lambda: ops.gdn_bwd_dx_p3(gg, x, nrm, acc, False, dx=out), 20),
-        ("gdn_bwd_dx (planes)", lambda: ops.gdn_bwd_dx_p3(gg, x, nrm, acc, False, dx_planes=pl), 22),
-        ("pixel_shuffle (fp32)", lambda: ops.pixel_shuffle_p3(small, out=out), 8),
-        ("pixel_shuffle (fp32 + planes)", lambda: ops.pixel_shuffle_p3(small, out=out, out_planes=pl), 14),
-        ("pixel_shuffle (planes)", lambda: ops.pixel_shuffle_p3(small, out_planes=pl), 10),
+        ("gdn_bwd_dx (fp32)", lambda: ops.gdn_bwd_dx_h2(gg, x, nrm, acc, False, dx=out), 20),
+        ("gdn_bwd_dx (planes)", lambda: ops.gdn_bwd_dx_h2(gg, x, nrm, acc, False, dx_planes=pl), 22),
+        ("pixel_shuffle (fp32)", lambda: ops.pixel_shuffle_h2(small, out=out), 8),
+        ("pixel_shuffle (fp32 + planes)", lambda: ops.pixel_shuffle_h2(small, out=out, out_planes=pl), 14),
+        ("pixel_shuffle (planes)", lambda: ops.pixel_shuffle_h2(small, out_planes=pl), 10),
         ("pixel_unshuffle (fp32)", lambda: ops.pixel_unshuffle2(x, out=small), 8),
         ("pixel_unshuffle (planes)", lambda: ops.pixel_unshuffle2(x, out_planes=spl), 10),
     ]

@@ -50,20 +50,20 @@ B, H, C = 4, 128, 192
 torch.manual_seed(0)
 x = torch.randn(B, H, H, C, device="cuda")
 w = torch.randn(C, 3, 3, C, device="cuda") / (C * 9) ** 0.5
-wpl, xp = ops.split_bf16x3(w), ops.split_p3(x)
+wpl6, wpl, xp = ops.split_bf16x3(w), ops.split_h2_conv(w), ops.split_h2(x)
 out = torch.empty(B, H, H, C, device="cuda")
 y = torch.empty_like(x)
 th = threading.Thread(target=sampler, daemon=True)
 th.start()
 time.sleep(1.5)
 phases = [("idle", None)]
-conv = lambda: ops.conv2d_fwd_p3(xp, tuple(x.shape), tuple(w.shape), wpl, None, 1, 1, out=out)
+conv = lambda: ops.conv2d_fwd_h2(xp, tuple(x.shape), tuple(w.shape), wpl, None, 1, 1, out=out)
 for name, abl in (("plane-input conv (halo kernel)", 0), ("same, no fragment reads", 8), ("same, no DMA (MFMAs + fragment reads)", 3),
                   ("same, no DMA, no fragment reads (MFMAs only)", 11), ("same, no MFMA (DMA + fragment reads)", 4)):
     ops.set_tuning("x6p_ablate", abl)
     phases.append((name, run_for(conv, 4.0)))
 ops.set_tuning("x6p_ablate", 0)
-phases.append(("fp32-input x6 conv (v6)", run_for(lambda: ops.conv2d_fwd(x, w, None, 1, 1, out=out, wplanes=wpl), 4.0)))
+phases.append(("fp32-input x6 conv (v6)", run_for(lambda: ops.conv2d_fwd(x, w, None, 1, 1, out=out, wplanes=wpl6), 4.0)))
 phases.append(("element-wise add (HBM-bound)", run_for(lambda: ops.add(x, out, out=y), 4.0)))
 stop.set()
 th.join()

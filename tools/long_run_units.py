@@ -62,7 +62,7 @@ for name, mk, qcls, shape in (("g_a.1 RB @128^2", lambda: lic.ResidualBlock(N, N
     dt = time.perf_counter() - t0
     total, rt, rd = eng.logs()
     h = torch.cat([torch.clamp(torch.sigmoid(eng.alpha_of(k)) * 1.2 - 0.1, 0, 1).reshape(-1) for k in eng.ops])
-    print(f"{name}: p3_plan={eng.p3_plan}; {a.iters - 20} iterations in {dt:.1f} s = {dt / (a.iters - 20) * 1e3:.3f} ms/iteration "
+    print(f"{name}: h2_plan={eng.h2_plan}; {a.iters - 20} iterations in {dt:.1f} s = {dt / (a.iters - 20) * 1e3:.3f} ms/iteration "
           f"(windows of {win}: {min(times):.3f} .. {max(times):.3f}); loss {float(total[0]):.4e} -> {float(total[a.iters // 5 - 1]):.4e} (end of warm-up) "
           f"-> {float(total[-1]):.4e}; round term last {float(rd[-1]):.4e}; soft targets in {{0,1}}: {float(((h < 1e-3) | (h > 1 - 1e-3)).float().mean()):.4f}")
     del eng, cq, cf, co
