@@ -67,13 +67,12 @@ struct H2Args {
     long tail_per_image;
     int tail_B, tail_act;
     float tail_coef, tail_inv_npix;
-    // diagnostic bit mask (tuning key "x6p_ablate"): 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads -- results are WRONG when
-    // non-zero, so the masks exist only in a `make DIAG=1` build (-DRDO_DIAG); the shipped library folds every test away
-#ifdef RDO_DIAG
+    // diagnostic bit mask: 1 no A DMA, 2 no B DMA, 4 no MFMA, 8 no fragment reads -- results are WRONG when non-zero.  The host sets it
+    // only in a `make DIAG=1` build (tuning key "x6p_ablate"); in the shipped library it is always 0.  It stays a RUN-TIME value on
+    // purpose: the basic-block boundaries its tests create pin the order of fragment reads, MFMA groups and DMA issue in the K loop;
+    // with the tests folded away at compile time the scheduler's own order was 13-20 % slower on the 4 x 128^2 conv (137-145 us
+    // against 121 us, same box).
     int ablate;
-#else
-    static constexpr int ablate = 0;
-#endif
 };
 
 // two-way split of 8 consecutive channels (times s) -> one 16-byte run per plane
@@ -374,18 +373,23 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2_kernel(H2Args a) {
         };
         dma_prepare();
         // fragments in the order the products need them: (A1,B0) (A0,B1) (A0,B0), small terms first
+        // (every MFMA group is fenced on both sides: left to itself the scheduler hoists the DMA issue and its address arithmetic in
+        // front of the group's MFMAs, which cost 20 % on the 4 x 128^2 conv)
         rd_a(1); rd_b(0);
         rd_a(0);
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
         rd_b(1);
         if (!late) { dma_issue(I0{}, nb); dma_issue(I1{}, nb); }
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (!late) { dma_issue(I2{}, nb); dma_issue(I3{}, nb); }
         else { dma_issue(I0{}, nb); dma_issue(I1{}, nb); }
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (late) { dma_issue(I2{}, nb); dma_issue(I3{}, nb); }
         __builtin_amdgcn_sched_barrier(0);
         buf = buf + 1 == RING ? 0 : buf + 1;
@@ -621,14 +625,17 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
         rd_a(0);
         __builtin_amdgcn_sched_barrier(0);
         mma(1, 0);
+        __builtin_amdgcn_sched_barrier(0);
         rd_b(1);
         if (!late) slot(0);
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 1);
+        __builtin_amdgcn_sched_barrier(0);
         if (!late) slot(1);
         else slot(0);
         __builtin_amdgcn_sched_barrier(0);
         mma(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
         if (late) slot(1);
         __builtin_amdgcn_sched_barrier(0);
         buf = buf + 1 == RING ? 0 : buf + 1;

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(WgPArgs a) {
                      for (int j = 0; j < 2; ++j)
                          acc[i][2 * T3 + j] =
                              __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 __builtin_amdgcn_sched_barrier(0);
                  if constexpr (SL == 2) {
                      if (more && ldx) dma_stage(buf ^ 1);
                  }
@@ -410,6 +411,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
                      for (int j = 0; j < 2; ++j)
                          acc[i][2 * T3 + j] =
                              __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 __builtin_amdgcn_sched_barrier(0);
                  if constexpr (SL == 2) {
                      if (more && late) dma_stage(buf ^ 1);
                  }

@@ -120,7 +120,7 @@ class _Op:
     def enable_planes(self, fwd: bool, dgrad: bool, h2: bool = False):
         """Allocate the plane buffers (called while the plan is being recorded: no kernel may run here; the engine fills them
         once eagerly after recording and re-fills them inside the plan after every AdaRound step).  h2: fp16 two-way planes of
-        w * wscale for the plane-input kernels (conv_fwd_h2.hip); else the bf16 three-way planes of the fh22-input kernels."""
+        w * wscale for the plane-input kernels (conv_fwd_h2.hip); else the bf16 three-way planes of the fp32-input kernels."""
         def alloc(like, cur):
             if cur is not None:
                 if isinstance(cur, ops.H2) != h2:
@@ -161,7 +161,7 @@ class UnitEngine:
             raise NotImplementedError(f"calibration engine: unit kind '{kind}'")
         for t in (cache_q, cache_fp, cache_out):
             if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and t.dim() == 4):
-                raise RuntimeError("calibration engine: caches must be contiguous fh22 NHWC CUDA tensors")
+                raise RuntimeError("calibration engine: caches must be contiguous fp32 NHWC CUDA tensors")
         self.kind, self.mods = kind, modules
         self.cq, self.cf, self.co = cache_q, cache_fp, cache_out
         self.B, self.iters = int(batch_size), int(iters)
@@ -173,7 +173,7 @@ class UnitEngine:
         self.dp_overlap = None if dp_overlap is None else bool(dp_overlap)
         if os.environ.get("RDO_USE_H2") is not None:
             use_h2 = os.environ["RDO_USE_H2"] != "0"      # A/B switch for whole runs (bench.py)
-        self.use_h2 = bool(use_h2)             # big units on H2 tensors (plane-input LDS-DMA GEMM kernels); False: fh22 activations only
+        self.use_h2 = bool(use_h2)             # big units on H2 tensors (plane-input LDS-DMA GEMM kernels); False: fp32 activations only
         self.P = {}                            # name -> planes of the H2 form of an activation buffer
         self.batch_step = bool(batch_step)     # one AdaRound-step launch per unit (False: one per weight tensor)
         self.fuse_splitk = os.environ.get("RDO_FUSE_SPLITK", "1") != "0"   # split-K conv + unit tail: the conv's second pass inside the tail
@@ -426,8 +426,9 @@ class UnitEngine:
     # for the 3x3 convs of the 128^2 units hides a collective; 10.9 GFLOP (~45 us, the 64^2 units) is about the latency of the second
     # all-reduce the split adds, and the 3 -> 192 stem of g_a.0 is 26 us
     DP_OVERLAP_MIN_FLOP = 30e9
-    H2_MIN_OUT = 65536 * 192        # plane-input forward kernel pays off from 4 x 128^2 x 192 output elements (profiles/r02a)
-    h2_lean = os.environ.get("RDO_H2_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fh22
+    # plane-input kernels from this many output elements of the conv (pixels x channels) on
+    H2_MIN_OUT = int(os.environ.get("RDO_H2_MIN_OUT", 65536 * 192))
+    h2_lean = os.environ.get("RDO_H2_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fp32
 
     def _h2(self, name, like):
         """Planes of activation buffer `name` (H2 form, scale from the probe iteration)."""
@@ -515,7 +516,7 @@ class UnitEngine:
 
     def _fb_gdn_block_h2(self):
         """RBWS / RBU whose second conv and GDN run at >= 4 x 128^2 x 192: that conv, its weight gradient and dgrad, and the
-        gamma'^T GEMM of the GDN backward on H2 tensors; the (cheap or thin) first convs stay on fh22 activations."""
+        gamma'^T GEMM of the GDN backward on H2 tensors; the (cheap or thin) first convs stay on fp32 activations."""
         o, t, x = self.ops, self.t, self.x_in
         rbu = self.kind == "rbu"
         ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,

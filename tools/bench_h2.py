@@ -51,7 +51,7 @@ for (B, H, Cin, Cout, K, s, p) in SHAPES:
     e_h2, e_6 = float((out[:1].double() - ref).abs().max()) / sc, float((out6[:1].double() - ref).abs().max()) / sc
     abl = []
     if os.environ.get("H2_ABLATE"):          # needs a `make DIAG=1` library
-        for m in (3, 4, 12):
+        for m in (3, 4, 8, 12, 15):
             ops.set_tuning("x6p_ablate", m)
             abl.append((m, timeit(lambda: ops.conv2d_fwd_h2(xp, tuple(x.shape), tuple(w.shape), wpl, b, s, p, out=out))))
         ops.set_tuning("x6p_ablate", 0)
