@@ -780,14 +780,14 @@ __global__ __launch_bounds__(256) void split_h2_conv_kernel(const float* w, long
 
 extern "C" int rdo_conv2d_fwd_uses_bf16x6(const rdo_conv_desc* d);
 
-// K split of the plane kernel: enough 256 x 192 x (K / ks) workgroups for one per CU, at least 12 K stages per split, at most 9 splits
+// K split of the plane kernel: enough 256 x 192 x (K / ks) workgroups for one per CU, at least 9 K stages per split, at most 12 splits
 static int h2_ksplit(const rdo_conv_desc* d) {
     const long M = (long)d->B * d->Ho * d->Wo;
     const long tiles = rdo::ceil_div(M, 256) * rdo::ceil_div(d->Cout, 192);
     const long stages = (long)d->KH * d->KW * (d->Cin / 16);
     int best = 0;
-    for (int ks = 1; ks <= 9; ++ks)
-        if (tiles * ks >= 192 && stages / ks >= 12) {
+    for (int ks = 1; ks <= 12; ++ks)
+        if (tiles * ks >= 192 && stages / ks >= 9) {
             best = ks;
             if (tiles * ks >= 256) break;
         }

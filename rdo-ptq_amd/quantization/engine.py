@@ -427,7 +427,7 @@ class UnitEngine:
     # all-reduce the split adds, and the 3 -> 192 stem of g_a.0 is 26 us
     DP_OVERLAP_MIN_FLOP = 30e9
     # plane-input kernels from this many output elements of the conv (pixels x channels) on
-    H2_MIN_OUT = int(os.environ.get("RDO_H2_MIN_OUT", 65536 * 192))
+    H2_MIN_OUT = int(os.environ.get("RDO_H2_MIN_OUT", 4096 * 192))
     h2_lean = os.environ.get("RDO_H2_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fp32
 
     def _h2(self, name, like):
@@ -483,7 +483,7 @@ class UnitEngine:
             cv, g = (o["conv2"], o["gdn"]) if k == "rbws" else (o["conv"], o["igdn"])
             hs = tuple(self.t["h1"].shape)
             if (hs[-1] % 16 == 0 and (k != "rbu" or self.r == 2) and self._conv_ok_h2(cv, hs) and self._conv_ok_h2(cv, hs, dgrad=True)
-                    and ops.wgrad_h2_supported(hs, cv.w4, 1, cv.pad) and self._conv_ok_h2(g, hs, dgrad=True)):
+                    and ops.wgrad_h2_supported(hs, cv.w4, 1, cv.pad)):
                 return k
         return None
 
@@ -515,49 +515,61 @@ class UnitEngine:
         self._wgrad_h2(c1, xp, x.shape, dh1p)
 
     def _fb_gdn_block_h2(self):
-        """RBWS / RBU whose second conv and GDN run at >= 4 x 128^2 x 192: that conv, its weight gradient and dgrad, and the
-        gamma'^T GEMM of the GDN backward on H2 tensors; the (cheap or thin) first convs stay on fp32 activations."""
+        """RBWS / RBU whose second conv runs on H2 tensors: that conv, its weight gradient and dgrad; where the shapes qualify also the
+        gamma'^T GEMM of the GDN backward, the first conv of an RBWS with >= 16 input channels and the two sub-pixel convs of an RBU
+        (each with its weight gradient).  What does not qualify (thin stems, small 1x1 GEMMs) stays on fp32 activations."""
         o, t, x = self.ops, self.t, self.x_in
         rbu = self.kind == "rbu"
-        ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
-                         iter_publish=self._it_pub())
+        xs = tuple(x.shape)
         if rbu:
             sp, cv, g, up = o["subpel_conv"], o["conv"], o["igdn"], o["upsample"]
             cname, dname = "c", "dc"
+            # the two 192 -> 768 sub-pixel convs and their weight gradients on planes as well when the shapes qualify
+            x_h2 = (x.shape[-1] % 16 == 0 and self._conv_ok_h2(sp, xs) and self._conv_ok_h2(up, xs)
+                    and ops.wgrad_h2_supported(xs, sp.w4, sp.stride, sp.pad) and ops.wgrad_h2_supported(xs, up.w4, up.stride, up.pad))
         else:
             c1, cv, g = o["conv1"], o["conv2"], o["gdn"]
             cname, dname = "c2", "dc2"
-        h1p, tp, dcp = self._h2("h1", t["h1"]), self._h2("t", t["h1"]), self._h2(dname, t["h1"])
+            x_h2 = x.shape[-1] % 16 == 0 and self._conv_ok_h2(c1, xs) and ops.wgrad_h2_supported(xs, c1.w4, c1.stride, c1.pad)
+        hs = tuple(t["h1"].shape)
+        g_h2 = self._conv_ok_h2(g, hs, dgrad=True)
+        h1p, dcp = self._h2("h1", t["h1"]), self._h2(dname, t["h1"])
+        tp = self._h2("t", t["h1"]) if g_h2 else None
+        xp = self._h2("x", x) if x_h2 else None
+        if x_h2:
+            ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, xp, self.batch_offset,
+                                iter_publish=self._it_pub())
+        else:
+            ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
+                             iter_publish=self._it_pub())
+        lean_h1 = self.h2_lean and (rbu or x_h2)          # h1 exists as planes only (its LeakyReLU mask is read off plane 0)
         if rbu:
             r = self.r
-            # the two 192 -> 768 sub-pixel convs and their weight gradients on planes as well when the shapes qualify
-            xs = tuple(x.shape)
-            sub_h2 = (x.shape[-1] % 16 == 0 and self._conv_ok_h2(sp, xs) and self._conv_ok_h2(up, xs)
-                      and ops.wgrad_h2_supported(xs, sp.w4, sp.stride, sp.pad) and ops.wgrad_h2_supported(xs, up.w4, up.stride, up.pad))
-            if sub_h2:
-                xp = self._h2("x", x)
-                ops.split_h2(x, xp)
+            if x_h2:
                 self._conv_h2(sp, xp, xs, out=t["sp"], epilogue=L.EPI_LRELU)
                 self._conv_h2(up, xp, xs, out=t["up"])
             else:
                 self._conv(sp, x, t["sp"], epilogue=L.EPI_LRELU)
                 self._conv(up, x, t["up"])
-            ops.pixel_shuffle_h2(t["sp"], out=None if self.h2_lean else t["h1"], out_planes=h1p)
+            ops.pixel_shuffle_h2(t["sp"], out=None if lean_h1 else t["h1"], out_planes=h1p)
             self._shuffle(t["up"], r, t["ups"])
             res = t["ups"]
         else:
-            self._conv(c1, x, t["h1"], epilogue=L.EPI_LRELU)
-            ops.split_h2(t["h1"], h1p)
+            if x_h2:
+                self._conv_h2(c1, xp, xs, out=None if lean_h1 else t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
+            else:
+                self._conv(c1, x, t["h1"], epilogue=L.EPI_LRELU)
+                ops.split_h2(t["h1"], h1p)
             res = x
             if "skip" in o:
                 self._conv(o["skip"], x, t["sk"])
                 res = t["sk"]
-        self._conv_h2(cv, h1p, t["h1"].shape, out=t[cname])
+        self._conv_h2(cv, h1p, hs, out=t[cname])
         self._conv(g, t[cname], t["norm"], square=True)
         self._task_is_rec = True
         ops.loss_gdn_bwd(t[cname], t["norm"], res, self.co, self.idx, self.it, 2.0, rbu, self.loss_log, t["dout"], t=t["t"], t_planes=tp)
         if rbu:
-            if sub_h2:
+            if x_h2:
                 dupp = self._h2("dup", t["dup"])
                 ops.pixel_unshuffle2(t["dout"], out_planes=dupp)
                 self._wgrad_h2(up, xp, xs, dupp)
@@ -566,14 +578,21 @@ class UnitEngine:
                 self._wgrad(up, x, t["dup"])
         elif "skip" in o:
             self._wgrad(o["skip"], x, t["dout"])
-        self._gdn_backward_h2(g, t["dout"], t[cname], t["norm"], tp, t["acc"], dcp)
+        if g_h2:
+            self._gdn_backward_h2(g, t["dout"], t[cname], t["norm"], tp, t["acc"], dcp)
+        else:                                             # gamma'^T GEMM on the fp32 t (small shapes), dx still as planes only
+            if ops.uses_bf16x6(hs, tuple(g.wd4().shape), 1, 0):
+                g.enable_planes(False, True)
+            ops.conv2d_fwd(t["t"], g.wd4(), None, 1, 0, out=t["acc"], wplanes=g.wd_planes)
+            ops.gdn_bwd_dx_h2(t["dout"], t[cname], t["norm"], t["acc"], g.inverse, dx_planes=dcp)
         self._wgrad(g, t[cname], t["t"], square=True)
-        self._wgrad_h2(cv, h1p, t["h1"].shape, dcp)
-        lean_aux = rbu and self.h2_lean
-        self._dgrad_h2(cv, dcp, t["h1"].shape, out=t["dh1"], epilogue=L.EPI_LRELU_BWD, aux=None if lean_aux else t["h1"],
-                       aux_planes=h1p if lean_aux else None)
+        self._wgrad_h2(cv, h1p, hs, dcp)
+        rbws_h2 = x_h2 and not rbu
+        dh1p = self._h2("dh1", t["h1"]) if rbws_h2 else None
+        self._dgrad_h2(cv, dcp, hs, out=None if rbws_h2 else t["dh1"], out_planes=dh1p, epilogue=L.EPI_LRELU_BWD,
+                       aux=None if lean_h1 else t["h1"], aux_planes=h1p if lean_h1 else None)
         if rbu:
-            if sub_h2:
+            if x_h2:
                 dspp = self._h2("dsp", t["dsp"])
                 ops.pixel_unshuffle2(t["dh1"], out_planes=dspp)
                 self._split_point()
@@ -584,9 +603,13 @@ class UnitEngine:
                 self._wgrad(sp, x, t["dsp"])
         else:
             self._split_point()
-            self._wgrad(c1, x, t["dh1"])
+            if x_h2:
+                self._wgrad_h2(c1, xp, xs, dh1p)
+            else:
+                self._wgrad(c1, x, t["dh1"])
 
-    H2_PROBED = {"rb": ("x", "h1", "dpre2", "dh1"), "rbws": ("h1", "t", "dc2"), "rbu": ("x", "h1", "t", "dc", "dup", "dsp")}
+    # activation buffers a plan may keep as planes (all probed: a scale that is never used costs nothing)
+    H2_PROBED = {"rb": ("x", "h1", "dpre2", "dh1"), "rbws": ("x", "h1", "t", "dc2", "dh1"), "rbu": ("x", "h1", "t", "dc", "dup", "dsp")}
 
     def _probe_scales(self):
         """fp16 planes need a per-tensor power-of-two scale (include/rdo_ptq_hip.h, "H2 tensors").  One PROBE iteration of the unit on
