@@ -80,6 +80,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=20, help="timed oracle iterations per unit for cpu_baseline")
+    ap.add_argument("--recon-iters", type=int, default=2000,
+                    help="after the timed region (N = 1 only): wall time of the whole `recon_model` schedule through the public "
+                         "layer_/block_reconstruction API with this many iterations per unit (SURVEY 8d's definition of the metric: cache "
+                         "building + plan recording + loops); 0: skip")
     ap.add_argument("--sustain-steps", type=int, default=1000,
                     help="steps run AFTER the timed region in windows of 100 to report a sustained rate (0: skip)")
     return ap.parse_args()
@@ -416,6 +420,17 @@ def main():
         if res["dp_paths"]:
             out["dp_graph"] = res["dp_paths"] == ["graph"]
             out["config"]["dp_loop"] = "+".join(res["dp_paths"])
+        if world == 1 and a.recon_iters > 0 and not os.environ.get("RDO_BENCH_FORCE_DP"):
+            # outside the timed region: the metric by SURVEY 8d's literal definition -- wall time of recon_model (main2.py:227-253)
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from full_schedule import run_schedule
+            log(f"recon_model wall: {a.recon_iters} iterations x {n_units} units through layer_/block_reconstruction")
+            rs = run_schedule(images=a.images, iters=a.recon_iters, batch=a.batch, log=log, quality=False)
+            out["recon_model"] = {"iters_per_unit": a.recon_iters, "wall_s": round(rs["recon_model_wall_s"], 3),
+                                  "cache_s": round(rs["cache_s"], 3), "record_s": round(rs["record_s"], 3), "loop_s": round(rs["loop_s"], 3),
+                                  "images_per_s": round(rs["images_per_s"], 1),
+                                  "note": "whole schedule through the public API incl. asymmetric cache building and plan recording; the "
+                                          "reference's 20000-iteration schedule is timed by tools/full_schedule.py (profiles/)"}
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_leg(a)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)

@@ -2,7 +2,7 @@
 # (never combined with other trace domains).  Run on the GPU box from the repo root; summaries: tools/summarize_rocprof.py.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-OUT=$R/gpurun_out/${1:-prof_r02}
+OUT=$R/gpurun_out/${1:-prof_r03}
 mkdir -p $OUT
 CMD="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-steps 0"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $CMD > $OUT/log_trace.txt 2>&1; echo trace rc=$?

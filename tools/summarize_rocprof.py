@@ -3,8 +3,9 @@
 
     python tools/summarize_rocprof.py <dir with *_kernel_trace.csv [and *_counter_collection.csv]> [--pmc NAME]
 
-Only dispatches from the first `gather_qdrop_kernel` launch onwards are counted (everything before it is model set-up and
-cache building, which is outside the timed region of bench.py).  With --pmc the per-dispatch counter values of a
+Only the hot loop is counted: dispatches from the first `gather_qdrop*` launch that FOLLOWS the last weight-plane split kernel
+(`split_*_conv_kernel`: the engines fill their weight planes once, after recording) -- everything before it is model set-up, cache
+building and the engines' probe iterations, which are outside the timed region of bench.py.  With --pmc the per-dispatch counter values of a
 `--pmc NAME` run are aggregated per kernel instead (FETCH_SIZE / WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE under-reports
 wide coalesced reads by 2x -- MI355X_MICROARCH.md, HBM section -- so the table prints both raw and corrected bytes)."""
 import csv
@@ -21,6 +22,11 @@ def short(name):
     return re.sub(r"\(.*$", "", name)[:70]
 
 
+def hot_start(rows):
+    last_split = max((i for i, r in enumerate(rows) if "_conv_kernel" in r["Kernel_Name"] and "split_" in r["Kernel_Name"]), default=-1)
+    return next(i for i, r in enumerate(rows) if i > last_split and "gather_qdrop" in r["Kernel_Name"])
+
+
 def main():
     d = sys.argv[1]
     pmc = sys.argv[sys.argv.index("--pmc") + 1] if "--pmc" in sys.argv else None
@@ -28,7 +34,7 @@ def main():
         f = glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True)[0]
         rows = list(csv.DictReader(open(f)))
         rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-        start = next(i for i, r in enumerate(rows) if "gather_qdrop" in r["Kernel_Name"])
+        start = hot_start(rows)
         agg = OrderedDict()
         for r in rows[start:]:
             if r["Counter_Name"] != pmc:
@@ -47,7 +53,7 @@ def main():
     f = glob.glob(os.path.join(d, "**", "*_kernel_trace.csv"), recursive=True)[0]
     rows = list(csv.DictReader(open(f)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-    start = next(i for i, r in enumerate(rows) if "gather_qdrop" in r["Kernel_Name"])
+    start = hot_start(rows)
     agg = {}
     for r in rows[start:]:
         dur = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
