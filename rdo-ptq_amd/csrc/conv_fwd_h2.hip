@@ -54,6 +54,7 @@ struct H2Args {
     int M;
     int epilogue, add_residual;
     int xcd_mode;
+    int stagger;          // halo kernel: waves 4-7 run two thirds of a stage behind waves 0-3 (tuning key "h2_stagger")
     float* partial;       // split-K: raw accumulators [ksplit][M][Cout]
     int ksplit;
     // unit tail folded into the halo kernel's epilogue (rdo_conv2d_fwd_h2_tail): out = act(conv + bias) + residual, loss against the
@@ -577,35 +578,25 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
 #pragma unroll
     for (int j = 0; j < 2; ++j) dma_b(j, 1);
 
-    int buf = 0, s = 0;
-    auto stage = [&](auto tapc, int cs) {
-        constexpr int TAP = decltype(tapc)::value;
-        constexpr int KH = TAP / 3, KW = TAP % 3;
-        // stage s (weights) and, in tap 0, this slice's halo have landed once at most the DMAs issued after them are outstanding
-        if (a.ablate & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if constexpr (TAP >= 1 && TAP <= AJ) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const int nb = buf >= 1 ? buf - 1 : RING - 1;        // (s + 2) % 3
-        const char* stb = smem + buf * BSTAGE;
-        const char* sta = smem + (cs & 1) * ABUF;
-        int fa_off[TM];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int q = q00[i] + KH * HWD + KW;
-            fa_off[i] = q * 32 + (((lh ^ (q >> 3)) & 1) << 4);
-        }
+    // products of a stage in the order (A1,B0) (A0,B1) (A0,B0), small terms first -- for every wave.  STAGGER: the two waves of a SIMD
+    // (w and w + 4) leave the barrier together; if both then read their fragments and both then multiply, the matrix pipe idles
+    // through every read / DMA / barrier phase (ablation: 58 us of skeleton + 63 us of MFMAs = the 121 us of the kernel, no overlap at
+    // all).  Waves 4-7 therefore run two thirds of a stage behind: after the barrier they first issue products two and three of the
+    // PREVIOUS stage from the fragments still in their registers -- while waves 0-3 read -- and read this stage's fragments while
+    // waves 0-3 multiply.  Every read of a stage still happens inside that stage's barrier interval; the DMA bookkeeping is unchanged.
+    // The two roles are two separate instantiations of the K loop (no per-stage branch, no register merge at a join).
+    auto k_loop = [&](auto late_c) {
+        constexpr bool LATE = decltype(late_c)::value;
         f16x8 fa[NP][TM], fb[NP][TN];
-        auto rd_a = [&](int p) {
-            if (a.ablate & 8) return;                        // diagnostic: no fragment reads (stale registers multiplied)
+        if constexpr (LATE) {                                // the "previous stage" of stage 0: zero fragments
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const f16x8*>(sta + p * APL + fa_off[i]);
-        };
-        auto rd_b = [&](int p) {
-            if (a.ablate & 8) return;
+            for (int p = 0; p < NP; ++p) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const f16x8*>(stb + fb_off[p][j]);
-        };
+                for (int i = 0; i < TM; ++i) fa[p][i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[p][j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            }
+        }
         auto mma = [&](int pa, int pb_) {
             if (a.ablate & 4) return;
 #pragma unroll
@@ -613,38 +604,86 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
 #pragma unroll
                 for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[pa][i], fb[pb_][j], acc[i][j], 0, 0, 0);
         };
-        set_wsrc(s + 2);
-        auto slot = [&](int k) {                             // DMA slot k of this wave's two: halo piece first (taps 0-2), then weight piece k
-            if (k == 0) {
-                if constexpr (TAP < AJ) dma_a(TAP, cs + 1);
+        int buf = 0, s = 0;
+        auto stage = [&](auto tapc, int cs) {
+            constexpr int TAP = decltype(tapc)::value;
+            constexpr int KH = TAP / 3, KW = TAP % 3;
+            // stage s (weights) and, in tap 0, this slice's halo have landed once at most the DMAs issued after them are outstanding
+            if (a.ablate & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (TAP >= 1 && TAP <= AJ) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int nb = buf >= 1 ? buf - 1 : RING - 1;    // (s + 2) % 3
+            const char* stb = smem + buf * BSTAGE;
+            const char* sta = smem + (cs & 1) * ABUF;
+            int fa_off[TM];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int q = q00[i] + KH * HWD + KW;
+                fa_off[i] = q * 32 + (((lh ^ (q >> 3)) & 1) << 4);
             }
-            dma_b(k, nb);
+            auto rd_a = [&](int p) {
+                if (a.ablate & 8) return;                    // diagnostic: no fragment reads (stale registers multiplied)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[p][i] = *reinterpret_cast<const f16x8*>(sta + p * APL + fa_off[i]);
+            };
+            auto rd_b = [&](int p) {
+                if (a.ablate & 8) return;
+#pragma unroll
+                for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const f16x8*>(stb + fb_off[p][j]);
+            };
+            set_wsrc(s + 2);
+            auto slot = [&](int k) {                         // DMA slot k of this wave's two: halo piece first (taps 0-2), then weight piece k
+                if (k == 0) {
+                    if constexpr (TAP < AJ) dma_a(TAP, cs + 1);
+                }
+                dma_b(k, nb);
+            };
+            if constexpr (!LATE) {
+                rd_a(1); rd_b(0);
+                rd_a(0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                rd_b(1);
+                slot(0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 1);
+                __builtin_amdgcn_sched_barrier(0);
+                slot(1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+                rd_a(1);                                     // fa[1] is free: (A1,B0) of the previous stage is done
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 1);                                   // previous stage
+                __builtin_amdgcn_sched_barrier(0);
+                rd_b(1);
+                slot(0);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(0, 0);                                   // previous stage
+                __builtin_amdgcn_sched_barrier(0);
+                rd_b(0); rd_a(0);
+                slot(1);
+                __builtin_amdgcn_sched_barrier(0);
+                mma(1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf = buf + 1 == RING ? 0 : buf + 1;
+            ++s;
         };
-        // fragments in the order the products need them: (A1,B0) (A0,B1) (A0,B0), small terms first
-        rd_a(1); rd_b(0);
-        rd_a(0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(1, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        rd_b(1);
-        if (!late) slot(0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, 1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (!late) slot(1);
-        else slot(0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(0, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (late) slot(1);
-        __builtin_amdgcn_sched_barrier(0);
-        buf = buf + 1 == RING ? 0 : buf + 1;
-        ++s;
+        for (int cs = 0; cs < csteps; ++cs) {
+            [&]<int... T>(std::integer_sequence<int, T...>) { (stage(std::integral_constant<int, T>{}, cs), ...); }
+            (std::make_integer_sequence<int, 9>{});
+        }
+        if constexpr (LATE) {                                // the two products of the last stage these waves still owe
+            mma(0, 1);
+            mma(0, 0);
+        }
     };
-    for (int cs = 0; cs < csteps; ++cs) {
-        [&]<int... T>(std::integer_sequence<int, T...>) { (stage(std::integral_constant<int, T>{}, cs), ...); }
-        (std::make_integer_sequence<int, 9>{});
-    }
+    if (late && a.stagger) k_loop(std::true_type{});
+    else k_loop(std::false_type{});
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail DMAs still target LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_barrier();
 
@@ -878,6 +917,7 @@ static int conv2d_fwd_h2_impl(const rdo_conv_desc* d, const void* x_planes, floa
     a.oplane = (long)a.M * a.Cout;
     a.epilogue = d->epilogue; a.add_residual = d->add_residual;
     a.xcd_mode = rdo::tuning(rdo::T_XCD);
+    a.stagger = rdo::tuning(rdo::T_H2_STAGGER);
 #ifdef RDO_DIAG
     a.ablate = rdo::tuning(rdo::T_X6P_ABLATE);
 #endif
