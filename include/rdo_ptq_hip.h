@@ -237,6 +237,17 @@ int rdo_iter_advance(int32_t* iter_ptr, void* stream);
  * with the weight re-laid out [co][K-1-kh][K-1-kw][ci]:  out[b][pt + h*s][pl + w*s][c] = x[b][h][w][c], zeros elsewhere */
 int rdo_zero_insert(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, int32_t stride, int32_t pad_top, int32_t pad_left,
                     int32_t Ho, int32_t Wo, float* out, void* stream);
+/* Transposed conv WITHOUT zero insertion (round 3): ConvTranspose2d(k, stride s, padding p) whose output is s x the input size
+ * (output_padding = s + 2p - k) equals a stride-1 conv with s^2 * Cout output channels and a K' x K' window (padding K' / 2) followed
+ * by F.pixel_shuffle(s): output pixel (s i + a, s j + b) meets only the taps kh = (a + p) mod s + s t, reading input rows
+ * i + (a + p) / s - t.  rdo_tconv_expand builds that phase weight [Cout * s^2][K'][K'][Cin] from the kernel-layout weight
+ * [Cout][taps][Cin] and a host-made `map` [s^2][K'^2] (tap index or -1 for a structural zero); rdo_tconv_fold gathers the gradient
+ * slabs of the phase weight back into slabs of the kernel weight (`inv` [taps] = window entry of each tap).  k = 5, s = 2 (the deconv
+ * of models/utils.py:107-116): 36 window entries for 25 taps, against 100 multiply-adds per input pixel through rdo_zero_insert. */
+int rdo_tconv_expand(const float* w, const int32_t* map, int32_t Cout, int32_t taps, int32_t Cin, int32_t S2, int32_t KK2, float* wphase,
+                     void* stream);
+int rdo_tconv_fold(const float* slabs_phase, const int32_t* inv, int32_t nsplit, int32_t Cout, int32_t taps, int32_t Cin, int32_t S2,
+                   int32_t KK2, float* slabs, void* stream);
 /* F.layer_norm over the last dimension (quant_layer.py:44-49,121): rows x C, biased variance, eps inside the sqrt */
 int rdo_layer_norm(const float* x, const float* weight, const float* bias, int64_t rows, int32_t C, float eps, float* out,
                    void* stream);

@@ -300,6 +300,43 @@ __global__ __launch_bounds__(256) void aq_apply_kernel(const float* x, long n, i
     }
 }
 
+// ---- transposed conv as a sub-pixel conv: phase weights ----------------------------------------------------------------------------
+// ConvTranspose2d(k, stride s, padding p) with output size s * H is a stride-1 conv with s^2 * Cout output channels followed by a
+// pixel shuffle: output pixel (s i + a, s j + b) only ever meets the taps kh = (a + p) mod s + s t, and those taps read input rows
+// i + q - t -- a K' x K' correlation window around pixel (i, j) whose entries are single taps of the kernel or zero (k = 5, s = 2: 36
+// window entries for 25 taps, against the 100 multiply-adds per input pixel of the zero-insertion form).  `map` [s^2][K'][K'] holds the
+// tap index (in the engine's kernel-layout weight [Cout][K][K][Cin]) of every window entry, -1 for a structural zero.
+__global__ __launch_bounds__(256) void tconv_expand_kernel(const float* w, const int32_t* map, long total, int S2, int KK2, int taps, int Cin,
+                                                          float* wp) {
+    // wp[(co * S2 + ph)][u][v][ci]
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int ci = (int)(e % Cin);
+        long t = e / Cin;
+        const int uv = (int)(t % KK2);
+        t /= KK2;
+        const int ph = (int)(t % S2);
+        const long co = t / S2;
+        const int tap = map[ph * KK2 + uv];
+        wp[e] = tap >= 0 ? w[(co * taps + tap) * Cin + ci] : 0.f;
+    }
+}
+// gradient slabs of the phase weight -> slabs of the kernel weight: every tap sits at exactly one window entry (`inv` [taps] = its
+// offset (ph * K'^2 + u * K' + v))
+__global__ __launch_bounds__(256) void tconv_fold_kernel(const float* sp, const int32_t* inv, long total, long per_slab, int S2, int KK2, int taps,
+                                                        int Cin, float* out) {
+    const long per_slab_p = per_slab / taps * ((long)S2 * KK2);
+    for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const long slab = e / per_slab, r = e - slab * per_slab;
+        const int ci = (int)(r % Cin);
+        long t = r / Cin;
+        const int tap = (int)(t % taps);
+        const long co = t / taps;
+        const int o = inv[tap];
+        const int ph = o / KK2, uv = o - ph * KK2;
+        out[e] = sp[slab * per_slab_p + (((co * S2 + ph) * KK2 + uv) * Cin + ci)];
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -447,6 +484,31 @@ int rdo_zero_insert(const float* x, int32_t B, int32_t H, int32_t W, int32_t C, 
             return rdo::check_launch("zero_insert");
         },
         stream);
+}
+
+int rdo_tconv_expand(const float* w, const int32_t* map, int32_t Cout, int32_t taps, int32_t Cin, int32_t S2, int32_t KK2, float* wp,
+                     void* stream) {
+    RDO_REQUIRE(w && map && wp && Cout > 0 && taps > 0 && Cin > 0 && S2 > 0 && KK2 > 0, "rdo_tconv_expand: bad argument");
+    const long total = (long)Cout * S2 * KK2 * Cin;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(tconv_expand_kernel, dim3(grid_for(total)), dim3(256), 0, s, w, map, total, S2, KK2, taps, Cin, wp);
+            return rdo::check_launch("tconv_expand");
+        },
+        stream, "tconv_expand", 0.0, 8.0 * total);
+}
+
+int rdo_tconv_fold(const float* slabs_phase, const int32_t* inv, int32_t nsplit, int32_t Cout, int32_t taps, int32_t Cin, int32_t S2,
+                   int32_t KK2, float* slabs, void* stream) {
+    RDO_REQUIRE(slabs_phase && inv && slabs && nsplit > 0 && Cout > 0 && taps > 0 && Cin > 0 && S2 > 0 && KK2 > 0, "rdo_tconv_fold: bad argument");
+    const long per_slab = (long)Cout * taps * Cin, total = per_slab * nsplit;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(tconv_fold_kernel, dim3(grid_for(total)), dim3(256), 0, s, slabs_phase, inv, total, per_slab, S2, KK2, taps, Cin,
+                               slabs);
+            return rdo::check_launch("tconv_fold");
+        },
+        stream, "tconv_fold", 0.0, 8.0 * total);
 }
 
 int rdo_layer_norm(const float* x, const float* weight, const float* bias, int64_t rows, int32_t C, float eps, float* out,

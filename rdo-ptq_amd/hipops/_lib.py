@@ -87,6 +87,8 @@ _SIGS = {
     "rdo_nchw_to_nhwc": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "rdo_iter_advance": (C.c_int, [P, P]),
     "rdo_zero_insert": (C.c_int, [P] + [C.c_int32] * 9 + [P, P]),
+    "rdo_tconv_expand": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
+    "rdo_tconv_fold": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "rdo_layer_norm": (C.c_int, [P, P, P, C.c_int64, C.c_int32, C.c_float, P, P]),
     "rdo_factorized_likelihood_fwd": (C.c_int, [P, P, P, C.c_int64, C.c_int32, P, P, P]),
     "rdo_gaussian_likelihood_fwd": (C.c_int, [P, P, P, C.c_int64, C.c_float, P, P, P]),

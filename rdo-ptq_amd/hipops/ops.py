@@ -379,10 +379,84 @@ def zero_insert(x, stride, pad_top, pad_left, Ho, Wo, out=None):
     return out
 
 
+class TconvPhase:
+    """Sub-pixel form of ConvTranspose2d(K, stride, pad) with output = stride x input (include/rdo_ptq_hip.h, rdo_tconv_expand): the
+    window size / padding of the equivalent stride-1 conv and the device index tables between the kernel-layout weight
+    [Cout][K][K][Cin] (`flipped`: taps stored as [K-1-kh][K-1-kw], the engine's layout; else as they lie in the module's weight) and
+    the phase weight [Cout * s^2][Kp][Kp][Cin]."""
+    _cache = {}
+
+    def __init__(self, K, stride, pad, flipped, device):
+        s = stride
+        win = []                                   # per phase a: [(d, kh)] input offset d and tap kh
+        for a in range(s):
+            r, q = (a + pad) % s, (a + pad) // s
+            win.append([(q - t, r + s * t) for t in range((K - r + s - 1) // s) if r + s * t < K])
+        dmax = max(max(d for d, _ in w) for w in win if w)
+        dmin = min(min(d for d, _ in w) for w in win if w)
+        self.pad = max(dmax, -dmin, 0)
+        self.Kp = 2 * self.pad + 1
+        self.S2, self.K, self.stride = s * s, K, s
+        fl = (lambda k: K - 1 - k) if flipped else (lambda k: k)
+        mp = [[-1] * (self.Kp * self.Kp) for _ in range(self.S2)]
+        inv = [-1] * (K * K)
+        for a in range(s):
+            for b in range(s):
+                for dh, kh in win[a]:
+                    for dw, kw in win[b]:
+                        u, v = dh + self.pad, dw + self.pad
+                        tap = fl(kh) * K + fl(kw)
+                        mp[a * s + b][u * self.Kp + v] = tap
+                        inv[tap] = (a * s + b) * self.Kp * self.Kp + u * self.Kp + v
+        assert all(i >= 0 for i in inv)
+        self.map = torch.tensor(mp, dtype=torch.int32, device=device).contiguous()
+        self.inv = torch.tensor(inv, dtype=torch.int32, device=device).contiguous()
+
+    @classmethod
+    def get(cls, K, stride, pad, output_padding, flipped, device):
+        """The phase form, or None when the geometry has none (output must be exactly stride x input)."""
+        if output_padding != stride + 2 * pad - K or stride < 2:
+            return None
+        key = (K, stride, pad, bool(flipped), str(device))
+        if key not in cls._cache:
+            cls._cache[key] = cls(K, stride, pad, flipped, device)
+        return cls._cache[key]
+
+    def w_shape(self, Cout, Cin):
+        return (Cout * self.S2, self.Kp, self.Kp, Cin)
+
+
+def tconv_expand(w_rows, ph, out=None):
+    """kernel-layout weight [Cout][K][K][Cin] -> phase weight [Cout * s^2][Kp][Kp][Cin] (structural zeros included)."""
+    Cout, K, _, Cin = w_rows.shape
+    out = torch.empty(ph.w_shape(Cout, Cin), device=w_rows.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_tconv_expand(_ptr(w_rows), _ptr(ph.map), Cout, K * K, Cin, ph.S2, ph.Kp * ph.Kp, _ptr(out), _stream()), "rdo_tconv_expand")
+    return out
+
+
+def tconv_fold(slabs_phase, ph, Cout, Cin, out=None):
+    """gradient slabs [ns][Cout * s^2][Kp][Kp][Cin] of the phase weight -> slabs [ns][Cout][K][K][Cin] of the kernel weight"""
+    ns = slabs_phase.shape[0]
+    out = torch.empty((ns, Cout, ph.K, ph.K, Cin), device=slabs_phase.device, dtype=torch.float32) if out is None else out
+    L.check(L.lib().rdo_tconv_fold(_ptr(slabs_phase), _ptr(ph.inv), ns, Cout, ph.K * ph.K, Cin, ph.S2, ph.Kp * ph.Kp, _ptr(out), _stream()),
+            "rdo_tconv_fold")
+    return out
+
+
 def conv_transpose2d(x, w_iohw_rows, bias, stride, pad, output_padding, epilogue=L.EPI_NONE):
-    """x [B,H,W,Cin]; w_iohw_rows = to_rows(W, tconv=True) = [Cout,KH,KW,Cin] (un-flipped taps of the [Cin,Cout,KH,KW] weight)."""
+    """x [B,H,W,Cin]; w_iohw_rows = to_rows(W, tconv=True) = [Cout,KH,KW,Cin] (un-flipped taps of the [Cin,Cout,KH,KW] weight).
+    Output = stride x input (the deconv of the LIC decoders): stride-1 conv with the phase weight + pixel shuffle, no zero insertion;
+    other geometries: zero insertion + dense conv."""
     Cout, KH, KW, Cin = w_iohw_rows.shape
     B, H, W, _ = x.shape
+    ph = TconvPhase.get(KH, stride, pad, output_padding, False, x.device) if KH == KW else None
+    if ph is not None:
+        wp = tconv_expand(w_iohw_rows.contiguous(), ph)
+        bp = None if bias is None else bias.repeat_interleave(ph.S2).contiguous()
+        # LeakyReLU / ReLU commute with the pixel shuffle; large problems on the split-precision path
+        planes = split_bf16x3(wp) if uses_bf16x6(tuple(x.shape), tuple(wp.shape), 1, ph.pad) else None
+        yp = conv2d_fwd(x, wp, bp, 1, ph.pad, epilogue=epilogue, wplanes=planes)
+        return pixel_shuffle(yp, stride)
     q = KH - 1 - pad
     if q < 0:
         raise ValueError("conv_transpose2d: padding larger than kernel_size - 1 is not supported")

@@ -113,6 +113,18 @@ class _Op:
         ops.adaround_init_alpha(self.desc, self.w, self.delta, self.alpha)
         ops.adaround_fwd(self.desc, self.w, self.alpha, self.delta, self.zp, True, self.wq, self.wd)
         self.slabs = None
+        # transposed conv whose output is stride x the input: run as a stride-1 conv with the "phase weight" [Cout * s^2][K'][K'][Cin]
+        # + pixel shuffle (include/rdo_ptq_hip.h, rdo_tconv_expand) instead of zero insertion + dense conv.  The AdaRound state stays in
+        # the kernel layout of the transposed conv; the phase weight is re-expanded after every step, its gradient folded back.
+        self.tc_phase = self.wp = self.wp_planes = self.wp_h2 = self.slabs_p = self.bias_p = None
+        if self.tconv is not None:
+            s_, p_, op_ = self.tconv
+            self.tc_phase = ops.TconvPhase.get(self.K, s_, p_, op_, True, dev) if os.environ.get("RDO_TCONV_PHASE", "1") != "0" else None
+            if self.tc_phase is not None:
+                self.wp4 = self.tc_phase.w_shape(self.rows, self.w4[3])
+                self.wp = torch.empty(self.wp4, device=dev, dtype=torch.float32)
+                self.bias_p = None if self.bias is None else self.bias.repeat_interleave(self.tc_phase.S2).contiguous()
+                self.expand_phase()
         # exact bf16 three-way splits of the kernel-layout weights, (re)made after every update for the convs that run on
         # the split-bf16 MFMA path (large problems only; decided by the library from the activation shape)
         self.wq_planes = self.wd_planes = None
@@ -134,7 +146,19 @@ class _Op:
         if dgrad and self.wd is not None:
             self.wd_planes = alloc(self.wd, self.wd_planes)
 
+    def expand_phase(self):
+        """phase weight of a transposed conv (and its bf16 planes) from the current soft weights"""
+        ops.tconv_expand(self.wq4(), self.tc_phase, out=self.wp)
+        if self.wp_planes is not None:
+            ops.split_bf16x3(self.wp, self.wp_planes)
+        if self.wp_h2 is not None:
+            ops.split_h2_conv(self.wp, planes=self.wp_h2)
+
     def refresh_planes(self):
+        if self.wp_planes is not None:
+            ops.split_bf16x3(self.wp, self.wp_planes)
+        if self.wp_h2 is not None:
+            ops.split_h2_conv(self.wp, planes=self.wp_h2)
         for planes, w4 in ((self.wq_planes, self.wq4), (self.wd_planes, self.wd4)):
             if isinstance(planes, ops.H2):
                 ops.split_h2_conv(w4(), planes=planes)
@@ -288,7 +312,12 @@ class UnitEngine:
         o, t = self.ops, {}
         if self.kind == "layer":
             op = o["layer"]
-            if op.tconv is not None:
+            if op.tc_phase is not None:
+                s_ = op.tc_phase.stride
+                Ho, Wo = H * s_, W * s_
+                t["yp"] = self._buf(B, H, W, op.wp4[0])
+                t["dyp"] = self._buf(B, H, W, op.wp4[0])
+            elif op.tconv is not None:
                 s_, p_, op_ = op.tconv
                 q_ = op.K - 1 - p_
                 if q_ < 0:
@@ -361,6 +390,32 @@ class UnitEngine:
             op.enable_planes(False, True)
         return ops.conv2d_fwd(dy, op.wd4(), None, 1, op.K - 1 - op.pad, epilogue=epilogue, aux=aux, out=out,
                               wplanes=op.wd_planes)
+
+    def _tconv_forward(self, op, x, y, epilogue=L.EPI_NONE):
+        """y [B, sH, sW, Cout] <- (activation of) the transposed conv of x with the soft weights: stride-1 conv with the phase weight,
+        then the pixel shuffle (LeakyReLU / ReLU commute with it)."""
+        ph = op.tc_phase
+        if ops.uses_bf16x6(tuple(x.shape), op.wp4, 1, ph.pad) and op.wp_planes is None:
+            op.wp_planes = torch.empty((3,) + tuple(op.wp4), device=self.dev, dtype=torch.int16)
+        ops.conv2d_fwd(x, op.wp, op.bias_p, 1, ph.pad, epilogue=epilogue, out=self.t["yp"], wplanes=op.wp_planes)
+        self._shuffle(self.t["yp"], ph.stride, y)
+
+    def _tconv_wgrad(self, op, x, dy):
+        """slabs of dL/d(kernel-layout weight) from dy [B, sH, sW, Cout]: unshuffle, weight gradient of the phase conv, fold"""
+        ph = op.tc_phase
+        self._unshuffle(dy, ph.stride, self.t["dyp"])
+        if op.slabs is None:
+            ns = ops.wgrad_nsplit(tuple(x.shape), op.wp4, 1, ph.pad)
+            op.slabs_p = self._buf(ns, *op.wp4)
+            op.slabs = self._buf(ns, *op.w4)
+        ops.conv2d_wgrad(x, self.t["dyp"], op.wp4, 1, ph.pad, slabs=op.slabs_p)
+        ops.tconv_fold(op.slabs_p, ph, op.rows, op.w4[3], out=op.slabs)
+
+    def _after_step(self):
+        """recorded right behind the AdaRound step: phase weights of transposed convs follow the new soft weights"""
+        for op in self.ops.values():
+            if op.tc_phase is not None:
+                op.expand_phase()
 
     def _loss(self, pred, grad):
         if self.rd is not None:
@@ -473,6 +528,13 @@ class UnitEngine:
         if not (self.use_h2 and self.fused):
             return None
         xs = tuple(self.x_in.shape)
+        if k == "layer":
+            # a transposed conv in phase form (stride 2): the 3 x 3 phase conv and its weight gradient on planes
+            op = o["layer"]
+            if (op.tc_phase is not None and op.tc_phase.stride == 2 and xs[-1] % 16 == 0 and ops.conv_h2_supported(xs, op.wp4, 1, op.tc_phase.pad)
+                    and ops.wgrad_h2_supported(xs, op.wp4, 1, op.tc_phase.pad) and xs[0] * xs[1] * xs[2] * op.wp4[0] >= self.H2_MIN_OUT):
+                return "tconv"
+            return None
         if k == "rb" and "skip" not in o:
             c1, c2 = o["conv1"], o["conv2"]
             hs = tuple(self.t["h1"].shape)
@@ -609,7 +671,7 @@ class UnitEngine:
                 self._wgrad(c1, x, t["dh1"])
 
     # activation buffers a plan may keep as planes (all probed: a scale that is never used costs nothing)
-    H2_PROBED = {"rb": ("x", "h1", "dpre2", "dh1"), "rbws": ("x", "h1", "t", "dc2", "dh1"), "rbu": ("x", "h1", "t", "dc", "dup", "dsp")}
+    H2_PROBED = {"tconv": ("x", "dpre"), "rb": ("x", "h1", "dpre2", "dh1"), "rbws": ("x", "h1", "t", "dc2", "dh1"), "rbu": ("x", "h1", "t", "dc", "dup", "dsp")}
 
     def _probe_scales(self):
         """fp16 planes need a per-tensor power-of-two scale (include/rdo_ptq_hip.h, "H2 tensors").  One PROBE iteration of the unit on
@@ -649,8 +711,9 @@ class UnitEngine:
             return self._fb_rb_h2()
         if self.h2_plan in ("rbws", "rbu"):
             return self._fb_gdn_block_h2()
-        ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
-                         iter_publish=self._it_pub())
+        if self.h2_plan != "tconv":                           # (that plan gathers straight into planes)
+            ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
+                             iter_publish=self._it_pub())
         if self.kind == "layer" and o["layer"].is_gdn:
             # a GDN / IGDN that is its own unit (sequential Minnen2018-style coders): only gamma is trained, no dx needed
             op = o["layer"]
@@ -664,14 +727,44 @@ class UnitEngine:
             self._wgrad(op, x, t["t"], square=True)
         elif self.kind == "layer":
             op = o["layer"]
-            if op.tconv is not None:
+            if op.tconv is not None and op.tc_phase is None:
                 s_, q_, Hu, Wu = self.tc_geom
                 x = ops.zero_insert(x, s_, q_, q_, Hu, Wu, out=t["xu"])
             epi = op.qm.fused_epilogue() if self.include_act else None
             if epi is None and self.include_act and type(op.qm.activation_function).__name__ != "StraightThrough":
                 raise NotImplementedError("calibration engine: only LeakyReLU(0.01) or ReLU may be fused into a layer unit")
-            if self.fused:
-                act = {None: ops.ACT_NONE, L.EPI_LRELU: ops.ACT_LRELU, L.EPI_RELU: ops.ACT_RELU}[epi]
+            act = {None: ops.ACT_NONE, L.EPI_LRELU: ops.ACT_LRELU, L.EPI_RELU: ops.ACT_RELU}[epi]
+            if self.h2_plan == "tconv":                      # ... with the phase conv and its weight gradient on H2 tensors
+                ph, xs = op.tc_phase, tuple(x.shape)
+                xp, dypp = self._h2("x", x), self._h2("dpre", t["dyp"])
+                if op.wp_h2 is None:
+                    op.wp_h2 = ops.H2(torch.empty((2,) + tuple(op.wp4), device=self.dev, dtype=torch.int16), op.wscale)
+                ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None, xp, self.batch_offset,
+                                    iter_publish=self._it_pub())
+                ops.conv2d_fwd_h2(xp, xs, op.wp4, op.wp_h2, op.bias_p, 1, ph.pad, out=t["yp"])
+                self._shuffle(t["yp"], 2, t["y"])
+                self._tail_act(t["y"], None, act, t["dpre"])
+                ops.pixel_unshuffle2(t["dpre"], out_planes=dypp)
+                if op.slabs is None:
+                    ns = ops.wgrad_nsplit(xs, op.wp4, 1, ph.pad)
+                    op.slabs_p = self._buf(ns, *op.wp4)
+                    op.slabs = self._buf(ns, *op.w4)
+                ops.conv2d_wgrad_h2(xp, xs, dypp, op.wp4, 1, ph.pad, slabs=op.slabs_p)
+                ops.tconv_fold(op.slabs_p, ph, op.rows, op.w4[3], out=op.slabs)
+            elif op.tc_phase is not None:                    # transposed conv without zero insertion
+                if self.fused:
+                    self._tconv_forward(op, x, t["y"])                                             # pre-activation
+                    self._tail_act(t["y"], None, act, t["dpre"])
+                    self._tconv_wgrad(op, x, t["dpre"])
+                else:
+                    self._tconv_forward(op, x, t["y"], epilogue=L.EPI_NONE if epi is None else epi)
+                    self._loss(t["y"], t["dy"])
+                    g = t["dy"]
+                    if epi is not None:
+                        (ops.lrelu_bwd if epi == L.EPI_LRELU else ops.relu_bwd)(t["dy"], t["y"], t["dpre"])
+                        g = t["dpre"]
+                    self._tconv_wgrad(op, x, g)
+            elif self.fused:
                 self._conv_tail(op, x, t["y"], None, act, t["dpre"])                              # t["y"]: pre-activation, if it is stored
                 self._wgrad(op, x, t["dpre"])
             elif epi is not None:
@@ -793,11 +886,13 @@ class UnitEngine:
                 ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, iter_shadow=self.it_shadow)
             else:
                 ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, advance_iter=self.it)
+            self._after_step()
             return
         for op in opl:
             ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
                               op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
         ops.iter_advance(self.it)
+        self._after_step()
 
     def _split_point(self):
         """Called by the backward pass right before its last weight-gradient kernel.  Data-parallel recording only: the gradients
@@ -842,6 +937,7 @@ class UnitEngine:
                         ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, 1.0 / self.world, self.weight, self.sched,
                                            self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
                     ops.iter_advance(self.it)
+                self._after_step()
 
     # ------------------------------------------------------------------------------------------------------------------
     def run(self, n_iters=None):

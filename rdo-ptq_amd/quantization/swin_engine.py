@@ -36,7 +36,7 @@ class _FpOp:
         self.qm, self.kind = qm, qm.kind
         w = qm.org_weight.detach()
         self.bias = None if qm.org_bias is None else qm.org_bias.detach().contiguous()
-        self.tconv = None
+        self.tconv = self.tc_phase = None
         if qm.kind == "linear":
             self.w = w.reshape(w.shape[0], 1, 1, w.shape[1]).contiguous()
             self.stride, self.pad = 1, 0
@@ -49,6 +49,11 @@ class _FpOp:
             self.w = to_rows(w, tconv=True).flip(1, 2).contiguous()      # forward = stride-1 conv on the zero-inserted input
             self.stride, self.pad = 1, 0
             self.w_bwd = w.permute(0, 2, 3, 1).contiguous()              # dgrad = strided conv of dy with [Cin_t][kh][kw][Cout_t]
+            # forward without zero insertion where the geometry allows: stride-1 conv with the phase weight + pixel shuffle
+            self.tc_phase = ops.TconvPhase.get(self.w.shape[1], *self.tconv, True, self.w.device)
+            if self.tc_phase is not None:
+                self.wp = ops.tconv_expand(self.w, self.tc_phase)
+                self.bias_p = None if self.bias is None else self.bias.repeat_interleave(self.tc_phase.S2).contiguous()
         else:
             raise NotImplementedError(f"tail stage of kind '{qm.kind}'")
         self.K = self.w.shape[1]
@@ -75,6 +80,8 @@ class _FpOp:
             self.wd_planes = torch.empty((3,) + tuple(self.wd.shape), device=self.wd.device, dtype=torch.int16)
 
     def fill_planes(self):
+        if getattr(self, "wp_planes", None) is not None:
+            ops.split_bf16x3(self.wp, self.wp_planes)
         if self.wq_planes is not None:
             ops.split_bf16x3(self.w, self.wq_planes)
         if self.wd_planes is not None:
@@ -326,12 +333,21 @@ class TapeEngine(UnitEngine):
             self.tape.append(bwd)
             return y
         s_, p_, op_ = p.tconv
-        q = p.K - 1 - p_
-        Hu, Wu = (H - 1) * s_ + 1 + 2 * q + op_, (W - 1) * s_ + 1 + 2 * q + op_
-        xu = self._buf(B, Hu, Wu, x.shape[-1])
-        ops.zero_insert(x, s_, q, q, Hu, Wu, out=xu)
-        y = self._buf(B, Hu - p.K + 1, Wu - p.K + 1, p.w4[0])
-        self._conv(p, xu, y)
+        if p.tc_phase is not None:
+            ph = p.tc_phase
+            yp = self._buf(B, H, W, p.wp.shape[0])
+            if ops.uses_bf16x6(tuple(x.shape), tuple(p.wp.shape), 1, ph.pad) and getattr(p, "wp_planes", None) is None:
+                p.wp_planes = torch.empty((3,) + tuple(p.wp.shape), device=self.dev, dtype=torch.int16)
+            ops.conv2d_fwd(x, p.wp, p.bias_p, 1, ph.pad, out=yp, wplanes=getattr(p, "wp_planes", None))
+            y = self._buf(B, H * s_, W * s_, p.w4[0])
+            self._shuffle(yp, s_, y)
+        else:
+            q = p.K - 1 - p_
+            Hu, Wu = (H - 1) * s_ + 1 + 2 * q + op_, (W - 1) * s_ + 1 + 2 * q + op_
+            xu = self._buf(B, Hu, Wu, x.shape[-1])
+            ops.zero_insert(x, s_, q, q, Hu, Wu, out=xu)
+            y = self._buf(B, Hu - p.K + 1, Wu - p.K + 1, p.w4[0])
+            self._conv(p, xu, y)
 
         def bwd():
             dx, first = self._grad_slot(x)
@@ -350,19 +366,26 @@ class TapeEngine(UnitEngine):
             raise NotImplementedError("TapeEngine: GDN units do not occur in Lu2022 coders")
         t = self.t
         xin = x
-        if op.tconv is not None:
+        phase = op.tconv is not None and op.tc_phase is not None
+        if op.tconv is not None and not phase:
             s_, q_, Hu, Wu = self.tc_geom
             xin = ops.zero_insert(x, s_, q_, q_, Hu, Wu, out=t["xu"])
         epi = op.qm.fused_epilogue() if self.include_act else None
         y = t["y"]
-        self._conv(op, xin, y, epilogue=L.EPI_NONE if epi is None else epi)
+        if phase:
+            self._tconv_forward(op, x, y, epilogue=L.EPI_NONE if epi is None else epi)
+        else:
+            self._conv(op, xin, y, epilogue=L.EPI_NONE if epi is None else epi)
 
         def bwd():
             dy = self.G[id(y)]
             if epi is not None:
                 (ops.lrelu_bwd if epi == L.EPI_LRELU else ops.relu_bwd)(dy, y, t["dpre"])
                 dy = t["dpre"]
-            self._wgrad(op, xin, dy)
+            if phase:
+                self._tconv_wgrad(op, x, dy)
+            else:
+                self._wgrad(op, xin, dy)
         self.tape.append(bwd)
         return y
 

@@ -468,3 +468,34 @@ def test_adaround_step_writes_fragment_ordered_planes(shape):
     wd4 = wd.reshape(ci, kh, kw, co)
     torch.testing.assert_close(wd4, wq.flip(1, 2).permute(3, 1, 2, 0).contiguous(), rtol=0, atol=0)
     assert torch.equal(wdp.reshape(3, -1), ops.split_bf16x3(wd4).reshape(3, -1))
+
+
+# ---- transposed conv without zero insertion (phase weights + pixel shuffle) ----------------------------------------------------------
+@pytest.mark.parametrize("K,s,p,op,Cin,Cout,H,W", [(5, 2, 2, 1, 16, 24, 9, 12), (3, 2, 1, 1, 8, 8, 7, 5), (4, 2, 1, 0, 12, 4, 6, 6),
+                                                  (6, 3, 2, 1, 4, 8, 5, 4), (5, 2, 2, 0, 8, 8, 6, 6), (5, 2, 2, 1, 192, 192, 16, 16)])
+def test_conv_transpose2d_phase_form_matches_torch(K, s, p, op, Cin, Cout, H, W):
+    """ops.conv_transpose2d (stride-1 conv with the phase weight + pixel shuffle where output = stride x input, zero insertion
+    otherwise -- the (5, 2, 2, 0) case) against F.conv_transpose2d, with bias and a fused LeakyReLU; rdo_tconv_fold inverts
+    rdo_tconv_expand on the taps."""
+    import torch.nn.functional as F
+    from hipops import _lib as L
+    from hipops import ops
+    g = torch.Generator(device="cuda").manual_seed(K * 100 + s * 10 + p)
+    x = torch.randn(2, H, W, Cin, device="cuda", generator=g)
+    wt = torch.randn(Cin, Cout, K, K, device="cuda", generator=g) / (Cin * K * K / (s * s)) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    rows = wt.permute(1, 2, 3, 0).contiguous()                                   # to_rows(W, tconv=True)
+    ref = F.conv_transpose2d(x.permute(0, 3, 1, 2).double(), wt.double(), b.double(), stride=s, padding=p, output_padding=op)
+    for epi in (L.EPI_NONE, L.EPI_LRELU):
+        want = (F.leaky_relu(ref, 0.01) if epi == L.EPI_LRELU else ref).permute(0, 2, 3, 1)
+        got = ops.conv_transpose2d(x, rows, b, s, p, op, epilogue=epi)
+        assert got.shape == want.shape
+        assert float((got.double() - want).abs().max()) <= 3e-6 * float(want.abs().max())
+    ph = ops.TconvPhase.get(K, s, p, op, False, x.device)
+    assert (ph is None) == (op != s + 2 * p - K)
+    if ph is not None:
+        wp = ops.tconv_expand(rows, ph)
+        assert wp.shape == (Cout * s * s, ph.Kp, ph.Kp, Cin)
+        assert int((wp != 0).sum()) <= rows.numel()                            # every tap once, the rest structural zeros
+        back = ops.tconv_fold(wp.unsqueeze(0).contiguous(), ph, Cout, Cin)
+        assert torch.equal(back[0], rows)
