@@ -364,6 +364,7 @@ extern "C" int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d);
 extern "C" int rdo_conv2d_fwd_uses_bf16x6(const rdo_conv_desc* d) {
     const bool enabled = rdo::tuning(rdo::T_CONV_X6) != 0;
     if (!d || !enabled) return 0;
+    if (3.0 * d->Cout * d->KH * d->KW * d->Cin >= 2147483648.0) return 0;      // 32-bit plane offsets in the LDS-DMA loaders
     return rdo_conv2d_fwd_bf16x6_ksplit(d) >= 1;
 }
 

@@ -113,6 +113,7 @@ __device__ __forceinline__ void finish(const X6Args& a, long o, float v) {
 // LDS rows are 32 B per plane (2 chunks of 8 bf16); chunk swizzle c ^= (row>>3)&1 keeps ds_read_b128 conflict-free.
 __device__ __forceinline__ int chunk_off16(int row, int c) { return row * 32 + ((c ^ ((row >> 3) & 1)) << 4); }
 
+#ifdef RDO_DIAG   // superseded variants: only in a `make DIAG=1` build (A/B measurements, tuning key "fwd_x6_ver" = 3 / 4)
 // ---- v3: as v2 with a 128 x 192 workgroup tile (wave tile 64 x 96): half the weight-tile traffic and fragment reads per MFMA
 // LDS rows are 32 B per plane (2 chunks); chunk swizzle c ^= (row>>3)&1.
 
@@ -362,6 +363,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
             }
     }
 }
+
+#endif  // RDO_DIAG
 
 // ---- v5: the v3/DMA tile with the fragment reads software-pipelined one stage ahead ---------------------------------------------
 // Measured on v3: with loads and stores ablated the kernel still took 194 us against ~125 us of MFMA time -- every stage began with
@@ -903,16 +906,20 @@ static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* w
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
     return rdo::dispatch(
         [a](hipStream_t s) {
-            // default: v6 where its geometry applies, else v5.  RDO_X6_VER=5 forces v5; 3 / 4 select the earlier register-staged /
-            // LDS-DMA variants of the same tile (kept for A/B measurements);
-            // the LDS-DMA loaders address the weight planes with 32-bit element offsets
+            // default: v6 where its geometry applies, else v5 ("fwd_x6_ver" = 5 forces v5; 3 / 4, the earlier register-staged / LDS-DMA
+            // variants of the same tile, exist only in a DIAG build).  The LDS-DMA loaders address the weight planes with 32-bit
+            // element offsets: rdo_conv2d_fwd_uses_bf16x6 refuses larger weights.
             const int ver_env = rdo::tuning(rdo::T_FWD_X6_VER);
-            const int ver = (ver_env != 3 && 3 * a.wplane >= (1L << 31)) ? 3 : (ver_env >= 5 ? 5 : ver_env);
+#ifdef RDO_DIAG
+            const int ver = ver_env >= 5 ? 5 : (ver_env < 3 ? 3 : ver_env);
+#else
+            constexpr int ver = 5;
+#endif
             // v6 (the three kw taps share one activation image) takes the stride-1 3-wide kernels whose tiles are whole image rows
             const bool v6_ok = a.stride == 1 && a.KW == 3 && a.pad == 1 && a.Cin % 16 == 0 && a.M % 128 == 0 && a.W >= 16 &&
                                (a.W % 128 == 0 || (128 % a.W == 0 && (a.H * a.W) % 128 == 0)) &&
                                a.ksplit <= (a.Cin / 16) * a.KH;
-            if (ver_env >= 6 && v6_ok && 3 * a.wplane < (1L << 31)) {
+            if (ver_env >= 6 && v6_ok) {
                 constexpr size_t lds6 = (size_t)2 * 3 * 144 * 32 + (size_t)2 * 3 * 192 * 32;
                 static rdo::PerDevice attr6;
                 if (!attr6.done()) {
@@ -931,20 +938,31 @@ static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* w
                 }
                 return RDO_OK;
             }
+            const size_t lds = (size_t)2 * 3 * (128 + 192) * 32 + (ver == 5 ? 0 : 4096);
+            dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
+#ifdef RDO_DIAG
             const void* kern = ver == 3 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<false>)
                              : ver == 4 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<true>)
                                         : reinterpret_cast<const void*>(conv_fwd_x6v5_kernel);
-            const size_t lds = (size_t)2 * 3 * (128 + 192) * 32 + (ver == 5 ? 0 : 4096);
             static rdo::PerDevice attr[3];
             if (!attr[ver - 3].done()) {
                 if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6 v%d) failed", ver);
                 attr[ver - 3].mark();
             }
-            dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
             if (ver == 3) hipLaunchKernelGGL(conv_fwd_x6v3_kernel<false>, grid, dim3(256), lds, s, a);
             else if (ver == 4) hipLaunchKernelGGL(conv_fwd_x6v3_kernel<true>, grid, dim3(256), lds, s, a);
             else hipLaunchKernelGGL(conv_fwd_x6v5_kernel, grid, dim3(256), lds, s, a);
+#else
+            static rdo::PerDevice attr5;
+            if (!attr5.done()) {
+                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
+                    hipSuccess)
+                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6 v5) failed");
+                attr5.mark();
+            }
+            hipLaunchKernelGGL(conv_fwd_x6v5_kernel, grid, dim3(256), lds, s, a);
+#endif
             if (int rc = rdo::check_launch("conv_fwd_x6")) return rc;
             if (a.ksplit > 1 && !a.partial_only) {
                 long g = rdo::ceil_div((long)a.M * a.Cout, 256);

@@ -62,6 +62,7 @@ __device__ __forceinline__ void split3_x4(float v0, float v1, float v2, float v3
 constexpr int ROWB = 64, GROUPB = 4 * ROWB + 16;     // bytes per row / per padded group of four rows
 __device__ __forceinline__ int chunk_off(int row, int c) { return (row >> 2) * GROUPB + (row & 3) * ROWB + (c << 4); }
 
+#ifdef RDO_DIAG   // the four-wave predecessor of conv_wgrad_x6w8_kernel: only in a `make DIAG=1` build (tuning key "wgrad_x6_w8" = 0)
 template <int TCO, int TCI, bool SQ>
 __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
     constexpr int WCO = TCO / 2, WCI = TCI / 2;
@@ -333,6 +334,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_x6_kernel(WgX6Args a) {
     }
 }
 
+#endif  // RDO_DIAG
+
 // ---- eight-wave variant: the same 192 x 192 tile and LDS images, but 512 threads ---------------------------------------------------
 // One wave per SIMD cannot keep the matrix pipe busy (tools/mfma_probe.hip: a wgrad-shaped loop reaches 0.35 of the nominal rate
 // with one workgroup of four waves per CU and 0.56-0.59 with two waves per SIMD), and the 144 accumulators + 144 KiB of LDS of the
@@ -602,33 +605,34 @@ int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy,
     a.x_bytes = (unsigned)((size_t)d->B * d->H * d->W * d->Cin * sizeof(float));     // < 2^32: checked by uses_bf16x6
     a.dy_bytes = (unsigned)((size_t)a.M * d->Cout * sizeof(float));
     constexpr size_t lds = (size_t)2 * 3 * (T + T) / 4 * (4 * 64 + 16);
-    static rdo::PerDevice attr_set;
-    if (!attr_set.done()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<T, T, false>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<T, T, true>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-            return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6, %zu B LDS) failed", lds);
-        attr_set.mark();
-    }
     dim3 grid((unsigned)nsplit, (unsigned)(a.KH * a.KW * a.tiles_co * a.tiles_ci));
-    // default: the eight-wave kernel (two waves per SIMD); RDO_WGX6_W8=0 selects the four-wave one (A/B: tools/wgrad_x6_check.py)
-    const int w8 = rdo::tuning(rdo::T_WGRAD_X6_W8);
-    if (w8) {
-        static rdo::PerDevice attr8;
-        if (!attr8.done()) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6w8_kernel<false>),
+    // the eight-wave kernel (two waves per SIMD); its four-wave predecessor ("wgrad_x6_w8" = 0) exists only in a DIAG build
+#ifdef RDO_DIAG
+    if (!rdo::tuning(rdo::T_WGRAD_X6_W8)) {
+        static rdo::PerDevice attr_set;
+        if (!attr_set.done()) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<T, T, false>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6w8_kernel<true>),
+                hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6_kernel<T, T, true>),
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-                return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6w8, %zu B LDS) failed", lds);
-            attr8.mark();
+                return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6, %zu B LDS) failed", lds);
+            attr_set.mark();
         }
-        if (a.square_input) hipLaunchKernelGGL((conv_wgrad_x6w8_kernel<true>), grid, dim3(512), lds, s, a);
-        else hipLaunchKernelGGL((conv_wgrad_x6w8_kernel<false>), grid, dim3(512), lds, s, a);
-        return rdo::check_launch("conv_wgrad_x6w8");
+        if (a.square_input) hipLaunchKernelGGL((conv_wgrad_x6_kernel<T, T, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((conv_wgrad_x6_kernel<T, T, false>), grid, dim3(256), lds, s, a);
+        return rdo::check_launch("conv_wgrad_x6");
     }
-    if (a.square_input) hipLaunchKernelGGL((conv_wgrad_x6_kernel<T, T, true>), grid, dim3(256), lds, s, a);
-    else hipLaunchKernelGGL((conv_wgrad_x6_kernel<T, T, false>), grid, dim3(256), lds, s, a);
-    return rdo::check_launch("conv_wgrad_x6");
+#endif
+    static rdo::PerDevice attr8;
+    if (!attr8.done()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6w8_kernel<false>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_x6w8_kernel<true>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_x6w8, %zu B LDS) failed", lds);
+        attr8.mark();
+    }
+    if (a.square_input) hipLaunchKernelGGL((conv_wgrad_x6w8_kernel<true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((conv_wgrad_x6w8_kernel<false>), grid, dim3(512), lds, s, a);
+    return rdo::check_launch("conv_wgrad_x6w8");
 }

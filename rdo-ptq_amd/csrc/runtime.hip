@@ -37,7 +37,11 @@ void tune_init() {
     std::call_once(g_tune_once, [] {
         for (int i = 0; i < T_COUNT; ++i) {
             const char* e = getenv(kTune[i].env);
-            g_tune[i].store(e ? atoi(e) : kTune[i].dflt);
+            int v = e ? atoi(e) : kTune[i].dflt;
+#ifndef RDO_DIAG   // values that select code compiled only into diagnostic builds are ignored (a stray variable must change nothing)
+            if (i == T_X6P_ABLATE || (i == T_FWD_X6_VER && v < 5) || (i == T_WGRAD_X6_W8 && v == 0)) v = kTune[i].dflt;
+#endif
+            g_tune[i].store(v);
         }
     });
 }
@@ -91,6 +95,8 @@ int rdo_set_tuning(const char* key, int32_t value) {
     RDO_REQUIRE(i >= 0, "rdo_set_tuning: unknown key '%s'", key ? key : "(null)");
 #ifndef RDO_DIAG
     RDO_REQUIRE(i != rdo::T_X6P_ABLATE || value == 0, "rdo_set_tuning: 'x6p_ablate' exists only in a diagnostic build (make DIAG=1)");
+    RDO_REQUIRE(i != rdo::T_FWD_X6_VER || value >= 5, "rdo_set_tuning: 'fwd_x6_ver' %d exists only in a diagnostic build (make DIAG=1)", value);
+    RDO_REQUIRE(i != rdo::T_WGRAD_X6_W8 || value != 0, "rdo_set_tuning: the four-wave weight gradient exists only in a diagnostic build (make DIAG=1)");
 #endif
     rdo::tune_init();
     rdo::g_tune[i].store(value);

@@ -145,7 +145,11 @@ def test_unit_seed_is_reproducible_and_distinct():
 def test_tuning_switches_round_trip():
     from hipops import _lib
     h = _lib.lib()
-    assert h.rdo_get_tuning(b"wgrad_x6_w8") == 1 and h.rdo_get_tuning(b"conv_x6") == 1
-    assert h.rdo_set_tuning(b"wgrad_x6_w8", 0) == 0 and h.rdo_get_tuning(b"wgrad_x6_w8") == 0
-    assert h.rdo_set_tuning(b"wgrad_x6_w8", 1) == 0
+    assert h.rdo_get_tuning(b"h2_stagger") == 1 and h.rdo_get_tuning(b"conv_x6") == 1
+    assert h.rdo_set_tuning(b"h2_stagger", 0) == 0 and h.rdo_get_tuning(b"h2_stagger") == 0
+    assert h.rdo_set_tuning(b"h2_stagger", 1) == 0
+    # switches that would select code compiled only into diagnostic builds (superseded kernel variants, ablation masks: wrong results)
+    # are refused by the shipped library
+    assert h.rdo_set_tuning(b"x6p_ablate", 7) != 0 and h.rdo_get_tuning(b"x6p_ablate") == 0
+    assert h.rdo_set_tuning(b"wgrad_x6_w8", 0) != 0 and h.rdo_set_tuning(b"fwd_x6_ver", 3) != 0
     assert h.rdo_set_tuning(b"no_such_key", 1) != 0 and h.rdo_get_tuning(b"no_such_key") == -1

@@ -39,7 +39,7 @@ def wgrad_fp64(x, dy, K, s, p):
     return dw
 
 
-@pytest.mark.parametrize("w8", [1, 0])
+@pytest.mark.parametrize("w8", [1])          # the four-wave predecessor ("wgrad_x6_w8" = 0) is compiled only into `make DIAG=1` builds
 @pytest.mark.parametrize("B,H,Cin,Cout,K,s,p", WGRAD_X6_SHAPES)
 def test_wgrad_x6_matches_fp64_all_channels(ops, w8, B, H, Cin, Cout, K, s, p):
     g = torch.Generator(device="cuda").manual_seed(H * 31 + Cout + K)
