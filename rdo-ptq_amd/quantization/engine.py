@@ -208,6 +208,9 @@ class UnitEngine:
         # (hipops.autograd) and losses.RateDistortionLoss is differentiated back to it; rec_loss stays the lp term.
         self.rd = rd
         if rd is not None:
+            if not include_act_func:
+                raise NotImplementedError("calibration engine: loss_mode='rd' substitutes the unit's module OUTPUT (after its fused "
+                                          "activation); include_act_func=False optimises the pre-activation and cannot be combined with it")
             fuse_tail = use_h2 = False
             self.use_h2 = False
         self.fuse_tail = bool(fuse_tail)       # False: the separate epilogue / loss / activation-backward kernels (A/B, tests)
@@ -1044,6 +1047,9 @@ class UnitEngine:
         finally:
             handle.remove()
             rd["model"].train(was_training)
+        if leaf.grad is None:
+            raise RuntimeError("loss_mode='rd': no gradient reached the unit's output -- a module behind it detaches the tape (dynamic "
+                               "activation quantisers of trained modules do); run the RD task loss with act_quant=False")
         self.g_task.copy_(leaf.grad.permute(0, 2, 3, 1))
         self.task_log[i, 0] += loss.detach()
 
