@@ -84,6 +84,9 @@ def parse():
                     help="after the timed region (N = 1 only): wall time of the whole `recon_model` schedule through the public "
                          "layer_/block_reconstruction API with this many iterations per unit (SURVEY 8d's definition of the metric: cache "
                          "building + plan recording + loops); 0: skip")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the extra measurements after the timed region (N = 1 only): batch 32 / 64 throughput of the same workload and "
+                         "one number each for BASELINE configs 3, 4, 5 (tools/bench_configs.py)")
     ap.add_argument("--sustain-steps", type=int, default=1000,
                     help="steps run AFTER the timed region in windows of 100 to report a sustained rate (0: skip)")
     return ap.parse_args()
@@ -259,9 +262,40 @@ def gpu_leg(a, rank, world, device):
         if not torch.isfinite(tot[:a.warmup + a.steps + sustain]).all():
             raise RuntimeError(f"non-finite loss in unit {name}")
     h2_units = [n for n, e in engines if getattr(e, "h2_plan", None)]
+    # ---- "throughput" configurations of SURVEY 8d (outside the timed region): the same schedule at mini-batch 32 and 64
+    batch_extra = {}
+    if world == 1 and not force_dp and not a.no_extras:
+        for bb in (32, 64):
+            if bb > a.images:
+                continue
+            try:
+                steps_b = 6
+                eb = []
+                for name, u in units:
+                    kind, mods = _unit_modules(u)
+                    cq, cf, co = caches[name]
+                    idx = torch.stack([torch.randperm(a.images, generator=gi)[:bb] for _ in range(steps_b + 2)])
+                    eb.append(UnitEngine(kind, mods, cq, cf, co, batch_size=bb, iters=steps_b + 2, weight=0.01, b_range=(20, 2), warmup=0.2,
+                                         input_prob=0.5, seed=1005, idx_table=idx, use_graph=not a.no_graph))
+                for e in eb:
+                    e.run(2)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for e in eb:
+                    e.run(steps_b)
+                torch.cuda.synchronize()
+                tb = time.perf_counter() - t1
+                batch_extra[f"batch{bb}"] = {"images_per_s": round(len(eb) * bb * steps_b / tb, 1), "ms_per_step": round(tb / steps_b * 1e3, 3),
+                                             "steps": steps_b}
+                log(f"batch {bb}: {tb / steps_b * 1e3:.2f} ms/step = {len(eb) * bb * steps_b / tb:.0f} images/s")
+                del eb
+                torch.cuda.empty_cache()
+            except Exception as ex:      # an extra must never cost the headline
+                batch_extra[f"batch{bb}"] = {"error": repr(ex)[:300]}
     # which data-parallel loop ran: "graph" (iteration + collectives replayed from one graph) or "host" (plan / all-reduce / plan)
     dp_paths = sorted({e.dp_path for _, e in engines if e.dp_path is not None})
-    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, h2_units=h2_units, dp_paths=dp_paths)
+    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, h2_units=h2_units, dp_paths=dp_paths,
+                batch_extra=batch_extra)
 
 
 # ----------------------------------------------------------------------------- CPU baseline (oracle = "port")
@@ -431,6 +465,18 @@ def main():
                                   "images_per_s": round(rs["images_per_s"], 1),
                                   "note": "whole schedule through the public API incl. asymmetric cache building and plan recording; the "
                                           "reference's 20000-iteration schedule is timed by tools/full_schedule.py (profiles/)"}
+        if world == 1 and not a.no_extras and not os.environ.get("RDO_BENCH_FORCE_DP"):
+            extra = dict(res["batch_extra"])
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_configs
+            for key, fn in (("config3_attn_w10", bench_configs.attn_w10), ("config4_lu2022_g_a1", bench_configs.lu2022_unit),
+                            ("config5_mbt2018_w8a8_eval", bench_configs.mbt2018_eval)):
+                try:
+                    torch.cuda.empty_cache()
+                    extra[key] = fn(log=log)
+                except Exception as ex:      # an extra must never cost the headline
+                    extra[key] = {"error": repr(ex)[:300]}
+            out["extra"] = extra
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_leg(a)
             out["cpu_baseline"]["value"] = round(out["cpu_baseline"]["value"], 3)

@@ -21,13 +21,15 @@ sys.path.insert(0, os.path.join(ROOT, "rdo-ptq_amd"))
 sys.path.insert(0, ROOT)
 
 
-def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2, log=print, quality=True):
+def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2, log=print, quality=True, arch="anchor", w_bits=8,
+                 a_bits=8, per_unit_log=True):
+    """arch: "anchor" | "attn" (Cheng2020-attn, BASELINE config 3); w_bits / a_bits: weight grid and dynamic activation grid."""
     import math
     import bench
     from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstruction, layer_reconstruction
     from test_datasets import evaluate_images
     dev = torch.device("cuda:0")
-    model = bench.seeded_model(192, 1005, dev)
+    model = bench.seeded_model(192, 1005, dev, arch=arch)
     g = torch.Generator().manual_seed(1005)
     with torch.no_grad():      # variance-preserving conv weights: the signal (and the quantisation error) reaches the output
         for name, p_ in model.named_parameters():
@@ -49,8 +51,10 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
         mse = float(((out - ref_out) ** 2).mean())
         peak = float(ref_out.max() - ref_out.min())
         return 10 * math.log10(peak * peak / max(mse, 1e-30))
-    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
-    aq = {"n_bits": 8, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    wq = {"n_bits": w_bits, "channel_wise": True, "scale_method": "max"}
+    aq = {"n_bits": a_bits, "channel_wise": True, "scale_method": "max", "leaf_param": False}
+    if a_bits != 8:
+        aq["dynamic_bits"] = a_bits           # the reference's dynamic activation quantiser hard-wires 8 bits (quantizer.py:81)
     qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True).to(dev).eval()
     qnn.set_first_last_layer_to_8bit()
     qnn.disable_network_output_quantization()
@@ -103,8 +107,9 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
         units.append(dict(unit=name, kind=e.kind, loop_s=round(t["loop_s"], 3), cache_s=round(t["cache_s"], 3), record_s=round(t["record_s"], 3),
                           hard_frac=done / tot, loss_first=float(rec[0] + task[0] + rnd[0]), loss_last=float(rec[-1] + task[-1] + rnd[-1]),
                           rec_first=float(rec[0]), rec_last=float(rec[-1]), round_last=float(rnd[-1])))
-        log(f"  {name:24s} {e.kind:5s} loop {t['loop_s']:7.2f} s  cache {t['cache_s']:5.2f} s  record {t['record_s']:5.2f} s  "
-            f"soft targets in {{0,1}}: {100 * done / tot:6.2f} %  rec {float(rec[0]):.4e} -> {float(rec[-1]):.4e}  round {float(rnd[-1]):.3e}")
+        if per_unit_log:
+            log(f"  {name:24s} {e.kind:5s} loop {t['loop_s']:7.2f} s  cache {t['cache_s']:5.2f} s  record {t['record_s']:5.2f} s  "
+                f"soft targets in {{0,1}}: {100 * done / tot:6.2f} %  rec {float(rec[0]):.4e} -> {float(rec[-1]):.4e}  round {float(rnd[-1]):.3e}")
     res["units"] = units
     if quality:
         qnn.set_quant_state(True, False)
