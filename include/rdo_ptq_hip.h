@@ -63,6 +63,8 @@ const char* rdo_last_error(void);
  *   "wgrad_p3_row" 1 (default): 3x3 stride-1 plane-input weight gradients share one input row image between the three kw taps
  *   "thin_mfma"    1 (default): weight gradients with <= 4 input channels and a patch of 5..32 values run the gather-operand MFMA kernel
  *   "h2_stagger"   1 (default): in the halo-tile plane-input conv waves 4-7 run two thirds of a K stage behind waves 0-3 (same results)
+ *   "ada_w1_min"   batched AdaRound step: tensors with at least this many gradient slabs are walked one element per thread (4x the
+ *                  threads on the slab chain) instead of four
  *   "tail_grid"    most workgroups of a fused loss kernel (each ends with one atomic add into the 32-slot loss log)
  *   "x6p_ablate"   ONLY in a diagnostic build (`make DIAG=1`, -DRDO_DIAG; the shipped library rejects a non-zero value and ignores
  *                  RDO_X6P_ABLATE): bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,

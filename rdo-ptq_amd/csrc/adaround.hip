@@ -262,8 +262,9 @@ __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
 // every weight tensor of a unit in ONE launch (the AdaRound step of a block unit was 3-5 launches of 6-36 us, each a few hundred
 // workgroups that left most of the chip idle): block ranges [blk_end[t-1], blk_end[t]) belong to tensor t
 constexpr int kMaxBatch = 8;
-constexpr int kManySlabs = 128;
+// (the slab count from which a tensor is walked one element per thread is the tuning key "ada_w1_min", default 128: lower values measured slower)
 struct AdaBatch {
+    int w1_min;             // tensors with at least this many gradient slabs run one element per thread (tuning key "ada_w1_min")
     int32_t* iter_shadow;   // nullable: block 0 leaves *iter_ptr + 1 here (iteration-counter hand-over, rdo_ptq_hip.h)
     AdaArgs a[kMaxBatch];
     int blk_end[kMaxBatch];
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256) void ada_step_batch_kernel(AdaBatch b) {
     const int beg = t ? b.blk_end[t - 1] : 0;
     // many slabs over a small tensor (the 1x1 GDN gamma gradient, 256 slabs of 36 K elements): one element per thread -- four times
     // the threads walking the slab chain; same per-element summation order
-    if (b.a[t].nsplit >= kManySlabs && b.a[t].mode != 2) ada_step_body<1>(b.a[t], (long)blockIdx.x - beg, (long)b.blk_end[t] - beg);
+    if (b.a[t].nsplit >= b.w1_min && b.a[t].mode != 2) ada_step_body<1>(b.a[t], (long)blockIdx.x - beg, (long)b.blk_end[t] - beg);
     else ada_step_body<4>(b.a[t], (long)blockIdx.x - beg, (long)b.blk_end[t] - beg);
 }
 
@@ -528,6 +529,8 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
     RDO_REQUIRE(!(advance_iter && iter_shadow), "rdo_adaround_step_batch: advance_iter and iter_shadow are alternatives");
     RDO_REQUIRE(!iter_shadow || iter_ptr, "rdo_adaround_step_batch: iter_shadow needs iter_ptr");
     AdaBatch b{}, bw{};
+    const int w1_min = rdo::tuning(rdo::T_ADA_W1_MIN);
+    b.w1_min = bw.w1_min = w1_min;
     int blocks = 0, wblocks = 0;
     double bytes = 0.0;
     for (int i = 0; i < n; ++i) {
@@ -546,7 +549,7 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
         a.wq_planes = static_cast<unsigned short*>(it.wq_planes);
         a.wd_planes = it.wd ? static_cast<unsigned short*>(it.wd_planes) : nullptr;
         a.wq_pscale = it.wq_plane_scale; a.wd_pscale = it.wd_plane_scale; a.ovf = rdo::h2_overflow_flag();
-        blocks += (int)grid_for((it.nsplit >= kManySlabs && mode != 2) ? it.d.numel : it.d.numel / 4);
+        blocks += (int)grid_for((it.nsplit >= w1_min && mode != 2) ? it.d.numel : it.d.numel / 4);
         b.blk_end[i] = blocks;
         bytes += 4.0 * it.d.numel * ((mode == 2 ? 1 : it.nsplit) + (mode == 1 ? 3.0 : 9.0));
         if (mode != 1 && it.wd && it.d.Cin > 0) {
