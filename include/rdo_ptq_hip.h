@@ -59,7 +59,8 @@ const char* rdo_last_error(void);
  *   "fwd_x6_ver"   forward bf16x6 kernel generation (default: newest)
  *   "xcd"          1 (default): XCD-aware tile numbering in the bf16x6 kernels
  *   "graph_unroll" iterations per replayed graph in rdo_plan_run for long runs (default 8; 1: one graph launch per iteration)
- *   "x6p_halo"     1 (default): 3x3 stride-1 pad-1 plane-input convs with H, W multiples of 16 run the halo-tile kernel; 0: the per-tap kernel
+ *   "x6p_halo"     1 (default): 3x3 stride-1 pad-1 plane-input convs with H, W multiples of 16 run the halo-tile kernel (256 x 192 tiles,
+ *                  or 256 x 64 tiles where the wide ones would need a K split); 2: wide tiles only; 0: the per-tap kernel
  *   "wgrad_p3_row" 1 (default): 3x3 stride-1 plane-input weight gradients share one input row image between the three kw taps
  *   "thin_mfma"    1 (default): weight gradients with <= 4 input channels and a patch of 5..32 values run the gather-operand MFMA kernel
  *   "h2_stagger"   1 (default): in the halo-tile plane-input conv waves 4-7 run two thirds of a K stage behind waves 0-3 (same results)

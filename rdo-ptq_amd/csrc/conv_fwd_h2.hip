@@ -473,24 +473,32 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2_kernel(H2Args a) {
 // and stage: two weight pieces for stage s + 2 and, in taps 0-2, one of the wave's three pieces of the next slice's halo; the counted
 // vmcnt at the top of a stage is therefore 3 in taps 1-3 and 2 otherwise (the halo piece is issued before the weight pieces of its
 // stage).
+// Wave layout WM x WN (8 waves), wave tile (TM x TN) MFMA tiles of 32 x 32: the 256 patch pixels are WM * TM * 32, the N tile is
+// WN * TN * 32 channels.  <4, 2, 2, 3>: 256 x 192, the shape for problems with >= ~190 such tiles (the 128^2 convs).  <8, 1, 1, 2>:
+// 256 x 64 -- three N tiles per 192 output channels -- for the 64^2 convs (64 patches: 192 workgroups) and the 32^2 convs with 768
+// output channels, which would otherwise run the per-tap kernel split over K with a second pass over 4-12 partial tensors.
+template <int WM, int WN, int TM, int TN>
 __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
-    constexpr int BN = 192;
-    constexpr int TM = 2, TN = 3;
+    static_assert(WM * WN == 8 && WM * TM == 8, "eight waves, 256 patch pixels");
+    constexpr int BN = WN * TN * 32;
     constexpr int PT = 16, HWD = PT + 2, HPIX = HWD * HWD;   // patch edge, halo edge, halo pixels (324)
     constexpr int APL = HPIX * 32;                           // one plane of the halo tile: 10368 B
     constexpr int APIECES = NP * HPIX * 2;                   // 16-byte pieces of the two planes: 1296 (21 wave instructions)
     constexpr int AJ = 3;                                    // pieces per wave (8 * 3 = 24 >= 21)
     constexpr int ABUF = 8 * AJ * 1024;                      // 24 KiB: every wave piece lands inside the buffer, masked ones as zeros
     constexpr int BPLANE = BN * 32, BSTAGE = NP * BPLANE;    // 12 KiB
-    constexpr int BPIECES = BSTAGE / 1024;
+    constexpr int BPIECES = BSTAGE / 1024;                   // 12 (BN = 192) or 4 (BN = 64)
+    constexpr int BJ = (BPIECES + 7) / 8;                    // weight pieces per wave and stage
     constexpr int RING = 3;
     constexpr int BBASE = 2 * ABUF;
-    constexpr int SROW = 196;
+    constexpr int SROW = BN + 4;
+    constexpr int PROWS = WM * 32;                           // tile rows finished per epilogue pass
 
     extern __shared__ __attribute__((aligned(16))) char smem[];   // [2][ABUF] halo tiles, [RING][BSTAGE] weights; epilogue: fp32 [128][SROW]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm0 = (wave >> 1) * 64, wn0 = (wave & 1) * 96;
+    const int wrow = wave / WN, wcol = wave - wrow * WN;
+    const int wm0 = wrow * (TM * 32), wn0 = wcol * (TN * 32);
     const int li = lane & 31, lh = lane >> 5;
     const TileId tile = xcd_tile_id(a.xcd_mode);
     const int n0 = tile.n * BN;
@@ -517,10 +525,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
         a_off[j] = ok ? (int)(pl * a.xplane) + ((pb * a.H + hi) * a.W + wi) * 16 + chunk * 8 : -1;
     }
     // ---- B loader: as in conv_fwd_h2_kernel
-    int dma_src[2], dma_k[2];
+    int dma_src[BJ], dma_k[BJ];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int k = wave + 8 * j < BPIECES ? wave + 8 * j : wave;
+    for (int j = 0; j < BJ; ++j) {
+        const int k = (wave + 8 * j) % BPIECES;              // (waves beyond the image repeat a piece: uniform DMA counts per wave)
         dma_k[j] = k;
         const int e = k * 64 + lane;
         const int pl = e / (BN * 2);
@@ -573,10 +581,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
     for (int j = 0; j < AJ; ++j) dma_a(j, 0);
     set_wsrc(0);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma_b(j, 0);
+    for (int j = 0; j < BJ; ++j) dma_b(j, 0);
     set_wsrc(1);
 #pragma unroll
-    for (int j = 0; j < 2; ++j) dma_b(j, 1);
+    for (int j = 0; j < BJ; ++j) dma_b(j, 1);
 
     // products of a stage in the order (A1,B0) (A0,B1) (A0,B0), small terms first -- for every wave.  STAGGER: the two waves of a SIMD
     // (w and w + 4) leave the barrier together; if both then read their fragments and both then multiply, the matrix pipe idles
@@ -610,8 +618,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
             constexpr int KH = TAP / 3, KW = TAP % 3;
             // stage s (weights) and, in tap 0, this slice's halo have landed once at most the DMAs issued after them are outstanding
             if (a.ablate & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if constexpr (TAP >= 1 && TAP <= AJ) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if constexpr (TAP >= 1 && TAP <= AJ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ + 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ) : "memory");
             __builtin_amdgcn_s_barrier();
             const int nb = buf >= 1 ? buf - 1 : RING - 1;    // (s + 2) % 3
             const char* stb = smem + buf * BSTAGE;
@@ -637,7 +645,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
                 if (k == 0) {
                     if constexpr (TAP < AJ) dma_a(TAP, cs + 1);
                 }
-                dma_b(k, nb);
+                if (k < BJ) dma_b(k, nb);
             };
             if constexpr (!LATE) {
                 rd_a(1); rd_b(0);
@@ -700,14 +708,14 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int rr = (r & 3) + 8 * (r >> 2) + 4 * lh;
-                stg[((wave >> 1) * 32 + rr) * SROW + wn0 + j * 32 + li] = acc[pass][j][r] * a.acc_scale;
+                stg[(wrow * 32 + rr) * SROW + wn0 + j * 32 + li] = acc[pass][j][r] * a.acc_scale;
             }
         __syncthreads();
 #pragma unroll 4
-        for (int k = 0; k < 12; ++k) {
-            const int q = tid + 512 * k;                     // 128 rows x 48 quads of channels
-            const int row = q / 48, c4 = q - row * 48;
-            const int tl = (row >> 5) * 64 + pass * 32 + (row & 31);
+        for (int k = 0; k < PROWS * (BN / 4) / 512; ++k) {
+            const int q = tid + 512 * k;                     // PROWS rows x BN / 4 quads of channels
+            const int row = q / (BN / 4), c4 = q - row * (BN / 4);
+            const int tl = (row >> 5) * (TM * 32) + pass * 32 + (row & 31);
             const int m = pbase + (tl >> 4) * a.W + (tl & 15);
             const int n = n0 + c4 * 4;
             if (n >= a.Cout) continue;
@@ -727,10 +735,10 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
         if (need_planes) {
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int q = tid + 512 * k;                 // 128 rows x 12 slices of 16 channels
-                const int row = q & 127, sl = q >> 7;
-                const int tl = (row >> 5) * 64 + pass * 32 + (row & 31);
+            for (int k = 0; k < PROWS * (BN / 16) / 512; ++k) {
+                const int q = tid + 512 * k;                 // PROWS rows x BN / 16 slices of 16 channels
+                const int row = q % PROWS, sl = q / PROWS;
+                const int tl = (row >> 5) * (TM * 32) + pass * 32 + (row & 31);
                 const int m = pbase + (tl >> 4) * a.W + (tl & 15);
                 const int n = n0 + sl * 16;
                 if (n >= a.Cout) continue;
@@ -881,9 +889,15 @@ extern "C" int64_t rdo_conv2d_fwd_h2_workspace(const rdo_conv_desc* d) {
     return ks > 1 ? (int64_t)ks * d->B * d->Ho * d->Wo * d->Cout : 0;
 }
 
-static bool h2_halo_shape(const rdo_conv_desc* d) {
-    return rdo::tuning(rdo::T_X6P_HALO) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H % 16 == 0 && d->W % 16 == 0 &&
-           h2_ksplit(d) == 1;
+// 3 x 3 "same" convs on 16 x 16 patches run the halo kernel: 1 = with the 256 x 192 tile (enough such tiles to fill the chip without a K
+// split), 2 = with the 256 x 64 tile (problems whose 256 x 192 tiles would need a K split but whose 256 x 64 tiles fill >= 5/8 of the
+// CUs: the 64^2 convs and the 32^2 convs with 768 output channels), 0 = no
+static int h2_halo_shape(const rdo_conv_desc* d) {
+    if (!(rdo::tuning(rdo::T_X6P_HALO) && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 && d->H % 16 == 0 && d->W % 16 == 0)) return 0;
+    if (h2_ksplit(d) == 1) return 1;
+    const long patches = (long)d->B * d->H * d->W / 256;
+    if (rdo::tuning(rdo::T_X6P_HALO) != 2 && d->Cout % 64 == 0 && patches * (d->Cout / 64) >= 160) return 2;    // "x6p_halo" = 2: wide tile only
+    return 0;
 }
 
 static int conv2d_fwd_h2_impl(const rdo_conv_desc* d, const void* x_planes, float x_scale, const void* wplanes, float w_scale, const float* bias,
@@ -938,24 +952,45 @@ static int conv2d_fwd_h2_impl(const rdo_conv_desc* d, const void* x_planes, floa
                                                  4.0 * (out_planes != nullptr));
     constexpr size_t lds = (size_t)128 * 196 * 4;            // the epilogue's fp32 staging tile is the largest user (98 KiB)
     // 3 x 3 "same" convs on 16 x 16 patches: the halo kernel (no K split: the shapes that qualify fill the chip with tiles)
-    const bool halo = h2_halo_shape(d) && ks == 1;
+    const int halo = h2_halo_shape(d);
     RDO_REQUIRE(!tail || halo, "rdo_conv2d_fwd_h2_tail: shape not on the halo kernel (rdo_conv2d_fwd_h2_tail_supported)");
-    if (halo)
+    if (halo == 1 && ks == 1)
         return rdo::dispatch(
             [a](hipStream_t s) {
                 static_assert(lds >= 2 * 24576 + 3 * 2 * 192 * 32, "halo kernel LDS");
                 static rdo::PerDevice attr;
                 if (!attr.done()) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_h2h_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds) != hipSuccess)
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_h2h_kernel<4, 2, 2, 3>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                         return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_h2h) failed");
                     attr.mark();
                 }
                 dim3 grid((unsigned)(a.M / 256), (unsigned)rdo::ceil_div(a.Cout, 192), 1);
-                hipLaunchKernelGGL(conv_fwd_h2h_kernel, grid, dim3(512), lds, s, a);
+                hipLaunchKernelGGL((conv_fwd_h2h_kernel<4, 2, 2, 3>), grid, dim3(512), lds, s, a);
                 return rdo::check_launch("conv_fwd_h2h");
             },
             stream, "conv_fwd_h2_halo", flops, bytes);
+    if (halo == 2) {
+        H2Args b = a;
+        b.ksplit = 1;
+        b.partial = nullptr;
+        return rdo::dispatch(
+            [b](hipStream_t s) {
+                constexpr size_t lds64 = (size_t)2 * 24576 + 3 * 2 * 64 * 32;      // K loop 60 KiB; the epilogue stages 256 x 68 floats = 68 KiB
+                constexpr size_t ldsn = lds64 > (size_t)256 * 68 * 4 ? lds64 : (size_t)256 * 68 * 4;
+                static rdo::PerDevice attr;
+                if (!attr.done()) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_h2h_kernel<8, 1, 1, 2>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsn) != hipSuccess)
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_h2h 256x64) failed");
+                    attr.mark();
+                }
+                dim3 grid((unsigned)(b.M / 256), (unsigned)(b.Cout / 64), 1);
+                hipLaunchKernelGGL((conv_fwd_h2h_kernel<8, 1, 1, 2>), grid, dim3(512), ldsn, s, b);
+                return rdo::check_launch("conv_fwd_h2h 256x64");
+            },
+            stream, "conv_fwd_h2_halo64", flops, bytes);
+    }
     return rdo::dispatch(
         [a](hipStream_t s) {
             static_assert(lds >= 3 * 2 * (256 + 192) * 32, "per-tap kernel LDS");
@@ -987,7 +1022,7 @@ extern "C" int rdo_conv2d_fwd_h2(const rdo_conv_desc* d, const void* x_planes, f
 }
 
 extern "C" int rdo_conv2d_fwd_h2_tail_supported(const rdo_conv_desc* d) {
-    return d && rdo_conv2d_fwd_h2_supported(d) && h2_halo_shape(d) && d->epilogue == RDO_EPI_NONE && !d->add_residual;
+    return d && rdo_conv2d_fwd_h2_supported(d) && h2_halo_shape(d) != 0 && d->epilogue == RDO_EPI_NONE && !d->add_residual;
 }
 
 // Last conv of a unit + its tail in ONE launch (halo kernel): the epilogue forms out = act(conv + bias) + residual, the loss against

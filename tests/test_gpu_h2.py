@@ -109,6 +109,7 @@ def test_conv_h2_scales_do_not_change_the_result(ops):
 
 
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, N, N), (4, 64, 64, N, 4 * N), (2, 128, 256, 64, N), (1, 256, 256, 32, 2 * N),
+                                            (4, 64, 64, N, N), (4, 32, 32, N, 4 * N), (2, 64, 96, 64, 320), (3, 64, 64, 48, 256),
                                             (1, 256, 256, 32, 48), (8, 96, 96, 48, 208), (2, 176, 208, 32, 16), (3, 112, 240, 80, 320)])
 def test_conv_h2_halo_kernel_equals_per_tap_kernel(ops, L, B, H, W, Cin, Cout):
     """3x3 / stride 1 / pad 1 on 16 x 16 patches with the halo tile resident in LDS: same K order and accumulation as the per-tap
@@ -130,8 +131,14 @@ def test_conv_h2_halo_kernel_equals_per_tap_kernel(ops, L, B, H, W, Cin, Cout):
             got[halo] = (out, pre, opl.t)
         finally:
             ops.set_tuning("x6p_halo", 1)
-    for u, v in zip(got[0], got[1]):
-        assert torch.equal(u, v)
+    if Cout * (B * H * W // 256) >= 192 * 192 or Cout * (B * H * W // 256) < 160 * 64:
+        # both runs walk K in one piece (halo kernel with 256 x 192 tiles / per-tap kernel without a K split): the same bits
+        for u, v in zip(got[0], got[1]):
+            assert torch.equal(u, v)
+    else:
+        # the halo kernel runs 256 x 64 tiles over the whole K, the per-tap kernel splits K and sums partial tiles: summation order
+        for u, v in zip(got[0][:2], got[1][:2]):
+            assert float((u - v).abs().max()) <= 2e-6 * float(v.abs().max())
     ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
     assert (got[1][1].double() - ref).abs().max() <= 2e-6 * ref.abs().max()
 
