@@ -394,3 +394,69 @@ def test_conv_h2_with_tail_in_its_epilogue(ops, L, B, H, W, Cin, Cout, act, with
     assert float(log[0].abs().sum()) == 0.0
     torch.testing.assert_close(log[1].sum(), log_ref[1].sum(), rtol=1e-5, atol=0)
     assert not ops.h2_overflow(reset=True)
+
+
+# ---- engine level: probe scales, overflow flag ----------------------------------------------------------------------------------------
+def _rb_engine(cq, cf, co, idx, iters, blk):
+    from quantization.engine import UnitEngine
+    from quantization.quant_block import QuantRB
+    from quantization.recon import _unit_modules
+    WQ = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    unit = QuantRB(blk, WQ, dict(WQ, leaf_param=False)).cuda()
+    kind, mods = _unit_modules(unit)
+    return UnitEngine(kind, mods, cq, cf, co, batch_size=idx.shape[1], iters=iters, warmup=0.0, input_prob=0.5, seed=3, idx_table=idx)
+
+
+@pytest.mark.parametrize("mag", [1e-4, 1.0, 3e3])
+def test_engine_scales_follow_the_magnitude_of_the_caches(mag):
+    """The same ResidualBlock unit (64^2, N = 192, H2 path) on caches scaled by 1e-4 / 1 / 3e3: the probe iteration picks power-of-two
+    scales that put every plane tensor near 2^7, no overflow, and the losses scale with mag^2 to fp32 accuracy (the unit is
+    positively homogeneous in its input only up to the bias terms, so the check is made with zero biases)."""
+    import lic
+    torch.manual_seed(5)
+    blk = lic.ResidualBlock(N, N)
+    with torch.no_grad():
+        for m in (blk.conv1, blk.conv2):
+            m.bias.zero_()
+    blk = blk.cuda()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.randn(6, 64, 64, N, device="cuda", generator=g)
+    noise = 0.01 * torch.randn(base.shape, device="cuda", generator=g)
+    idx = torch.stack([torch.tensor([0, 1, 2, 3], dtype=torch.int32), torch.tensor([2, 3, 4, 5], dtype=torch.int32), torch.tensor([5, 0, 1, 4], dtype=torch.int32)])
+    losses = {}
+    for mg in (1.0, mag):
+        cq, cf = base * mg, (base + noise) * mg
+        with torch.no_grad():
+            co = blk(cf.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+        eng = _rb_engine(cq, cf, co, idx, 3, blk)
+        assert eng.h2_plan == "rb"
+        for name, s in eng.scales.items():
+            m, e = __import__("math").frexp(s)
+            assert m == 0.5, (name, s)                          # a power of two
+        amax_x = float(torch.maximum(cq.abs().amax(), cf.abs().amax()))
+        assert 16.0 <= eng.scales["x"] * amax_x <= 256.0        # the probed mini-batch puts the largest |x s| in (2^6, 2^7]; other images stay close
+        eng.run()
+        losses[mg] = eng.logs()[1]                               # logs() raises if a value left fp16's range
+    torch.testing.assert_close(losses[mag] / mag ** 2, losses[1.0], rtol=2e-4, atol=0)
+
+
+def test_engine_raises_when_a_value_leaves_fp16_range():
+    """The probe sees iteration 0's mini-batch only; images 10^6 times larger in a later iteration overflow the planes: the sticky
+    device flag turns that into an error when the logs are read (never a silently wrong run)."""
+    import lic
+    from hipops import ops
+    torch.manual_seed(6)
+    blk = lic.ResidualBlock(N, N).cuda()
+    g = torch.Generator(device="cuda").manual_seed(6)
+    cq = torch.randn(8, 64, 64, N, device="cuda", generator=g)
+    cq[4:] *= 1e6
+    cf = cq.clone()
+    with torch.no_grad():
+        co = blk(cf.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    idx = torch.tensor([[0, 1, 2, 3], [4, 5, 6, 7]], dtype=torch.int32)
+    ops.h2_overflow(reset=True)
+    eng = _rb_engine(cq, cf, co, idx, 2, blk)
+    eng.run()
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        eng.logs()
+    assert not ops.h2_overflow(reset=True)                     # the check consumed the flag
