@@ -288,6 +288,9 @@ int rdo_round(const float* x, int64_t n, float* out, void* stream);             
  * losses/losses.py:15-35; test_datasets.py:21-33 */
 int rdo_factorized_likelihood_fwd(const float* z, const float* params, const float* medians, int64_t n, int32_t C, float* zhat,
                                   float* lik, void* stream);
+/* gradient of grad_scale * sum(-log2 p) w.r.t. z^ (handed to z by the straight-through rounding): the R term of the opt-in
+ * R + lambda*D task loss (losses/losses.py:15-35) through the factorised prior */
+int rdo_factorized_likelihood_bwd(const float* zhat, const float* params, int64_t n, int32_t C, float grad_scale, float* dz, void* stream);
 int rdo_gaussian_likelihood_fwd(const float* y, const float* scales, const float* means /* nullable */, int64_t n,
                                 float scale_bound, float* yhat /* nullable */, float* lik, void* stream);
 /* gradients of grad_scale * sum(-log2 p) w.r.t. scales / means (y^ constant: straight-through rounding) */

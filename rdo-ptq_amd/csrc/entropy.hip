@@ -59,6 +59,71 @@ __global__ __launch_bounds__(256) void eb_fwd_kernel(const float* z, const float
     }
 }
 
+// value and derivative dF/dx of the cumulative-logits net (forward-mode through the five layers)
+__device__ __forceinline__ float eb_logits_d(const float* p, float x, float& dFdx) {
+    const float* M = p;
+    const float* Bv = p + 33;
+    const float* Fv = p + 46;
+    float h[3], dh[3], g[3], dg[3];
+#pragma unroll
+    for (int o = 0; o < 3; ++o) {
+        const float v = M[o] * x + Bv[o];
+        const float th = tanhf(v);
+        h[o] = v + Fv[o] * th;
+        dh[o] = M[o] * (1.f + Fv[o] * (1.f - th * th));
+    }
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+#pragma unroll
+        for (int o = 0; o < 3; ++o) {
+            float v = Bv[3 + 3 * l + o], dv = 0.f;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                v += M[3 + 9 * l + 3 * o + i] * h[i];
+                dv += M[3 + 9 * l + 3 * o + i] * dh[i];
+            }
+            const float th = tanhf(v);
+            g[o] = v + Fv[3 + 3 * l + o] * th;
+            dg[o] = dv * (1.f + Fv[3 + 3 * l + o] * (1.f - th * th));
+        }
+#pragma unroll
+        for (int o = 0; o < 3; ++o) { h[o] = g[o]; dh[o] = dg[o]; }
+    }
+    float v = Bv[12], dv = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        v += M[30 + i] * h[i];
+        dv += M[30 + i] * dh[i];
+    }
+    dFdx = dv;
+    return v;
+}
+
+// d(grad_scale * -log2 p)/dz^ of the factorised prior (z^ = the rounded value: the straight-through estimator hands it to z):
+// p = |sigmoid(s hi) - sigmoid(s lo)|, hi = F(z^ + .5), lo = F(z^ - .5);  dp/dz^ = sign(.) * s * (sig'(s hi) F'(z^ + .5) - sig'(s lo) F'(z^ - .5));
+// zero where the 1e-9 floor is active.
+__global__ __launch_bounds__(256) void eb_bwd_kernel(const float* zhat, const float* params, long n, int C, float gscale, float* dz) {
+    const float inv_ln2 = 1.4426950408889634f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const float q = zhat[i];
+        const float* p = params + (long)c * kParamsPerChannel;
+        float dlo, dhi;
+        const float lo = eb_logits_d(p, q - 0.5f, dlo), hi = eb_logits_d(p, q + 0.5f, dhi);
+        const float t = lo + hi;
+        const float sgn = t > 0.f ? -1.f : (t < 0.f ? 1.f : 0.f);
+        const float sh = sigm(sgn * hi), sl = sigm(sgn * lo);
+        const float diff = sh - sl;
+        const float pr = fabsf(diff);
+        float g = 0.f;
+        if (pr > 1e-9f) {
+            const float dp = (diff > 0.f ? 1.f : -1.f) * sgn * (sh * (1.f - sh) * dhi - sl * (1.f - sl) * dlo);
+            g = -gscale * inv_ln2 / pr * dp;
+        }
+        dz[i] = g;
+    }
+}
+
 __device__ __forceinline__ float std_cum(float x) { return 0.5f * erfcf(-0.70710678118654752440f * x); }
 
 __global__ __launch_bounds__(256) void gc_fwd_kernel(const float* y, const float* scales, const float* means, long n,
@@ -146,6 +211,16 @@ int rdo_factorized_likelihood_fwd(const float* z, const float* params, const flo
             return rdo::check_launch("factorized_likelihood_fwd");
         },
         stream, "entropy", 0.0, 12.0 * n);
+}
+
+int rdo_factorized_likelihood_bwd(const float* zhat, const float* params, int64_t n, int32_t C, float grad_scale, float* dz, void* stream) {
+    RDO_REQUIRE(zhat && params && dz && n > 0 && C > 0, "rdo_factorized_likelihood_bwd: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(eb_bwd_kernel, dim3(grid_for(n)), dim3(256), 0, s, zhat, params, (long)n, C, grad_scale, dz);
+            return rdo::check_launch("factorized_likelihood_bwd");
+        },
+        stream, "entropy", 0.0, 8.0 * n);
 }
 
 int rdo_gaussian_likelihood_fwd(const float* y, const float* scales, const float* means, int64_t n, float scale_bound, float* yhat,

@@ -91,6 +91,7 @@ _SIGS = {
     "rdo_tconv_fold": (C.c_int, [P, P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, P, P]),
     "rdo_layer_norm": (C.c_int, [P, P, P, C.c_int64, C.c_int32, C.c_float, P, P]),
     "rdo_factorized_likelihood_fwd": (C.c_int, [P, P, P, C.c_int64, C.c_int32, P, P, P]),
+    "rdo_factorized_likelihood_bwd": (C.c_int, [P, P, C.c_int64, C.c_int32, C.c_float, P, P]),
     "rdo_gaussian_likelihood_fwd": (C.c_int, [P, P, P, C.c_int64, C.c_float, P, P, P]),
     "rdo_gaussian_likelihood_bwd": (C.c_int, [P, P, P, C.c_int64, C.c_float, C.c_float, P, P, P]),
     "rdo_neg_log2_sum": (C.c_int, [P, C.c_int64, C.c_float, P, P]),

@@ -129,6 +129,26 @@ class GaussianLikelihoodFn(torch.autograd.Function):
         return _nchw(-dm), _nchw(ds), _nchw(dm), None
 
 
+class FactorizedLikelihoodFn(torch.autograd.Function):
+    """(z^, likelihood) of the factorised prior for a 4-D latent in evaluation mode: rounding about the medians with a straight-through
+    gradient, the likelihood through rdo_factorized_likelihood_fwd / _bwd (which yields d(-log2 p)/dz^; dp = -p ln2 d(-log2 p))."""
+
+    @staticmethod
+    def forward(ctx, z, params, medians):
+        zr = _nhwc(z)
+        zhat, lik = ops.factorized_likelihood(zr, params, medians)
+        ctx.save_for_backward(zhat, lik, params)
+        return _nchw(zhat), _nchw(lik)
+
+    @staticmethod
+    def backward(ctx, g_zhat, g_lik):
+        zhat, lik, params = ctx.saved_tensors
+        dz = ops.factorized_likelihood_bwd(zhat, params, 1.0)
+        f = _nhwc(g_lik) * lik * (-math.log(2.0))
+        f = torch.where(lik > 1e-9, f, torch.zeros_like(f))                  # the likelihood floor has no gradient
+        return g_zhat + _nchw(dz * f), None, None
+
+
 def round_ste(x):
     return x + (torch.round(x) - x).detach()
 

@@ -557,6 +557,14 @@ def factorized_likelihood(z_cl, params, medians):
     return zhat, lik
 
 
+def factorized_likelihood_bwd(zhat_cl, params, grad_scale=1.0):
+    """d(grad_scale * sum(-log2 p)) / dz^ of the factorised prior, element-wise (z^ channels-last)"""
+    dz = torch.empty_like(zhat_cl)
+    L.check(L.lib().rdo_factorized_likelihood_bwd(_ptr(zhat_cl), _ptr(params), zhat_cl.numel(), zhat_cl.shape[-1], grad_scale, _ptr(dz), _stream()),
+            "rdo_factorized_likelihood_bwd")
+    return dz
+
+
 def gaussian_likelihood(y, scales, means=None, scale_bound=0.11):
     yhat, lik = torch.empty_like(y), torch.empty_like(y)
     L.check(L.lib().rdo_gaussian_likelihood_fwd(_ptr(y), _ptr(scales), _ptr(means), y.numel(), scale_bound, _ptr(yhat), _ptr(lik),

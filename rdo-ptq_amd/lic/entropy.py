@@ -41,9 +41,13 @@ class EntropyBottleneck(nn.Module):
         return torch.cat(mats + bias + fac, dim=1).contiguous()
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad and not self.training and x.is_cuda and self.filters == (3, 3, 3, 3) and x.dim() == 4:
+            # differentiable evaluation path (R + lambda*D task loss) on the HIP kernels: rounding with a straight-through gradient,
+            # likelihood forward / backward element-wise (rdo_factorized_likelihood_fwd / _bwd)
+            from hipops.autograd import FactorizedLikelihoodFn
+            return FactorizedLikelihoodFn.apply(x, self.kernel_params().detach(), self.quantiles[:, 0, 1].detach().contiguous())
         if torch.is_grad_enabled() and x.requires_grad and not self.training:
-            # differentiable evaluation path (R + lambda*D task loss): rounding with a straight-through gradient; the hyper-latent
-            # is a few thousand values, its CDF network stays in torch
+            # the same in torch (other filter shapes, CPU tensors)
             order = [1, 0] + list(range(2, x.dim()))
             xt = x.permute(*order).contiguous()
             flat = xt.reshape(xt.shape[0], 1, -1)

@@ -243,3 +243,35 @@ def test_mbt2018_full_width_w8_w8a8_eval_matches_oracle(hw):
     finally:
         torch.distributed.destroy_process_group()
     assert abs(psnr_d - psnr) < 1e-4 and abs(bpp_d - bpp) < 1e-5 * bpp
+
+
+def test_factorized_likelihood_backward_matches_autograd():
+    """rdo_factorized_likelihood_bwd (the R term of the opt-in R + lambda*D task loss through the factorised prior, straight-through
+    rounding) against torch autograd of the same EntropyBottleneck evaluated in float64 on the CPU."""
+    import copy
+    from lic.entropy import EntropyBottleneck
+    torch.manual_seed(4)
+    eb = EntropyBottleneck(24).eval()
+    with torch.no_grad():
+        for n, p in eb.named_parameters():
+            if n.startswith("_factor"):
+                p.uniform_(-0.8, 0.8)
+            elif n.startswith("_matrix"):
+                p.add_(0.5 * torch.randn_like(p))
+            elif n == "quantiles":
+                p[:, 0, 1] = torch.randn(24) * 0.3
+    ref = copy.deepcopy(eb).double()
+    eb = eb.cuda()
+    g = torch.Generator().manual_seed(5)
+    z0 = torch.randn(2, 24, 6, 5, generator=g) * 3
+    wz = torch.randn(z0.shape, generator=g)
+    z = z0.cuda().requires_grad_(True)
+    zhat, lik = eb(z)                                             # HIP forward, HIP backward
+    ((-torch.log2(lik)).sum() * 0.37 + (zhat * wz.cuda()).sum()).backward()
+    zc = z0.double().requires_grad_(True)
+    zh_c, lik_c = ref(zc)                                         # torch path (CPU tensors)
+    ((-torch.log2(lik_c)).sum() * 0.37 + (zh_c * wz.double()).sum()).backward()
+    torch.testing.assert_close(zhat.detach().cpu().double(), zh_c.detach(), rtol=0, atol=1e-6)
+    torch.testing.assert_close(lik.detach().cpu().double(), lik_c.detach(), rtol=2e-4, atol=1e-9)
+    scale = float(zc.grad.abs().max())
+    assert float((z.grad.cpu().double() - zc.grad).abs().max()) <= 2e-4 * scale
