@@ -245,6 +245,8 @@ class UnitEngine:
         self.split = self.world > 1 or force_dp_split
         self.dp_path = None                    # "graph" | "host" once a data-parallel run has started (_run_dp)
         self._dp_graph, self._dp_graph_failed = None, False
+        self.rd_path = None                    # "graph" | "host" once an R + lambda*D run has started (_run_rd)
+        self._rd_graph, self._rd_graph_failed = None, False
         self._build_ops()
         self._alloc()
         self.scales = {}                       # activation buffer name -> power-of-two scale of its H2 planes
@@ -291,7 +293,7 @@ class UnitEngine:
             lo = o[late]
             ho, wo = self._out_hw(lo, self.cq.shape[1], self.cq.shape[2])
             overlap = 2.0 * self.B * ho * wo * lo.numel() >= self.DP_OVERLAP_MIN_FLOP
-        self._late = late if (self.split and overlap) else None
+        self._late = late if (self.split and overlap and self.rd is None) else None
         if self.split:
             total = sum(op.numel() for op in o.values())
             self.bucket = torch.zeros(total, device=self.dev)
@@ -912,8 +914,6 @@ class UnitEngine:
     def _record(self):
         self.plan_a = Plan()
         self.plan_a2 = self.plan_b = self.plan_rd = None
-        if self.rd is not None and self.split:
-            raise NotImplementedError("calibration engine: loss_mode='rd' is single-process (no data-parallel split)")
         self._rec_ctx = self.plan_a.record()
         self._rec_ctx.__enter__()
         try:
@@ -950,10 +950,7 @@ class UnitEngine:
         if n < 0 or done + n > self.iters:
             raise ValueError(f"cannot run {n} iterations: {done} of {self.iters} already done")
         if self.plan_rd is not None:
-            for k in range(n):
-                self.plan_a.run(1, graph=self.use_graph)          # gather, unit forward, rec_loss and its gradient
-                self._rd_tail(done + k)                           # task term: R + lambda*D of the whole model -> g_task
-                self.plan_rd.run(1, graph=self.use_graph)         # + g_task, backward, AdaRound step
+            self._run_rd(n)
         elif not self.split:
             self.plan_a.run(n, graph=self.use_graph)
         else:
@@ -1025,16 +1022,59 @@ class UnitEngine:
         dist = torch.distributed
         return dist.get_rank(self.group) if (dist.is_available() and dist.is_initialized()) else 0
 
-    def _rd_tail(self, i):
-        """Iteration i's task loss: the images of the mini-batch through the wrapped model with this unit's output replaced by the
-        engine's soft-quantised output, `RateDistortionLoss` (lambda * 255^2 * MSE + bpp) on the result, gradient back to that
-        output (HIP kernels under torch's tape: hipops.autograd).  The modules behind the unit are whatever the calibration flow
-        left them: trained ones hard-quantised, the others full precision (layer_opt.py:15-43)."""
+    def _rd_iteration(self, graph):
+        """One iteration of the R + lambda*D mode on the current stream: plan A (gather, unit forward, rec_loss and its gradient) ->
+        the task term (the whole model behind the unit, `_rd_tail`) -> plan RD (+ g_task, backward, AdaRound step -- or, data
+        parallel, the gradient bucket) [-> all-reduce -> plan B]."""
+        self.plan_a.run(1, graph=graph)
+        self._rd_tail()
+        self.plan_rd.run(1, graph=graph)
+        if self.split:
+            dist = torch.distributed
+            if self.world > 1 or (dist.is_available() and dist.is_initialized()):
+                dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+            self.plan_b.run(1, graph=graph)
+
+    def _run_rd(self, n):
+        """n iterations of the R + lambda*D mode.  Single process with graphs on: the WHOLE iteration -- the recorded kernels of both
+        plans and the model tail with its autograd backward (every op of which is a device-side kernel: the mini-batch rows are
+        selected with the device iteration counter) -- is captured once into one graph (torch.cuda.graph) and replayed, no host work
+        per iteration.  `RDO_RD_GRAPH=0`, a refused capture, or the data-parallel split (a collective per iteration): host-driven."""
+        import logging
+        want = self.use_graph and not self.split and os.environ.get("RDO_RD_GRAPH", "1") != "0"
+        if want and self._rd_graph is None and not self._rd_graph_failed and n > 2:
+            self._rd_iteration(False)                 # eager: every lazy initialisation (scratch buffers, kernel attributes, autograd)
+            n -= 1
+            torch.cuda.synchronize()
+            try:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._rd_iteration(False)
+                self._rd_graph = g
+            except Exception as e:      # pragma: no cover - depends on the driver stack
+                logging.warning("R + lambda*D iteration could not be captured into a graph (%s): host-driven loop", e)
+                self._rd_graph_failed = True
+                torch.cuda.synchronize()
+        self.rd_path = "graph" if self._rd_graph is not None else "host"
+        if self._rd_graph is not None:
+            for _ in range(n):
+                self._rd_graph.replay()
+            return
+        for _ in range(n):
+            self._rd_iteration(self.use_graph)
+
+    def _rd_tail(self):
+        """The current iteration's task loss: the images of the mini-batch through the wrapped model with this unit's output replaced
+        by the engine's soft-quantised output, `RateDistortionLoss` (lambda * 255^2 * MSE + bpp) on the result, gradient back to that
+        output (HIP kernels under torch's tape: hipops.autograd; the factorised prior and the Gaussian conditional included).  The
+        modules behind the unit are whatever the calibration flow left them: trained ones hard-quantised, the others full precision
+        (layer_opt.py:15-43).  Device-side throughout (capturable): the mini-batch rows come from the index table through the device
+        iteration counter."""
         from losses.losses import RateDistortionLoss
         rd = self.rd
-        if not hasattr(self, "_idx_host"):
-            self._idx_host = self.idx.cpu()
-        x = rd["cali"].index_select(0, self._idx_host[i].to(rd["cali"].device, torch.long))
+        it = self.it.long()                                                   # [1], published by this iteration's gather
+        rows = self.idx.index_select(0, it).view(-1).long()
+        x = rd["cali"].index_select(0, rows)
         leaf = self._rd_pred.permute(0, 3, 1, 2).detach().requires_grad_(True)
         handle = rd["unit"].register_forward_hook(lambda m, inp, out: leaf)
         was_training = rd["model"].training
@@ -1043,15 +1083,15 @@ class UnitEngine:
             with torch.enable_grad():
                 out = rd["model"](x)
                 loss = RateDistortionLoss(lmbda=rd["lmbda"], metric="mse")(out, x)["loss"]
-                loss.backward()
+                (g,) = torch.autograd.grad(loss, [leaf], allow_unused=True)
         finally:
             handle.remove()
             rd["model"].train(was_training)
-        if leaf.grad is None:
+        if g is None:
             raise RuntimeError("loss_mode='rd': no gradient reached the unit's output -- a module behind it detaches the tape (dynamic "
                                "activation quantisers of trained modules do); run the RD task loss with act_quant=False")
-        self.g_task.copy_(leaf.grad.permute(0, 2, 3, 1))
-        self.task_log[i, 0] += loss.detach()
+        self.g_task.copy_(g.permute(0, 2, 3, 1))
+        self.task_log.view(-1).index_add_(0, it * L.LOG_SLOTS, loss.detach().reshape(1))
 
     def _data_terms(self):
         """(rec, task) per iteration on the device, averaged over the data-parallel ranks."""

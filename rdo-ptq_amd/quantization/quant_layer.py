@@ -59,6 +59,10 @@ class QuantModule(nn.Module):
             self.kind = "gdn"
             self.fwd_kwargs = dict(inverse=org_module.inverse, gamma_reparam=org_module.gamma_reparam,
                                    beta_reparam=org_module.beta_reparam)
+            # (bound, pedestal) of both parametrisers as Python floats, read ONCE: the buffers may live on the GPU, and a
+            # float() of a device tensor inside forward is a host sync (not permitted while a stream is capturing)
+            self._reparam_consts = {id(p): (float(p.lower_bound.bound), float(p.pedestal))
+                                    for p in (org_module.gamma_reparam, org_module.beta_reparam)}
         elif isinstance(org_module, nn.PixelShuffle):
             self.kind, self.is_ps = "ps", True
             self.fwd_kwargs = org_module.upscale_factor
@@ -114,17 +118,16 @@ class QuantModule(nn.Module):
             return L.EPI_RELU
         return None
 
-    @staticmethod
-    def _reparam(p, t):
+    def _reparam(self, p, t):
         """NonNegativeParametrizer forward, max(t, bound)^2 - pedestal, with the constants taken as Python floats: the
         reparam modules live in `fwd_kwargs` (as in the reference), so `.to(device)` on the wrapper does not move them."""
-        return torch.clamp(t, min=float(p.lower_bound.bound)) ** 2 - float(p.pedestal)
+        bound, pedestal = self._reparam_consts[id(p)]
+        return torch.clamp(t, min=bound) ** 2 - pedestal
 
     def gdn_constants(self):
         """beta' (re-parametrised, fp32 tensor) and the gamma (bound, pedestal) pair."""
         beta = self._reparam(self.fwd_kwargs["beta_reparam"], self.bias.detach() if self.use_weight_quant else self.org_bias)
-        g = self.fwd_kwargs["gamma_reparam"]
-        return beta.contiguous(), (float(g.lower_bound.bound), float(g.pedestal))
+        return beta.contiguous(), self._reparam_consts[id(self.fwd_kwargs["gamma_reparam"])]
 
     # forward --------------------------------------------------------------------------------------------------------
     def _weights(self):

@@ -177,8 +177,6 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     # (layer_opt.py:146-148).  args.loss_mode = 'rd' (default 'lp' = the reference's lp_loss pair)
     rd = None
     if getattr(args, "loss_mode", "lp") == "rd":
-        if world_size > 1:
-            raise NotImplementedError("loss_mode='rd' is single-process")
         rd = dict(model=model, unit=unit, cali=cali_data.to(next(model.parameters()).device), lmbda=float(getattr(args, "lmbda", 0.01)))
     elif getattr(args, "loss_mode", "lp") != "lp":
         raise ValueError(f"unknown loss_mode {args.loss_mode!r} ('lp' or 'rd')")

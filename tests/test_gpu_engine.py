@@ -436,6 +436,7 @@ def test_rd_task_loss_mode_matches_oracle(where):
         np.testing.assert_array_equal(op.delta.cpu().numpy(), ops_o[n_].init_scale().delta.reshape(-1).numpy())
     eng.run()
     torch.cuda.synchronize()
+    assert eng.rd_path == "graph"          # the iteration (both plans + the model tail with its backward) replays from ONE captured graph
     rec, task, rd_, _ = eng.logs_terms()
     np.testing.assert_allclose(rec.numpy(), np.array(log.rec), rtol=3e-4, atol=1e-7)
     # the rate term counts rounded latents: one latent within float noise of .5 moves the loss by a few bits of several thousand
@@ -449,3 +450,47 @@ def test_rd_task_loss_mode_matches_oracle(where):
         flips += int(((a_gpu >= 0) != (op.alpha >= 0)).sum())
         tot += a_gpu.numel()
     assert flips <= 0.01 * tot
+
+
+def test_rd_mode_graph_host_and_data_parallel_sequences_agree(monkeypatch):
+    """loss_mode='rd' three ways on the same unit (g_s.2 of a toy Cheng2020): the captured-graph iteration, the host-driven iteration
+    (RDO_RD_GRAPH=0) and the data-parallel op sequence on one rank (gradient bucket -> apply): the same alphas bit for bit, the
+    same losses."""
+    import lic
+    from helpers import AQ, WQ
+    from quantization import QuantModel
+    from quantization.engine import UnitEngine
+    from quantization.recon import _unit_modules
+    torch.manual_seed(43)
+    N, n_img, B, iters, lmbda = 8, 6, 2, 7, 0.0483
+    g = torch.Generator().manual_seed(44)
+    cali = torch.rand(n_img, 3, 64, 64, generator=g).cuda()
+    idx = torch.from_numpy(np.stack([np.random.RandomState(i).permutation(n_img)[:B] for i in range(iters)]))
+    res = {}
+    for mode in ("graph", "host", "dp"):
+        torch.manual_seed(43)
+        prod = lic.Cheng2020Anchor(N=N).eval()
+        qnn = QuantModel(prod.cuda(), WQ, AQ, is_cheng=True).cuda().eval()
+        qnn.set_quant_state(False, False)
+        unit = qnn.model.g_s[2]
+        store = {}
+        h = unit.register_forward_hook(lambda m, i, o: store.update(inp=i[0].detach().clone(), out=o.detach().clone()))
+        with torch.no_grad():
+            qnn(cali)
+        h.remove()
+        nh = lambda t: t.permute(0, 2, 3, 1).contiguous()
+        inp, out = nh(store["inp"]), nh(store["out"])
+        inp_q = inp + 1e-3 * torch.randn(inp.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+        monkeypatch.setenv("RDO_RD_GRAPH", "0" if mode == "host" else "1")
+        k, mods = _unit_modules(unit)
+        eng = UnitEngine(k, mods, inp_q, inp, out, batch_size=B, iters=iters, weight=0.01, b_range=(20, 2), warmup=0.2, input_prob=0.5, seed=SEED,
+                         idx_table=idx, force_dp_split=(mode == "dp"), rd=dict(model=qnn, unit=unit, cali=cali, lmbda=lmbda))
+        eng.run()
+        torch.cuda.synchronize()
+        assert eng.rd_path == ("graph" if mode == "graph" else "host")
+        res[mode] = ({n: eng.alpha_of(n).clone() for n in eng.ops}, [t.clone() for t in eng.logs_terms()[:3]])
+    for mode in ("host", "dp"):
+        for n in res["graph"][0]:
+            assert torch.equal(res[mode][0][n], res["graph"][0][n]), (mode, n)
+        for a, b in zip(res[mode][1], res["graph"][1]):
+            torch.testing.assert_close(a, b, rtol=1e-6, atol=0)
