@@ -25,84 +25,93 @@ def _nchw(y):
     return y.permute(0, 3, 1, 2)
 
 
+def _pack(w):
+    return w if isinstance(w, ops.WeightPack) else ops.WeightPack(w)
+
+
+def _act_bwd(gr, y, epilogue):
+    if epilogue == L.EPI_LRELU:
+        return ops.lrelu_bwd(gr, y)
+    if epilogue == L.EPI_RELU:
+        return ops.relu_bwd(gr, y)
+    return gr
+
+
 class Conv2dFn(torch.autograd.Function):
-    """y = act(conv2d(x, w) + b); `w_rows` = OHWI weight [Cout,KH,KW,Cin]; epilogue in {EPI_NONE, EPI_LRELU, EPI_RELU}."""
+    """y = act(conv2d(x, w) + b); `w_rows` = OHWI weight [Cout,KH,KW,Cin] or an `ops.WeightPack` of it (the caller keeps the pack
+    while the weight is unchanged: planes, flipped and transposed forms are then built once); epilogue in {EPI_NONE, EPI_LRELU,
+    EPI_RELU}.  Forward and input gradient take the split-precision MFMA kernels wherever rdo_conv2d_fwd does."""
 
     @staticmethod
     def forward(ctx, x, w_rows, bias, stride, pad, epilogue):
         xr = _nhwc(x)
-        y = ops.conv2d_fwd(xr, w_rows, bias, stride, pad, epilogue=epilogue)
-        ctx.geom = (stride, pad, epilogue, tuple(xr.shape))
-        ctx.save_for_backward(w_rows, y if epilogue != L.EPI_NONE else None)
+        pack = _pack(w_rows)
+        y = ops.conv2d_fwd(xr, pack.w, bias, stride, pad, epilogue=epilogue, wplanes=pack.planes(xr.shape, stride, pad))
+        ctx.geom = (stride, pad, epilogue, tuple(xr.shape), pack)
+        ctx.save_for_backward(y if epilogue != L.EPI_NONE else None)
         return _nchw(y)
 
     @staticmethod
     def backward(ctx, g):
-        stride, pad, epilogue, xs = ctx.geom
-        w_rows, y = ctx.saved_tensors
-        gr = _nhwc(g)
-        if epilogue == L.EPI_LRELU:
-            gr = ops.lrelu_bwd(gr, y)
-        elif epilogue == L.EPI_RELU:
-            gr = ops.relu_bwd(gr, y)
-        K = w_rows.shape[1]
+        stride, pad, epilogue, xs, pack = ctx.geom
+        (y,) = ctx.saved_tensors
+        gr = _act_bwd(_nhwc(g), y, epilogue)
+        K = pack.w.shape[1]
         if stride == 1 and 2 * pad == K - 1:
-            wd = w_rows.flip(1, 2).permute(3, 1, 2, 0).contiguous()          # [Cin][KH'][KW'][Cout], taps flipped
-            dx = ops.conv2d_fwd(gr, wd, None, 1, K - 1 - pad)
+            dx = ops.conv2d_fwd_pack(gr, pack.flipped(), 1, K - 1 - pad)     # [Cin][KH'][KW'][Cout], taps flipped
         else:
             # dgrad of a strided conv = the transposed conv with the same weight tensor read as [Cin_t = Cout][Cout_t = Cin][K][K]
             out_pad = (xs[1] + 2 * pad - K) % stride
-            dx = ops.conv_transpose2d(gr, w_rows.permute(3, 1, 2, 0).contiguous(), None, stride, pad, out_pad)
+            dx = ops.conv_transpose2d(gr, None, None, stride, pad, out_pad, pack=pack.transposed())
         return _nchw(dx), None, None, None, None, None
 
 
 class ConvTranspose2dFn(torch.autograd.Function):
-    """y = act(conv_transpose2d(x, W) + b); `w_t_rows` = to_rows(W, tconv=True) = [Cout,KH,KW,Cin] (un-flipped taps)."""
+    """y = act(conv_transpose2d(x, W) + b); `w_t_rows` = to_rows(W, tconv=True) = [Cout,KH,KW,Cin] (un-flipped taps) or an
+    `ops.WeightPack` of it WITH the bias (the phase bias is derived from it)."""
 
     @staticmethod
     def forward(ctx, x, w_t_rows, bias, stride, pad, output_padding, epilogue):
         xr = _nhwc(x)
-        y = ops.conv_transpose2d(xr, w_t_rows, bias, stride, pad, output_padding, epilogue=epilogue)
-        ctx.geom = (stride, pad, epilogue)
-        ctx.save_for_backward(w_t_rows, y if epilogue != L.EPI_NONE else None)
+        pack = w_t_rows if isinstance(w_t_rows, ops.WeightPack) else ops.WeightPack(w_t_rows, bias)
+        y = ops.conv_transpose2d(xr, None, None, stride, pad, output_padding, epilogue=epilogue, pack=pack)
+        ctx.geom = (stride, pad, epilogue, pack)
+        ctx.save_for_backward(y if epilogue != L.EPI_NONE else None)
         return _nchw(y)
 
     @staticmethod
     def backward(ctx, g):
-        stride, pad, epilogue = ctx.geom
-        w_t_rows, y = ctx.saved_tensors
-        gr = _nhwc(g)
-        if epilogue == L.EPI_LRELU:
-            gr = ops.lrelu_bwd(gr, y)
-        elif epilogue == L.EPI_RELU:
-            gr = ops.relu_bwd(gr, y)
+        stride, pad, epilogue, pack = ctx.geom
+        (y,) = ctx.saved_tensors
+        gr = _act_bwd(_nhwc(g), y, epilogue)
         # dx = conv2d(dy, W read as a conv weight [O = Cin_t][I = Cout_t][K][K]) with the same stride / padding
-        w_conv = w_t_rows.permute(3, 1, 2, 0).contiguous()                   # [Cin_t][KH][KW][Cout_t]
-        dx = ops.conv2d_fwd(gr, w_conv, None, stride, pad)
+        dx = ops.conv2d_fwd_pack(gr, pack.transposed(), stride, pad)
         return _nchw(dx), None, None, None, None, None, None
 
 
 class GDNFn(torch.autograd.Function):
-    """y = x * (beta' + sum_j gamma'_ij x_j^2)^(-1/2 | +1/2); gamma_p [C,C] and beta_p [C] already re-parametrised."""
+    """y = x * (beta' + sum_j gamma'_ij x_j^2)^(-1/2 | +1/2); gamma_p [C,C] (or an `ops.WeightPack` of it as [C,1,1,C]) and
+    beta_p [C] already re-parametrised."""
 
     @staticmethod
     def forward(ctx, x, gamma_p, beta_p, inverse):
         xr = _nhwc(x)
         c = xr.shape[-1]
+        pack = gamma_p if isinstance(gamma_p, ops.WeightPack) else ops.WeightPack(gamma_p.reshape(c, 1, 1, c))
         norm = torch.empty_like(xr)
-        y = ops.conv2d_fwd(xr, gamma_p.reshape(c, 1, 1, c).contiguous(), beta_p.contiguous(), 1, 0,
-                           epilogue=L.EPI_IGDN if inverse else L.EPI_GDN, aux=xr, square_input=True, pre=norm)
+        y = ops.conv2d_fwd(xr, pack.w, beta_p.contiguous(), 1, 0, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN, aux=xr,
+                           square_input=True, pre=norm, wplanes=pack.planes(xr.shape, 1, 0))
         ctx.inverse = bool(inverse)
-        ctx.save_for_backward(xr, norm, gamma_p)
+        ctx.pack = pack
+        ctx.save_for_backward(xr, norm)
         return _nchw(y)
 
     @staticmethod
     def backward(ctx, g):
-        xr, norm, gamma_p = ctx.saved_tensors
-        c = xr.shape[-1]
+        xr, norm = ctx.saved_tensors
         gr = _nhwc(g)
         t = ops.gdn_bwd_t(gr, xr, norm, ctx.inverse)
-        acc = ops.conv2d_fwd(t, gamma_p.t().contiguous().reshape(c, 1, 1, c), None, 1, 0)      # t . gamma'
+        acc = ops.conv2d_fwd_pack(t, ctx.pack.transposed(), 1, 0)           # t . gamma'
         dx = ops.gdn_bwd_dx(gr, xr, norm, acc, ctx.inverse)
         return _nchw(dx), None, None, None
 

@@ -443,26 +443,69 @@ def tconv_fold(slabs_phase, ph, Cout, Cin, out=None):
     return out
 
 
-def conv_transpose2d(x, w_iohw_rows, bias, stride, pad, output_padding, epilogue=L.EPI_NONE):
-    """x [B,H,W,Cin]; w_iohw_rows = to_rows(W, tconv=True) = [Cout,KH,KW,Cin] (un-flipped taps of the [Cin,Cout,KH,KW] weight).
-    Output = stride x input (the deconv of the LIC decoders): stride-1 conv with the phase weight + pixel shuffle, no zero insertion;
-    other geometries: zero insertion + dense conv."""
-    Cout, KH, KW, Cin = w_iohw_rows.shape
+class WeightPack:
+    """Constant tensors derived from ONE weight in kernel layout (`w` = [Cout,KH,KW,Cin] rows), each built on first use and kept:
+    the bf16x3 planes the split-precision MFMA forward reads, the flipped / transposed forms the input-gradient convolutions read
+    (with their planes), the phase weight of a transposed conv.  The callers that hold a pack (QuantModule, hipops.autograd) own
+    its validity: a pack is made for one value of the weight and dropped when that value changes."""
+
+    def __init__(self, w_rows, bias=None):
+        self.w = w_rows.detach().contiguous()
+        self.bias = None if bias is None else bias.detach().contiguous()
+        self._d = {}
+
+    def get(self, key, make):
+        v = self._d.get(key)
+        if v is None:
+            v = self._d[key] = make()
+        return v
+
+    def planes(self, x_shape, stride, pad):
+        """bf16x3 planes of `w` when rdo_conv2d_fwd takes the split-precision path for this problem, else None."""
+        if not uses_bf16x6(tuple(x_shape), tuple(self.w.shape), stride, pad):
+            return None
+        return self.get("planes", lambda: split_bf16x3(self.w))
+
+    def flipped(self):
+        """Pack of the stride-1 input-gradient weight [Cin][KH'][KW'][Cout] (taps flipped)."""
+        return self.get("flipped", lambda: WeightPack(self.w.flip(1, 2).permute(3, 1, 2, 0)))
+
+    def transposed(self):
+        """Pack of `w` read with input and output channels exchanged, [Cin][KH][KW][Cout] (taps as they lie)."""
+        return self.get("transposed", lambda: WeightPack(self.w.permute(3, 1, 2, 0)))
+
+    def phase(self, ph):
+        """(pack of the phase weight, phase bias) of the transposed conv with this weight as `to_rows(W, tconv=True)`."""
+        def make():
+            wp = tconv_expand(self.w, ph)
+            return WeightPack(wp, None if self.bias is None else self.bias.repeat_interleave(ph.S2))
+        return self.get(("phase", id(ph)), make)
+
+
+def conv2d_fwd_pack(x, pack, stride=1, pad=0, bias=True, **kw):
+    """conv2d_fwd with the weight, bias and (where the split-precision path applies) the weight planes of a WeightPack."""
+    return conv2d_fwd(x, pack.w, pack.bias if bias else None, stride, pad, wplanes=pack.planes(x.shape, stride, pad), **kw)
+
+
+def conv_transpose2d(x, w_iohw_rows, bias, stride, pad, output_padding, epilogue=L.EPI_NONE, pack=None):
+    """x [B,H,W,Cin]; w_iohw_rows = to_rows(W, tconv=True) = [Cout,KH,KW,Cin] (un-flipped taps of the [Cin,Cout,KH,KW] weight), or
+    `pack` = a WeightPack of it (weight-derived tensors are then built once).  Output = stride x input (the deconv of the LIC
+    decoders): stride-1 conv with the phase weight + pixel shuffle, no zero insertion; other geometries: zero insertion + dense conv."""
+    if pack is None:
+        pack = WeightPack(w_iohw_rows, bias)
+    Cout, KH, KW, Cin = pack.w.shape
     B, H, W, _ = x.shape
     ph = TconvPhase.get(KH, stride, pad, output_padding, False, x.device) if KH == KW else None
     if ph is not None:
-        wp = tconv_expand(w_iohw_rows.contiguous(), ph)
-        bp = None if bias is None else bias.repeat_interleave(ph.S2).contiguous()
         # LeakyReLU / ReLU commute with the pixel shuffle; large problems on the split-precision path
-        planes = split_bf16x3(wp) if uses_bf16x6(tuple(x.shape), tuple(wp.shape), 1, ph.pad) else None
-        yp = conv2d_fwd(x, wp, bp, 1, ph.pad, epilogue=epilogue, wplanes=planes)
+        yp = conv2d_fwd_pack(x, pack.phase(ph), 1, ph.pad, epilogue=epilogue)
         return pixel_shuffle(yp, stride)
     q = KH - 1 - pad
     if q < 0:
         raise ValueError("conv_transpose2d: padding larger than kernel_size - 1 is not supported")
     Hup, Wup = (H - 1) * stride + 1 + 2 * q + output_padding, (W - 1) * stride + 1 + 2 * q + output_padding
     xu = zero_insert(x, stride, q, q, Hup, Wup)
-    return conv2d_fwd(xu, w_iohw_rows.flip(1, 2).contiguous(), bias, 1, 0, epilogue=epilogue)
+    return conv2d_fwd_pack(xu, pack.get("zi", lambda: WeightPack(pack.w.flip(1, 2), pack.bias)), 1, 0, epilogue=epilogue)
 
 
 def layer_norm(x, weight, bias, eps=1e-5, out=None):

@@ -1076,16 +1076,16 @@ class UnitEngine:
         rows = self.idx.index_select(0, it).view(-1).long()
         x = rd["cali"].index_select(0, rows)
         leaf = self._rd_pred.permute(0, 3, 1, 2).detach().requires_grad_(True)
-        handle = rd["unit"].register_forward_hook(lambda m, inp, out: leaf)
         was_training = rd["model"].training
         rd["model"].eval()
+        rd["unit"].forward = lambda *a, **k: leaf      # the unit itself is not run: its output is the engine's
         try:
             with torch.enable_grad():
                 out = rd["model"](x)
                 loss = RateDistortionLoss(lmbda=rd["lmbda"], metric="mse")(out, x)["loss"]
                 (g,) = torch.autograd.grad(loss, [leaf], allow_unused=True)
         finally:
-            handle.remove()
+            del rd["unit"].forward
             rd["model"].train(was_training)
         if g is None:
             raise RuntimeError("loss_mode='rd': no gradient reached the unit's output -- a module behind it detaches the tape (dynamic "

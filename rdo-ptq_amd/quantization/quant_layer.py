@@ -135,6 +135,50 @@ class QuantModule(nn.Module):
             return self.weight_quantizer(self.weight), self.bias
         return self.org_weight, self.org_bias
 
+    @staticmethod
+    def _tkey(t):
+        return (t.data_ptr(), t._version) if torch.is_tensor(t) else None
+
+    def _weight_state(self):
+        """Everything the effective (weight, bias) of the next forward depends on, as a comparable key; None while the weight
+        quantiser has not seen its weight yet (its first call initialises the scales)."""
+        if not self.use_weight_quant:
+            return ("fp", self._tkey(self.org_weight), self._tkey(self.org_bias))
+        q = self.weight_quantizer
+        if not getattr(q, "inited", True):
+            return None
+        return ("q", id(q), q.n_levels, getattr(q, "soft_targets", None), self._tkey(self.weight), self._tkey(self.bias),
+                self._tkey(getattr(q, "alpha", None)), self._tkey(q.delta), self._tkey(q.zero_point))
+
+    def weight_pack(self):
+        """`ops.WeightPack` of the effective weight in kernel layout (conv: OHWI rows; transposed conv: to_rows(., tconv=True) with
+        the bias; GDN: re-parametrised gamma as a 1x1 weight with beta' as its bias), memoised while `_weight_state()` is unchanged:
+        a model evaluated or differentiated many times with fixed weights (cache building, evaluation, the R + lambda*D tail of the
+        calibration loop) quantises, re-lays-out and splits each weight once.  A weight changed behind torch's version counters
+        (`.data` writes) needs `drop_weight_pack()`."""
+        key = self._weight_state()
+        memo = getattr(self, "_pack_memo", None)
+        if key is not None and memo is not None and memo[0] == key:
+            return memo[1]
+        weight, bias = self._weights()
+        weight = weight.detach()
+        bias = None if bias is None else bias.detach()
+        if self.kind == "gdn":
+            c = weight.shape[0]
+            pack = ops.WeightPack(self._reparam(self.fwd_kwargs["gamma_reparam"], weight).reshape(c, 1, 1, c),
+                                  self._reparam(self.fwd_kwargs["beta_reparam"], bias))
+        elif self.kind == "linear":
+            pack = ops.WeightPack(weight.reshape(weight.shape[0], 1, 1, weight.shape[1]), bias)
+        else:
+            pack = ops.WeightPack(to_rows(weight, tconv=self.kind == "tconv"), bias)
+        if key is None:
+            key = self._weight_state()             # the quantiser initialised its scales inside _weights()
+        self._pack_memo = (key, pack)
+        return pack
+
+    def drop_weight_pack(self):
+        self._pack_memo = None
+
     def _forward_autograd(self, input):
         """Forward whose output carries a grad_fn with respect to the INPUT (hipops.autograd; weights are constants): what the
         opt-in R + lambda*D task loss differentiates through the modules behind a unit.  The reference's dynamic activation
@@ -143,25 +187,21 @@ class QuantModule(nn.Module):
         if self.is_ps:
             y = torch.nn.functional.pixel_shuffle(input, int(self.fwd_kwargs))
             return torch.nn.functional.leaky_relu(y, 0.01) if isinstance(self.activation_function, nn.LeakyReLU) else y
-        weight, bias = self._weights()
-        weight = weight.detach()
-        bias = None if bias is None else bias.detach().contiguous()
         epi = self.fused_epilogue() if self.se_module is None else None
         fuse = epi is not None
         epi = L.EPI_NONE if epi is None else epi
+        if self.kind not in ("conv", "tconv", "gdn"):
+            raise NotImplementedError(f"QuantModule({self.kind}): no autograd forward (conv / transposed conv / GDN / pixel shuffle only)")
+        pack = self.weight_pack()
         if self.kind == "conv":
             stride, pad = self.conv_geometry()
-            out = A.Conv2dFn.apply(input, to_rows(weight), bias, stride, pad, epi)
+            out = A.Conv2dFn.apply(input, pack, pack.bias, stride, pad, epi)
         elif self.kind == "tconv":
             kw = self.fwd_kwargs
-            out = A.ConvTranspose2dFn.apply(input, to_rows(weight, tconv=True), bias, _sq(kw["stride"]), _sq(kw["padding"]),
+            out = A.ConvTranspose2dFn.apply(input, pack, pack.bias, _sq(kw["stride"]), _sq(kw["padding"]),
                                             _sq(kw["output_padding"]), epi)
         elif self.kind == "gdn":
-            gp = self._reparam(self.fwd_kwargs["gamma_reparam"], weight)
-            bp = self._reparam(self.fwd_kwargs["beta_reparam"], bias)
-            out = A.GDNFn.apply(input, gp, bp, bool(self.fwd_kwargs["inverse"]))
-        else:
-            raise NotImplementedError(f"QuantModule({self.kind}): no autograd forward (conv / transposed conv / GDN / pixel shuffle only)")
+            out = A.GDNFn.apply(input, pack, pack.bias, bool(self.fwd_kwargs["inverse"]))
         if self.se_module is not None:
             out = self.se_module(out)
         if not fuse:
@@ -178,41 +218,38 @@ class QuantModule(nn.Module):
         if self.is_ps:
             y = ops.pixel_shuffle(_nhwc(input), int(self.fwd_kwargs))
             return _nchw_view(ops.lrelu(y) if isinstance(self.activation_function, nn.LeakyReLU) else y)
-        weight, bias = self._weights()
-        bias = None if bias is None else bias.detach().contiguous()
         epi = self.fused_epilogue() if self.se_module is None else None
         fuse = epi is not None
         epi = L.EPI_NONE if epi is None else epi
         if self.kind == "conv":
             stride, pad = self.conv_geometry()
-            y = ops.conv2d_fwd(_nhwc(input), to_rows(weight.detach()), bias, stride, pad, epilogue=epi)
+            y = ops.conv2d_fwd_pack(_nhwc(input), self.weight_pack(), stride, pad, epilogue=epi)
             out = _nchw_view(y)
         elif self.kind == "gdn":
-            c = input.shape[1]
-            gp = self._reparam(self.fwd_kwargs["gamma_reparam"], weight.detach()).reshape(c, 1, 1, c).contiguous()
-            bp = self._reparam(self.fwd_kwargs["beta_reparam"], bias)
             x = _nhwc(input)
-            y = ops.conv2d_fwd(x, gp, bp.contiguous(), 1, 0,
-                               epilogue=L.EPI_IGDN if self.fwd_kwargs["inverse"] else L.EPI_GDN, aux=x, square_input=True)
+            y = ops.conv2d_fwd_pack(x, self.weight_pack(), 1, 0, epilogue=L.EPI_IGDN if self.fwd_kwargs["inverse"] else L.EPI_GDN,
+                                    aux=x, square_input=True)
             out = _nchw_view(y)
         elif self.kind == "tconv":
             kw = self.fwd_kwargs
             if _sq(kw["dilation"]) != 1 or kw["groups"] != 1:
                 raise NotImplementedError("dilated / grouped transposed convolutions are not on the supported path")
-            y = ops.conv_transpose2d(_nhwc(input), to_rows(weight.detach(), tconv=True), bias, _sq(kw["stride"]),
-                                     _sq(kw["padding"]), _sq(kw["output_padding"]), epilogue=epi)
+            y = ops.conv_transpose2d(_nhwc(input), None, None, _sq(kw["stride"]), _sq(kw["padding"]), _sq(kw["output_padding"]),
+                                     epilogue=epi, pack=self.weight_pack())
             out = _nchw_view(y)
         elif self.kind == "layernorm":
+            weight, bias = self._weights()
+            bias = None if bias is None else bias.detach().contiguous()
             ns = tuple(self.fwd_kwargs["normalized_shape"])
             if len(ns) != 1 or ns[0] != input.shape[-1]:
                 raise NotImplementedError("LayerNorm over more than the last dimension is not on the supported path")
             out = ops.layer_norm(input.contiguous(), None if weight is None else weight.detach().contiguous(), bias)
             fuse = False
         elif self.kind == "linear":
+            pack = self.weight_pack()
             x = input.reshape(1, 1, -1, input.shape[-1]).contiguous()
-            w = weight.detach().reshape(weight.shape[0], 1, 1, weight.shape[1]).contiguous()
-            y = ops.conv2d_fwd(x, w, bias, 1, 0, epilogue=epi)
-            out = y.reshape(*input.shape[:-1], weight.shape[0])
+            y = ops.conv2d_fwd_pack(x, pack, 1, 0, epilogue=epi)
+            out = y.reshape(*input.shape[:-1], pack.w.shape[0])
         else:
             raise NotImplementedError(f"QuantModule({self.kind}) forward is not built yet (SURVEY 8f rows 3: Lu2022 / Minnen2018)")
         if self.se_module is not None:

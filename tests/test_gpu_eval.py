@@ -275,3 +275,92 @@ def test_factorized_likelihood_backward_matches_autograd():
     torch.testing.assert_close(lik.detach().cpu().double(), lik_c.detach(), rtol=2e-4, atol=1e-9)
     scale = float(zc.grad.abs().max())
     assert float((z.grad.cpu().double() - zc.grad).abs().max()) <= 2e-4 * scale
+
+
+@pytest.mark.parametrize("case", ["conv3s1", "conv3s2", "conv1", "tconv5s2", "gdn", "igdn"])
+def test_autograd_functions_on_the_split_precision_path(case):
+    """hipops.autograd Conv2dFn / ConvTranspose2dFn / GDNFn with a WeightPack at 192 channels and enough pixels that forward and
+    input gradient take the bf16x6 MFMA kernels: value and input gradient against torch in float64."""
+    import torch.nn.functional as F
+    from hipops import _lib as HL
+    from hipops import autograd as A
+    from hipops import ops
+    g = torch.Generator().manual_seed(17)
+    C, B, H = 192, 2, 128
+    x0 = torch.randn(B, C, H, H, generator=g)
+    go = None
+    if case.startswith("conv"):
+        K, s = (3, 1) if case == "conv3s1" else ((3, 2) if case == "conv3s2" else (1, 1))
+        w = torch.randn(C, C, K, K, generator=g) / math.sqrt(C * K * K)
+        b = torch.randn(C, generator=g) * 0.1
+        pack = ops.WeightPack(w.permute(0, 2, 3, 1).cuda(), b.cuda())
+        assert pack.planes((B, H, H, C), s, K // 2) is not None
+        run = lambda x: A.Conv2dFn.apply(x, pack, pack.bias, s, K // 2, HL.EPI_LRELU)
+        ref = lambda x: F.leaky_relu(F.conv2d(x, w.double(), b.double(), stride=s, padding=K // 2), 0.01)
+    elif case == "tconv5s2":
+        H = 64
+        x0 = x0[:, :, :H, :H].contiguous()
+        w = torch.randn(C, C, 5, 5, generator=g) / math.sqrt(C * 25 / 4)          # [Cin, Cout, K, K]
+        b = torch.randn(C, generator=g) * 0.1
+        pack = ops.WeightPack(w.permute(1, 2, 3, 0).cuda(), b.cuda())              # to_rows(W, tconv=True)
+        run = lambda x: A.ConvTranspose2dFn.apply(x, pack, pack.bias, 2, 2, 1, HL.EPI_NONE)
+        ref = lambda x: F.conv_transpose2d(x, w.double(), b.double(), stride=2, padding=2, output_padding=1)
+    else:
+        inverse = case == "igdn"
+        gamma = 0.1 * torch.eye(C) + 0.01 * torch.rand(C, C, generator=g)
+        beta = 1.0 + torch.rand(C, generator=g)
+        pack = ops.WeightPack(gamma.reshape(C, 1, 1, C).cuda(), beta.cuda())
+        assert pack.planes((B, H, H, C), 1, 0) is not None
+        run = lambda x: A.GDNFn.apply(x, pack, pack.bias, inverse)
+
+        def ref(x):
+            n = torch.sqrt(F.conv2d(x * x, gamma.double().reshape(C, C, 1, 1), beta.double()))
+            return x * n if inverse else x / n
+    xg = x0.cuda().requires_grad_(True)
+    y = run(xg)
+    xr = x0.double().requires_grad_(True)
+    yr = ref(xr)
+    if case.startswith("conv"):
+        # LeakyReLU's derivative jumps at 0: take the branch the kernel took (pre-activations within rounding of 0 differ in sign)
+        slope = torch.where(y.detach().cpu() > 0, 1.0, 0.01).double()
+        yr_lin = F.conv2d(xr, w.double(), b.double(), stride=s, padding=K // 2) * slope
+    go = torch.randn(yr.shape, generator=g)
+    (dx,) = torch.autograd.grad(y, xg, go.cuda())
+    (dxr,) = torch.autograd.grad(yr_lin if case.startswith("conv") else yr, xr, go.double())
+    for what, got, want in (("value", y, yr), ("input gradient", dx, dxr)):
+        err = (got.detach().cpu().double() - want.detach()).abs().max().item()
+        assert err <= 2e-6 * want.detach().abs().max().item() + 1e-7, (case, what, err)
+    # the pack's derived tensors were built once and are reused by a second pass
+    before = {k: (v.w.data_ptr() if isinstance(v, ops.WeightPack) else None) for k, v in pack._d.items()}
+    (dx2,) = torch.autograd.grad(run(xg), xg, go.cuda())
+    assert torch.equal(dx2, dx)
+    assert before == {k: (v.w.data_ptr() if isinstance(v, ops.WeightPack) else None) for k, v in pack._d.items()}
+
+
+def test_quant_module_weight_pack_follows_the_quant_state():
+    """QuantModule.weight_pack(): one pack per value of the effective weight -- reused across forwards, rebuilt when the quant
+    state, the quantiser or the weight changes (the forward then matches a fresh module)."""
+    import torch.nn as nn
+    from helpers import AQ, WQ
+    from quantization.quant_layer import QuantModule
+    torch.manual_seed(5)
+    conv = nn.Conv2d(16, 24, 3, padding=1).cuda()
+    qm = QuantModule(conv, WQ, AQ).cuda()
+    x = torch.randn(2, 16, 20, 20, device="cuda")
+    p_fp = qm.weight_pack()
+    assert qm.weight_pack() is p_fp
+    y_fp = qm(x).clone()
+    qm.set_quant_state(True, False)
+    y_q = qm(x).clone()
+    p_q = qm.weight_pack()
+    assert p_q is not p_fp and qm.weight_pack() is p_q
+    assert not torch.equal(y_q, y_fp)
+    with torch.no_grad():
+        qm.weight.mul_(1.5)
+    assert qm.weight_pack() is not p_q
+    fresh = QuantModule(conv, WQ, AQ).cuda()
+    fresh.weight_quantizer = qm.weight_quantizer
+    fresh.set_quant_state(True, False)
+    assert torch.equal(qm(x), fresh(x))
+    qm.set_quant_state(False, False)
+    assert torch.equal(qm(x), y_fp)
