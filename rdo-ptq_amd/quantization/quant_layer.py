@@ -61,8 +61,8 @@ class QuantModule(nn.Module):
                                    beta_reparam=org_module.beta_reparam)
             # (bound, pedestal) of both parametrisers as Python floats, read ONCE: the buffers may live on the GPU, and a
             # float() of a device tensor inside forward is a host sync (not permitted while a stream is capturing)
-            self._reparam_consts = {id(p): (float(p.lower_bound.bound), float(p.pedestal))
-                                    for p in (org_module.gamma_reparam, org_module.beta_reparam)}
+            self._reparam_consts = {n: (float(p.lower_bound.bound), float(p.pedestal))
+                                    for n, p in (("gamma_reparam", org_module.gamma_reparam), ("beta_reparam", org_module.beta_reparam))}
         elif isinstance(org_module, nn.PixelShuffle):
             self.kind, self.is_ps = "ps", True
             self.fwd_kwargs = org_module.upscale_factor
@@ -92,6 +92,7 @@ class QuantModule(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         """`.to()/.cuda()` also moves the detached FP copies (plain attributes in the reference, quant_layer.py:82-89)."""
         super()._apply(fn, *args, **kwargs)
+        self._pack_memo = None
         for name in ("org_weight", "org_bias"):
             t = getattr(self, name, None)
             if t is not None:
@@ -118,16 +119,16 @@ class QuantModule(nn.Module):
             return L.EPI_RELU
         return None
 
-    def _reparam(self, p, t):
-        """NonNegativeParametrizer forward, max(t, bound)^2 - pedestal, with the constants taken as Python floats: the
-        reparam modules live in `fwd_kwargs` (as in the reference), so `.to(device)` on the wrapper does not move them."""
-        bound, pedestal = self._reparam_consts[id(p)]
+    def _reparam(self, which, t):
+        """NonNegativeParametrizer forward of `fwd_kwargs[which]`, max(t, bound)^2 - pedestal, with the constants taken as Python
+        floats: the reparam modules live in `fwd_kwargs` (as in the reference), so `.to(device)` on the wrapper does not move them."""
+        bound, pedestal = self._reparam_consts[which]
         return torch.clamp(t, min=bound) ** 2 - pedestal
 
     def gdn_constants(self):
         """beta' (re-parametrised, fp32 tensor) and the gamma (bound, pedestal) pair."""
-        beta = self._reparam(self.fwd_kwargs["beta_reparam"], self.bias.detach() if self.use_weight_quant else self.org_bias)
-        return beta.contiguous(), self._reparam_consts[id(self.fwd_kwargs["gamma_reparam"])]
+        beta = self._reparam("beta_reparam", self.bias.detach() if self.use_weight_quant else self.org_bias)
+        return beta.contiguous(), self._reparam_consts["gamma_reparam"]
 
     # forward --------------------------------------------------------------------------------------------------------
     def _weights(self):
@@ -165,8 +166,8 @@ class QuantModule(nn.Module):
         bias = None if bias is None else bias.detach()
         if self.kind == "gdn":
             c = weight.shape[0]
-            pack = ops.WeightPack(self._reparam(self.fwd_kwargs["gamma_reparam"], weight).reshape(c, 1, 1, c),
-                                  self._reparam(self.fwd_kwargs["beta_reparam"], bias))
+            pack = ops.WeightPack(self._reparam("gamma_reparam", weight).reshape(c, 1, 1, c),
+                                  self._reparam("beta_reparam", bias))
         elif self.kind == "linear":
             pack = ops.WeightPack(weight.reshape(weight.shape[0], 1, 1, weight.shape[1]), bias)
         else:
