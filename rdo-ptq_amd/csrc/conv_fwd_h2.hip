@@ -32,6 +32,9 @@ using rdo::h2_hi;
 using rdo::h2_lo;
 constexpr int NP = 2;                                          // planes of an H2 tensor
 
+#ifdef RDO_DIAG
+__device__ unsigned long long g_h2_stamps[256 * 4];
+#endif
 __device__ __attribute__((aligned(64))) unsigned g_zero_page[16];      // zero-initialised: source of masked DMA lanes
 
 struct H2Args {
@@ -690,12 +693,22 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
             mma(0, 0);
         }
     };
+#ifdef RDO_DIAG
+    const unsigned long long st_c0 = clock64(), st_r0 = wall_clock64();
+#endif
     if (late && a.stagger) k_loop(std::true_type{});
     else k_loop(std::false_type{});
+#ifdef RDO_DIAG
+    if (tid == 0 && blockIdx.x < 256 && blockIdx.y == 0) {   // shader-clock cycles and 100 MHz wall ticks of the K loop (rdo_diag_h2_stamps)
+        g_h2_stamps[blockIdx.x * 4 + 0] = st_c0; g_h2_stamps[blockIdx.x * 4 + 1] = st_r0;
+        g_h2_stamps[blockIdx.x * 4 + 2] = clock64(); g_h2_stamps[blockIdx.x * 4 + 3] = wall_clock64();
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail DMAs still target LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_barrier();
 
     // ---- epilogue: as in conv_fwd_h2_kernel, tile row tl = pixel (tl / 16, tl % 16) of the patch
+    if (a.ablate & 16) return;                               // diagnostic: no epilogue at all
     float* const stg = reinterpret_cast<float*>(smem);
     const bool need_planes = a.outp != nullptr;
     float tail_loss = 0.f;
@@ -1044,3 +1057,12 @@ extern "C" int rdo_conv2d_fwd_h2_tail(const rdo_conv_desc* d, const void* x_plan
     return conv2d_fwd_h2_impl(d, x_planes, x_scale, wplanes, w_scale, bias, nullptr, nullptr, nullptr, nullptr, nullptr, dpre_planes, dpre_scale,
                               nullptr, 0, stream, &t);
 }
+
+#ifdef RDO_DIAG
+// diagnostic build only: per workgroup {shader clock at K-loop start, 100 MHz wall ticks at start, clock at end, ticks at end} of the
+// last halo-kernel launch (tools/bench_h2.py H2_STAMPS=1)
+extern "C" int rdo_diag_h2_stamps(unsigned long long* out, int n) {
+    if (!out || n <= 0 || n > 1024) return RDO_EINVAL;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h2_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? RDO_OK : RDO_EHIP;
+}
+#endif

@@ -56,9 +56,9 @@ for (B, H, Cin, Cout, K, s, p) in SHAPES:
             ops.set_tuning(key, v)
             abl.append((f"{key}={v}", timeit(lambda: ops.conv2d_fwd_h2(xp, tuple(x.shape), tuple(w.shape), wpl, b, s, p, out=out), 60)))
     if os.environ.get("H2_ABLATE"):          # needs a `make DIAG=1` library
-        for m in (3, 4, 8, 12, 15):
+        for m in (3, 4, 8, 12, 15, 16, 31):
             ops.set_tuning("x6p_ablate", m)
-            abl.append((f"abl{m}", timeit(lambda: ops.conv2d_fwd_h2(xp, tuple(x.shape), tuple(w.shape), wpl, b, s, p, out=out))))
+            abl.append((f"abl{m}", timeit(lambda: ops.conv2d_fwd_h2(xp, tuple(x.shape), tuple(w.shape), wpl, b, s, p, out_planes=opl))))
         ops.set_tuning("x6p_ablate", 0)
     print(f"B={B} H={H} {Cin}->{Cout} k{K} s{s}: fp32-in x6 {t_old:7.1f} us ({gf / t_old * 1e3:6.1f} TF, err {e_6:.1e}) | h2 out {t_h2:7.1f} us ({gf / t_h2 * 1e3:6.1f} TF, err {e_h2:.1e})"
           f" | out+planes {t_h2b:7.1f} | planes only {t_h2p:7.1f}" + "".join(f" | {m}: {t:6.1f}" for m, t in abl))
