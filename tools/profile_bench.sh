@@ -4,7 +4,7 @@ cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/${1:-prof_r03}
 mkdir -p $OUT
-CMD="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-steps 0"
+CMD="python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --sustain-steps 0 --no-extras --recon-iters 0"
 timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace -o t --output-format csv -- $CMD > $OUT/log_trace.txt 2>&1; echo trace rc=$?
 timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d $OUT/fetch -o f --output-format csv -- $CMD > $OUT/log_fetch.txt 2>&1; echo fetch rc=$?
 timeout 600 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d $OUT/write -o w --output-format csv -- $CMD > $OUT/log_write.txt 2>&1; echo write rc=$?
