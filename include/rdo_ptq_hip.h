@@ -390,6 +390,9 @@ int rdo_plan_begin_record(rdo_plan* p);      /* subsequent rdo_* calls on this t
 int rdo_plan_end_record(rdo_plan* p);
 int rdo_plan_num_ops(const rdo_plan* p);
 int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream);
+/* one iteration of `p` then one of `q` as ONE graph launch (cached per partner): "apply of iteration i + forward/backward of iteration
+ * i + 1" between two collectives of the data-parallel host loop */
+int rdo_plan_run_then(rdo_plan* p, rdo_plan* q, int use_graph, void* stream);
 /* measurement: kernel family tag + algorithmic FLOPs / bytes of op i; one eager iteration timed op by op with hipEvents
  * on `stream` (ms[num_ops]; synchronises the stream). */
 int rdo_plan_op_info(const rdo_plan* p, int i, const char** tag, double* flops, double* bytes);

@@ -83,6 +83,11 @@ struct rdo_plan {
     int unroll_k = 0;                    // iterations inside exec_k (the tuning value at ITS capture, not the current one)
     hipStream_t cap_stream = nullptr;
     bool recording = false;
+    // rdo_plan_run_then: this plan's ops followed by another plan's in ONE graph (cached for that partner)
+    const rdo_plan* then_with = nullptr;
+    size_t then_ops = 0;                 // the partner's op count at capture (a re-recorded partner invalidates the graph)
+    hipGraph_t graph_then = nullptr;
+    hipGraphExec_t exec_then = nullptr;
 };
 
 extern "C" {
@@ -128,6 +133,8 @@ void rdo_plan_destroy(rdo_plan* p) {
     if (p->graph) (void)hipGraphDestroy(p->graph);
     if (p->exec_k) (void)hipGraphExecDestroy(p->exec_k);
     if (p->graph_k) (void)hipGraphDestroy(p->graph_k);
+    if (p->exec_then) (void)hipGraphExecDestroy(p->exec_then);
+    if (p->graph_then) (void)hipGraphDestroy(p->graph_then);
     if (p->cap_stream) (void)hipStreamDestroy(p->cap_stream);
     delete p;
 }
@@ -140,6 +147,9 @@ int rdo_plan_begin_record(rdo_plan* p) {
     if (p->graph) { (void)hipGraphDestroy(p->graph); p->graph = nullptr; }
     if (p->exec_k) { (void)hipGraphExecDestroy(p->exec_k); p->exec_k = nullptr; }
     if (p->graph_k) { (void)hipGraphDestroy(p->graph_k); p->graph_k = nullptr; }
+    if (p->exec_then) { (void)hipGraphExecDestroy(p->exec_then); p->exec_then = nullptr; }
+    if (p->graph_then) { (void)hipGraphDestroy(p->graph_then); p->graph_then = nullptr; }
+    p->then_with = nullptr;
     p->recording = true;
     rdo::recorder().active = true;
     rdo::recorder().sink = &p->ops;
@@ -217,6 +227,41 @@ int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream) {
         hipError_t e = hipGraphLaunch(p->exec, s);
         if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
     }
+    return RDO_OK;
+}
+
+// One iteration of `p` followed by one iteration of `q` as ONE graph launch (or eagerly): the data-parallel host loop enqueues
+// "apply of iteration i + forward/backward of iteration i + 1" with one call between two collectives.
+int rdo_plan_run_then(rdo_plan* p, rdo_plan* q, int use_graph, void* stream) {
+    RDO_REQUIRE(p != nullptr && q != nullptr && !p->recording && !q->recording, "rdo_plan_run_then: plan is null or still recording");
+    hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+    if (!use_graph) {
+        if (int rc = run_ops(p, s)) return rc;
+        return run_ops(q, s);
+    }
+    if (p->exec_then && (p->then_with != q || p->then_ops != q->ops.size())) {
+        (void)hipGraphExecDestroy(p->exec_then);
+        (void)hipGraphDestroy(p->graph_then);
+        p->exec_then = nullptr;
+        p->graph_then = nullptr;
+    }
+    if (!p->exec_then) {
+        if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess)
+            return rdo::set_error(RDO_EHIP, "hipStreamCreate failed");
+        if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
+            return rdo::set_error(RDO_EHIP, "hipStreamBeginCapture failed");
+        int rc = run_ops(p, p->cap_stream);
+        if (rc == RDO_OK) rc = run_ops(q, p->cap_stream);
+        hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph_then);
+        if (rc != RDO_OK) return rc;
+        if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        e = hipGraphInstantiate(&p->exec_then, p->graph_then, nullptr, nullptr, 0);
+        if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        p->then_with = q;
+        p->then_ops = q->ops.size();
+    }
+    hipError_t e = hipGraphLaunch(p->exec_then, s);
+    if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
     return RDO_OK;
 }
 

@@ -32,6 +32,11 @@ class Plan:
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L.check(L.lib().rdo_plan_run(self._h, int(n_iters), int(bool(graph)), s), "rdo_plan_run")
 
+    def run_then(self, other, graph=True):
+        """One iteration of this plan followed by one of `other` in one graph launch."""
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(L.lib().rdo_plan_run_then(self._h, other._h, int(bool(graph)), s), "rdo_plan_run_then")
+
     def op_info(self):
         """[(tag, flops, bytes)] of the recorded ops."""
         out = []

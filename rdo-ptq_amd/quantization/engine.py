@@ -958,12 +958,16 @@ class UnitEngine:
         self._done = done + n
         return n
 
-    def _dp_iteration(self, graph):
+    def _dp_iteration(self, graph, first=True, last=True):
         """One data-parallel iteration on the current stream: plan A -> all-reduce of the front of the bucket (asynchronous, on the
-        process group's stream) overlapped with plan A2 = the last weight gradient -> all-reduce of the rest -> plan B."""
+        process group's stream) overlapped with plan A2 = the last weight gradient -> all-reduce of the rest -> plan B.
+        Inside a host-driven run of several iterations plan B of iteration i and plan A of iteration i + 1 go out as ONE graph launch
+        (`first=False`: plan A was enqueued with the previous iteration's plan B; `last=False`: enqueue the next plan A with this
+        plan B): two host enqueues per iteration and collective instead of three -- the small units are host-bound in this loop."""
         dist = torch.distributed
         comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
-        self.plan_a.run(1, graph=graph)
+        if first:
+            self.plan_a.run(1, graph=graph)
         if self.plan_a2 is None:
             if comm:
                 dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
@@ -974,7 +978,10 @@ class UnitEngine:
             if comm:
                 w1.wait()
                 w2.wait()
-        self.plan_b.run(1, graph=graph)
+        if last:
+            self.plan_b.run(1, graph=graph)
+        else:
+            self.plan_b.run_then(self.plan_a, graph=graph)
 
     def _run_dp(self, n):
         """n data-parallel iterations.  Default: the HOST drives plan A -> all-reduce -> plan B (each plan a graph replay, the
@@ -1015,8 +1022,9 @@ class UnitEngine:
             for _ in range(n):
                 self._dp_graph.replay()
             return
-        for _ in range(n):
-            self._dp_iteration(self.use_graph)
+        merge = self.use_graph and os.environ.get("RDO_DP_MERGE", "1") != "0"
+        for i in range(n):
+            self._dp_iteration(self.use_graph, first=(i == 0 or not merge), last=(i == n - 1 or not merge))
 
     def _rank(self):
         dist = torch.distributed
