@@ -640,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
             };
             auto rd_b = [&](int p) {
                 if (a.ablate & 8) return;
+                if ((a.ablate & 32) && p == 1) return;       // diagnostic: 30 % fewer fragment bytes (what a 128 x 96 wave tile would read)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) fb[p][j] = *reinterpret_cast<const f16x8*>(stb + fb_off[p][j]);
             };

@@ -27,9 +27,9 @@ fn = L.lib().rdo_diag_h2_stamps
 fn.argtypes = [C.c_void_p, C.c_int]
 buf = np.zeros(1024, dtype=np.uint64)
 stages = 9 * Cc // 16
-for stagger in (1, 0):
+for stagger in (1,):
     ops.set_tuning("h2_stagger", stagger)
-    for name, abl in (("complete", 0), ("no fragment reads", 8), ("no DMA", 3), ("MFMAs only", 11), ("no MFMA", 4), ("skeleton", 15)):
+    for name, abl in (("complete", 0), ("no fragment reads", 8), ("30 % fewer fragment bytes", 32), ("no DMA", 3), ("MFMAs only", 11), ("no MFMA", 4), ("skeleton", 15)):
         ops.set_tuning("x6p_ablate", abl)
         t0 = time.perf_counter()
         n = 0
