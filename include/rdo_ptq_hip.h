@@ -69,8 +69,9 @@ const char* rdo_last_error(void);
  *   "tail_grid"    most workgroups of a fused loss kernel (each ends with one atomic add into the 32-slot loss log)
  *   "x6p_ablate"   ONLY in a diagnostic build (`make DIAG=1`, -DRDO_DIAG; the shipped library rejects a non-zero value and ignores
  *                  RDO_X6P_ABLATE): bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
- *                  8 no fragment reads, 16 rotate the K order per tile (results stay right), 32 the weight-gradient kernel's DMA issue
- *                  schedule, 64 activation tile fetched for tap (0,0) only (per-tap kernel; the traffic of the halo kernel)
+ *                  8 no fragment reads; halo kernel only: 16 no epilogue, 32 the second weight plane is not read (30 % fewer
+ *                  LDS->register bytes).  The same build exports rdo_diag_h2_stamps (shader-clock cycles and 100 MHz wall ticks of the
+ *                  halo kernel's K loop per workgroup: tools/h2_stamps.py)
  * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */
 int rdo_set_tuning(const char* key, int32_t value);
 int rdo_get_tuning(const char* key);
