@@ -70,8 +70,8 @@ const char* rdo_last_error(void);
  *   "x6p_ablate"   ONLY in a diagnostic build (`make DIAG=1`, -DRDO_DIAG; the shipped library rejects a non-zero value and ignores
  *                  RDO_X6P_ABLATE): bit mask for the plane-input conv (results are WRONG when non-zero): 1 no A DMA, 2 no B DMA, 4 no MFMA,
  *                  8 no fragment reads; halo kernel only: 16 no epilogue, 32 the second weight plane is not read (30 % fewer
- *                  LDS->register bytes).  The same build exports rdo_diag_h2_stamps (shader-clock cycles and 100 MHz wall ticks of the
- *                  halo kernel's K loop per workgroup: tools/h2_stamps.py)
+ *                  LDS->register bytes).  The same build exports the stamp reader used by tools/h2_stamps.py: shader-clock
+ *                  cycles and 100 MHz wall ticks of the halo kernel's K loop per workgroup
  * Returns RDO_EINVAL for an unknown key.  rdo_get_tuning returns the current value (or -1). */
 int rdo_set_tuning(const char* key, int32_t value);
 int rdo_get_tuning(const char* key);
@@ -191,7 +191,8 @@ int rdo_uaq_init_minmax(const float* w, int32_t rows, int64_t inner, int32_t n_l
  * zp = min_c, r = max(max_c - zp, 1e-6), out = round(clamp((x - zp)/r, -1, 1) * (2^n_bits - 1)) / (2^n_bits - 1) * r + zp.
  * The reference hard-wires n_bits = 8 (`b_w=8`, quantizer.py:81); other widths (BASELINE config "W10A10") are an extension. */
 int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, int32_t n_bits, float* out,
-                            float* ws_minmax /* 2*C floats */, void* stream);
+                            float* ws_minmax /* rdo_actquant_workspace(C) floats of scratch, no initial state needed */, void* stream);
+int64_t rdo_actquant_workspace(int32_t C);   /* floats: the 2 C results + the per-workgroup partial minima / maxima */
 
 /* ---- K7: mini-batch assembly: out[b] = keep ? cache_q[idx[b]] : cache_fp[idx[b]], keep ~ counter RNG(seed, iter, i)
  * replaces cached_inps[..][idx] + torch.where(torch.rand_like(x) < p, x_q, x_fp)                layer_opt.py:289-292

@@ -256,47 +256,109 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* x, const f
 }
 
 // ---- K6: per-channel dynamic activation quantisation (NHWC: channel = fastest dim)
-__device__ __forceinline__ unsigned f2ord(float f) {
-    unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-}
-__device__ __forceinline__ float ord2f(unsigned o) {
-    return __uint_as_float((o & 0x80000000u) ? (o & 0x7FFFFFFFu) : ~o);
-}
+// Two-level reduction, no atomics: up to kAqBlocks workgroups each leave the min / max of their share of the pixels per channel
+// ([block][2][C] behind the 2 C result floats of the workspace), a small second kernel folds the blocks, the third applies.  (The first
+// version let 1024 workgroups atomicMin / atomicMax into the same 2 C words: 0.4 M contended atomics per call were most of its time.)
+constexpr int kAqBlocks = 256;
 
-__global__ __launch_bounds__(256) void aq_init_kernel(unsigned* ws, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) { ws[c] = 0xFFFFFFFFu; ws[C + c] = 0u; }
-}
-
-// each block scans a slab of pixels; thread handles channel (tid % Cblk) strided over pixels, then LDS column reduce
-__global__ __launch_bounds__(256) void aq_minmax_kernel(const float* x, long npix, int C, unsigned* ws) {
-    // one thread per (pixel-lane, channel) with channels fastest for coalescing
-    const int cpt = (C + 255) / 256;  // channels handled per thread when C > 256
-    const long pix_per_block = rdo::kWave;  // rows scanned per block step
-    for (int cc = 0; cc < cpt; ++cc) {
-        const int c = threadIdx.x + cc * 256;
-        if (c >= C) continue;
-        float mn = INFINITY, mx = -INFINITY;
-        for (long p = blockIdx.x; p < npix; p += gridDim.x) {
-            const float v = x[p * C + c];
-            mn = fminf(mn, v);
-            mx = fmaxf(mx, v);
+// thread = (pixel lane, group of W channels): W-wide loads down the pixels, four in flight, then an LDS fold over the pixel lanes
+template <int W>
+__global__ __launch_bounds__(256) void aq_partial_kernel(const float* x, long npix, int C, float* part) {
+    typedef float vec_t __attribute__((ext_vector_type(W)));
+    const int QN = C / W;
+    const int qpb = QN < 256 ? QN : 256;
+    const int PL = 256 / qpb;
+    const int pl = threadIdx.x / qpb, ql = threadIdx.x - pl * qpb;
+    __shared__ float smn[256 * W], smx[256 * W];
+    const long step = (long)gridDim.x * PL;
+    for (int qb = 0; qb < QN; qb += qpb) {
+        const int q = qb + ql;
+        const bool live = pl < PL && q < QN;
+        vec_t mn, mx;
+#pragma unroll
+        for (int k = 0; k < W; ++k) { mn[k] = INFINITY; mx[k] = -INFINITY; }
+        if (live) {
+            const float* src = x + (long)q * W;
+            long p = (long)blockIdx.x * PL + pl;
+            for (; p + 3 * step < npix; p += 4 * step) {
+                vec_t v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const vec_t*>(src + (p + u * step) * C);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int k = 0; k < W; ++k) { mn[k] = fminf(mn[k], v[u][k]); mx[k] = fmaxf(mx[k], v[u][k]); }
+            }
+            for (; p < npix; p += step) {
+                const vec_t v = *reinterpret_cast<const vec_t*>(src + p * C);
+#pragma unroll
+                for (int k = 0; k < W; ++k) { mn[k] = fminf(mn[k], v[k]); mx[k] = fmaxf(mx[k], v[k]); }
+            }
+#pragma unroll
+            for (int k = 0; k < W; ++k) { smn[(pl * qpb + ql) * W + k] = mn[k]; smx[(pl * qpb + ql) * W + k] = mx[k]; }
         }
-        atomicMin(ws + c, f2ord(mn));
-        atomicMax(ws + C + c, f2ord(mx));
+        __syncthreads();
+        if (live && pl == 0) {
+            for (int r = 1; r < PL; ++r)
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    mn[k] = fminf(mn[k], smn[(r * qpb + ql) * W + k]);
+                    mx[k] = fmaxf(mx[k], smx[(r * qpb + ql) * W + k]);
+                }
+            float* dst = part + (long)blockIdx.x * 2 * C + (long)q * W;
+#pragma unroll
+            for (int k = 0; k < W; ++k) { dst[k] = mn[k]; dst[C + k] = mx[k]; }
+        }
+        __syncthreads();
     }
-    (void)pix_per_block;
 }
 
-__global__ __launch_bounds__(256) void aq_apply_kernel(const float* x, long n, int C, const unsigned* ws, float bit_range, float* out) {
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        const float zp = ord2f(ws[c]);
-        const float rng = fmaxf(ord2f(ws[C + c]) - zp, 1e-6f);
-        const float xn = x[i] - zp;
-        const float q = rintf(fminf(fmaxf(xn / rng, -1.f), 1.f) * bit_range);
-        out[i] = (q / bit_range) * rng + zp;
+// ws[0 .. C) = min, ws[C .. 2C) = max over the `nblk` partial rows: sixteen lanes per entry walk the rows (independent loads, no
+// serial chain of nblk round trips), then fold across the lanes
+__global__ __launch_bounds__(256) void aq_fold_kernel(const float* part, int nblk, int C, float* ws) {
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4), j = threadIdx.x & 15;
+    const bool live = i < 2 * C;
+    const bool is_max = i >= C;
+    float r = is_max ? -INFINITY : INFINITY;
+    if (live) {
+        const float* src = part + i;
+        int b = j;
+        for (; b + 48 < nblk; b += 64) {
+            float v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = src[(long)(b + 16 * u) * 2 * C];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) r = is_max ? fmaxf(r, v[u]) : fminf(r, v[u]);
+        }
+        for (; b < nblk; b += 16) {
+            const float v = src[(long)b * 2 * C];
+            r = is_max ? fmaxf(r, v) : fminf(r, v);
+        }
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) {
+        const float v = __shfl_xor(r, o, 16);
+        r = is_max ? fmaxf(r, v) : fminf(r, v);
+    }
+    if (live && j == 0) ws[i] = r;
+}
+
+template <int W>
+__global__ __launch_bounds__(256) void aq_apply_kernel(const float* x, long nvec, int C, const float* ws, float bit_range, float* out) {
+    typedef float vec_t __attribute__((ext_vector_type(W)));
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)((i * W) % C);
+        const vec_t xv = *reinterpret_cast<const vec_t*>(x + i * W);
+        vec_t o;
+#pragma unroll
+        for (int k = 0; k < W; ++k) {
+            const float zp = ws[c + k];
+            const float rng = fmaxf(ws[C + c + k] - zp, 1e-6f);
+            const float xn = xv[k] - zp;
+            const float q = rintf(fminf(fmaxf(xn / rng, -1.f), 1.f) * bit_range);
+            o[k] = (q / bit_range) * rng + zp;
+        }
+        *reinterpret_cast<vec_t*>(out + i * W) = o;
     }
 }
 
@@ -537,16 +599,27 @@ int rdo_actquant_perchannel(const float* x, int64_t npix, int32_t C, int32_t n_b
     RDO_REQUIRE(x && out && ws_minmax && npix > 0 && C > 0, "rdo_actquant_perchannel: bad argument");
     RDO_REQUIRE(n_bits >= 2 && n_bits <= 16, "rdo_actquant_perchannel: n_bits %d outside [2, 16]", n_bits);
     const float bit_range = (float)((1 << n_bits) - 1);
-    unsigned* ws = reinterpret_cast<unsigned*>(ws_minmax);
+    float* ws = ws_minmax;
+    float* part = ws_minmax + 2 * (long)C;
+    const bool vec = C % 4 == 0 && (reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(out)) % 16 == 0;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(aq_init_kernel, dim3((unsigned)rdo::ceil_div(C, 256)), dim3(256), 0, s, ws, C);
-            long g = npix < 1024 ? npix : 1024;
-            hipLaunchKernelGGL(aq_minmax_kernel, dim3((unsigned)g), dim3(256), 0, s, x, (long)npix, C, ws);
-            hipLaunchKernelGGL(aq_apply_kernel, dim3(grid_for(npix * C)), dim3(256), 0, s, x, (long)npix * C, C, ws, bit_range, out);
+            const int W = vec ? 4 : 1;
+            const int QN = C / W, qpb = QN < 256 ? QN : 256, PL = 256 / qpb;
+            // enough workgroups to keep HBM busy, few enough that each has >= 8 pixels per lane to amortise its fold
+            long g = rdo::ceil_div(npix, (long)PL * 8);
+            const int nblk = (int)(g < 1 ? 1 : (g > kAqBlocks ? kAqBlocks : g));
+            if (vec) hipLaunchKernelGGL(aq_partial_kernel<4>, dim3(nblk), dim3(256), 0, s, x, (long)npix, C, part);
+            else hipLaunchKernelGGL(aq_partial_kernel<1>, dim3(nblk), dim3(256), 0, s, x, (long)npix, C, part);
+            hipLaunchKernelGGL(aq_fold_kernel, dim3((unsigned)rdo::ceil_div(2 * C, 16)), dim3(256), 0, s, part, nblk, C, ws);
+            const long nvec = (long)npix * C / W;
+            if (vec) hipLaunchKernelGGL(aq_apply_kernel<4>, dim3(grid_for(nvec)), dim3(256), 0, s, x, nvec, C, ws, bit_range, out);
+            else hipLaunchKernelGGL(aq_apply_kernel<1>, dim3(grid_for(nvec)), dim3(256), 0, s, x, nvec, C, ws, bit_range, out);
             return rdo::check_launch("actquant_perchannel");
         },
         stream);
 }
+
+int64_t rdo_actquant_workspace(int32_t C) { return C > 0 ? 2 * (int64_t)C * (kAqBlocks + 1) : 0; }
 
 }  // extern "C"

@@ -64,6 +64,7 @@ _SIGS = {
     "rdo_uaq_fakequant": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, P]),
     "rdo_uaq_init_minmax": (C.c_int, [P, C.c_int32, C.c_int64, C.c_int32, P, P, P]),
     "rdo_actquant_perchannel": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, P]),
+    "rdo_actquant_workspace": (C.c_int64, [C.c_int32]),
     "rdo_gather_qdrop": (C.c_int, [P, P, P, P, C.c_int32, C.c_int32, C.c_int64, C.c_float, C.c_uint32, P, P, P]),
     "rdo_lp2_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, P, P, P]),
     "rdo_lp_loss_grad": (C.c_int, [P, P, P, P, C.c_int32, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_float, P, P, P, P]),

@@ -262,7 +262,9 @@ def actquant_perchannel(x, out=None, ws=None, n_bits=8):
     Cc = x.shape[-1]
     npix = x.numel() // Cc
     out = torch.empty_like(x) if out is None else out
-    ws = torch.empty(2 * Cc, device=x.device, dtype=torch.float32) if ws is None else ws
+    need = int(L.lib().rdo_actquant_workspace(Cc))
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(need, device=x.device, dtype=torch.float32)
     L.check(L.lib().rdo_actquant_perchannel(_ptr(x), npix, Cc, int(n_bits), _ptr(out), _ptr(ws), _stream()), "rdo_actquant_perchannel")
     return out
 

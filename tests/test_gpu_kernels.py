@@ -155,6 +155,26 @@ def test_actquant_matches_oracle(ops):
     torch.testing.assert_close(got, ref, rtol=0, atol=2e-7)
 
 
+@pytest.mark.parametrize("shape", [(1, 192, 128, 96), (2, 1280, 5, 7), (1, 3, 33, 17), (4, 64, 64, 64), (1, 6, 1, 1)])
+def test_actquant_shapes_match_oracle(ops, shape):
+    """the two-level min / max reduction at sizes that use many workgroups, more channel groups than threads, scalar (C % 4 != 0) lanes"""
+    from oracle import rdo_oracle as O
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(*shape, generator=g) * 3 + 0.5
+    ref = O.act_quant(x)
+    got = ops.actquant_perchannel(x.permute(0, 2, 3, 1).contiguous().cuda()).cpu().permute(0, 3, 1, 2)
+    torch.testing.assert_close(got, ref, rtol=0, atol=5e-7)
+    # per-tensor use (one channel = the whole tensor, quantizer.py's non-4-D branch) and a reused workspace
+    flat = x.reshape(-1, 1).contiguous().cuda()
+    ws = torch.empty(int(ops.L.lib().rdo_actquant_workspace(1)), device="cuda")
+    a = ops.actquant_perchannel(flat, ws=ws)
+    b = ops.actquant_perchannel(flat, ws=ws)
+    assert torch.equal(a, b)
+    lo, hi = float(x.min()), float(x.max())
+    q = torch.round(((x - lo) / max(hi - lo, 1e-6)).clamp(-1, 1) * 255) / 255 * max(hi - lo, 1e-6) + lo
+    torch.testing.assert_close(a.cpu().reshape(x.shape), q, rtol=0, atol=5e-6)
+
+
 def test_uaq_init_and_fakequant_match_oracle(ops):
     from oracle import rdo_oracle as O
     g = torch.Generator().manual_seed(10)
