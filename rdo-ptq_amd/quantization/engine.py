@@ -1071,6 +1071,143 @@ class UnitEngine:
         for _ in range(n):
             self._rd_iteration(self.use_graph)
 
+    # ---- R + lambda*D: what does not depend on this unit is computed once per calibration image -----------------------------------
+    RD_CACHE_LIMIT = 8 << 30            # bytes of cached module outputs per unit (a coder's latent for 256 images is 50-100 MB)
+
+    @staticmethod
+    def _tree(fn, t):
+        if torch.is_tensor(t):
+            return fn(t)
+        if isinstance(t, dict):
+            return {k: UnitEngine._tree(fn, v) for k, v in t.items()}
+        if isinstance(t, (tuple, list)):
+            return type(t)(UnitEngine._tree(fn, v) for v in t)
+        return t
+
+    def _rd_prepare(self):
+        """Modules of the wrapped model whose INPUTS do not depend on this unit's output produce the same output for an image in every
+        iteration (weights behind and before the unit are fixed for the unit's run): found by running the model twice on one
+        mini-batch with two different random tensors in place of the unit's output, on torch's tape: a candidate is independent when
+        its inputs are bit-equal in both runs AND none of them carries a grad_fn back to the substituted tensor (values alone are not
+        enough: two different hyper-latents can round to the same z^; the tape alone is not either: a detached activation
+        quantiser cuts it).  Independent modules are evaluated ONCE per calibration image (in mini-batches of B, the shape the iterations run at) and looked up by row afterwards.
+        Candidates: the children of the model (the coders and entropy models) that do not contain the unit.  Inside the coder that
+        does, the modules in front of the unit in an nn.Sequential only feed the unit, whose forward is replaced: they are skipped.
+        A candidate holding a live dynamic activation quantiser (statistics over the mini-batch) is left alone.  `RDO_RD_CACHE=0`
+        turns all of this off."""
+        rd = self.rd
+        rd["memo"], rd["skip"] = {}, []
+        if os.environ.get("RDO_RD_CACHE", "1") == "0":
+            return
+        from .quant_block import BaseQuantBlock
+        from .quant_layer import QuantModule
+        model, unit, cali = rd["model"], rd["unit"], rd["cali"]
+        root = model.model if isinstance(getattr(model, "model", None), torch.nn.Module) else model
+        holds = lambda m: any(c is unit for c in m.modules())
+        cands = []
+        for _, child in root.named_children():
+            if not holds(child):
+                cands.append(child)
+                continue
+            box = child
+            while box is not unit and isinstance(box, torch.nn.Sequential):       # descend to the unit: skip what only feeds it
+                kids = list(box.children())
+                k = next(i for i, c in enumerate(kids) if holds(c))
+                rd["skip"] += kids[:k]
+                box = kids[k]
+        live_aq = lambda m: any(isinstance(c, (QuantModule, BaseQuantBlock)) and c.use_act_quant and c.trained
+                                and not getattr(c, "disable_act_quant", False) for c in m.modules())
+        cands = [c for c in cands if not live_aq(c)]
+        if not cands:
+            return
+        was_training = model.training
+        model.eval()
+        B = self.B
+        shape = tuple(self._rd_pred.permute(0, 3, 1, 2).shape)
+        seen = [{}, {}]
+        try:
+            tainted = set()
+
+            def note(m, a, k, run):
+                flag = [False]
+                self._tree(lambda t: flag.__setitem__(0, flag[0] or t.requires_grad), (a, k))
+                if flag[0]:
+                    tainted.add(id(m))
+                seen[run][id(m)] = self._tree(lambda t: t.detach().clone(), (a, k))
+            for run in range(2):
+                fake = torch.randn(shape, device=self.dev, generator=torch.Generator(device=self.dev).manual_seed(17 + run)).requires_grad_(True)
+                hooks = [c.register_forward_pre_hook(lambda m, a, k, run=run: note(m, a, k, run), with_kwargs=True) for c in cands]
+                unit.forward = lambda *a, fake=fake, **k: fake
+                for s_ in rd["skip"]:
+                    s_.forward = lambda x, *a, **k: x
+                try:
+                    with torch.enable_grad():
+                        model(cali[:B])
+                finally:
+                    for h in hooks:
+                        h.remove()
+                    del unit.forward
+                    for s_ in rd["skip"]:
+                        del s_.forward
+            with torch.no_grad():
+
+                def same(a, b):
+                    if torch.is_tensor(a):
+                        return torch.is_tensor(b) and a.shape == b.shape and bool(torch.equal(a, b))
+                    if isinstance(a, dict):
+                        return isinstance(b, dict) and a.keys() == b.keys() and all(same(a[k], b[k]) for k in a)
+                    if isinstance(a, (tuple, list)):
+                        return isinstance(b, (tuple, list)) and len(a) == len(b) and all(same(x, y) for x, y in zip(a, b))
+                    return a == b
+                free = [c for c in cands if id(c) in seen[0] and id(c) in seen[1] and id(c) not in tainted and same(seen[0][id(c)], seen[1][id(c)])]
+                seen = None
+                if not free:
+                    return
+                # one pass over the calibration images: outputs of the unit-independent modules, image-major
+                parts = {id(c): [] for c in free}
+                hooks = [c.register_forward_hook(lambda m, a, o: parts[id(m)].append(self._tree(lambda t: t.detach().clone(), o))) for c in free]
+                unit.forward = lambda *a, **k: torch.zeros(shape, device=self.dev)
+                for s_ in rd["skip"]:
+                    s_.forward = lambda x, *a, **k: x
+                try:
+                    n = cali.shape[0]
+                    for i in range(0, n, B):
+                        xb = cali[i:i + B]
+                        if xb.shape[0] < B:                                   # ragged end: pad the mini-batch with the first images
+                            xb = torch.cat([xb, cali[:B - xb.shape[0]]])
+                        model(xb)
+                finally:
+                    for h in hooks:
+                        h.remove()
+                    del unit.forward
+                    for s_ in rd["skip"]:
+                        del s_.forward
+
+                def cat(chunks):
+                    first = chunks[0]
+                    if torch.is_tensor(first):
+                        return torch.cat(chunks)[:n] if first.dim() > 0 and first.shape[0] == B else None
+                    if isinstance(first, dict):
+                        out = {k: cat([c[k] for c in chunks]) for k in first}
+                        return None if any(v is None for v in out.values()) else out
+                    if isinstance(first, (tuple, list)):
+                        out = [cat([c[j] for c in chunks]) for j in range(len(first))]
+                        return None if any(v is None for v in out) else type(first)(out)
+                    return None
+                total = 0
+                for c in free:
+                    memo = cat(parts.pop(id(c)))
+                    if memo is None:
+                        continue                                              # an output that is not per-image: leave the module alone
+                    nbytes = [0]
+                    self._tree(lambda v: nbytes.__setitem__(0, nbytes[0] + v.numel() * v.element_size()), memo)
+                    if total + nbytes[0] > self.RD_CACHE_LIMIT:
+                        continue
+                    total += nbytes[0]
+                    rd["memo"][c] = memo
+        finally:
+            model.train(was_training)
+
     def _rd_tail(self):
         """The current iteration's task loss: the images of the mini-batch through the wrapped model with this unit's output replaced
         by the engine's soft-quantised output, `RateDistortionLoss` (lambda * 255^2 * MSE + bpp) on the result, gradient back to that
@@ -1084,16 +1221,26 @@ class UnitEngine:
         rows = self.idx.index_select(0, it).view(-1).long()
         x = rd["cali"].index_select(0, rows)
         leaf = self._rd_pred.permute(0, 3, 1, 2).detach().requires_grad_(True)
+        if "memo" not in rd:
+            self._rd_prepare()
         was_training = rd["model"].training
         rd["model"].eval()
+        patched = [rd["unit"]]
         rd["unit"].forward = lambda *a, **k: leaf      # the unit itself is not run: its output is the engine's
+        for m_ in rd["skip"]:                          # ... nor what only feeds it
+            m_.forward = lambda x_, *a, **k: x_
+            patched.append(m_)
+        for m_, memo in rd["memo"].items():            # ... and what does not depend on it is looked up per image
+            m_.forward = lambda *a, memo=memo, **k: self._tree(lambda t: t.index_select(0, rows), memo)
+            patched.append(m_)
         try:
             with torch.enable_grad():
                 out = rd["model"](x)
                 loss = RateDistortionLoss(lmbda=rd["lmbda"], metric="mse")(out, x)["loss"]
                 (g,) = torch.autograd.grad(loss, [leaf], allow_unused=True)
         finally:
-            del rd["unit"].forward
+            for m_ in patched:
+                del m_.forward
             rd["model"].train(was_training)
         if g is None:
             raise RuntimeError("loss_mode='rd': no gradient reached the unit's output -- a module behind it detaches the tape (dynamic "

@@ -452,7 +452,8 @@ def test_rd_task_loss_mode_matches_oracle(where):
     assert flips <= 0.01 * tot
 
 
-def test_rd_mode_graph_host_and_data_parallel_sequences_agree(monkeypatch):
+@pytest.mark.parametrize("path", ["g_s.2", "h_a.2", "g_a.3", "entropy_parameters.2"])
+def test_rd_mode_graph_host_and_data_parallel_sequences_agree(monkeypatch, path):
     """loss_mode='rd' three ways on the same unit (g_s.2 of a toy Cheng2020): the captured-graph iteration, the host-driven iteration
     (RDO_RD_GRAPH=0) and the data-parallel op sequence on one rank (gradient bucket -> apply): the same alphas bit for bit, the
     same losses."""
@@ -467,12 +468,14 @@ def test_rd_mode_graph_host_and_data_parallel_sequences_agree(monkeypatch):
     cali = torch.rand(n_img, 3, 64, 64, generator=g).cuda()
     idx = torch.from_numpy(np.stack([np.random.RandomState(i).permutation(n_img)[:B] for i in range(iters)]))
     res = {}
-    for mode in ("graph", "host", "dp"):
+    for mode in ("graph", "host", "dp", "nocache"):
         torch.manual_seed(43)
         prod = lic.Cheng2020Anchor(N=N).eval()
         qnn = QuantModel(prod.cuda(), WQ, AQ, is_cheng=True).cuda().eval()
         qnn.set_quant_state(False, False)
-        unit = qnn.model.g_s[2]
+        unit = qnn.model
+        for part in path.split("."):
+            unit = unit[int(part)] if part.isdigit() else getattr(unit, part)
         store = {}
         h = unit.register_forward_hook(lambda m, i, o: store.update(inp=i[0].detach().clone(), out=o.detach().clone()))
         with torch.no_grad():
@@ -482,14 +485,18 @@ def test_rd_mode_graph_host_and_data_parallel_sequences_agree(monkeypatch):
         inp, out = nh(store["inp"]), nh(store["out"])
         inp_q = inp + 1e-3 * torch.randn(inp.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
         monkeypatch.setenv("RDO_RD_GRAPH", "0" if mode == "host" else "1")
+        monkeypatch.setenv("RDO_RD_CACHE", "0" if mode == "nocache" else "1")      # per-image cache of the unit-independent modules
         k, mods = _unit_modules(unit)
         eng = UnitEngine(k, mods, inp_q, inp, out, batch_size=B, iters=iters, weight=0.01, b_range=(20, 2), warmup=0.2, input_prob=0.5, seed=SEED,
                          idx_table=idx, force_dp_split=(mode == "dp"), rd=dict(model=qnn, unit=unit, cali=cali, lmbda=lmbda))
         eng.run()
         torch.cuda.synchronize()
-        assert eng.rd_path == ("graph" if mode == "graph" else "host")
+        assert eng.rd_path == ("graph" if mode in ("graph", "nocache") else "host")
+        # g_s / hyper-path units leave whole coders unit-independent; a g_a unit only has the modules in front of it to skip
+        assert bool(eng.rd["memo"]) == (mode != "nocache" and not path.startswith("g_a")), (path, mode, len(eng.rd["memo"]))
+        assert bool(eng.rd["skip"]) == (mode != "nocache")
         res[mode] = ({n: eng.alpha_of(n).clone() for n in eng.ops}, [t.clone() for t in eng.logs_terms()[:3]])
-    for mode in ("host", "dp"):
+    for mode in ("host", "dp", "nocache"):
         for n in res["graph"][0]:
             assert torch.equal(res[mode][0][n], res["graph"][0][n]), (mode, n)
         for a, b in zip(res[mode][1], res["graph"][1]):
