@@ -7,6 +7,7 @@
 
 namespace {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 constexpr int PMAX = 96;     // max KH*KW*Cin
 constexpr int PB = 32;       // pixels per LDS batch
 
@@ -43,7 +44,11 @@ __device__ __forceinline__ void load_rows(const ThinArgs& a, int m0, int mend, f
 // grid: (pixel chunks, ceil(Cout / blockDim.x)); thread = output channel
 template <int P>
 __global__ __launch_bounds__(256) void thin_fwd_kernel(ThinArgs a) {
-    __shared__ float rows[PB][P + 1];
+    // every lane of a wave reads the same patch value (its own weight is in a register): the reads are LDS broadcasts, and one
+    // ds_read_b32 per fma made the kernel LDS-issue-bound (198 us for the 5x5 stem at 768 x 512); rows are 16-byte aligned and read
+    // four values at a time
+    static_assert(P % 4 == 0, "thin_fwd_kernel: patch slots in fours");
+    __shared__ __attribute__((aligned(16))) float rows[PB][P];
     const int co = blockIdx.y * blockDim.x + threadIdx.x;
     const bool live = co < a.Cout;
     float wr[P];
@@ -51,7 +56,7 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(ThinArgs a) {
     for (int t = 0; t < P; ++t) wr[t] = (live && t < a.patch) ? a.w[(long)co * a.patch + t] : 0.f;
     const float bv = (live && a.bias) ? a.bias[co] : 0.f;
     const int mbeg = blockIdx.x * a.mchunk, mend = min(a.M, mbeg + a.mchunk);
-    for (int e = threadIdx.x; e < PB * (P + 1); e += blockDim.x) (&rows[0][0])[e] = 0.f;     // columns >= patch stay zero
+    for (int e = threadIdx.x; e < PB * P; e += blockDim.x) (&rows[0][0])[e] = 0.f;           // columns >= patch stay zero
     for (int m0 = mbeg; m0 < mend; m0 += PB) {
         __syncthreads();
         load_rows(a, m0, mend, rows);
@@ -60,7 +65,11 @@ __global__ __launch_bounds__(256) void thin_fwd_kernel(ThinArgs a) {
         for (int p = 0; p < PB && m0 + p < mend; ++p) {
             float acc = 0.f;
 #pragma unroll
-            for (int t = 0; t < P; ++t) acc = fmaf(rows[p][t], wr[t], acc);
+            for (int t = 0; t < P; t += 4) {
+                const f32x4 r4 = *reinterpret_cast<const f32x4*>(&rows[p][t]);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc = fmaf(r4[k], wr[t + k], acc);
+            }
             acc += bv;
             if (a.epilogue == RDO_EPI_LRELU) acc = acc > 0.f ? acc : 0.01f * acc;
             else if (a.epilogue == RDO_EPI_RELU) acc = acc > 0.f ? acc : 0.f;
