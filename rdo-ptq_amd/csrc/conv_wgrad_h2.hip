@@ -47,7 +47,14 @@ struct WgPArgs {
     int M, Min, mchunk, nsplit;
     int tiles_co, tiles_ci;
     float inv_scale;           // 1 / (s_x * s_dy): the accumulators hold s_x s_dy times the gradient sums
+    int ablate;                // diagnostic build only (tuning key "x6p_ablate"): 1 no DMA, 4 no MFMA, 8 no fragment reads (row kernel)
 };
+#ifdef RDO_DIAG
+#define WG_ABL(bit) (a.ablate & (bit))
+__device__ unsigned long long g_wg_stamps[256 * 4];
+#else
+#define WG_ABL(bit) false
+#endif
 
 __device__ __forceinline__ f16x8 tr_pair(const char* p) {
     typedef __attribute__((address_space(3))) s16x4 lds_v4;
@@ -256,12 +263,13 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(WgPArgs a) {
 constexpr int XROWS = 40;                      // 34 used; five 8-row DMA pieces per plane
 constexpr int XPLANEB = XROWS * 128;
 constexpr int STAGE3B = OPB + NP * XPLANEB;    // 24 + 10 = 34 KiB
+constexpr int RING3 = 2;                       // stages of the row kernel's LDS ring (3: measured slower, see the kernel)
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     constexpr int T = 192;
     constexpr int TM = 3, TN = 6;
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][STAGE3B]
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [RING3][STAGE3B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, lc = lane >> 4;
@@ -290,7 +298,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     const u16* const zero = reinterpret_cast<const u16*>(g_zero_page_w);
     const int prow8 = lane >> 3, cpos = lane & 7;
     // dY pieces of this wave: k = wave + 8 j of the 24 [plane][sub-tile][8-row group] pieces
-    constexpr int YP = NP * 12, XP = NP * 5;
+    constexpr int XP = NP * 5;                                          // X pieces (dY: 24 = three per wave)
     int yoff[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
@@ -298,29 +306,36 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
         const int plane = k / 12, sub = (k % 12) >> 2, rg = k & 3;
         const int row = 8 * rg + prow8;
         const int ch = co0 + 64 * sub + 8 * (cpos ^ (2 * ((row >> 1) & 3)));
-        yoff[j] = (k < YP && ch < a.Cout) ? (int)(plane * a.yplane) + ((ch >> 4) * a.M + row) * 16 + (ch & 15) : -1;
+        yoff[j] = ch < a.Cout ? (int)(plane * a.yplane) + ((ch >> 4) * a.M + row) * 16 + (ch & 15) : -1;
     }
     // X pieces: k = wave + 8 j of the 10 [plane][8-row group] pieces; row r of the image is input pixel wo0 - 1 + r
     int xoff[2], xrow[2];
+    int xk[2];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
-        const int k = wave + 8 * j;
+        const int k = wave + 8 * j < XP ? wave + 8 * j : wave;           // (waves 2-7 repeat their one piece: five DMAs per wave and stage)
+        xk[j] = k;
         const int plane = k / 5, rg = k - plane * 5;
         const int row = 8 * rg + prow8;
         const int ch = ci0 + 8 * (cpos ^ (2 * ((row >> 1) & 3)));
         xrow[j] = row;
-        xoff[j] = (k < XP && row < PK + 2) ? (int)(plane * a.xplane) + (ch >> 4) * a.Min * 16 + (ch & 15) : -1;
+        xoff[j] = row < PK + 2 ? (int)(plane * a.xplane) + (ch >> 4) * a.Min * 16 + (ch & 15) : -1;
     }
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
+    // segment cursor (image, output row, 32-pixel segment of the row), advanced by increments: the three integer divisions per stage
+    // were a measurable part of the loop skeleton
     int seg = sbeg;
+    int cb = sbeg / (a.Ho * segs_row);
+    int cho = (sbeg - cb * (a.Ho * segs_row)) / segs_row;
+    int cws = sbeg - (cb * a.Ho + cho) * segs_row;
     auto dma_stage = [&](int buf) {
-        const int sg = seg < send ? seg : send - 1;
-        ++seg;
-        const int b = sg / (a.Ho * segs_row);
-        const int rem = sg - b * (a.Ho * segs_row);
-        const int ho = rem / segs_row;
-        const int wo0 = (rem - ho * segs_row) * PK;
+        const int b = cb, ho = cho, wo0 = cws * PK;
+        if (seg + 1 < send) {                                            // advance, clamped at the chunk's last segment
+            ++seg;
+            if (++cws == segs_row) { cws = 0; if (++cho == a.Ho) { cho = 0; ++cb; } }
+        }
+        if (WG_ABL(1)) return;
         const int m0 = (b * a.Ho + ho) * a.Wo + wo0;
         const int hi = ho + kh - 1;
         const bool rowok = (unsigned)hi < (unsigned)a.H;
@@ -328,15 +343,14 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
         char* const dst = smem + buf * STAGE3B;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
-            const int k = wave + 8 * j;
-            if (k >= YP) break;
+            const int k = wave + 8 * j;                                  // 24 pieces: three per wave
             const u16* src = yoff[j] >= 0 ? a.yp + yoff[j] + (long)m0 * 16 : zero;
             __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + (k / 12) * PLANEB + ((k % 12) >> 2) * SUBB + (k & 3) * 1024), 16, 0, 0);
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int k = wave + 8 * j;
-            if (k >= XP) break;
+            const int k = xk[j];
+            if (RING3 == 2 && wave + 8 * j >= XP) break;                 // (no counted wait: the repeated piece is not needed)
             const int wi = wo0 - 1 + xrow[j];
             const bool ok = xoff[j] >= 0 && rowok && (unsigned)wi < (unsigned)a.W;
             const u16* src = ok ? a.xp + xoff[j] + (long)(xbase + xrow[j]) * 16 : zero;
@@ -374,11 +388,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     constexpr int PA[3] = {1, 0, 0};             // (dy2, x1) (dy1, x2) (dy1, x1): small terms first
     constexpr int PB[3] = {0, 1, 0};
 
+    // RING3 stages, RING3 - 1 in flight.  In-kernel clocks (tools/h2_stamps.py, 4 x 128^2, cycles per stage at 2.36-2.39 GHz -- this
+    // kernel is NOT at the power limit): complete 3436, DMA ablated 2521, fragment reads ablated 2532, MFMAs only 2094 (1728 = back to
+    // back), no MFMA 2394, skeleton 609.  The DMA share is issue cost and LDS write bandwidth against the transposed reads, not
+    // latency: a ring of three (two stages in flight, counted vmcnt(5), five DMAs per wave and stage) ran 3660 cycles per stage.
     const bool late = wave >= 4;
-    if (nsteps > 0) dma_stage(0);
+    if (nsteps > 0) {
+#pragma unroll
+        for (int r = 0; r < RING3 - 1; ++r) dma_stage(r);
+    }
     f16x8 fa[NP][TM], fb[2][NP][2];
     auto read_b = [&](auto setc, const char* st, int third) {
         constexpr int S = decltype(setc)::value;
+        if (WG_ABL(8)) return;
 #pragma unroll
         for (int p = 0; p < NP; ++p)
 #pragma unroll
@@ -386,17 +408,33 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     };
     using S0 = std::integral_constant<int, 0>;
     using S1 = std::integral_constant<int, 1>;
+#ifdef RDO_DIAG
+    const unsigned long long st_c0 = clock64(), st_r0 = wall_clock64();
+    if (WG_ABL(8)) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[p][i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[0][p][j] = fb[1][p][j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+        }
+    }
+#endif
+    int buf = 0;
     for (int s = 0; s < nsteps; ++s) {
-        const int buf = s & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        const bool more = s + 1 < nsteps;
-        if (more && !late) dma_stage(buf ^ 1);
+        if (WG_ABL(1) || RING3 == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (RING3 - 2)) : "memory");
+        __builtin_amdgcn_s_barrier();                                    // ... everybody's have, and nobody reads buffer (s - 1) % RING3 any more
+        const int nb = buf >= 1 ? buf - 1 : RING3 - 1;                   // (s + RING3 - 1) % RING3
+        const bool more = RING3 > 2 || s + 1 < nsteps;                   // (a counted wait needs the same DMA count in every stage)
+        if (more && !late) dma_stage(nb);
         const char* st = smem + buf * STAGE3B;
+        if (!WG_ABL(8)) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p)
+            for (int p = 0; p < NP; ++p)
 #pragma unroll
-            for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
+                for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
+        }
         read_b(S0{}, st, 0);
         [&]<int... SL>(std::integer_sequence<int, SL...>) {
             (([&] {
@@ -405,22 +443,32 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
                      if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
                      else read_b(S0{}, st, T3 + 1);
                  }
+                 if (!WG_ABL(4)) {
 #pragma unroll
-                 for (int i = 0; i < TM; ++i)
+                     for (int i = 0; i < TM; ++i)
 #pragma unroll
-                     for (int j = 0; j < 2; ++j)
-                         acc[i][2 * T3 + j] =
-                             __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                         for (int j = 0; j < 2; ++j)
+                             acc[i][2 * T3 + j] =
+                                 __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 }
                  __builtin_amdgcn_sched_barrier(0);
                  if constexpr (SL == 2) {
-                     if (more && late) dma_stage(buf ^ 1);
+                     if (more && late) dma_stage(nb);
                  }
                  __builtin_amdgcn_sched_barrier(0);
              }()),
              ...);
         }
         (std::make_integer_sequence<int, 9>{});
+        buf = buf + 1 == RING3 ? 0 : buf + 1;
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the clamped tail DMAs still target this workgroup's LDS
+#ifdef RDO_DIAG
+    if (tid == 0 && lin < 256) {       // shader-clock cycles and 100 MHz wall ticks of the K loop, stage count in the low bits of slot 1
+        g_wg_stamps[lin * 4 + 0] = clock64() - st_c0; g_wg_stamps[lin * 4 + 1] = wall_clock64() - st_r0;
+        g_wg_stamps[lin * 4 + 2] = (unsigned long long)nsteps; g_wg_stamps[lin * 4 + 3] = 0;
+    }
+#endif
 
     const long wsize = (long)a.Cout * 9 * a.Cin;
     float* slab = a.slabs + (long)chunk * wsize;
@@ -468,6 +516,9 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
     a.nsplit = nsplit;
     RDO_REQUIRE(x_scale > 0.f && dy_scale > 0.f, "rdo_conv2d_wgrad_h2: scales must be positive powers of two");
     a.inv_scale = 1.f / (x_scale * dy_scale);
+#ifdef RDO_DIAG
+    a.ablate = rdo::tuning(rdo::T_X6P_ABLATE);
+#endif
     // same chunking as rdo_conv2d_wgrad: whole 32-pixel steps per chunk
     long mchunk = rdo::ceil_div(rdo::ceil_div((long)a.M, nsplit), 32) * 32;
     a.mchunk = (int)mchunk;
@@ -483,7 +534,7 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
         b.tiles_ci = a.Cin / 64;
         return rdo::dispatch(
             [b](hipStream_t s) {
-                constexpr size_t lds = (size_t)2 * STAGE3B;
+                constexpr size_t lds = (size_t)RING3 * STAGE3B;
                 static rdo::PerDevice attr;
                 if (!attr.done()) {
                     if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -513,3 +564,11 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
         },
         stream, "conv_wgrad_h2_192x192", flops, bytes);
 }
+
+#ifdef RDO_DIAG
+// diagnostic build only: per workgroup {K-loop cycles, K-loop 100 MHz ticks, stages, 0} of the last row-kernel launch (tools/h2_stamps.py)
+extern "C" int rdo_diag_wgrad_stamps(unsigned long long* out, int n) {
+    if (!out || n <= 0 || n > 1024) return RDO_EINVAL;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? RDO_OK : RDO_EHIP;
+}
+#endif

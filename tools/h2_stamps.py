@@ -51,3 +51,33 @@ for stagger in (1,):
         print(f"stagger={stagger} {name:18s}: launch {us:6.1f} us | K loop median {np.median(cyc):8.0f} cycles = {np.median(cyc) / stages:6.0f} per stage, "
               f"{loop_us:6.1f} us wall -> {np.median(cyc) / loop_us / 1e3:5.2f} GHz", flush=True)
 ops.set_tuning("x6p_ablate", 0)
+
+# ---- the row weight-gradient kernel of the same conv
+dy = torch.randn(B, H, H, Cc, device="cuda") * 0.1
+dyp = ops.split_h2(dy)
+slabs = ops.conv2d_wgrad(x, dy, tuple(w.shape), 1, 1)
+wg = lambda: ops.conv2d_wgrad_h2(xp, tuple(x.shape), dyp, tuple(w.shape), 1, 1, slabs=slabs)
+fw = L.lib().rdo_diag_wgrad_stamps
+fw.argtypes = [C.c_void_p, C.c_int]
+for name, abl in (("complete", 0), ("no fragment reads", 8), ("no DMA", 1), ("MFMAs only", 9), ("no MFMA", 4), ("skeleton", 13)):
+    ops.set_tuning("x6p_ablate", abl)
+    t0 = time.perf_counter()
+    n = 0
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    while time.perf_counter() - t0 < 1.0:
+        for _ in range(100):
+            wg()
+        n += 100
+        torch.cuda.synchronize()
+    e1.record()
+    torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / n * 1e3
+    assert fw(buf.ctypes.data, 1024) == 0
+    s = buf.reshape(256, 4).astype(np.int64)
+    cyc, ticks, st = s[:252, 0], s[:252, 1], s[:252, 2]
+    loop_us = np.median(ticks) / 100.0
+    print(f"wgrad rows {name:18s}: launch {us:6.1f} us | K loop median {np.median(cyc):8.0f} cycles = {np.median(cyc / np.maximum(st, 1)):6.0f} per stage "
+          f"({int(np.median(st))} stages), {loop_us:6.1f} us wall -> {np.median(cyc) / loop_us / 1e3:5.2f} GHz", flush=True)
+ops.set_tuning("x6p_ablate", 0)
