@@ -85,7 +85,8 @@ struct rdo_plan {
     bool recording = false;
     // rdo_plan_run_then: this plan's ops followed by another plan's in ONE graph (cached for that partner)
     const rdo_plan* then_with = nullptr;
-    size_t then_ops = 0;                 // the partner's op count at capture (a re-recorded partner invalidates the graph)
+    unsigned long then_gen = 0;          // the partner's recording generation at capture (a re-recorded partner invalidates the graph)
+    unsigned long generation = 0;        // process-wide recording serial, set by every rdo_plan_begin_record (unique across plans)
     hipGraph_t graph_then = nullptr;
     hipGraphExec_t exec_then = nullptr;
 };
@@ -150,6 +151,8 @@ int rdo_plan_begin_record(rdo_plan* p) {
     if (p->exec_then) { (void)hipGraphExecDestroy(p->exec_then); p->exec_then = nullptr; }
     if (p->graph_then) { (void)hipGraphDestroy(p->graph_then); p->graph_then = nullptr; }
     p->then_with = nullptr;
+    static std::atomic<unsigned long> serial{0};
+    p->generation = ++serial;
     p->recording = true;
     rdo::recorder().active = true;
     rdo::recorder().sink = &p->ops;
@@ -239,7 +242,7 @@ int rdo_plan_run_then(rdo_plan* p, rdo_plan* q, int use_graph, void* stream) {
         if (int rc = run_ops(p, s)) return rc;
         return run_ops(q, s);
     }
-    if (p->exec_then && (p->then_with != q || p->then_ops != q->ops.size())) {
+    if (p->exec_then && (p->then_with != q || p->then_gen != q->generation)) {
         (void)hipGraphExecDestroy(p->exec_then);
         (void)hipGraphDestroy(p->graph_then);
         p->exec_then = nullptr;
@@ -258,7 +261,7 @@ int rdo_plan_run_then(rdo_plan* p, rdo_plan* q, int use_graph, void* stream) {
         e = hipGraphInstantiate(&p->exec_then, p->graph_then, nullptr, nullptr, 0);
         if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
         p->then_with = q;
-        p->then_ops = q->ops.size();
+        p->then_gen = q->generation;
     }
     hipError_t e = hipGraphLaunch(p->exec_then, s);
     if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));

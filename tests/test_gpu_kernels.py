@@ -519,3 +519,44 @@ def test_conv_transpose2d_phase_form_matches_torch(K, s, p, op, Cin, Cout, H, W)
         assert int((wp != 0).sum()) <= rows.numel()                            # every tap once, the rest structural zeros
         back = ops.tconv_fold(wp.unsqueeze(0).contiguous(), ph, Cout, Cin)
         assert torch.equal(back[0], rows)
+
+
+def test_plan_run_then_equals_two_runs(ops):
+    """rdo_plan_run_then: the ops of two recorded plans in ONE graph launch (what the data-parallel host loop enqueues between two
+    collectives) leave the same values as the two plans run one after the other, eagerly and as graphs; re-recording the partner
+    re-captures the chained graph."""
+    from hipops.plan import Plan
+    g = torch.Generator().manual_seed(21)
+    a = torch.randn(4, 64, generator=g).cuda()
+    b = torch.randn(4, 64, generator=g).cuda()
+    t1, t2, t3 = torch.empty_like(a), torch.empty_like(a), torch.empty_like(a)
+    p, q = Plan(), Plan()
+    with p.record():
+        ops.add(a, b, out=t1)              # t1 = a + b
+        ops.lrelu(t1, out=t2)              # t2 = lrelu(t1)
+    with q.record():
+        ops.add(t2, a, out=t3)             # t3 = t2 + a
+        ops.add(t3, t3, out=a)             # a  = 2 t3   (feeds the next p)
+    assert p.num_ops == 2 and q.num_ops == 2
+
+    def reference(a0, n):
+        x = a0.clone()
+        for _ in range(n):
+            t = torch.nn.functional.leaky_relu(x + b, 0.01)
+            x = 2 * (t + x)
+        return x
+    a0 = a.clone()
+    for graph in (False, True):
+        a.copy_(a0)
+        for _ in range(3):
+            p.run_then(q, graph=graph)
+        torch.cuda.synchronize()
+        torch.testing.assert_close(a, reference(a0, 3), rtol=0, atol=0)
+    with q.record():                        # a different partner op list: the chained graph must follow it
+        ops.add(t2, a, out=t3)
+        ops.add(t3, b, out=a)               # a = t3 + b
+    a.copy_(a0)
+    p.run_then(q, graph=True)
+    torch.cuda.synchronize()
+    t = torch.nn.functional.leaky_relu(a0 + b, 0.01)
+    torch.testing.assert_close(a, (t + a0) + b, rtol=0, atol=0)
