@@ -178,7 +178,8 @@ def gpu_leg(a, rank, world, device):
     force_dp = bool(os.environ.get("RDO_BENCH_FORCE_DP"))    # exercise the grad -> RCCL all-reduce -> apply sequence on 1 rank
     unit_wall = bool(os.environ.get("RDO_BENCH_UNIT_WALL"))   # diagnostic: per-unit wall time of graph replays after the timed region
     sustain = (a.sustain_steps // 100) * 100
-    iters = a.warmup + a.steps + sustain + 1 + (a.steps if unit_wall else 0)   # +1: the event-profiled iteration after the timed region
+    dp_probe = 10 if (world > 1 or force_dp) else 0             # per-unit wall / collective probe after the timed region (N > 1)
+    iters = a.warmup + a.steps + sustain + 1 + (a.steps if unit_wall else 0) + dp_probe   # +1: the event-profiled iteration after the timed region
     gi = torch.Generator().manual_seed(77 + rank)
     engines = []
     for name, u in units:
@@ -227,6 +228,26 @@ def gpu_leg(a, rank, world, device):
         windows.append(w / 100 * 1e3)
     if windows:
         log(f"sustained: {sum(windows) / len(windows):.3f} ms/step over {sustain} steps (windows {min(windows):.3f} .. {max(windows):.3f})")
+    # ---- N > 1: where a step's time goes, unit by unit -- wall per iteration of the data-parallel loop and the cost of the unit's
+    # collective(s) alone (the same persistent bucket, back to back) -- so that a scaling run explains itself
+    dp_units = {}
+    if dp_probe:
+        for uname, e in engines:
+            barrier()
+            t1 = time.perf_counter()
+            e.run(dp_probe)
+            torch.cuda.synchronize()
+            it_us = (time.perf_counter() - t1) / dp_probe * 1e6
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(dp_probe):
+                e.bucket.reduce()
+            torch.cuda.synchronize()
+            ar_us = (time.perf_counter() - t1) / dp_probe * 1e6
+            dp_units[uname] = {"bucket_kb": round(e.bucket.nbytes() / 1024, 1), "collectives_per_iter": 1 if e.bucket.back is None else 2,
+                               "iter_us": round(it_us, 1), "allreduce_us": round(ar_us, 1)}
+        log("data-parallel per unit (rank 0): " + "; ".join(f"{n} {d['iter_us']:.0f}us (coll {d['allreduce_us']:.0f}us, {d['bucket_kb']:.0f} KB)"
+                                                              for n, d in dp_units.items()))
     if unit_wall:
         for uname, e in engines:
             torch.cuda.synchronize()
@@ -249,7 +270,7 @@ def gpu_leg(a, rank, world, device):
             ms += e.plan_a2.profile()
         if e.plan_b is not None:
             if torch.distributed.is_initialized():
-                torch.distributed.all_reduce(e.bucket, group=e.group)
+                e.bucket.reduce()
             info += e.plan_b.op_info()
             ms += e.plan_b.profile()
         for (tag, fl, by), m in zip(info, ms):
@@ -295,7 +316,7 @@ def gpu_leg(a, rank, world, device):
     # which data-parallel loop ran: "graph" (iteration + collectives replayed from one graph) or "host" (plan / all-reduce / plan)
     dp_paths = sorted({e.dp_path for _, e in engines if e.dp_path is not None})
     return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, h2_units=h2_units, dp_paths=dp_paths,
-                batch_extra=batch_extra)
+                batch_extra=batch_extra, dp_units=dp_units)
 
 
 # ----------------------------------------------------------------------------- CPU baseline (oracle = "port")
@@ -336,14 +357,42 @@ def cpu_leg(a):
                        f"iteration(s) after 1 warm-up, B={n}, {a.crop}x{a.crop}, {cores} threads")
 
 
+def visible_gpu_count():
+    """GPUs this process would see, counted WITHOUT touching the HIP runtime: KFD topology nodes with compute units
+    (/sys/class/kfd/kfd/topology/nodes/*/properties, `simd_count` > 0), capped by ROCR_VISIBLE_DEVICES and HIP_/CUDA_VISIBLE_DEVICES.
+    None when the topology is not readable (then every rank checks its own device when it starts).  torch.cuda.device_count() is
+    NOT used here: on ROCm without amdsmi it is hipGetDeviceCount, i.e. it opens the runtime in the process that must stay clean."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):
+        return 0                                  # no KFD driver: no AMD GPU
+    try:
+        n = 0
+        for node in os.listdir(base):
+            props = dict(l.split(None, 1) for l in open(os.path.join(base, node, "properties")).read().splitlines() if " " in l)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except Exception:
+        return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([t for t in v.split(",") if t.strip() != ""]))
+    return n
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (one per GPU, rendezvous on 127.0.0.1)
-    and return the worst exit status.  The parent only COUNTS devices -- it must not initialise HIP (a process that has may neither
-    fork GPU children safely nor be replaced by exec)."""
+    and return the worst exit status.  The parent never initialises HIP (a process that has may neither fork GPU children safely
+    nor be replaced by exec): devices are counted from sysfs (`visible_gpu_count`).  It is also the watchdog: when one rank exits
+    non-zero (or is killed) the others -- which would wait in a collective for ever -- are terminated and the status is non-zero.
+    Only a single-rank `bench.py` may be run under rocprofv3 (the profiler's preload initialises the GPU in every process it starts).
+    RDO_BENCH_SHARE_GPU=1 (tests only, with RDO_BENCH_BACKEND=gloo): every rank uses cuda:0 -- RCCL refuses two ranks on one device,
+    gloo with device tensors does not -- so the N-rank code runs on a one-GPU box."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()
-    if have < a.gpus:
+    share = os.environ.get("RDO_BENCH_SHARE_GPU") == "1"
+    have = visible_gpu_count()
+    if not share and have is not None and have < a.gpus:
         raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible on this box -- refusing to run a smaller world "
                          f"under the label n_gpus={a.gpus}")
     with socket.socket() as sk:
@@ -351,7 +400,7 @@ def launch_ranks(a):
         port = sk.getsockname()[1]
     procs = []
     for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share else str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
     rc = 0
@@ -363,7 +412,8 @@ def launch_ranks(a):
                     continue
                 procs.remove(p)
                 if c != 0:
-                    rc = rc or c
+                    rc = rc or (c if c > 0 else 128 - c)      # killed by signal s: Popen reports -s
+                    print(f"[bench] rank process {p.pid} ended with status {c}: stopping the other ranks", file=sys.stderr, flush=True)
                     for q in procs:          # one rank failed: the others would wait in a collective for ever
                         q.terminate()
             time.sleep(0.2)
@@ -398,7 +448,12 @@ def main():
     if world > 1 or os.environ.get("RDO_BENCH_FORCE_DP"):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        torch.distributed.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        # RDO_BENCH_BACKEND=gloo exists for the tests (two ranks on ONE GPU: RCCL refuses that); measurements use nccl = RCCL
+        backend = os.environ.get("RDO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.distributed.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+        else:
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
     res = gpu_leg(a, rank, world, device)
     log("gpu leg done")
     n_units, dt = res["n_units"], res["dt"]
@@ -454,6 +509,13 @@ def main():
         if res["dp_paths"]:
             out["dp_graph"] = res["dp_paths"] == ["graph"]
             out["config"]["dp_loop"] = "+".join(res["dp_paths"])
+        if res["dp_units"]:
+            du = res["dp_units"]
+            out["dp"] = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,
+                         "sum_iter_ms": round(sum(d["iter_us"] for d in du.values()) / 1e3, 3),
+                         "sum_allreduce_ms": round(sum(d["allreduce_us"] for d in du.values()) / 1e3, 3),
+                         "note": "rank 0, after the timed region: wall per iteration of each unit's data-parallel loop and of its collective(s) alone",
+                         "units": du}
         if world == 1 and a.recon_iters > 0 and not os.environ.get("RDO_BENCH_FORCE_DP"):
             # outside the timed region: the metric by SURVEY 8d's literal definition -- wall time of recon_model (main2.py:227-253)
             sys.path.insert(0, os.path.join(ROOT, "tools"))

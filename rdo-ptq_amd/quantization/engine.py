@@ -29,6 +29,7 @@ from hipops import _lib as L
 from hipops import ops
 from hipops.plan import Plan
 
+from . import dp
 from .quant_layer import QuantModule
 from .quantizer import AdaRoundQuantizer, from_rows, to_rows
 
@@ -295,14 +296,9 @@ class UnitEngine:
             overlap = 2.0 * self.B * ho * wo * lo.numel() >= self.DP_OVERLAP_MIN_FLOP
         self._late = late if (self.split and overlap and self.rd is None) else None
         if self.split:
-            total = sum(op.numel() for op in o.values())
-            self.bucket = torch.zeros(total, device=self.dev)
-            order = [n for n in o if n != self._late] + ([self._late] if self._late else [])
-            off = 0
-            for n in order:
-                o[n].dalpha = self.bucket[off:off + o[n].numel()]
-                off += o[n].numel()
-            self._early_numel = total - (o[self._late].numel() if self._late else 0)
+            self.bucket = dp.GradBucket(OrderedDict((n, op.numel()) for n, op in o.items()), late=self._late, device=self.dev, group=self.group)
+            for n, op in o.items():
+                op.dalpha = self.bucket.view(n)
 
     def _buf(self, *shape):
         return torch.empty(shape, device=self.dev, dtype=torch.float32)
@@ -932,12 +928,12 @@ class UnitEngine:
             with self.plan_b.record():
                 opl = list(self.ops.values())
                 if self._batchable(opl):
-                    ops.adaround_step_batch(self._items(opl), 1.0 / self.world, self.weight, self.sched, self.it, self.round_log,
+                    ops.adaround_step_batch(self._items(opl), self.bucket.scale, self.weight, self.sched, self.it, self.round_log,
                                             advance_iter=None if self._handover else self.it, mode=2,
                                             iter_shadow=self.it_shadow if self._handover else None)
                 else:
                     for op in opl:
-                        ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, 1.0 / self.world, self.weight, self.sched,
+                        ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, self.bucket.scale, self.weight, self.sched,
                                            self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
                     ops.iter_advance(self.it)
                 self._after_step()
@@ -964,20 +960,9 @@ class UnitEngine:
         Inside a host-driven run of several iterations plan B of iteration i and plan A of iteration i + 1 go out as ONE graph launch
         (`first=False`: plan A was enqueued with the previous iteration's plan B; `last=False`: enqueue the next plan A with this
         plan B): two host enqueues per iteration and collective instead of three -- the small units are host-bound in this loop."""
-        dist = torch.distributed
-        comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
         if first:
             self.plan_a.run(1, graph=graph)
-        if self.plan_a2 is None:
-            if comm:
-                dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
-        else:
-            w1 = dist.all_reduce(self.bucket[:self._early_numel], op=dist.ReduceOp.SUM, group=self.group, async_op=True) if comm else None
-            self.plan_a2.run(1, graph=graph)
-            w2 = dist.all_reduce(self.bucket[self._early_numel:], op=dist.ReduceOp.SUM, group=self.group, async_op=True) if comm else None
-            if comm:
-                w1.wait()
-                w2.wait()
+        self.bucket.reduce(between=None if self.plan_a2 is None else (lambda: self.plan_a2.run(1, graph=graph)))
         if last:
             self.plan_b.run(1, graph=graph)
         else:
@@ -1038,9 +1023,7 @@ class UnitEngine:
         self._rd_tail()
         self.plan_rd.run(1, graph=graph)
         if self.split:
-            dist = torch.distributed
-            if self.world > 1 or (dist.is_available() and dist.is_initialized()):
-                dist.all_reduce(self.bucket, op=dist.ReduceOp.SUM, group=self.group)
+            self.bucket.reduce()
             self.plan_b.run(1, graph=graph)
 
     def _run_rd(self, n):

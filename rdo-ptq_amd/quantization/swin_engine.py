@@ -21,6 +21,7 @@ import torch
 from hipops import _lib as L
 from hipops import ops
 
+from . import dp
 from .engine import UnitEngine, _Op
 from .quant_layer import QuantModule
 from .quantizer import to_rows
@@ -131,13 +132,9 @@ class TapeEngine(UnitEngine):
         self.ops = o
         self._late = None                      # one bucket, one all-reduce (no early/late split for the tape units)
         if self.split:
-            total = sum(op.numel() for op in o.values())
-            self._early_numel = total
-            self.bucket = torch.zeros(total, device=self.dev)
-            off = 0
-            for op in o.values():
-                op.dalpha = self.bucket[off:off + op.numel()]
-                off += op.numel()
+            self.bucket = dp.GradBucket(OrderedDict((n, op.numel()) for n, op in o.items()), device=self.dev, group=self.group)
+            for n, op in o.items():
+                op.dalpha = self.bucket.view(n)
 
     def _alloc(self):
         if self.kind != "rstb":

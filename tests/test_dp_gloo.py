@@ -1,5 +1,10 @@
-"""world_size-2 (gloo, CPU) check of the data-parallel calibration step: averaging the alpha-gradient bucket across ranks
-that each hold half of the mini-batch reproduces the single-process run on the concatenated mini-batch."""
+"""world_size-2 (gloo, CPU) check of the data-parallel calibration step: summing the alpha-gradient bucket across ranks that each
+hold half of the mini-batch and applying it with 1 / world reproduces the single-process run on the concatenated mini-batch.
+
+The collective side is PRODUCT code: `quantization.dp.GradBucket` -- the flat bucket `engine.UnitEngine` writes its chained gradients
+into and reduces between its recorded plans (layout with the unit's last weight gradient at the end, persistent front / back views,
+asynchronous front all-reduce overlapped with a callback, `scale` = 1 / world) -- here on CPU tensors, with the oracle's loop
+standing in for the HIP kernels that fill and consume it."""
 import os
 import socket
 
@@ -20,7 +25,7 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, golden, tag, kind, iters, out_q):
+def _run(rank, world, port, golden, tag, kind, iters, late, out_q):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,18 +44,39 @@ def _run(rank, world, port, golden, tag, kind, iters, out_q):
     gidx = [[i % 3, 3 + i % 3] for i in range(iters)]
     rand = T(fx[f"{tag}/rand"])                       # [iters, 2, C, H, W] uniforms recorded from the reference run
     ops = oracle_ops(fx, tag, kind)
+    from collections import OrderedDict
+    bucket = dp.GradBucket(OrderedDict((n_, op.weight.numel()) for n_, op in ops.items()), late=late)
+    assert bucket.world == world and bucket.scale == 1.0 / world
+    assert bucket.order[-1] == (late or list(ops)[-1]) and (bucket.back is None) == (late is None)
+    calls = []
+
+    def hook(grads):
+        # what plan A / A2 of the engine do: chained gradients into the bucket's views; `between` = the slot of the last weight gradient
+        names = list(ops)
+        for n_, g_ in zip(names, grads):
+            if n_ != late:
+                bucket.view(n_).copy_(g_.reshape(-1))
+
+        def between():
+            calls.append(1)
+            if late is not None:
+                bucket.view(late).copy_(grads[names.index(late)].reshape(-1))
+        bucket.reduce(between=between)
+        for n_, g_ in zip(names, grads):                 # plan B: apply with 1 / world
+            g_.copy_((bucket.view(n_) * bucket.scale).view_as(g_))
     O.reconstruct_unit(kind, ops, T(fx[f"{tag}/inp_q"])[lo:hi], T(fx[f"{tag}/inp_fp"])[lo:hi], T(fx[f"{tag}/out"])[lo:hi],
                        iters=iters, batch_size=1, idx_stream=[[g[rank] - lo] for g in gidx],
                        mask_fn=lambda i, shape: rand[i, rank:rank + 1] < 0.5,
-                       grad_hook=lambda grads: dp.allreduce_mean_(grads))
+                       grad_hook=hook)
+    assert len(calls) == iters and bucket.n_collectives == iters * (2 if late else 1)
     if rank == 0:
         out_q.put({n_: op.alpha.numpy() for n_, op in ops.items()})
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tag,kind", [("g_a.1", "rb"), ("g_a.6", "layer")])
-def test_two_rank_gradient_average_equals_single_rank(golden_dir, tag, kind):
+@pytest.mark.parametrize("tag,kind,late", [("g_a.1", "rb", "conv1"), ("g_a.1", "rb", None), ("g_a.6", "layer", None)])
+def test_two_rank_gradient_average_equals_single_rank(golden_dir, tag, kind, late):
     from oracle import rdo_oracle as O
     golden = os.path.join(golden_dir, "recon_toy.npz")
     fx = np.load(golden)
@@ -63,7 +89,7 @@ def test_two_rank_gradient_average_equals_single_rank(golden_dir, tag, kind):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_run, args=(r, 2, port, golden, tag, kind, iters, q)) for r in range(2)]
+    procs = [ctx.Process(target=_run, args=(r, 2, port, golden, tag, kind, iters, late, q)) for r in range(2)]
     for p in procs:
         p.start()
     got = q.get(timeout=240)
@@ -83,3 +109,18 @@ def test_shard_range_covers_everything():
             assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
             sizes = [b - a for a, b in edges]
             assert max(sizes) - min(sizes) <= 1
+
+
+def test_grad_bucket_layout_single_process():
+    from collections import OrderedDict
+    from quantization import dp
+    b = dp.GradBucket(OrderedDict(conv1=6, conv2=4, gdn=2), late="conv1")
+    assert b.order == ["conv2", "gdn", "conv1"] and b.early_numel == 6 and b.flat.numel() == 12 and b.nbytes() == 48
+    b.view("conv1").fill_(1.0); b.view("gdn").fill_(2.0)
+    assert b.flat.tolist() == [0.0] * 4 + [2.0] * 2 + [1.0] * 6
+    assert b.front.data_ptr() == b.flat.data_ptr() and b.back.data_ptr() == b.view("conv1").data_ptr()
+    ran = []
+    b.reduce(between=lambda: ran.append(1))            # no process group: the sequence still runs, no collective
+    assert ran == [1] and b.n_collectives == 0 and b.world == 1 and b.scale == 1.0
+    with pytest.raises(KeyError):
+        dp.GradBucket(OrderedDict(a=1), late="b")
