@@ -318,6 +318,14 @@ int rdo_sq_diff_sum(const float* a, const float* b, int64_t n, float scale, int3
  * rdo_pixel_shuffle_h2, rdo_pixel_unshuffle2, rdo_split_h2 (from an fp32 tensor); weights: rdo_adaround_step* (plane scale > 0),
  * rdo_split_h2_conv. */
 int rdo_h2_overflow(int reset);   /* 1: some producer met a value outside fp16 range since the last reset (synchronises); -1: error */
+/* The flag word the H2 producers LAUNCHED (or recorded into a plan) BY THIS THREAD from now on raise: a caller-owned, zero-initialised
+ * PAIR of int32 in device memory -- flag[0] holds the fp32 bit pattern of the largest FINITE |x s| that did not fit (atomic max), i.e. by
+ * how much the scale was outgrown; flag[1] is set when an inf / NaN was met (everything downstream of a first overflow) --, so that every calibration unit (and every plane tensor of it) watches its own flag (one engine's overflow is not consumed by another, and a
+ * data-parallel group can MAX-reduce the words before deciding); NULL re-binds the per-device default read by rdo_h2_overflow().  The
+ * pointer is a kernel argument fixed at launch / record time: replays of a recorded plan keep raising the flag bound when it was
+ * recorded.  The engine polls its word during long runs and restarts the unit with re-probed scales (or on fp32 activations) instead
+ * of losing the run -- the reference's fp32 arithmetic (quant_layer.py:123) cannot overflow at all. */
+int rdo_h2_bind_flag(int32_t* flag);
 int rdo_split_h2(const float* x, int64_t npix, int32_t C, float scale, void* planes /* 2*npix*C fp16 */, void* stream);
 /* conv weight [Cout][KH][KW][Cin] -> two fp16 planes of w * scale in fragment order (see rdo_split_bf16x3_conv for the order) */
 int rdo_split_h2_conv(const float* w, int32_t Cout, int32_t KH, int32_t KW, int32_t Cin, float scale, void* planes /* 2*numel fp16 */,

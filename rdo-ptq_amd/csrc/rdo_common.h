@@ -100,7 +100,14 @@ int* h2_overflow_flag();                   // device pointer of the sticky flag 
 #if defined(__HIPCC__)
 typedef _Float16 h2_f16x2 __attribute__((ext_vector_type(2)));
 typedef float h2_f32x2 __attribute__((ext_vector_type(2)));
-// two values -> packed h1 pair, packed h2 pair; `bad` is OR-ed with 1 when a value does not fit fp16
+// two values -> packed h1 pair, packed h2 pair.  `bad` accumulates the LARGEST |x s| met, as the fp32 bit pattern with the sign
+// cleared (an integer max: inf and NaN patterns are larger than every finite one); h2_report raises the word when that exceeds fp16's
+// 65504 -- the word then tells the engine by how much the scale was outgrown (quantization/engine.py, _recover).
+constexpr int kH2MaxBits = 0x477FE000;      // bit pattern of 65504.0f
+__device__ __forceinline__ int h2_mag(float a, float b, int bad) {
+    const int ia = __builtin_bit_cast(int, a) & 0x7FFFFFFF, ib = __builtin_bit_cast(int, b) & 0x7FFFFFFF;
+    return max(max(ia, ib), bad);
+}
 __device__ __forceinline__ void h2_split_pk(float a, float b, float s, unsigned& hi, unsigned& lo, int& bad) {
     const float xa = a * s, xb = b * s;
     const h2_f16x2 h = __builtin_convertvector(h2_f32x2{xa, xb}, h2_f16x2);
@@ -108,7 +115,7 @@ __device__ __forceinline__ void h2_split_pk(float a, float b, float s, unsigned&
     const h2_f16x2 l = __builtin_convertvector(h2_f32x2{xa - hf[0], xb - hf[1]}, h2_f16x2);
     hi = __builtin_bit_cast(unsigned, h);
     lo = __builtin_bit_cast(unsigned, l);
-    bad |= (int)(!(__builtin_fabsf(xa) <= 65504.f) | !(__builtin_fabsf(xb) <= 65504.f));
+    bad = h2_mag(xa, xb, bad);
 }
 __device__ __forceinline__ float h2_lo(unsigned pk) { return (float)__builtin_bit_cast(h2_f16x2, pk)[0]; }
 __device__ __forceinline__ float h2_hi(unsigned pk) { return (float)__builtin_bit_cast(h2_f16x2, pk)[1]; }
@@ -119,10 +126,16 @@ __device__ __forceinline__ void h2_split_store(float v, float s, unsigned short*
     const _Float16 l = (_Float16)(x - (float)h);
     planes[i] = __builtin_bit_cast(unsigned short, h);
     planes[n + i] = __builtin_bit_cast(unsigned short, l);
-    bad |= (int)!(__builtin_fabsf(x) <= 65504.f);
+    bad = h2_mag(x, x, bad);
 }
+// flag[0]: atomic max of the FINITE magnitudes beyond fp16's range (what the scale must grow by); flag[1]: set when a value was inf / NaN
+// (after a first overflow everything downstream is: those must not bury the finite magnitude that started it)
 __device__ __forceinline__ void h2_report(int bad, int* flag) {
-    if (bad) atomicOr(flag, 1);
+    // flag == nullptr: the default word could not be allocated (rdo_h2_overflow then returns -1)
+    if (bad > kH2MaxBits && flag) {
+        if (bad < 0x7F800000) atomicMax(flag, bad);
+        else atomicOr(flag + 1, 1);
+    }
 }
 #endif
 

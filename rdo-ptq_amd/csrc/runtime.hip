@@ -58,7 +58,11 @@ int tuning(Tune t) {
     return g_tune[t].load(std::memory_order_relaxed);
 }
 
+// rdo_h2_bind_flag: the caller's own flag word for the launches of this thread (nullptr: the per-device default below)
+static thread_local int* t_h2_bound = nullptr;
+
 int* h2_overflow_flag() {
+    if (t_h2_bound) return t_h2_bound;
     static std::mutex mu;
     static int* ptr[64] = {};
     int dev = 0;
@@ -116,13 +120,18 @@ int rdo_get_tuning(const char* key) {
     return rdo::g_tune[i].load();
 }
 
+int rdo_h2_bind_flag(int32_t* flag) {
+    rdo::t_h2_bound = flag;
+    return RDO_OK;
+}
+
 int rdo_h2_overflow(int reset) {
     int* p = rdo::h2_overflow_flag();
     if (!p) return -1;
-    int v = 0;
-    if (hipMemcpy(&v, p, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (reset && v) (void)hipMemset(p, 0, sizeof v);
-    return v;
+    int v[2] = {0, 0};
+    if (hipMemcpy(v, p, sizeof v, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (reset && (v[0] | v[1])) (void)hipMemset(p, 0, sizeof v);
+    return (v[0] | v[1]) != 0;
 }
 
 rdo_plan* rdo_plan_create(void) { return new rdo_plan(); }

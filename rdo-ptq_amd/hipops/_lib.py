@@ -98,6 +98,7 @@ _SIGS = {
     "rdo_neg_log2_sum": (C.c_int, [P, C.c_int64, C.c_float, P, P]),
     "rdo_sq_diff_sum": (C.c_int, [P, P, C.c_int64, C.c_float, C.c_int32, P, P]),
     "rdo_h2_overflow": (C.c_int, [C.c_int]),
+    "rdo_h2_bind_flag": (C.c_int, [C.c_void_p]),
     "rdo_split_h2": (C.c_int, [P, C.c_int64, C.c_int32, C.c_float, P, P]),
     "rdo_split_h2_conv": (C.c_int, [P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, P, P]),
     "rdo_conv2d_fwd_h2_workspace": (C.c_int64, [C.POINTER(ConvDesc)]),

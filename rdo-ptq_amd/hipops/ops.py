@@ -14,10 +14,11 @@ from . import _lib as L
 class H2:
     """Planes of an H2 tensor (include/rdo_ptq_hip.h): `.t` int16 [2, ...] holding fp16 bit patterns -- the two-way split of the values
     times `.scale` (a power of two) -- for activations in slice-major order [2, C/16, pixels, 16], for conv weights in fragment order."""
-    __slots__ = ("t", "scale")
+    __slots__ = ("t", "scale", "flag")
 
-    def __init__(self, t, scale):
+    def __init__(self, t, scale, flag=None):
         self.t, self.scale = t, float(scale)
+        self.flag = flag          # this tensor's own overflow words (2-element int32 device tensor; see h2_flag) or None: the bound default
         m, e = math.frexp(self.scale)
         if not (self.scale > 0 and m == 0.5):
             raise ValueError(f"H2 scale must be a positive power of two, got {scale}")
@@ -212,6 +213,7 @@ def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_
                   wq_planes=None, wd_planes=None):
     """`wq_planes` / `wd_planes`: optional planes of the new weights in fragment order -- an int16 [3, numel] tensor receives the bf16
     three-way split, an `H2` object the fp16 two-way split of w * scale."""
+    _bind_out(None)            # weight planes raise the enclosing block's word
     L.check(L.lib().rdo_adaround_step(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(slabs), slabs.shape[0], grad_scale,
                                       round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(alpha), _ptr(m), _ptr(v), _ptr(wq),
                                       _ptr(wd), _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _pscale(wq_planes), _pscale(wd_planes),
@@ -222,6 +224,7 @@ def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_
     """items: list of dicts(d, w, delta, zp, slabs, alpha, m, v, wq, wd, wq_planes, wd_planes[, dalpha]) -- one launch for every
     weight tensor of a unit (<= 8, numel % 4 == 0): mode 0 the fused AdaRound step, 1 the data gradient into `dalpha`, 2 the update
     from an (all-reduced) `dalpha`; `advance_iter`: the device iteration counter to increment afterwards."""
+    _bind_out(None)            # weight planes raise the enclosing block's word
     arr = (L.AdaStepItem * len(items))()
     dp = lambda t: None if t is None else _ptr(t).value
     for k, it in enumerate(items):
@@ -244,6 +247,7 @@ def adaround_grad(d, w, alpha, delta, zp, slabs, dalpha):
 
 def adaround_apply(d, w, delta, zp, dalpha, grad_scale, round_weight, sched, iter_ptr, alpha, m, v, wq, wd, round_log,
                    wq_planes=None, wd_planes=None):
+    _bind_out(None)            # weight planes raise the enclosing block's word
     L.check(L.lib().rdo_adaround_apply(C.byref(d), _ptr(w), _ptr(delta), _ptr(zp), _ptr(dalpha), grad_scale, round_weight,
                                        _ptr(sched), _ptr(iter_ptr), _ptr(alpha), _ptr(m), _ptr(v), _ptr(wq), _ptr(wd),
                                        _ptr(round_log), _ptr(wq_planes), _ptr(wd_planes), _pscale(wq_planes), _pscale(wd_planes), _stream()),
@@ -675,7 +679,7 @@ def pow2_scale(amax, target=H2_TARGET):
     return 2.0 ** min(60, max(-60, math.floor(math.log2(target / amax))))
 
 
-def h2_empty(shape, device, scale=1.0):
+def h2_empty(shape, device, scale=1.0, flag=None):
     """Planes of an H2 tensor for an fp32 NHWC tensor of `shape` [..., C] (C % 16 == 0): int16 [2, C/16, pixels, 16] -- slice-major
     planes, include/rdo_ptq_hip.h."""
     Cc = shape[-1]
@@ -684,7 +688,7 @@ def h2_empty(shape, device, scale=1.0):
     npix = 1
     for d in shape[:-1]:
         npix *= int(d)
-    return H2(torch.empty((2, Cc // 16, npix, 16), device=device, dtype=torch.int16), scale)
+    return H2(torch.empty((2, Cc // 16, npix, 16), device=device, dtype=torch.int16), scale, flag)
 
 
 def h2_to_float(planes, shape):
@@ -701,12 +705,57 @@ def h2_overflow(reset=True):
     return bool(rc)
 
 
+class h2_flag:
+    """with h2_flag(word): the H2 producers launched -- or recorded into a plan -- by this thread inside the block raise `word` (a
+    zero-initialised int32 device tensor the caller keeps alive as long as the recorded plans) instead of the per-device default flag
+    (rdo_h2_bind_flag).  An output `H2` that carries its own `.flag` raises that one instead (`_bind_out`).  A raised word holds the
+    fp32 bit pattern of the largest FINITE |x * scale| that did not fit in word 0 (`overflow_magnitude`) and a non-finite mark in word 1.  Blocks nest; leaving restores the previous
+    binding."""
+    _stack = []
+    _bound = None
+
+    def __init__(self, word):
+        if word is not None and not (word.is_cuda and word.dtype == torch.int32 and word.numel() >= 2):
+            raise ValueError("h2_flag: expected an int32 CUDA tensor of two words (finite magnitude, non-finite mark)")
+        self.word = word
+
+    @staticmethod
+    def bind(word):
+        if word is not h2_flag._bound:
+            L.check(L.lib().rdo_h2_bind_flag(None if word is None else _ptr(word)), "rdo_h2_bind_flag")
+            h2_flag._bound = word
+
+    def __enter__(self):
+        h2_flag._stack.append(self.word)
+        h2_flag.bind(self.word)
+        return self.word
+
+    def __exit__(self, *exc):
+        h2_flag._stack.pop()
+        h2_flag.bind(h2_flag._stack[-1] if h2_flag._stack else None)
+        return False
+
+
+def _bind_out(planes):
+    """the overflow word the next producer raises: the output tensor's own, else the enclosing h2_flag block's, else the default"""
+    own = getattr(planes, "flag", None)
+    h2_flag.bind(own if own is not None else (h2_flag._stack[-1] if h2_flag._stack else None))
+
+
+def overflow_magnitude(word_value):
+    """Largest |x * scale| a raised overflow word recorded (its int32 value is the fp32 bit pattern; inf for NaN / inf inputs)."""
+    import struct
+    v = struct.unpack("<f", struct.pack("<i", int(word_value)))[0]
+    return float("inf") if not math.isfinite(v) else v
+
+
 def split_h2(x, planes=None, scale=None):
     """fp32 NHWC tensor -> H2 planes; without `planes` / `scale` the scale comes from the tensor's own largest magnitude (a device
     synchronisation: set-up and tests only)."""
     if planes is None:
         planes = h2_empty(x.shape, x.device, pow2_scale(x.abs().max()) if scale is None else scale)
     Cc = x.shape[-1]
+    _bind_out(planes)
     L.check(L.lib().rdo_split_h2(_ptr(x), x.numel() // Cc, Cc, planes.scale, _ptr(planes), _stream()), "rdo_split_h2")
     return planes
 
@@ -721,6 +770,7 @@ def split_h2_conv(w, planes=None, scale=None):
     if planes is None:
         planes = H2(torch.empty((2,) + tuple(w.shape), device=w.device, dtype=torch.int16), pow2_scale(w.abs().max()) if scale is None else scale)
     co, kh, kw, ci = w.shape
+    _bind_out(planes)
     L.check(L.lib().rdo_split_h2_conv(_ptr(w), co, kh, kw, ci, planes.scale, _ptr(planes), _stream()), "rdo_split_h2_conv")
     return planes
 
@@ -741,6 +791,7 @@ def conv2d_fwd_h2(xp, x_shape, w_shape, wplanes, bias=None, stride=1, pad=0, epi
     d = conv_desc(x_shape, w_shape, stride, pad, epilogue, False, residual is not None)
     need = int(L.lib().rdo_conv2d_fwd_h2_workspace(C.byref(d)))
     ws = _scratch(xp.device, need) if need else None
+    _bind_out(out_planes)
     L.check(L.lib().rdo_conv2d_fwd_h2(C.byref(d), _ptr(xp), xp.scale, _ptr(wplanes), wplanes.scale, _ptr(bias), _ptr(aux), _ptr(aux_planes),
                                       _ptr(residual), _ptr(out), _ptr(pre), _ptr(out_planes), _oscale(out_planes), _ptr(ws),
                                       ws.numel() if ws is not None else 0, _stream()), "rdo_conv2d_fwd_h2")
@@ -756,6 +807,7 @@ def conv2d_fwd_h2_tail(xp, x_shape, w_shape, wplanes, bias, stride, pad, residua
                        loss_log):
     """Plane-input conv + unit tail in one launch: dpre_planes <- dL/dpre of out = act(conv + bias) + residual against tgt_cache[idx]."""
     d = conv_desc(x_shape, w_shape, stride, pad)
+    _bind_out(dpre_planes)
     L.check(L.lib().rdo_conv2d_fwd_h2_tail(C.byref(d), _ptr(xp), xp.scale, _ptr(wplanes), wplanes.scale, _ptr(bias), _ptr(residual_planes),
                                            _oscale(residual_planes), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), x_shape[0], coef, int(act),
                                            _ptr(dpre_planes), dpre_planes.scale, _ptr(loss_log), _stream()), "rdo_conv2d_fwd_h2_tail")
@@ -763,6 +815,7 @@ def conv2d_fwd_h2_tail(xp, x_shape, w_shape, wplanes, bias, stride, pad, residua
 
 def gather_qdrop_h2(cache_q, cache_fp, idx_table, iter_ptr, B, prob, seed, out, out_planes, batch_offset=0, iter_publish=None):
     per_image = cache_q[0].numel()
+    _bind_out(out_planes)
     L.check(L.lib().rdo_gather_qdrop_h2(_ptr(cache_q), _ptr(cache_fp), _ptr(idx_table), _ptr(iter_ptr), B, int(batch_offset), per_image,
                                         cache_q.shape[-1], prob, seed, _ptr(out), _ptr(out_planes), out_planes.scale, _ptr(iter_publish),
                                         _stream()), "rdo_gather_qdrop_h2")
@@ -774,6 +827,7 @@ ACT_NONE, ACT_LRELU, ACT_RELU = 0, 1, 2
 def loss_act_bwd(pre, residual, tgt_cache, idx_table, iter_ptr, coef, act, loss_log, out=None, grad_out=None, dpre=None, dpre_planes=None,
                  residual_planes=None):
     B, per_image = pre.shape[0], pre[0].numel()
+    _bind_out(dpre_planes)
     L.check(L.lib().rdo_loss_act_bwd(_ptr(pre), _ptr(residual), _ptr(residual_planes), _oscale(residual_planes), _ptr(tgt_cache), _ptr(idx_table),
                                      _ptr(iter_ptr), B, per_image, pre.shape[-1], coef, int(act), _ptr(out), _ptr(grad_out), _ptr(dpre),
                                      _ptr(dpre_planes), _oscale(dpre_planes), _ptr(loss_log), _stream()), "rdo_loss_act_bwd")
@@ -781,12 +835,14 @@ def loss_act_bwd(pre, residual, tgt_cache, idx_table, iter_ptr, coef, act, loss_
 
 def loss_gdn_bwd(x, norm, residual, tgt_cache, idx_table, iter_ptr, coef, inverse, loss_log, grad_out, t=None, t_planes=None, out=None):
     B, per_image = x.shape[0], x[0].numel()
+    _bind_out(t_planes)
     L.check(L.lib().rdo_loss_gdn_bwd(_ptr(x), _ptr(norm), _ptr(residual), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), B, per_image,
                                      x.shape[-1], coef, int(inverse), _ptr(out), _ptr(grad_out), _ptr(t), _ptr(t_planes), _oscale(t_planes),
                                      _ptr(loss_log), _stream()), "rdo_loss_gdn_bwd")
 
 
 def gdn_bwd_dx_h2(g, x, norm, acc, inverse, dx=None, dx_planes=None):
+    _bind_out(dx_planes)
     L.check(L.lib().rdo_gdn_bwd_dx_h2(_ptr(g), _ptr(x), _ptr(norm), _ptr(acc), g.numel(), g.shape[-1], int(inverse), _ptr(dx),
                                       _ptr(dx_planes), _oscale(dx_planes), _stream()), "rdo_gdn_bwd_dx_h2")
 
@@ -794,6 +850,7 @@ def gdn_bwd_dx_h2(g, x, norm, acc, inverse, dx=None, dx_planes=None):
 def pixel_shuffle_h2(x, out=None, out_planes=None):
     """[B,H,W,4C] -> [B,2H,2W,C] (r = 2) as fp32 and / or planes."""
     B, H, W, CC = x.shape
+    _bind_out(out_planes)
     L.check(L.lib().rdo_pixel_shuffle_h2(_ptr(x), B, H, W, CC // 4, _ptr(out), _ptr(out_planes), _oscale(out_planes), _stream()),
             "rdo_pixel_shuffle_h2")
 
@@ -803,6 +860,7 @@ def pixel_unshuffle2(x, out=None, out_planes=None):
     B, Hr, Wr, Cc = x.shape
     if out is None and out_planes is None:
         out = torch.empty((B, Hr // 2, Wr // 2, 4 * Cc), device=x.device, dtype=torch.float32)
+    _bind_out(out_planes)
     L.check(L.lib().rdo_pixel_unshuffle2(_ptr(x), B, Hr // 2, Wr // 2, Cc, _ptr(out), _ptr(out_planes), _oscale(out_planes), _stream()),
             "rdo_pixel_unshuffle2")
     return out

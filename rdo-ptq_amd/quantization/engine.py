@@ -248,14 +248,22 @@ class UnitEngine:
         self._dp_graph, self._dp_graph_failed = None, False
         self.rd_path = None                    # "graph" | "host" once an R + lambda*D run has started (_run_rd)
         self._rd_graph, self._rd_graph_failed = None, False
-        self._build_ops()
-        self._alloc()
-        self.scales = {}                       # activation buffer name -> power-of-two scale of its H2 planes
-        self._probing = False
-        self._probe_scales()
-        self._record()
-        for op in self.ops.values():
-            op.refresh_planes()          # initial soft weights -> bf16 planes (eager, before the first iteration)
+        # this unit's own fp16-overflow word (rdo_h2_bind_flag): raised by every H2 producer of its plans, polled during long runs
+        # (pairs: finite magnitude, non-finite mark; pair 0 for the weight planes, one pair per activation tensor kept as planes)
+        self._ovf = torch.zeros(2 * self.OVF_PAIRS, dtype=torch.int32, device=self.dev)
+        self._ovf_slot = {}                    # plane tensor name -> its pair
+        self.h2_restarts = 0                   # times the unit was restarted after an overflow (0 in every measured run so far)
+        self._done = 0
+        with ops.h2_flag(self._ovf[0:2]):
+            self._build_ops()
+            self._alloc()
+            self.scales = {}                   # activation buffer name -> power-of-two scale of its H2 planes
+            self._amax = {}                    # ... and the magnitude it was derived from
+            self._probing = False
+            self._probe_scales()
+            self._record()
+            for op in self.ops.values():
+                op.refresh_planes()      # initial soft weights -> bf16 planes (eager, before the first iteration)
 
     # ------------------------------------------------------------------------------------------------------------------
     def _build_ops(self):
@@ -486,10 +494,13 @@ class UnitEngine:
     H2_MIN_OUT = int(os.environ.get("RDO_H2_MIN_OUT", 4096 * 192))
     h2_lean = os.environ.get("RDO_H2_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fp32
 
+    OVF_PAIRS = 8
+
     def _h2(self, name, like):
-        """Planes of activation buffer `name` (H2 form, scale from the probe iteration)."""
+        """Planes of activation buffer `name` (H2 form, scale from the probe iterations, its own overflow words)."""
         if name not in self.P:
-            self.P[name] = ops.h2_empty(like.shape, self.dev, self.scales[name])
+            k = self._ovf_slot.setdefault(name, 1 + len(self._ovf_slot))
+            self.P[name] = ops.h2_empty(like.shape, self.dev, self.scales[name], flag=self._ovf[2 * k:2 * k + 2])
         return self.P[name]
 
     def _conv_ok_h2(self, op, x_shape, dgrad=False):
@@ -674,15 +685,9 @@ class UnitEngine:
     # activation buffers a plan may keep as planes (all probed: a scale that is never used costs nothing)
     H2_PROBED = {"tconv": ("x", "dpre"), "rb": ("x", "h1", "dpre2", "dh1"), "rbws": ("x", "h1", "t", "dc2", "dh1"), "rbu": ("x", "h1", "t", "dc", "dup", "dsp")}
 
-    def _probe_scales(self):
-        """fp16 planes need a per-tensor power-of-two scale (include/rdo_ptq_hip.h, "H2 tensors").  One PROBE iteration of the unit on
-        fp32 activations and the plain fp32 kernels (no planes, no AdaRound step), run eagerly before the plan is recorded, gives the
-        magnitude of every tensor the plan will keep as planes; the scale puts that magnitude at 2^7 -- a x512 margin before fp16
-        overflows (which the producers flag, see `_check_overflow`) and x512 down before accuracy would start to degrade.  The
-        reconstruction error, hence the gradients, changes by far less than that over a run (profiles/r03_full_schedule.log)."""
-        plan = self._plan_h2()
-        if plan is None:
-            return
+    def _probe_amax(self, names):
+        """One eager iteration of the unit on fp32 activations and the plain fp32 kernels (no planes, no AdaRound step) at the CURRENT
+        weights and iteration counter -> largest magnitude of every tensor the plan keeps as planes (CPU tensor)."""
         saved = ops.set_tuning("conv_x6", 0)
         self._probing = True
         try:
@@ -690,20 +695,124 @@ class UnitEngine:
         finally:
             self._probing = False
             ops.set_tuning("conv_x6", saved)
+        return torch.stack([(self.x_in if n == "x" else self.t[n]).abs().max() for n in names]).cpu()
+
+    def _set_weights(self, soft):
+        """soft-rounded (the state the loop runs in) or hard-rounded weights in every op's wq / wd (set-up only)"""
+        for op in self.ops.values():
+            ops.adaround_fwd(op.desc, op.w, op.alpha, op.delta, op.zp, bool(soft), op.wq, op.wd)
+            if op.tc_phase is not None:
+                op.expand_phase()
+
+    def _probe_scales(self):
+        """fp16 planes need a per-tensor power-of-two scale (include/rdo_ptq_hip.h, "H2 tensors"), fixed before the plan is recorded.
+        TWO probe iterations bracket what the run will see: one at the initial soft weights (= the full-precision weights: the
+        reconstruction error is whatever the quantised input alone causes -- nothing at all for the first unit of a model) and one at
+        the HARD-rounded weights (every weight up to delta / 2 off: the error level the soft weights move towards while b decays --
+        the practical upper end of the run's gradients).  The scale puts the larger of the two magnitudes at 2^7: x512 before fp16
+        overflows, and fp32-chain accuracy down to 2^-2, i.e. for tensors up to 512 x smaller than probed (tools/f16_probe.hip).
+        A tensor that is exactly zero in both probes gives no scale: the unit then runs on fp32 activations.  Should a run outgrow
+        its scales all the same, `_recover` restarts the unit (scales from the recorded magnitudes, then fp32 activations): loud, never a lost run."""
+        plan = self._plan_h2()
+        if plan is None:
+            return
         names = self.H2_PROBED[plan]
-        amax = torch.stack([(self.x_in if n == "x" else self.t[n]).abs().max() for n in names]).cpu()
+        amax = self._probe_amax(names)
+        self._set_weights(soft=False)
+        try:
+            amax = torch.maximum(amax, self._probe_amax(names))
+        finally:
+            self._set_weights(soft=True)
+        self._clear_probe()
         if not torch.isfinite(amax).all():
             raise RuntimeError("calibration engine: non-finite activations in the probe iteration")
-        self.scales = {n: ops.pow2_scale(float(a)) for n, a in zip(names, amax)}
-        # the probe leaves no trace: logs of iteration 0, counters, gradient slabs (the recorded kernels may want another split count)
+        if bool((amax <= 0).any()):
+            import logging
+            logging.getLogger("rdo_ptq.engine").warning(
+                "unit with an all-zero tensor in both probe iterations (%s): no fp16 plane scale can be derived, running it on fp32 activations",
+                [n for n, a in zip(names, amax) if float(a) <= 0])
+            self.use_h2 = False
+            return
+        self._amax = {n: float(a) for n, a in zip(names, amax)}
+        self.scales = {n: ops.pow2_scale(a) for n, a in self._amax.items()}
+
+    def _clear_probe(self):
+        """a probe leaves no trace: logs, counters, gradient slabs (the recorded kernels may want another split count)"""
         self.loss_log.zero_(); self.task_log.zero_(); self.round_log.zero_(); self._it2.zero_()
         for op in self.ops.values():
             op.slabs = None
 
+    # ---- fp16 range: poll, restart ------------------------------------------------------------------------------------------------
+    H2_POLL = int(os.environ.get("RDO_H2_POLL", 512))        # iterations between two reads of the overflow word inside one run() call
+
+    H2_RESTARTS = 2                                           # restarts on re-scaled planes before the unit goes to fp32 activations
+
+    def _overflowed(self):
+        """Has an H2 producer of this unit met a value outside fp16's range?  (A 64-byte read: synchronises.)  Data parallel: MAX over
+        the ranks -- every rank restarts, with the same new scales, or none does."""
+        if not self.P:
+            return False
+        v = self._ovf.clone()
+        if self.world > 1:
+            torch.distributed.all_reduce(v, op=torch.distributed.ReduceOp.MAX, group=self.group)
+        self._ovf_seen = v.cpu().tolist()
+        return any(self._ovf_seen)
+
+    def _recover(self):
+        """A value left the fp16 range of its planes: the iterations since the unit's start are invalid.  Restart the unit from its
+        initial state (alpha from the weights, zero Adam moments, iteration 0: the index table and the counter-RNG masks make the
+        re-run the same run).  The overflow words say what happened: a tensor's word 0 is the largest finite |x s| that did not fit
+        -> its magnitude is now known exactly and its scale is re-derived from it with x8 head-room; a tensor that only met
+        inf / NaN sits downstream of such an overflow and is re-scaled by the largest growth seen in the unit.  After H2_RESTARTS such
+        restarts, or when nothing finite was recorded (the data themselves are not finite), the unit re-runs on fp32 activations
+        (`use_h2 = False`: the split-bf16 / fp32-MFMA kernels cannot overflow).  The reference's arithmetic is plain fp32
+        (quant_layer.py:123)."""
+        import logging
+        lg = logging.getLogger("rdo_ptq.engine")
+        seen = self._ovf_seen
+        self.h2_restarts += 1
+        grown = {}                                            # tensor -> observed magnitude / the magnitude its scale was made for
+        for name, k in self._ovf_slot.items():
+            if seen[2 * k]:
+                grown[name] = ops.overflow_magnitude(seen[2 * k]) / self.scales[name] / self._amax[name]
+        if self.h2_restarts <= self.H2_RESTARTS and grown and not (seen[0] or seen[1]):
+            r = max(grown.values())
+            for name, k in self._ovf_slot.items():
+                if name in grown or seen[2 * k + 1]:
+                    self._amax[name] *= 8.0 * grown.get(name, r)
+            self.scales = {n: ops.pow2_scale(a) for n, a in self._amax.items()}
+            lg.warning("calibration unit outgrew the fp16 range of its H2 planes within %d iterations (%s): restarting it with scales %s",
+                       self._done, {n: f"x{g:.3g}" for n, g in grown.items()}, self.scales)
+        else:
+            self.use_h2 = False
+            lg.warning("calibration unit left the fp16 range of its H2 planes%s: restarting it on fp32 activations",
+                       " again" if self.h2_restarts > 1 else " with non-finite values")
+        for op in self.ops.values():
+            ops.adaround_init_alpha(op.desc, op.w, op.delta, op.alpha)
+            op.m.zero_(); op.v.zero_()
+            op.wq_planes = op.wd_planes = op.wp_h2 = op.wp_planes = None
+        self._set_weights(soft=True)
+        self.P, self._ovf_slot = {}, {}
+        self._clear_probe()
+        self._ovf.zero_()
+        self._done = 0
+        self._dp_graph = self._rd_graph = None
+        self._record()
+        for op in self.ops.values():
+            op.refresh_planes()
+
     def _check_overflow(self):
-        if self.P and ops.h2_overflow(reset=True):
-            raise RuntimeError("calibration engine: a value left the fp16 range of its H2 planes (scales from the probe iteration: "
-                               f"{self.scales}); results of this run are invalid")
+        """Called where results leave the engine (logs, finish): an overflow not yet seen by the polls of `run` is handled here."""
+        guard = 0
+        while self._overflowed():
+            guard += 1
+            if guard > 2:
+                raise RuntimeError("calibration engine: H2 overflow persists after the fp32 restart (library fault)")
+            target = self._done
+            with ops.h2_flag(self._ovf[0:2]):
+                self._recover()
+            self.run(target)
+            torch.cuda.synchronize()
 
     def _forward_backward(self):
         o, t, x = self.ops, self.t, self.x_in
@@ -940,18 +1049,28 @@ class UnitEngine:
 
     # ------------------------------------------------------------------------------------------------------------------
     def run(self, n_iters=None):
-        """Enqueue `n_iters` (default: all remaining) calibration iterations on the current stream."""
-        done = getattr(self, "_done", 0)
+        """Enqueue `n_iters` (default: all remaining) calibration iterations on the current stream.  Units on H2 planes read their
+        overflow word every `H2_POLL` iterations of a long call (a 4-byte read; calls of at most H2_POLL iterations stay fully
+        asynchronous, the word is then read by `logs` / `finish`) and restart themselves when it is set (`_recover`)."""
+        done = self._done
         n = self.iters - done if n_iters is None else int(n_iters)
         if n < 0 or done + n > self.iters:
             raise ValueError(f"cannot run {n} iterations: {done} of {self.iters} already done")
-        if self.plan_rd is not None:
-            self._run_rd(n)
-        elif not self.split:
-            self.plan_a.run(n, graph=self.use_graph)
-        else:
-            self._run_dp(n)
-        self._done = done + n
+        target = done + n
+        with ops.h2_flag(self._ovf[0:2]):
+            while self._done < target:
+                k = target - self._done
+                if self.P and self.H2_POLL > 0:
+                    k = min(k, self.H2_POLL)
+                if self.plan_rd is not None:
+                    self._run_rd(k)
+                elif not self.split:
+                    self.plan_a.run(k, graph=self.use_graph)
+                else:
+                    self._run_dp(k)
+                self._done += k
+                if self._done < target and self._overflowed():
+                    self._recover()                  # back to iteration 0 with new scales / on fp32 activations
         return n
 
     def _dp_iteration(self, graph, first=True, last=True):
@@ -1245,8 +1364,8 @@ class UnitEngine:
 
     def logs(self):
         """(total, rec+task, round) per iteration as CPU tensors (synchronises)."""
-        rec, task = self._data_terms()
         self._check_overflow()
+        rec, task = self._data_terms()
         rt = (rec + task).cpu()
         rd = self.round_log.sum(1).cpu()
         return rt + rd, rt, rd
@@ -1254,6 +1373,7 @@ class UnitEngine:
     def logs_terms(self):
         """(rec, task, round, b) per iteration as CPU tensors: the four numbers of the reference's periodic log line
         (layer_opt.py:168-170); b is the temperature of the schedule table (0 while the rounding loss is off)."""
+        self._check_overflow()
         rec, task = self._data_terms()
         return rec.cpu(), task.cpu(), self.round_log.sum(1).cpu(), self.sched[:, 0].cpu()
 

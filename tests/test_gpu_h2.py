@@ -440,23 +440,111 @@ def test_engine_scales_follow_the_magnitude_of_the_caches(mag):
     torch.testing.assert_close(losses[mag] / mag ** 2, losses[1.0], rtol=2e-4, atol=0)
 
 
-def test_engine_raises_when_a_value_leaves_fp16_range():
-    """The probe sees iteration 0's mini-batch only; images 10^6 times larger in a later iteration overflow the planes: the sticky
-    device flag turns that into an error when the logs are read (never a silently wrong run)."""
+def _jump_caches(factor):
     import lic
-    from hipops import ops
     torch.manual_seed(6)
     blk = lic.ResidualBlock(N, N).cuda()
     g = torch.Generator(device="cuda").manual_seed(6)
-    cq = torch.randn(8, 64, 64, N, device="cuda", generator=g)
-    cq[4:] *= 1e6
-    cf = cq.clone()
+    cf = torch.randn(8, 64, 64, N, device="cuda", generator=g)
+    cf[4:] *= factor
+    cq = cf + 0.01 * cf.abs().mean(dim=(1, 2, 3), keepdim=True) * torch.randn(cf.shape, device="cuda", generator=g)
     with torch.no_grad():
         co = blk(cf.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
-    idx = torch.tensor([[0, 1, 2, 3], [4, 5, 6, 7]], dtype=torch.int32)
+    idx = torch.tensor([[0, 1, 2, 3], [4, 5, 6, 7], [1, 6, 2, 7], [0, 3, 5, 4]], dtype=torch.int32)
+    return blk, cq, cf, co, idx
+
+
+def _fp32_engine(cq, cf, co, idx, blk):
+    from quantization.engine import UnitEngine
+    from quantization.quant_block import QuantRB
+    from quantization.recon import _unit_modules
+    WQ = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    kind, mods = _unit_modules(QuantRB(blk, WQ, dict(WQ, leaf_param=False)).cuda())
+    return UnitEngine(kind, mods, cq, cf, co, batch_size=idx.shape[1], iters=idx.shape[0], warmup=0.0, input_prob=0.5, seed=3, idx_table=idx,
+                      use_h2=False)
+
+
+def test_engine_restarts_with_reprobed_scales_when_the_caches_outgrow_them(caplog):
+    """The probes see iteration 0's mini-batch only; images 2000 x larger in a later iteration leave the fp16 range of the planes
+    (missing 4 / ADVICE round 3).  The unit's own overflow word is raised, the engine restarts the unit from its
+    initial state with scales re-derived from the magnitudes the overflow words recorded and finishes on H2 planes with the alphas of the fp32-activation
+    path -- a warning, never a lost run; the per-device default flag and a neighbouring engine are untouched."""
+    import logging
+    from hipops import ops
+    blk, cq, cf, co, idx = _jump_caches(2000.0)
     ops.h2_overflow(reset=True)
-    eng = _rb_engine(cq, cf, co, idx, 2, blk)
+    eng = _rb_engine(cq, cf, co, idx, 4, blk)
+    other = _rb_engine(cq[:4], cf[:4], co[:4], idx[:1], 1, blk)
+    assert eng.h2_plan == "rb" and other.h2_plan == "rb"
+    s0 = dict(eng.scales)
     eng.run()
-    with pytest.raises(RuntimeError, match="fp16 range"):
-        eng.logs()
-    assert not ops.h2_overflow(reset=True)                     # the check consumed the flag
+    other.run()
+    with caplog.at_level(logging.WARNING, logger="rdo_ptq.engine"):
+        _, rt_o, _ = other.logs()                                # reads ITS word: clean
+        assert other.h2_restarts == 0
+        tot, rt, rd = eng.logs()
+    assert 1 <= eng.h2_restarts <= eng.H2_RESTARTS and eng.h2_plan == "rb" and eng.use_h2
+    assert any("restarting it with scales" in r.getMessage() for r in caplog.records)
+    assert eng.scales["x"] < s0["x"] / 256                       # the planes now hold the large images
+    assert not ops.h2_overflow(reset=True)                       # nobody used the shared default flag
+    ref = _fp32_engine(cq, cf, co, idx, blk)
+    assert ref.h2_plan is None
+    ref.run()
+    tot_r, rt_r, rd_r = ref.logs()
+    torch.testing.assert_close(rt, rt_r, rtol=1e-3, atol=0)
+    torch.testing.assert_close(rd, rd_r, rtol=1e-3, atol=1e-7)
+    for n_ in ref.ops:
+        a, b = eng.alpha_of(n_), ref.alpha_of(n_)
+        assert float(((a >= 0) != (b >= 0)).float().mean()) < 1e-3, n_
+        assert float(((a - b).abs() > 2e-3).float().mean()) < 2e-3, n_
+    eng.finish()                                                 # hands the rounding back without raising
+    assert blk is not None
+
+
+def test_engine_falls_back_to_fp32_activations_when_rescaled_planes_overflow_too():
+    """Second line of defence: a unit that overflows again after its re-scaled restarts (here: forced by marking them as used)
+    re-runs on fp32 activations -- the alphas bit-identical to an engine built with use_h2=False."""
+    blk, cq, cf, co, idx = _jump_caches(1e6)
+    eng = _rb_engine(cq, cf, co, idx, 4, blk)
+    assert eng.h2_plan == "rb"
+    eng.h2_restarts = eng.H2_RESTARTS
+    eng.run()
+    tot = eng.logs()[0]
+    assert eng.h2_restarts == eng.H2_RESTARTS + 1 and eng.h2_plan is None and not eng.use_h2
+    ref = _fp32_engine(cq, cf, co, idx, blk)
+    ref.run()
+    torch.testing.assert_close(tot, ref.logs()[0], rtol=1e-6, atol=0)      # (the loss log is summed by float atomics: order varies)
+    for n_ in ref.ops:
+        assert torch.equal(eng.alpha_of(n_), ref.alpha_of(n_)), n_          # the gradients are not: deterministic slabs
+
+
+def test_long_run_polls_the_overflow_word_and_restarts_early():
+    """run() of more than H2_POLL iterations reads the unit's word between chunks: the overflow of iteration 1 is met after the first
+    chunk, not after the whole schedule."""
+    from quantization.engine import UnitEngine
+    blk, cq, cf, co, idx4 = _jump_caches(2000.0)
+    iters = 40
+    idx = idx4.repeat(10, 1)
+    eng = _rb_engine(cq, cf, co, idx, iters, blk)
+    eng.H2_POLL = 8
+    eng.run(24)
+    assert 1 <= eng.h2_restarts <= eng.H2_RESTARTS and eng._done == 24     # restarted inside run(), then ran on to the requested iteration
+    n_restarts = eng.h2_restarts
+    eng.run()
+    eng.logs()
+    assert eng.h2_restarts == n_restarts and eng._done == iters and eng.h2_plan == "rb"
+
+
+def test_zero_probe_tensor_runs_the_unit_on_fp32_activations():
+    """a tensor that is exactly zero in the probes must not get scale 1.0 -- the unit leaves the H2 path."""
+    import lic
+    torch.manual_seed(7)
+    blk = lic.ResidualBlock(N, N).cuda()
+    z = torch.zeros(4, 64, 64, N, device="cuda")
+    with torch.no_grad():
+        co = blk(z.permute(0, 3, 1, 2)).permute(0, 2, 3, 1).contiguous()
+    idx = torch.tensor([[0, 1, 2, 3]], dtype=torch.int32)
+    eng = _rb_engine(z, z.clone(), co, idx, 1, blk)
+    assert eng.h2_plan is None and not eng.use_h2                # all-zero input planes: no scale
+    eng.run()
+    assert torch.isfinite(eng.logs()[0]).all()
