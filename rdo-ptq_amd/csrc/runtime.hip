@@ -260,15 +260,22 @@ int rdo_plan_run_then(rdo_plan* p, rdo_plan* q, int use_graph, void* stream) {
     if (!p->exec_then) {
         if (!p->cap_stream && hipStreamCreateWithFlags(&p->cap_stream, hipStreamNonBlocking) != hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipStreamCreate failed");
+        hipStreamCaptureStatus cst = hipStreamCaptureStatusNone;
+        if (hipStreamIsCapturing(p->cap_stream, &cst) != hipSuccess || cst != hipStreamCaptureStatusNone)
+            return rdo::set_error(RDO_EHIP, "rdo_plan_run_then: the plan's capture stream is still capturing (an earlier capture failed)");
         if (hipStreamBeginCapture(p->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipStreamBeginCapture failed");
         int rc = run_ops(p, p->cap_stream);
         if (rc == RDO_OK) rc = run_ops(q, p->cap_stream);
-        hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph_then);
-        if (rc != RDO_OK) return rc;
-        if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+        hipError_t e = hipStreamEndCapture(p->cap_stream, &p->graph_then);     // always ended: the stream must leave capture mode
+        auto drop = [&]() {                                                     // every error path: no half-built graph is kept
+            if (p->exec_then) { (void)hipGraphExecDestroy(p->exec_then); p->exec_then = nullptr; }
+            if (p->graph_then) { (void)hipGraphDestroy(p->graph_then); p->graph_then = nullptr; }
+        };
+        if (rc != RDO_OK) { drop(); return rc; }
+        if (e != hipSuccess) { drop(); return rdo::set_error(RDO_EHIP, "hipStreamEndCapture: %s", hipGetErrorString(e)); }
         e = hipGraphInstantiate(&p->exec_then, p->graph_then, nullptr, nullptr, 0);
-        if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e));
+        if (e != hipSuccess) { drop(); return rdo::set_error(RDO_EHIP, "hipGraphInstantiate: %s", hipGetErrorString(e)); }
         p->then_with = q;
         p->then_gen = q->generation;
     }

@@ -1233,7 +1233,9 @@ class UnitEngine:
             def note(m, a, k, run):
                 flag = [False]
                 self._tree(lambda t: flag.__setitem__(0, flag[0] or t.requires_grad), (a, k))
-                if flag[0]:
+                if flag[0] or id(m) in seen[run]:
+                    # depends on the unit -- or is called more than once per model forward (a shared / looped module): its outputs
+                    # could not be told apart by image row, so it is never memoised
                     tainted.add(id(m))
                 seen[run][id(m)] = self._tree(lambda t: t.detach().clone(), (a, k))
             for run in range(2):
@@ -1273,11 +1275,13 @@ class UnitEngine:
                     s_.forward = lambda x, *a, **k: x
                 try:
                     n = cali.shape[0]
+                    n_fwd = 0
                     for i in range(0, n, B):
                         xb = cali[i:i + B]
                         if xb.shape[0] < B:                                   # ragged end: pad the mini-batch with the first images
                             xb = torch.cat([xb, cali[:B - xb.shape[0]]])
                         model(xb)
+                        n_fwd += 1
                 finally:
                     for h in hooks:
                         h.remove()
@@ -1298,7 +1302,10 @@ class UnitEngine:
                     return None
                 total = 0
                 for c in free:
-                    memo = cat(parts.pop(id(c)))
+                    chunks = parts.pop(id(c))
+                    if len(chunks) != n_fwd:                                  # exactly one call per model forward, or the rows of the
+                        continue                                              # concatenation would not be the calibration images
+                    memo = cat(chunks)
                     if memo is None:
                         continue                                              # an output that is not per-image: leave the module alone
                     nbytes = [0]
@@ -1403,3 +1410,6 @@ class UnitEngine:
             ada.soft_targets = False
             qm.weight_quantizer = ada
             qm.act_quantizer.is_training = False
+            qm.drop_weight_pack()              # packs of the pre-calibration weights (nearest rounding) are stale from here on
+        if self.rd is not None:
+            self.rd.pop("memo", None)          # per-image outputs of the unit-independent modules (up to RD_CACHE_LIMIT bytes)

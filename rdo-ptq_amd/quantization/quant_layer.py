@@ -1,5 +1,6 @@
 """`QuantModule`: one fake-quantised layer (reference surface: quantization/quant_layer.py:11-138), forward on the
-HIP kernels: Conv2d and ConvTranspose2d (dilation 1, groups 1; the transposed conv is zero-insertion + the forward conv
+HIP kernels: Conv2d and ConvTranspose2d (dilation 1, groups 1; a transposed conv whose output is stride x its input runs as a
+stride-1 conv with the phase weight + pixel shuffle, `hipops.ops.TconvPhase`; other geometries as zero insertion + the forward conv
 kernel), Linear (as a 1x1 conv), LayerNorm over the last dimension, GDN/IGDN (`f_gdn`, :142-154) and PixelShuffle."""
 from typing import Union
 
@@ -92,7 +93,7 @@ class QuantModule(nn.Module):
     def _apply(self, fn, *args, **kwargs):
         """`.to()/.cuda()` also moves the detached FP copies (plain attributes in the reference, quant_layer.py:82-89)."""
         super()._apply(fn, *args, **kwargs)
-        self._pack_memo = None
+        self._pack_memo = {}
         for name in ("org_weight", "org_bias"):
             t = getattr(self, name, None)
             if t is not None:
@@ -151,15 +152,30 @@ class QuantModule(nn.Module):
         return ("q", id(q), q.n_levels, getattr(q, "soft_targets", None), self._tkey(self.weight), self._tkey(self.bias),
                 self._tkey(getattr(q, "alpha", None)), self._tkey(q.delta), self._tkey(q.zero_point))
 
+    def _weight_refs(self):
+        """the tensor OBJECTS `_weight_state()` keys on: held by the memo, so that none of them can be freed and its address reused by
+        another tensor with the same version count while the memo lives"""
+        if not self.use_weight_quant:
+            return (self.org_weight, self.org_bias)
+        q = self.weight_quantizer
+        return (self.weight, self.bias, getattr(q, "alpha", None), q.delta, q.zero_point)
+
     def weight_pack(self):
         """`ops.WeightPack` of the effective weight in kernel layout (conv: OHWI rows; transposed conv: to_rows(., tconv=True) with
-        the bias; GDN: re-parametrised gamma as a 1x1 weight with beta' as its bias), memoised while `_weight_state()` is unchanged:
-        a model evaluated or differentiated many times with fixed weights (cache building, evaluation, the R + lambda*D tail of the
-        calibration loop) quantises, re-lays-out and splits each weight once.  A weight changed behind torch's version counters
-        (`.data` writes) needs `drop_weight_pack()`."""
+        the bias; GDN: re-parametrised gamma as a 1x1 weight with beta' as its bias), memoised per quant state (one entry for the
+        full-precision weights, one for the quantised ones: cache building toggles between the two for every batch) while
+        `_weight_state()` is unchanged and the tensors it was made from are the SAME objects: a model evaluated or differentiated many
+        times with fixed weights (cache building, evaluation, the R + lambda*D tail of the calibration loop) quantises, re-lays-out and
+        splits each weight once.  A weight changed behind torch's version counters (`.data` writes, raw-pointer kernel writes) needs
+        `drop_weight_pack()`: the calibration engine calls it when it hands its rounding back (`finish`), `bitwidth_refactor` and a
+        new quantiser object change the key by themselves."""
         key = self._weight_state()
-        memo = getattr(self, "_pack_memo", None)
-        if key is not None and memo is not None and memo[0] == key:
+        memos = self.__dict__.get("_pack_memo")
+        if not isinstance(memos, dict):            # (a pickled model of an earlier version carries None here)
+            memos = self.__dict__["_pack_memo"] = {}
+        slot = "q" if self.use_weight_quant else "fp"
+        memo = memos.get(slot)
+        if key is not None and memo is not None and memo[0] == key and all(a is b for a, b in zip(memo[2], self._weight_refs())):
             return memo[1]
         weight, bias = self._weights()
         weight = weight.detach()
@@ -174,11 +190,16 @@ class QuantModule(nn.Module):
             pack = ops.WeightPack(to_rows(weight, tconv=self.kind == "tconv"), bias)
         if key is None:
             key = self._weight_state()             # the quantiser initialised its scales inside _weights()
-        self._pack_memo = (key, pack)
+        memos[slot] = (key, pack, self._weight_refs())
         return pack
 
     def drop_weight_pack(self):
-        self._pack_memo = None
+        self.__dict__["_pack_memo"] = {}
+
+    def __getstate__(self):
+        d = self.__dict__.copy()
+        d["_pack_memo"] = {}                       # derived data: not part of the saved artefact (main2.py:285-290)
+        return d
 
     def _forward_autograd(self, input):
         """Forward whose output carries a grad_fn with respect to the INPUT (hipops.autograd; weights are constants): what the
