@@ -143,6 +143,42 @@ def test_conv_h2_halo_kernel_equals_per_tap_kernel(ops, L, B, H, W, Cin, Cout):
     assert (got[1][1].double() - ref).abs().max() <= 2e-6 * ref.abs().max()
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, N, N), (4, 64, 64, N, 4 * N), (4, 64, 64, N, N), (4, 32, 32, N, 4 * N), (2, 64, 96, 64, 320),
+                                            (1, 256, 256, 32, 2 * N), (2, 128, 256, 64, N), (3, 112, 240, 96, 320)])
+def test_conv_h2_k32_halo_kernel_equals_k16_halo_kernel(ops, L, B, H, W, Cin, Cout):
+    """The halo kernel with 32-channel stages on v_mfma_f32_16x16x32_f16 (conv_fwd_h2k.hip, tuning key h2_k32) against the 16-channel
+    kernel on 32x32x16: per output element the same three products per stage pair in the same order, only the MFMA's internal
+    summation width differs -- agreement to 1e-6 of the output range, against fp64 within the same bound as the 16-channel kernel,
+    bit-identical planes given equal fp32 results, borders / epilogue outputs / both tile shapes (256 x 192, 256 x 64) included."""
+    g = torch.Generator(device="cuda").manual_seed(H + Cin + 1)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5
+    b = torch.randn(Cout, device="cuda", generator=g)
+    res = torch.randn(B, H, W, Cout, device="cuda", generator=g)
+    wpl, xp = ops.split_h2_conv(w), ops.split_h2(x)
+    got = {}
+    saved = ops.set_tuning("h2_k32", 0)
+    try:
+        for k32 in (0, 1):
+            ops.set_tuning("h2_k32", k32)
+            out, pre = torch.zeros(B, H, W, Cout, device="cuda"), torch.zeros(B, H, W, Cout, device="cuda")
+            opl = ops.h2_empty(out.shape, "cuda", 16.0)
+            opl.t.zero_()
+            ops.conv2d_fwd_h2(xp, tuple(x.shape), tuple(w.shape), wpl, b, 1, 1, epilogue=L.EPI_LRELU, residual=res, out=out, pre=pre,
+                              out_planes=opl)
+            got[k32] = (out, pre, opl)
+    finally:
+        ops.set_tuning("h2_k32", saved)
+    ref = torch.nn.functional.conv2d(x.permute(0, 3, 1, 2).double(), w.permute(0, 3, 1, 2).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    sc = float(ref.abs().max())
+    for k32 in (0, 1):
+        assert float((got[k32][1].double() - ref).abs().max()) <= 2e-6 * sc, k32
+    assert float((got[1][1] - got[0][1]).abs().max()) <= 1e-6 * sc
+    # finished output: LeakyReLU is continuous, the residual is added exactly
+    assert float((got[1][0] - got[0][0]).abs().max()) <= 1e-6 * float(got[0][0].abs().max())
+    _close_planes(ops, got[1][2], got[1][0])
+
+
 @pytest.mark.parametrize("H,Cout", [(128, N), (64, N)])
 def test_conv_h2_epilogues(ops, L, H, Cout):
     g = torch.Generator(device="cuda").manual_seed(H)
