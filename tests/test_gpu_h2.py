@@ -112,8 +112,17 @@ def test_conv_h2_scales_do_not_change_the_result(ops):
                                             (4, 64, 64, N, N), (4, 32, 32, N, 4 * N), (2, 64, 96, 64, 320), (3, 64, 64, 48, 256),
                                             (1, 256, 256, 32, 48), (8, 96, 96, 48, 208), (2, 176, 208, 32, 16), (3, 112, 240, 80, 320)])
 def test_conv_h2_halo_kernel_equals_per_tap_kernel(ops, L, B, H, W, Cin, Cout):
-    """3x3 / stride 1 / pad 1 on 16 x 16 patches with the halo tile resident in LDS: same K order and accumulation as the per-tap
-    kernel, so the same bits -- borders (zero halo), all epilogue outputs and the H2 planes included."""
+    """3x3 / stride 1 / pad 1 on 16 x 16 patches with the halo tile resident in LDS (the 16-channel-stage form, h2_k32 = 0: the kernel
+    of the shapes whose Cin is not a multiple of 32): same K order and accumulation as the per-tap kernel, so the same bits -- borders
+    (zero halo), all epilogue outputs and the H2 planes included."""
+    saved_k32 = ops.set_tuning("h2_k32", 0)
+    try:
+        _halo_vs_per_tap(ops, L, B, H, W, Cin, Cout)
+    finally:
+        ops.set_tuning("h2_k32", saved_k32)
+
+
+def _halo_vs_per_tap(ops, L, B, H, W, Cin, Cout):
     g = torch.Generator(device="cuda").manual_seed(H + Cin)
     x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
     w = torch.randn(Cout, 3, 3, Cin, device="cuda", generator=g) / (9 * Cin) ** 0.5
