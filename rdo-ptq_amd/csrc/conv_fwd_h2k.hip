@@ -27,11 +27,49 @@ namespace {
 
 typedef float f32x4k __attribute__((ext_vector_type(4)));
 __device__ __attribute__((aligned(64))) unsigned g_zero_page_k[16];    // zero-initialised: source of masked DMA lanes
+#ifdef RDO_DIAG
+__device__ unsigned long long g_h2k_stamps[256 * 4];
+#endif
 
 __device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
+// Unit tail on the four finished channels [n, n + 4) of pixel m (v = conv + bias, the pre-activation): v becomes dL/dpre, the return value
+// is sum d^2.  The arithmetic of tail16 (conv_h2_common.h) / loss_act_quad (fused_tail.hip), operation for operation per element.
+__device__ __forceinline__ float tail4(const H2Args& a, int m, int n, f32x4& v) {
+    const int b = (int)(((long)m * a.Cout) / a.tail_per_image);
+    const int it = *a.tail_iter;
+    const float* y = a.tail_tgt + (long)a.tail_idx[(long)it * a.tail_B + b] * a.tail_per_image + ((long)m * a.Cout - (long)b * a.tail_per_image) + n;
+    const float slope = a.tail_act == 1 ? 0.01f : 0.f;
+    const float gs = a.tail_coef * 2.f * a.tail_inv_npix;
+    f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (a.tail_resp) {                                       // the residual from its planes: (h1 + h2) / s, the sum is exact in fp32
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u16* rp = a.tail_resp + ((long)(n >> 4) * a.M + m) * 16 + (n & 15);
+        const u32x2 p0 = *reinterpret_cast<const u32x2*>(rp), p1 = *reinterpret_cast<const u32x2*>(rp + a.oplane);
+        r[0] = (h2_lo(p0[0]) + h2_lo(p1[0])) * a.tail_res_inv;
+        r[1] = (h2_hi(p0[0]) + h2_hi(p1[0])) * a.tail_res_inv;
+        r[2] = (h2_lo(p0[1]) + h2_lo(p1[1])) * a.tail_res_inv;
+        r[3] = (h2_hi(p0[1]) + h2_hi(p1[1])) * a.tail_res_inv;
+    }
+    const f32x4 y4 = *reinterpret_cast<const f32x4*>(y);
+    float dd[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float p = v[k];
+        float o = p;
+        if (a.tail_act) o = p > 0.f ? p : slope * p;
+        if (a.tail_resp) o += r[k];
+        dd[k] = o - y4[k];
+        const float g = dd[k] * gs;
+        v[k] = a.tail_act ? (p > 0.f ? g : slope * g) : g;
+    }
+    return (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
+}
+
 // WM x WN waves (8), wave tile TP pixel tiles x TC channel tiles of 16 x 16: WM * TP = 16 (256 patch pixels), BN = WN * TC * 16
-template <int WM, int WN, int TP, int TC>
+// ABL (diagnostic builds only, `make DIAG=1`; the shipped library instantiates ABL = 0): compile-time ablation mask -- 1 no halo DMA,
+// 2 no weight DMA, 4 no MFMA, 8 no fragment reads, 16 no epilogue.  Results are wrong when non-zero.
+template <int WM, int WN, int TP, int TC, int ABL = 0>
 __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     static_assert(WM * WN == 8 && WM * TP == 16, "eight waves, 256 patch pixels");
     constexpr int BN = WN * TC * 16;
@@ -47,10 +85,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     constexpr int BPIECES = BSTAGE / 1024;                   // 24 / 8
     constexpr int BJ = BPIECES / 8;                          // weight pieces per wave and stage: 3 / 1
     constexpr int RING = 3;
-    constexpr int SROW = BN + 4;
-    constexpr int PROWS = 128;                               // tile rows (pixels) finished per epilogue pass
     static_assert(BPIECES % 8 == 0, "uniform weight-piece count per wave");
-    static_assert(TP % 2 == 0, "two epilogue passes of TP / 2 pixel tiles per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -115,11 +150,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
         const int off = halo_off(piece);
         const u16* src = off >= 0 ? a.xp + off + (long)cn * Min * 32 : zero;
         char* dst = piece < APIECES ? smem + (cp_next & 1) * ABUF + piece * 1024 : smem + ADUMMY;
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+        if constexpr (!(ABL & 1)) __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
     };
     const u16* wsrc = a.wp;
     auto dma_b = [&](int j, int nb) {
-        __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_uni(j) + dma_lane), (lds_void*)(smem + BBASE + nb * BSTAGE + (wave + 8 * j) * 1024), 16, 0, 0);
+        if constexpr (!(ABL & 2))
+            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_uni(j) + dma_lane), (lds_void*)(smem + BBASE + nb * BSTAGE + (wave + 8 * j) * 1024), 16, 0, 0);
     };
     // stage s = slice pair s / 9, tap s % 9: its weights start at slice 2 (s / 9), tap s % 9 of the fragment-ordered planes
     auto set_wsrc = [&](int stage) {
@@ -159,6 +195,13 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
             }
         }
         auto mma = [&](int px, int pw) {
+            if constexpr (ABL & 4) {                         // keep the fragments alive without multiplying
+#pragma unroll
+                for (int i = 0; i < TC; ++i) asm volatile("" ::"v"(fw[pw][i]));
+#pragma unroll
+                for (int j = 0; j < TP; ++j) asm volatile("" ::"v"(fx[px][j]));
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < TC; ++i)
 #pragma unroll
@@ -169,7 +212,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
             constexpr int TAP = decltype(tapc)::value;
             constexpr int KH = TAP / 3, KW = TAP % 3;
             // stage s (weights) and, in tap 0, this slice pair's halo have landed once at most the DMAs issued after them are outstanding
-            if constexpr (TAP >= 1 && TAP <= AJ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ + 1) : "memory");
+            if constexpr (ABL & 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if constexpr (TAP >= 1 && TAP <= AJ) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ + 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BJ) : "memory");
             __builtin_amdgcn_s_barrier();
             const int nb = buf >= 1 ? buf - 1 : RING - 1;    // (s + 2) % 3
@@ -183,10 +227,12 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
                 fx_off[j] = q * 64 + ((kg ^ swz(q)) << 4);
             }
             auto rd_x = [&](int p) {
+                if constexpr (ABL & 8) return;
 #pragma unroll
                 for (int j = 0; j < TP; ++j) fx[p][j] = *reinterpret_cast<const f16x8*>(stx + p * APL + fx_off[j]);
             };
             auto rd_w = [&](int p) {
+                if constexpr (ABL & 8) return;
 #pragma unroll
                 for (int i = 0; i < TC; ++i) fw[p][i] = *reinterpret_cast<const f16x8*>(stw + fw_base + p * BPLANE + i * 1024);
             };
@@ -244,42 +290,45 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
             mma(0, 0);
         }
     };
+#ifdef RDO_DIAG
+    const unsigned long long st_c0 = clock64(), st_r0 = wall_clock64();
+#endif
     if (late && a.stagger) k_loop(std::true_type{});
     else k_loop(std::false_type{});
+#ifdef RDO_DIAG
+    if (tid == 0 && blockIdx.x < 256 && blockIdx.y == 0) {   // shader-clock cycles and 100 MHz wall ticks of the K loop (rdo_diag_h2k_stamps)
+        g_h2k_stamps[blockIdx.x * 4 + 0] = st_c0; g_h2k_stamps[blockIdx.x * 4 + 1] = st_r0;
+        g_h2k_stamps[blockIdx.x * 4 + 2] = clock64(); g_h2k_stamps[blockIdx.x * 4 + 3] = wall_clock64();
+    }
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // the clamped tail DMAs still target LDS: drain before the epilogue reuses it
     __builtin_amdgcn_s_barrier();
-
-    // ---- epilogue through LDS, two passes of 128 patch pixels (pass p: pixel tiles p * TP / 2 ... of every wave).  Per pass: the
-    // accumulators to the staging tile [pixel][channel] (one 16-byte store per MFMA tile and lane), then (1) consecutive lanes along
-    // the CHANNELS finish quads -- bias, activation, residual, coalesced 16-byte loads / stores of the fp32 tensors -- and put the
-    // finished values back; (2) consecutive lanes along the PIXELS split the 16 channels of one slice and write the two H2 records.
-    float* const stg = reinterpret_cast<float*>(smem);
-    const bool need_planes = a.outp != nullptr;
-    float tail_loss = 0.f;
-    int bad = 0;
-    constexpr int HP = TP / 2;                               // pixel tiles of a wave per pass
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-        if (pass) __syncthreads();
+    if constexpr (ABL & 16) {
 #pragma unroll
         for (int i = 0; i < TC; ++i)
 #pragma unroll
-            for (int j = 0; j < HP; ++j) {
-                const f32x4k v = acc[i][pass * HP + j] * a.acc_scale;
-                *reinterpret_cast<f32x4k*>(stg + (wrow * (HP * 16) + j * 16 + l16) * SROW + wn0 + i * 16 + 4 * kg) = v;
-            }
-        __syncthreads();
-#pragma unroll 4
-        for (int k = 0; k < PROWS * (BN / 4) / 512; ++k) {
-            const int q = tid + 512 * k;                     // PROWS rows x BN / 4 quads of channels
-            const int row = q / (BN / 4), c4 = q - row * (BN / 4);
-            const int tl = (row / (HP * 16)) * (TP * 16) + pass * (HP * 16) + (row % (HP * 16));
-            const int m = pbase + (tl >> 4) * a.W + (tl & 15);
-            const int n = n0 + c4 * 4;
-            if (n >= a.Cout) continue;
-            f32x4 v = *reinterpret_cast<const f32x4*>(stg + row * SROW + c4 * 4);
+            for (int j = 0; j < TP; ++j) asm volatile("" ::"v"(acc[i][j]));
+        return;
+    }
+
+    // ---- epilogue straight from the accumulators: lane (kg, l16) of tile (i, j) holds channels n .. n + 3 (n = n0 + wn0 + 16 i + 4 kg)
+    // of pixel m = patch row wrow * TP + j, column l16 -- a quad of the fp32 NHWC tensors (16-byte accesses; the four lanes of a pixel
+    // cover one 64-byte slice, a tile row of 16 pixels is 16 such segments) and a quarter of an H2 record (8 bytes per plane; the 64 lanes
+    // of a tile cover 16 consecutive records = 512 contiguous bytes per plane).  No staging tile, no barrier.
+    const bool need_planes = a.outp != nullptr;
+    float tail_loss = 0.f;
+    int bad = 0;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int i = 0; i < TC; ++i) {
+        const int n = n0 + wn0 + 16 * i + 4 * kg;
+        f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int m = pbase + (wrow * TP + j) * a.W + l16;
             const long o = (long)m * a.Cout + n;
-            if (a.bias) v += *reinterpret_cast<const f32x4*>(a.bias + n);
+            f32x4 v = acc[i][j] * a.acc_scale + b4;
             if (a.pre) *reinterpret_cast<f32x4*>(a.pre + o) = v;
             if (a.epilogue != RDO_EPI_NONE) {
                 const f32x4 x4 = aux_quad(a, m, n, o);
@@ -288,31 +337,20 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
             }
             if (a.add_residual) v += *reinterpret_cast<const f32x4*>(a.residual + o);
             if (a.out) *reinterpret_cast<f32x4*>(a.out + o) = v;
-            if (need_planes) *reinterpret_cast<f32x4*>(stg + row * SROW + c4 * 4) = v;
-        }
-        if (need_planes) {
-            __syncthreads();
-#pragma unroll
-            for (int k = 0; k < PROWS * (BN / 16) / 512; ++k) {
-                const int q = tid + 512 * k;                 // PROWS rows x BN / 16 slices of 16 channels
-                const int row = q % PROWS, sl = q / PROWS;
-                const int tl = (row / (HP * 16)) * (TP * 16) + pass * (HP * 16) + (row % (HP * 16));
-                const int m = pbase + (tl >> 4) * a.W + (tl & 15);
-                const int n = n0 + sl * 16;
-                if (n >= a.Cout) continue;
-                float v[16];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(stg + row * SROW + sl * 16 + 4 * c);
-                    v[4 * c] = t4[0]; v[4 * c + 1] = t4[1]; v[4 * c + 2] = t4[2]; v[4 * c + 3] = t4[3];
-                }
-                if (a.tail_tgt) tail_loss += tail16(a, m, n, v);
-                store_slice(a, m, n, v, bad);
+            if (need_planes) {
+                if (a.tail_tgt) tail_loss += tail4(a, m, n, v);
+                u16* dst = a.outp + ((long)(n >> 4) * a.M + m) * 16 + (n & 15);
+                u32x2 hi, lo;
+                unsigned h, l;
+                rdo::h2_split_pk(v[0], v[1], a.out_scale, h, l, bad); hi[0] = h; lo[0] = l;
+                rdo::h2_split_pk(v[2], v[3], a.out_scale, h, l, bad); hi[1] = h; lo[1] = l;
+                *reinterpret_cast<u32x2*>(dst) = hi;
+                *reinterpret_cast<u32x2*>(dst + a.oplane) = lo;
             }
         }
     }
     if (a.tail_tgt) {                                        // one atomic per workgroup
-        __shared__ float red[8];
+        float* red = reinterpret_cast<float*>(smem);         // (every wave is past the K loop's last LDS read: the barrier above)
         for (int o = 32; o > 0; o >>= 1) tail_loss += __shfl_down(tail_loss, o, 64);
         if (lane == 0) red[wave] = tail_loss;
         __syncthreads();
@@ -323,21 +361,21 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     rdo::h2_report(bad, a.ovf);
 }
 
-template <int WM, int WN, int TP, int TC>
-int launch(const H2Args& a, const char* what) {
+template <int WM, int WN, int TP, int TC, int ABL = 0>
+int launch(const H2Args& a, const char* what, hipStream_t s) {
     constexpr int BN = WN * TC * 16;
-    constexpr size_t k_lds = (size_t)2 * 42 * 1024 + 1024 + (size_t)3 * 2 * BN * 64;
-    constexpr size_t e_lds = (size_t)128 * (BN + 4) * 4;
-    constexpr size_t lds = k_lds > e_lds ? k_lds : e_lds;
+    constexpr size_t lds = (size_t)2 * 42 * 1024 + 1024 + (size_t)3 * 2 * BN * 64;
     static_assert(lds <= 160 * 1024, "LDS of the K32 halo kernel");
     static rdo::PerDevice attr;
     if (!attr.done()) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_h2k_kernel<WM, WN, TP, TC>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_h2k_kernel<WM, WN, TP, TC, ABL>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)lds) != hipSuccess)
             return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(%s) failed", what);
         attr.mark();
     }
-    return 0;
+    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.Cout / BN), 1);
+    hipLaunchKernelGGL((conv_fwd_h2k_kernel<WM, WN, TP, TC, ABL>), grid, dim3(512), lds, s, a);
+    return rdo::check_launch(what);
 }
 
 }  // namespace
@@ -345,23 +383,34 @@ int launch(const H2Args& a, const char* what) {
 namespace rdo {
 
 bool h2k_supported(const H2Args& a, int shape) {
-    return a.Cout % (shape == 1 ? 192 : 64) == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 && a.W % 16 == 0 && a.Cin % 32 == 0 && a.Cout % 64 == 0 && a.ksplit == 1 &&
-           a.partial == nullptr && (long)a.Cin * 9 * a.Cout * 16 < (1L << 31);
+    return a.Cout % (shape == 1 ? 192 : 64) == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 && a.W % 16 == 0 &&
+           a.Cin % 32 == 0 && a.ksplit == 1 && a.partial == nullptr && (long)a.Cin * 9 * a.Cout * 16 < (1L << 31);
 }
 
 int h2k_launch(const H2Args& a, int shape, hipStream_t s) {
     if (shape == 1) {
-        constexpr size_t lds = (size_t)2 * 42 * 1024 + 1024 + (size_t)3 * 2 * 192 * 64;
-        if (int rc = launch<4, 2, 4, 6>(a, "conv_fwd_h2k 256x192")) return rc;
-        dim3 grid((unsigned)(a.M / 256), (unsigned)rdo::ceil_div(a.Cout, 192), 1);
-        hipLaunchKernelGGL((conv_fwd_h2k_kernel<4, 2, 4, 6>), grid, dim3(512), lds, s, a);
-        return rdo::check_launch("conv_fwd_h2k 256x192");
+#ifdef RDO_DIAG
+        switch (a.ablate) {                                  // tuning key "x6p_ablate" (diagnostic builds)
+            case 3: return launch<4, 2, 4, 6, 3>(a, "conv_fwd_h2k abl3", s);
+            case 4: return launch<4, 2, 4, 6, 4>(a, "conv_fwd_h2k abl4", s);
+            case 8: return launch<4, 2, 4, 6, 8>(a, "conv_fwd_h2k abl8", s);
+            case 11: return launch<4, 2, 4, 6, 11>(a, "conv_fwd_h2k abl11", s);
+            case 15: return launch<4, 2, 4, 6, 15>(a, "conv_fwd_h2k abl15", s);
+            case 16: return launch<4, 2, 4, 6, 16>(a, "conv_fwd_h2k abl16", s);
+            case 31: return launch<4, 2, 4, 6, 31>(a, "conv_fwd_h2k abl31", s);
+            default: break;
+        }
+#endif
+        return launch<4, 2, 4, 6>(a, "conv_fwd_h2k 256x192", s);
     }
-    constexpr size_t k64 = (size_t)2 * 42 * 1024 + 1024 + (size_t)3 * 2 * 64 * 64;
-    if (int rc = launch<8, 1, 2, 4>(a, "conv_fwd_h2k 256x64")) return rc;
-    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.Cout / 64), 1);
-    hipLaunchKernelGGL((conv_fwd_h2k_kernel<8, 1, 2, 4>), grid, dim3(512), k64, s, a);
-    return rdo::check_launch("conv_fwd_h2k 256x64");
+    return launch<8, 1, 2, 4>(a, "conv_fwd_h2k 256x64", s);
 }
 
 }  // namespace rdo
+
+#ifdef RDO_DIAG
+extern "C" int rdo_diag_h2k_stamps(unsigned long long* out, int n) {
+    if (!out || n <= 0 || n > 1024) return RDO_EINVAL;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_h2k_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? RDO_OK : RDO_EHIP;
+}
+#endif
