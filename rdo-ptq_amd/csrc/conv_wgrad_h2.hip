@@ -52,15 +52,29 @@ struct WgPArgs {
 #ifdef RDO_DIAG
 #define WG_ABL(bit) (a.ablate & (bit))
 __device__ unsigned long long g_wg_stamps[256 * 4];
+__device__ unsigned long long g_wg_phase[256 * 2 * 8];      // [workgroup][wave 0 / wave 4][phase]: cycles summed over the stages (ablate bit 64)
 #else
 #define WG_ABL(bit) false
 #endif
 
+// Two transposed reads = the eight pixels of one lane's MFMA operand.  Issued as INLINE ASSEMBLY on purpose: for the builtin
+// (__builtin_amdgcn_ds_read_tr16_b64_v4i16) hipcc's wait-count pass assumes that the read may alias every LDS-DMA in flight and puts
+// `s_waitcnt vmcnt(0)` in front of the first such read behind a global_load_lds -- every wave then waited for its just-issued DMA
+// pieces to LAND at the top of every stage (the "739 cycles of DMA issue" of tools/wgrad_phases.py), whatever the ring depth; plain
+// LDS loads do not get that wait.  The asm is invisible to that pass, so the caller orders reads and uses itself: `tr_wait()` (lgkmcnt(0)
+// + a scheduling fence, cdna_hip_programming.md rule 18) between the last read of a set and its first use; which buffer a read may
+// touch is the K loop's counted vmcnt + barrier, as for every other DMA consumer.
 __device__ __forceinline__ f16x8 tr_pair(const char* p) {
-    typedef __attribute__((address_space(3))) s16x4 lds_v4;
-    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p));
-    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(p + 16 * 128));      // pixels + 16
+    typedef __attribute__((address_space(3))) const char lds_char;
+    const unsigned addr = (unsigned)(unsigned long long)(lds_char*)p;
+    s16x4 lo, hi;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo) : "v"(addr));
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(hi) : "v"(addr));      // pixels + 16 (16 rows of 128 bytes)
     return __builtin_bit_cast(f16x8, s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+}
+__device__ __forceinline__ void tr_wait() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
 }
 
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(WgPArgs a) {
@@ -214,9 +228,12 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(WgPArgs a) {
         [&]<int... SL>(std::integer_sequence<int, SL...>) {
             (([&] {
                  constexpr int T3 = SL / 3, Q = SL % 3, SET = T3 & 1;
-                 if constexpr (Q == 0 && T3 < 2) {
-                     if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
-                     else read_b(S0{}, st, T3 + 1);
+                 if constexpr (Q == 0) {
+                     tr_wait();                                          // this third's fragments (and, in slot 0, the A fragments) are there
+                     if constexpr (T3 < 2) {
+                         if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
+                         else read_b(S0{}, st, T3 + 1);
+                     }
                  }
 #pragma unroll
                  for (int i = 0; i < TM; ++i)
@@ -263,13 +280,23 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(WgPArgs a) {
 constexpr int XROWS = 40;                      // 34 used; five 8-row DMA pieces per plane
 constexpr int XPLANEB = XROWS * 128;
 constexpr int STAGE3B = OPB + NP * XPLANEB;    // 24 + 10 = 34 KiB
-constexpr int RING3 = 2;                       // stages of the row kernel's LDS ring (3: measured slower, see the kernel)
 
+// SUB: 32-pixel segments per stage (per barrier / DMA wait).  SUB = 2 (tuning key "wgrad_sub", the default): the images of two segments
+// per ring slot -- half as many barriers, waits and loop skeletons per MFMA (MFMAs-only ablation of the SUB = 1 kernel: 2094 cycles per
+// stage for 1728 cycles of back-to-back MFMAs); 136 KiB of LDS instead of 68.
+// RING3: LDS ring slots (RING3 - 1 stages of DMA in flight); LSLOT: the MFMA slot (0..8 of the stage's first segment) behind which waves 4-7
+// issue their DMAs.  In-kernel phase stamps (tools/wgrad_phases.py) showed what the loop was bound by: ISSUING an LDS-DMA piece costs the
+// wave ~150 cycles here (five pieces per wave and stage: 640-775 cycles against 864 cycles of its MFMAs), waves 0-3 paid it at the top of
+// the stage, waves 4-7 a third into their MFMAs, and waves 0-3 then idled ~650 cycles per stage at the barrier.  <1, 3, 8>: waves 4-7
+// issue at the END of the stage -- for stage s + 2, a ring of three, counted vmcnt(5) -- so that each half multiplies while the other
+// issues.
+template <int SUB, int RING3, int LSLOT>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     constexpr int T = 192;
     constexpr int TM = 3, TN = 6;
+    constexpr int SLOTB = SUB * STAGE3B;                                 // one ring slot
 
-    extern __shared__ __attribute__((aligned(16))) char smem[];          // [RING3][STAGE3B]
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [RING3][SUB][STAGE3B]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l16 = lane & 15, lc = lane >> 4;
@@ -293,7 +320,8 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     const int spc = (segs_total + a.nsplit - 1) / a.nsplit;
     const int sbeg = chunk * spc;
     const int send = min(segs_total, sbeg + spc);
-    const int nsteps = send > sbeg ? send - sbeg : 0;
+    const int nsegs = send > sbeg ? send - sbeg : 0;
+    const int nsteps = (nsegs + SUB - 1) / SUB;                          // a short last stage multiplies zeros for its missing segment
 
     const u16* const zero = reinterpret_cast<const u16*>(g_zero_page_w);
     const int prow8 = lane >> 3, cpos = lane & 7;
@@ -329,22 +357,20 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     int cb = sbeg / (a.Ho * segs_row);
     int cho = (sbeg - cb * (a.Ho * segs_row)) / segs_row;
     int cws = sbeg - (cb * a.Ho + cho) * segs_row;
-    auto dma_stage = [&](int buf) {
+    auto dma_seg = [&](char* const dst) {
         const int b = cb, ho = cho, wo0 = cws * PK;
-        if (seg + 1 < send) {                                            // advance, clamped at the chunk's last segment
-            ++seg;
-            if (++cws == segs_row) { cws = 0; if (++cho == a.Ho) { cho = 0; ++cb; } }
-        }
+        const bool live = seg < send;                                    // beyond the chunk: zeros (the stage's MFMAs add nothing)
+        ++seg;
+        if (++cws == segs_row) { cws = 0; if (++cho == a.Ho) { cho = 0; ++cb; } }
         if (WG_ABL(1)) return;
         const int m0 = (b * a.Ho + ho) * a.Wo + wo0;
         const int hi = ho + kh - 1;
-        const bool rowok = (unsigned)hi < (unsigned)a.H;
+        const bool rowok = live && (unsigned)hi < (unsigned)a.H;
         const int xbase = (b * a.H + hi) * a.W + wo0 - 1;
-        char* const dst = smem + buf * STAGE3B;
 #pragma unroll
         for (int j = 0; j < 3; ++j) {
             const int k = wave + 8 * j;                                  // 24 pieces: three per wave
-            const u16* src = yoff[j] >= 0 ? a.yp + yoff[j] + (long)m0 * 16 : zero;
+            const u16* src = (yoff[j] >= 0 && live) ? a.yp + yoff[j] + (long)m0 * 16 : zero;
             __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + (k / 12) * PLANEB + ((k % 12) >> 2) * SUBB + (k & 3) * 1024), 16, 0, 0);
         }
 #pragma unroll
@@ -356,6 +382,10 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
             const u16* src = ok ? a.xp + xoff[j] + (long)(xbase + xrow[j]) * 16 : zero;
             __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + OPB + (k / 5) * XPLANEB + (k % 5) * 1024), 16, 0, 0);
         }
+    };
+    auto dma_stage = [&](int buf) {
+#pragma unroll
+        for (int u = 0; u < SUB; ++u) dma_seg(smem + buf * SLOTB + u * STAGE3B);
     };
 
     f32x4acc acc[TM][TN];
@@ -421,53 +451,86 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     }
 #endif
     int buf = 0;
+#ifdef RDO_DIAG
+    unsigned long long ph[6] = {0, 0, 0, 0, 0, 0};
+    const bool phase_on = WG_ABL(64);
+#define WG_T(v) unsigned long long v = phase_on ? clock64() : 0ull
+#else
+#define WG_T(v)
+#endif
     for (int s = 0; s < nsteps; ++s) {
+        WG_T(t0);
         if (WG_ABL(1) || RING3 == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(5 * (RING3 - 2)) : "memory");
+        WG_T(t1);
         __builtin_amdgcn_s_barrier();                                    // ... everybody's have, and nobody reads buffer (s - 1) % RING3 any more
+        WG_T(t2);
         const int nb = buf >= 1 ? buf - 1 : RING3 - 1;                   // (s + RING3 - 1) % RING3
         const bool more = RING3 > 2 || s + 1 < nsteps;                   // (a counted wait needs the same DMA count in every stage)
         if (more && !late) dma_stage(nb);
-        const char* st = smem + buf * STAGE3B;
-        if (!WG_ABL(8)) {
+        WG_T(t3);
+#ifdef RDO_DIAG
+        if (phase_on) { ph[0] += t1 - t0; ph[1] += t2 - t1; ph[2] += t3 - t2; }
+#endif
 #pragma unroll
-            for (int p = 0; p < NP; ++p)
+        for (int u = 0; u < SUB; ++u) {
+            const char* st = smem + buf * SLOTB + u * STAGE3B;
+            if (!WG_ABL(8)) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
+                for (int p = 0; p < NP; ++p)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
+            }
+            read_b(S0{}, st, 0);
+#ifdef RDO_DIAG
+            if (phase_on) {                                              // how long until the first fragments are there
+                const unsigned long long ta = clock64();
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                ph[3] += clock64() - ta;
+            }
+            const unsigned long long tb = phase_on ? clock64() : 0ull;
+#endif
+            [&]<int... SL>(std::integer_sequence<int, SL...>) {
+                (([&] {
+                     constexpr int T3 = SL / 3, Q = SL % 3, SET = T3 & 1;
+                     if constexpr (Q == 0) {
+                         tr_wait();                                      // this third's fragments (and, in slot 0, the A fragments) are there
+                         if constexpr (T3 < 2) {
+                             if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
+                             else read_b(S0{}, st, T3 + 1);
+                         }
+                     }
+                     if (!WG_ABL(4)) {
+#pragma unroll
+                         for (int i = 0; i < TM; ++i)
+#pragma unroll
+                             for (int j = 0; j < 2; ++j)
+                                 acc[i][2 * T3 + j] =
+                                     __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                     }
+                     __builtin_amdgcn_sched_barrier(0);
+                     if constexpr (SL == LSLOT) {
+                         if (u == SUB - 1 && more && late) dma_stage(nb);
+                     }
+                     __builtin_amdgcn_sched_barrier(0);
+                 }()),
+                 ...);
+            }
+            (std::make_integer_sequence<int, 9>{});
+#ifdef RDO_DIAG
+            if (phase_on) ph[4] += clock64() - tb;
+#endif
         }
-        read_b(S0{}, st, 0);
-        [&]<int... SL>(std::integer_sequence<int, SL...>) {
-            (([&] {
-                 constexpr int T3 = SL / 3, Q = SL % 3, SET = T3 & 1;
-                 if constexpr (Q == 0 && T3 < 2) {
-                     if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
-                     else read_b(S0{}, st, T3 + 1);
-                 }
-                 if (!WG_ABL(4)) {
-#pragma unroll
-                     for (int i = 0; i < TM; ++i)
-#pragma unroll
-                         for (int j = 0; j < 2; ++j)
-                             acc[i][2 * T3 + j] =
-                                 __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
-                 }
-                 __builtin_amdgcn_sched_barrier(0);
-                 if constexpr (SL == 2) {
-                     if (more && late) dma_stage(nb);
-                 }
-                 __builtin_amdgcn_sched_barrier(0);
-             }()),
-             ...);
-        }
-        (std::make_integer_sequence<int, 9>{});
         buf = buf + 1 == RING3 ? 0 : buf + 1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the clamped tail DMAs still target this workgroup's LDS
 #ifdef RDO_DIAG
     if (tid == 0 && lin < 256) {       // shader-clock cycles and 100 MHz wall ticks of the K loop, stage count in the low bits of slot 1
         g_wg_stamps[lin * 4 + 0] = clock64() - st_c0; g_wg_stamps[lin * 4 + 1] = wall_clock64() - st_r0;
-        g_wg_stamps[lin * 4 + 2] = (unsigned long long)nsteps; g_wg_stamps[lin * 4 + 3] = 0;
+        g_wg_stamps[lin * 4 + 2] = (unsigned long long)(nsteps * SUB); g_wg_stamps[lin * 4 + 3] = 0;
     }
+    if (phase_on && lane == 0 && (wave == 0 || wave == 4) && lin < 256)
+        for (int k = 0; k < 6; ++k) g_wg_phase[(lin * 2 + (wave >> 2)) * 8 + k] = ph[k];
 #endif
 
     const long wsize = (long)a.Cout * 9 * a.Cin;
@@ -532,19 +595,37 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
         a.Wo == a.W && a.Ho == a.H && (long)(a.M / 32) >= nsplit) {
         WgPArgs b = a;
         b.tiles_ci = a.Cin / 64;
+        // tuning key "wgrad_sub": 1 = <1, 2, 2> (round 3), 2 = two segments per stage, 3 = ring of three with waves 4-7 issuing at the end
+        // of the stage, 4 = ring of three, issue behind slot 5
+        const int variant = rdo::tuning(rdo::T_WGRAD_SUB);
         return rdo::dispatch(
-            [b](hipStream_t s) {
-                constexpr size_t lds = (size_t)RING3 * STAGE3B;
-                static rdo::PerDevice attr;
-                if (!attr.done()) {
-                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2r_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)lds) != hipSuccess)
-                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_h2r) failed");
-                    attr.mark();
+            [b, variant](hipStream_t s) {
+                auto go = [&](auto subc, auto ringc, auto slotc) -> int {
+                    constexpr int SUB = decltype(subc)::value, RING = decltype(ringc)::value, LS = decltype(slotc)::value;
+                    constexpr size_t lds = (size_t)RING * SUB * STAGE3B;
+                    static_assert(lds <= 160 * 1024, "row weight-gradient LDS");
+                    static rdo::PerDevice attr;
+                    if (!attr.done()) {
+                        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2r_kernel<SUB, RING, LS>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+                            return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_h2r) failed");
+                        attr.mark();
+                    }
+                    dim3 grid((unsigned)b.nsplit, (unsigned)(3 * b.tiles_co * b.tiles_ci));
+                    hipLaunchKernelGGL((conv_wgrad_h2r_kernel<SUB, RING, LS>), grid, dim3(512), lds, s, b);
+                    return rdo::check_launch("conv_wgrad_h2r");
+                };
+                using rdo_i1 = std::integral_constant<int, 1>; using rdo_i2 = std::integral_constant<int, 2>; using rdo_i3 = std::integral_constant<int, 3>;
+                using rdo_i5 = std::integral_constant<int, 5>; using rdo_i8 = std::integral_constant<int, 8>;
+                switch (variant) {
+                    case 2: return go(rdo_i2{}, rdo_i2{}, rdo_i2{});
+                    case 3: return go(rdo_i1{}, rdo_i3{}, rdo_i8{});
+                    case 4: return go(rdo_i1{}, rdo_i3{}, rdo_i5{});
+                    case 5: return go(rdo_i1{}, rdo_i2{}, rdo_i5{});
+                    case 6: return go(rdo_i1{}, rdo_i2{}, rdo_i8{});
+                    case 7: return go(rdo_i1{}, rdo_i2{}, std::integral_constant<int, 0>{});
+                    default: return go(rdo_i1{}, rdo_i2{}, rdo_i2{});
                 }
-                dim3 grid((unsigned)b.nsplit, (unsigned)(3 * b.tiles_co * b.tiles_ci));
-                hipLaunchKernelGGL(conv_wgrad_h2r_kernel, grid, dim3(512), lds, s, b);
-                return rdo::check_launch("conv_wgrad_h2r");
             },
             stream, "conv_wgrad_h2_rows", flops, bytes);
     }
@@ -567,6 +648,10 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
 
 #ifdef RDO_DIAG
 // diagnostic build only: per workgroup {K-loop cycles, K-loop 100 MHz ticks, stages, 0} of the last row-kernel launch (tools/h2_stamps.py)
+extern "C" int rdo_diag_wgrad_phases(unsigned long long* out, int n) {
+    if (!out || n <= 0 || n > 256 * 2 * 8) return RDO_EINVAL;
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_phase), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? RDO_OK : RDO_EHIP;
+}
 extern "C" int rdo_diag_wgrad_stamps(unsigned long long* out, int n) {
     if (!out || n <= 0 || n > 1024) return RDO_EINVAL;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_stamps), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? RDO_OK : RDO_EHIP;
