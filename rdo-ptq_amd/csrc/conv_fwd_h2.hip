@@ -655,6 +655,22 @@ static int h2_ksplit(const rdo_conv_desc* d) {
     return best;
 }
 
+// 3 x 3 "same" convs on 16 x 16 patches with too few 256 x 64 tiles for the chip (the 32^2 convs with 192 output channels: 48): the K32
+// halo kernel with its slice pairs split over workgroups -- the smallest split that reaches 192 workgroups -- and the second pass of the
+// per-tap kernel.  Against the per-tap kernel's 12-way split the partial sums shrink (6 x 3.1 MB instead of 12 x 3.1 MB for those convs)
+// and the K loop is the halo kernel's.  0: not applicable.
+static int h2k_ksplit(const rdo_conv_desc* d) {
+    if (!(rdo::tuning(rdo::T_X6P_HALO) && rdo::tuning(rdo::T_H2_K32) >= 2 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+          d->H % 16 == 0 && d->W % 16 == 0 && d->Cin % 32 == 0 && d->Cout % 64 == 0))
+        return 0;
+    const long tiles = (long)d->B * d->H * d->W / 256 * (d->Cout / 64);
+    if (tiles >= 160 || tiles < 24) return 0;
+    const int cpairs = d->Cin / 32;
+    for (int ks = 2; ks <= cpairs; ++ks)
+        if (cpairs % ks == 0 && tiles * ks >= 192) return ks;
+    return 0;
+}
+
 static bool pow2_scale(float s) {
     int e;
     return s > 0.f && std::isfinite(s) && std::frexp(s, &e) == 0.5f;
@@ -699,7 +715,8 @@ extern "C" int rdo_conv2d_fwd_h2_supported(const rdo_conv_desc* d) {
 
 extern "C" int64_t rdo_conv2d_fwd_h2_workspace(const rdo_conv_desc* d) {
     if (!d || !rdo_conv2d_fwd_h2_supported(d)) return 0;
-    const int ks = h2_ksplit(d);
+    int ks = h2_ksplit(d);
+    if (h2k_ksplit(d) > ks) ks = h2k_ksplit(d);
     return ks > 1 ? (int64_t)ks * d->B * d->Ho * d->Wo * d->Cout : 0;
 }
 
@@ -768,6 +785,24 @@ static int conv2d_fwd_h2_impl(const rdo_conv_desc* d, const void* x_planes, floa
     // 3 x 3 "same" convs on 16 x 16 patches: the halo kernel (no K split: the shapes that qualify fill the chip with tiles)
     const int halo = h2_halo_shape(d);
     RDO_REQUIRE(!tail || halo, "rdo_conv2d_fwd_h2_tail: shape not on the halo kernel (rdo_conv2d_fwd_h2_tail_supported)");
+    // few tiles: the K32 halo kernel split over slice pairs + the second pass (h2k_ksplit)
+    if (!halo && !tail) {
+        const int ks2 = h2k_ksplit(d);
+        if (ks2 >= 2 && workspace && (long)ks2 * a.M * a.Cout <= workspace_floats) {
+            H2Args k = a;
+            k.ksplit = ks2;
+            k.partial = workspace;
+            if (rdo::h2k_supported(k, 2))
+                return rdo::dispatch(
+                    [k](hipStream_t s) {
+                        if (int rc = rdo::h2k_launch(k, 2, s)) return rc;
+                        long g = rdo::ceil_div((long)k.M * k.Cout / 16, 256);
+                        hipLaunchKernelGGL(h2_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, k);
+                        return rdo::check_launch("h2_splitk_epilogue");
+                    },
+                    stream, "conv_fwd_h2_halo64k", flops, bytes);
+        }
+    }
     // ... in its 32-channel-stage / 16x16x32 form where the shape allows (conv_fwd_h2k.hip; tuning key "h2_k32")
     if (halo && rdo::tuning(rdo::T_H2_K32) && (halo == 2 || ks == 1)) {
         H2Args k = a;

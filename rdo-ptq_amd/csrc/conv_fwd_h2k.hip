@@ -139,13 +139,16 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
 #pragma unroll
         for (int j = 0; j < TP; ++j) acc[i][j] = f32x4k{0.f, 0.f, 0.f, 0.f};
 
-    const int cpairs = a.Cin / 32;
+    // K split (a.ksplit > 1: few tiles, e.g. the 32^2 convs): workgroup z owns the slice pairs [cp0, cp1) and writes raw partial sums
+    const int cpairs_all = a.Cin / 32;
+    const int cp0 = cpairs_all * tile.z / a.ksplit, cp1 = cpairs_all * (tile.z + 1) / a.ksplit;
+    const int cpairs = cp1 - cp0;
     const int nstages = 9 * cpairs;
 
     typedef __attribute__((address_space(3))) void lds_void;
     typedef const __attribute__((address_space(1))) void glb_void;
     auto dma_a = [&](int j, int cp_next) {                   // piece j of the wave, halo of slice pair cp_next into buffer cp_next & 1
-        const int cn = cp_next < cpairs ? cp_next : cpairs - 1;
+        const int cn = cp0 + (cp_next < cpairs ? cp_next : cpairs - 1);
         const int piece = wave + 8 * j;
         const int off = halo_off(piece);
         const u16* src = off >= 0 ? a.xp + off + (long)cn * Min * 32 : zero;
@@ -161,7 +164,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     auto set_wsrc = [&](int stage) {
         const int st = stage < nstages ? stage : nstages - 1;
         const int cp = st / 9, tap = st - cp * 9;
-        wsrc = a.wp + ((long)(2 * cp) * 9 + tap) * a.Cout * 16;
+        wsrc = a.wp + ((long)(2 * (cp0 + cp)) * 9 + tap) * a.Cout * 16;
     };
 
     // fragment addresses.  Weights: row = wn0 + 16 i + l16 with wn0 and 16 i multiples of 8, so the swizzle depends on the lane only:
@@ -315,6 +318,17 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     // of pixel m = patch row wrow * TP + j, column l16 -- a quad of the fp32 NHWC tensors (16-byte accesses; the four lanes of a pixel
     // cover one 64-byte slice, a tile row of 16 pixels is 16 such segments) and a quarter of an H2 record (8 bytes per plane; the 64 lanes
     // of a tile cover 16 consecutive records = 512 contiguous bytes per plane).  No staging tile, no barrier.
+    if (a.partial) {                                         // K split: raw sums (already divided by s_x s_w) for the second pass
+        float* const part = a.partial + (long)tile.z * a.M * a.Cout;
+#pragma unroll
+        for (int i = 0; i < TC; ++i)
+#pragma unroll
+            for (int j = 0; j < TP; ++j) {
+                const int m = pbase + (wrow * TP + j) * a.W + l16;
+                *reinterpret_cast<f32x4*>(part + (long)m * a.Cout + n0 + wn0 + 16 * i + 4 * kg) = acc[i][j] * a.acc_scale;
+            }
+        return;
+    }
     const bool need_planes = a.outp != nullptr;
     float tail_loss = 0.f;
     int bad = 0;
@@ -373,7 +387,7 @@ int launch(const H2Args& a, const char* what, hipStream_t s) {
             return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(%s) failed", what);
         attr.mark();
     }
-    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.Cout / BN), 1);
+    dim3 grid((unsigned)(a.M / 256), (unsigned)(a.Cout / BN), (unsigned)a.ksplit);
     hipLaunchKernelGGL((conv_fwd_h2k_kernel<WM, WN, TP, TC, ABL>), grid, dim3(512), lds, s, a);
     return rdo::check_launch(what);
 }
@@ -384,7 +398,8 @@ namespace rdo {
 
 bool h2k_supported(const H2Args& a, int shape) {
     return a.Cout % (shape == 1 ? 192 : 64) == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 && a.W % 16 == 0 &&
-           a.Cin % 32 == 0 && a.ksplit == 1 && a.partial == nullptr && (long)a.Cin * 9 * a.Cout * 16 < (1L << 31);
+           a.Cin % 32 == 0 && a.ksplit >= 1 && a.ksplit <= a.Cin / 32 && (a.ksplit == 1) == (a.partial == nullptr) && (shape == 2 || a.ksplit == 1) &&
+           (long)a.Cin * 9 * a.Cout * 16 < (1L << 31);
 }
 
 int h2k_launch(const H2Args& a, int shape, hipStream_t s) {

@@ -155,6 +155,17 @@ def _halo_vs_per_tap(ops, L, B, H, W, Cin, Cout):
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, N, N), (4, 64, 64, N, 4 * N), (4, 64, 64, N, N), (4, 32, 32, N, 4 * N), (2, 64, 96, 64, 320),
                                             (1, 256, 256, 32, 2 * N), (2, 128, 256, 64, N), (3, 112, 240, 96, 320)])
 def test_conv_h2_k32_halo_kernel_equals_k16_halo_kernel(ops, L, B, H, W, Cin, Cout):
+    _k32_vs_k16(ops, L, B, H, W, Cin, Cout, 1)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 32, 32, N, N), (8, 32, 32, N, N), (6, 32, 32, N, N)])
+def test_conv_h2_k32_halo_kernel_with_k_split(ops, L, B, H, W, Cin, Cout):
+    """Few 256 x 64 tiles (the 32^2 convs): the K32 halo kernel split over slice pairs + the second pass (h2_k32 = 2) against the
+    per-tap path these shapes take otherwise (h2_k32 = 0 / 1: 12-way K split of the 16-channel per-tap kernel)."""
+    _k32_vs_k16(ops, L, B, H, W, Cin, Cout, 2)
+
+
+def _k32_vs_k16(ops, L, B, H, W, Cin, Cout, k32_value):
     """The halo kernel with 32-channel stages on v_mfma_f32_16x16x32_f16 (conv_fwd_h2k.hip, tuning key h2_k32) against the 16-channel
     kernel on 32x32x16: per output element the same three products per stage pair in the same order, only the MFMA's internal
     summation width differs -- agreement to 1e-6 of the output range, against fp64 within the same bound as the 16-channel kernel,
@@ -169,7 +180,7 @@ def test_conv_h2_k32_halo_kernel_equals_k16_halo_kernel(ops, L, B, H, W, Cin, Co
     saved = ops.set_tuning("h2_k32", 0)
     try:
         for k32 in (0, 1):
-            ops.set_tuning("h2_k32", k32)
+            ops.set_tuning("h2_k32", k32 * k32_value)
             out, pre = torch.zeros(B, H, W, Cout, device="cuda"), torch.zeros(B, H, W, Cout, device="cuda")
             opl = ops.h2_empty(out.shape, "cuda", 16.0)
             opl.t.zero_()

@@ -11,8 +11,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "rdo-ptq_amd"))
 from hipops import ops  # noqa: E402
 
-SHAPES = [(4, 128, 192, 192), (4, 64, 192, 192), (4, 64, 192, 768), (4, 32, 192, 768)]
+SHAPES = [(4, 128, 192, 192), (4, 64, 192, 192), (4, 64, 192, 768), (4, 32, 192, 768), (4, 32, 192, 192)]
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+VA, VB = (int(sys.argv[2]), int(sys.argv[3])) if len(sys.argv) > 3 else (0, 1)
 
 
 def timeit(fn, n=40):
@@ -36,14 +37,14 @@ for (B, H, Cin, Cout) in SHAPES:
     out = torch.empty(B, H, H, Cout, device="cuda")
     opl = ops.h2_empty(out.shape, "cuda", 16.0)
     gf = 2.0 * out.numel() * Cin * 9 / 1e9
-    res = {0: [], 1: []}
-    resp = {0: [], 1: []}
+    res = {VA: [], VB: []}
+    resp = {VA: [], VB: []}
     for _ in range(ROUNDS):
-        for v in (0, 1):
+        for v in (VA, VB):
             ops.set_tuning("h2_k32", v)
             res[v].append(timeit(lambda: ops.conv2d_fwd_h2(xp, tuple(x.shape), tuple(w.shape), wpl, b, 1, 1, out=out)))
             resp[v].append(timeit(lambda: ops.conv2d_fwd_h2(xp, tuple(x.shape), tuple(w.shape), wpl, b, 1, 1, out_planes=opl)))
-    ops.set_tuning("h2_k32", 0)
+    ops.set_tuning("h2_k32", 1)
     med = lambda l: sorted(l)[len(l) // 2]
-    print(f"B={B} H={H} {Cin}->{Cout}: k16 out {med(res[0]):6.1f} us (min {min(res[0]):6.1f}, {gf / med(res[0]) * 1e3:5.0f} TF)  k32 out {med(res[1]):6.1f} us "
-          f"(min {min(res[1]):6.1f}, {gf / med(res[1]) * 1e3:5.0f} TF) | planes only: k16 {med(resp[0]):6.1f}  k32 {med(resp[1]):6.1f}", flush=True)
+    print(f"B={B} H={H} {Cin}->{Cout}: h2_k32={VA} out {med(res[VA]):6.1f} us (min {min(res[VA]):6.1f}, {gf / med(res[VA]) * 1e3:5.0f} TF)  h2_k32={VB} out {med(res[VB]):6.1f} us "
+          f"(min {min(res[VB]):6.1f}, {gf / med(res[VB]) * 1e3:5.0f} TF) | planes only: {med(resp[VA]):6.1f}  {med(resp[VB]):6.1f}", flush=True)
