@@ -1,7 +1,7 @@
 // Halo forward / dgrad conv on H2 tensors, second form ("K32"): 3 x 3, stride 1, pad 1 convs whose H and W are multiples of 16 and whose
 // Cin is a multiple of 32.  Same tile as conv_fwd_h2h_kernel (conv_fwd_h2.hip) -- the 256 output pixels of a workgroup are a 16 x 16
 // patch of one image, the 18 x 18 halo of the patch is fetched once per channel group and serves all nine taps, eight waves, one
-// workgroup per CU, staggered SIMD partners -- but
+// workgroup per CU -- but
 //   * a K stage is 32 input channels (two slices of the H2 layout) of one tap: half as many stages, barriers and loop skeletons
 //     (measured on the 16-channel kernel: 229 of the 1 704 cycles of a stage were barrier + skeleton with nothing else in it);
 //   * the products run on v_mfma_f32_16x16x32_f16: under the board's power limit the chip holds a higher clock on that shape than on
@@ -173,7 +173,6 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     // would cost 36 registers and spill the accumulators).
     const int fw_base = BBASE + (wn0 + l16) * 64 + ((kg ^ swz(l16)) << 4);
     int qlane = (wrow * TP) * HWD + l16;
-    const bool late = wave >= 4;
 
     // prologue: halo of slice pair 0, weights of stages 0 and 1
 #pragma unroll
@@ -185,18 +184,14 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
 #pragma unroll
     for (int j = 0; j < BJ; ++j) dma_b(j, 1);
 
-    auto k_loop = [&](auto late_c) {
-        constexpr bool LATE = decltype(late_c)::value;
+    // All eight waves run the K loop in lock-step.  The staggered SIMD partners of the 16-channel kernel (waves 4-7 two thirds of a
+    // stage behind, conv_fwd_h2.hip) measured 2.5-8 % SLOWER here (same-process A/B, 4 x 128^2: 105.3 vs 102.6 us; 4 x 64^2: 37.8 vs
+    // 34.9): with 72 MFMAs per wave and stage the two partners of a SIMD drift apart by themselves.
+#ifdef RDO_DIAG
+    const unsigned long long st_c0 = clock64(), st_r0 = wall_clock64();
+#endif
+    {
         f16x8 fx[NP][TP], fw[NP][TC];
-        if constexpr (LATE) {                                // the "previous stage" of stage 0: zero fragments
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-#pragma unroll
-                for (int j = 0; j < TP; ++j) fx[p][j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-                for (int i = 0; i < TC; ++i) fw[p][i] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
-            }
-        }
         auto mma = [&](int px, int pw) {
             if constexpr (ABL & 4) {                         // keep the fragments alive without multiplying
 #pragma unroll
@@ -250,37 +245,20 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
                     for (int j = 1; j < BJ; ++j) dma_b(j, nb);
                 }
             };
-            if constexpr (!LATE) {
-                rd_x(1); rd_w(0);
-                rd_x(0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                rd_w(1);
-                slot(0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(0, 1);
-                __builtin_amdgcn_sched_barrier(0);
-                slot(1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(0, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            } else {
-                rd_x(1);                                     // fx[1] is free: (X1, W0) of the previous stage is done
-                __builtin_amdgcn_sched_barrier(0);
-                mma(0, 1);                                   // previous stage
-                __builtin_amdgcn_sched_barrier(0);
-                rd_w(1);
-                slot(0);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(0, 0);                                   // previous stage
-                __builtin_amdgcn_sched_barrier(0);
-                rd_w(0); rd_x(0);
-                slot(1);
-                __builtin_amdgcn_sched_barrier(0);
-                mma(1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            rd_x(1); rd_w(0);
+            rd_x(0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(1, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            rd_w(1);
+            slot(0);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            slot(1);
+            __builtin_amdgcn_sched_barrier(0);
+            mma(0, 0);
+            __builtin_amdgcn_sched_barrier(0);
             buf = buf + 1 == RING ? 0 : buf + 1;
             ++s;
         };
@@ -288,16 +266,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
             [&]<int... T>(std::integer_sequence<int, T...>) { (stage(std::integral_constant<int, T>{}, cp), ...); }
             (std::make_integer_sequence<int, 9>{});
         }
-        if constexpr (LATE) {                                // the two products of the last stage these waves still owe
-            mma(0, 1);
-            mma(0, 0);
-        }
-    };
-#ifdef RDO_DIAG
-    const unsigned long long st_c0 = clock64(), st_r0 = wall_clock64();
-#endif
-    if (late && a.stagger) k_loop(std::true_type{});
-    else k_loop(std::false_type{});
+    }
 #ifdef RDO_DIAG
     if (tid == 0 && blockIdx.x < 256 && blockIdx.y == 0) {   // shader-clock cycles and 100 MHz wall ticks of the K loop (rdo_diag_h2k_stamps)
         g_h2k_stamps[blockIdx.x * 4 + 0] = st_c0; g_h2k_stamps[blockIdx.x * 4 + 1] = st_r0;
