@@ -808,9 +808,16 @@ static int conv2d_fwd_h2_impl(const rdo_conv_desc* d, const void* x_planes, floa
         H2Args k = a;
         k.ksplit = 1;
         k.partial = nullptr;
-        if (rdo::h2k_supported(k, halo))
-            return rdo::dispatch([k, halo](hipStream_t s) { return rdo::h2k_launch(k, halo, s); }, stream,
-                                 halo == 1 ? "conv_fwd_h2_halo" : "conv_fwd_h2_halo64", flops, bytes);
+        // 256 x 64 tiles that leave a quarter of the CUs idle (the 64^2 convs with 192 output channels: 192 workgroups) run 256 x 48
+        // tiles instead (256 workgroups; tuning key "h2_n48")
+        int shape = halo;
+        const long patches = (long)d->B * d->H * d->W / 256;
+        if (halo == 2 && rdo::tuning(rdo::T_H2_N48) && d->Cout % 48 == 0 && patches * (d->Cout / 64) < 256 && patches * (d->Cout / 48) <= 256 &&
+            rdo::h2k_supported(k, 3))
+            shape = 3;
+        if (rdo::h2k_supported(k, shape))
+            return rdo::dispatch([k, shape](hipStream_t s) { return rdo::h2k_launch(k, shape, s); }, stream,
+                                 shape == 1 ? "conv_fwd_h2_halo" : "conv_fwd_h2_halo64", flops, bytes);
     }
     if (halo == 1 && ks == 1)
         return rdo::dispatch(

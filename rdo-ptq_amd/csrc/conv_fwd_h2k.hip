@@ -83,9 +83,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     constexpr int BBASE = ADUMMY + 1024;
     constexpr int BPLANE = BN * 64, BSTAGE = NP * BPLANE;    // 24 KiB (BN = 192) / 8 KiB
     constexpr int BPIECES = BSTAGE / 1024;                   // 24 / 8
-    constexpr int BJ = BPIECES / 8;                          // weight pieces per wave and stage: 3 / 1
+    constexpr int BJ = (BPIECES + 7) / 8;                    // weight pieces per wave and stage: 3 / 1 (BN = 48: six pieces, waves 6 and 7 fetch a dummy)
     constexpr int RING = 3;
-    static_assert(BPIECES % 8 == 0, "uniform weight-piece count per wave");
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -127,8 +126,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
         const int g = (lane & 3) ^ swz(row);
         dma_lane = (g >> 1) * 9 * a.Cout * 16 + row * 16 + (g & 1) * 8;
     }
-    auto dma_uni = [&](int j) -> int {                       // wave-uniform part of piece wave + 8 j
-        const int k = wave + 8 * j;
+    auto dma_uni = [&](int j) -> int {                       // wave-uniform part of piece wave + 8 j (beyond the image: piece 0 again)
+        const int k = wave + 8 * j < BPIECES ? wave + 8 * j : 0;
         const int pl = k / (BN / 16), kk = k - pl * (BN / 16);
         return (int)(pl * a.wplane) + (n0 + kk * 16) * 16;
     };
@@ -158,7 +157,8 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     const u16* wsrc = a.wp;
     auto dma_b = [&](int j, int nb) {
         if constexpr (!(ABL & 2))
-            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_uni(j) + dma_lane), (lds_void*)(smem + BBASE + nb * BSTAGE + (wave + 8 * j) * 1024), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_uni(j) + dma_lane),
+                                             (lds_void*)(wave + 8 * j < BPIECES ? smem + BBASE + nb * BSTAGE + (wave + 8 * j) * 1024 : smem + ADUMMY), 16, 0, 0);
     };
     // stage s = slice pair s / 9, tap s % 9: its weights start at slice 2 (s / 9), tap s % 9 of the fragment-ordered planes
     auto set_wsrc = [&](int stage) {
@@ -366,7 +366,7 @@ int launch(const H2Args& a, const char* what, hipStream_t s) {
 namespace rdo {
 
 bool h2k_supported(const H2Args& a, int shape) {
-    return a.Cout % (shape == 1 ? 192 : 64) == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 && a.W % 16 == 0 &&
+    return a.Cout % (shape == 1 ? 192 : (shape == 3 ? 48 : 64)) == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 && a.W % 16 == 0 &&
            a.Cin % 32 == 0 && a.ksplit >= 1 && a.ksplit <= a.Cin / 32 && (a.ksplit == 1) == (a.partial == nullptr) && (shape == 2 || a.ksplit == 1) &&
            (long)a.Cin * 9 * a.Cout * 16 < (1L << 31);
 }
@@ -387,6 +387,7 @@ int h2k_launch(const H2Args& a, int shape, hipStream_t s) {
 #endif
         return launch<4, 2, 4, 6>(a, "conv_fwd_h2k 256x192", s);
     }
+    if (shape == 3) return launch<8, 1, 2, 3>(a, "conv_fwd_h2k 256x48", s);
     return launch<8, 1, 2, 4>(a, "conv_fwd_h2k 256x64", s);
 }
 

@@ -215,7 +215,7 @@ __device__ __forceinline__ float tail16(const H2Args& a, int m, int n, float (&v
 }  // namespace
 
 namespace rdo {
-// conv_fwd_h2k.hip: the halo kernel with 32-channel K stages on v_mfma_f32_16x16x32_f16.  shape 1: 256 x 192 tile, 2: 256 x 64.
+// conv_fwd_h2k.hip: the halo kernel with 32-channel K stages on v_mfma_f32_16x16x32_f16.  shape 1: 256 x 192 tile, 2: 256 x 64, 3: 256 x 48.
 bool h2k_supported(const H2Args& a, int shape);
 int h2k_launch(const H2Args& a, int shape, hipStream_t s);
 }  // namespace rdo

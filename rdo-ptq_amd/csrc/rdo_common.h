@@ -67,7 +67,7 @@ struct PerDevice {
 
 // Process-wide kernel-variant switches (rdo_set_tuning / rdo_get_tuning; initialised once from the RDO_* environment variables
 // of the same meaning so that command-line A/B runs keep working).
-enum Tune { T_WGRAD_X6_W8 = 0, T_CONV_X6, T_FWD_X6_VER, T_XCD, T_X6P_ABLATE, T_GRAPH_UNROLL, T_TAIL_GRID, T_X6P_HALO, T_WGRAD_P3_ROW, T_THIN_MFMA, T_H2_STAGGER, T_ADA_W1_MIN, T_H2_K32, T_WGRAD_SUB, T_COUNT };
+enum Tune { T_WGRAD_X6_W8 = 0, T_CONV_X6, T_FWD_X6_VER, T_XCD, T_X6P_ABLATE, T_GRAPH_UNROLL, T_TAIL_GRID, T_X6P_HALO, T_WGRAD_P3_ROW, T_THIN_MFMA, T_H2_STAGGER, T_ADA_W1_MIN, T_H2_K32, T_WGRAD_SUB, T_H2_N48, T_COUNT };
 int tuning(Tune t);
 
 // bf16x6 weight planes ("fragment order"): element (co, kh, kw, ci) of a conv weight [Cout][KH][KW][Cin] lives at
