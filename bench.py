@@ -313,6 +313,35 @@ def gpu_leg(a, rank, world, device):
                 torch.cuda.empty_cache()
             except Exception as ex:      # an extra must never cost the headline
                 batch_extra[f"batch{bb}"] = {"error": repr(ex)[:300]}
+        # mini-batch 256 (BASELINE.md section 2's largest throughput configuration): the activations of 29 engines at that batch do not fit
+        # next to each other, so the units run ONE AT A TIME -- engine built, 1 warm-up + `steps_b` timed iterations between two device
+        # synchronisations, engine and its buffers released -- and the rate is units * B * steps / (sum of the units' timed intervals)
+        if 256 <= a.images:
+            try:
+                bb, steps_b, tsum = 256, 3, 0.0
+                for name, u in units:
+                    kind, mods = _unit_modules(u)
+                    cq, cf, co = caches[name]
+                    idx = torch.stack([torch.randperm(a.images, generator=gi)[:bb] for _ in range(steps_b + 1)])
+                    e = UnitEngine(kind, mods, cq, cf, co, batch_size=bb, iters=steps_b + 1, weight=0.01, b_range=(20, 2), warmup=0.2,
+                                   input_prob=0.5, seed=1005, idx_table=idx, use_graph=not a.no_graph)
+                    e.run(1)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    e.run(steps_b)
+                    torch.cuda.synchronize()
+                    tsum += time.perf_counter() - t1
+                    if not torch.isfinite(e.logs()[0]).all():
+                        raise RuntimeError(f"non-finite loss in unit {name} at batch {bb}")
+                    del e
+                    torch.cuda.empty_cache()
+                batch_extra["batch256_units_in_sequence"] = {"images_per_s": round(len(units) * bb * steps_b / tsum, 1),
+                                                              "ms_per_step": round(tsum / steps_b * 1e3, 3), "steps": steps_b,
+                                                              "peak_mem_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1)}
+                log(f"batch 256 (units in sequence): {tsum / steps_b * 1e3:.2f} ms/step = {len(units) * bb * steps_b / tsum:.0f} images/s")
+            except Exception as ex:      # an extra must never cost the headline
+                batch_extra["batch256_units_in_sequence"] = {"error": repr(ex)[:300]}
+                torch.cuda.empty_cache()
     # which data-parallel loop ran: "graph" (iteration + collectives replayed from one graph) or "host" (plan / all-reduce / plan)
     dp_paths = sorted({e.dp_path for _, e in engines if e.dp_path is not None})
     return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, h2_units=h2_units, dp_paths=dp_paths,
@@ -470,7 +499,7 @@ def main():
                        "gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[3] else None}
                    for t, v in sorted(res["per_tag"].items(), key=lambda kv: -kv[1][1])}
         traffic, traffic_src = None, None
-        for tf in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM-side bytes per launch of the dominant kernel, last committed --pmc passes
+        for tf in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM-side bytes per launch of the dominant kernel, last committed --pmc passes
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                 if dom in tj:
@@ -506,6 +535,14 @@ def main():
             out["sustained_value"] = round(n_units * a.batch * world / (sum(w) / len(w) * 1e-3), 2)
             out["sustained_window_ms"] = {"min": round(min(w), 3), "max": round(max(w), 3), "windows_of": 100}
         out["config"]["h2_units"] = res["h2_units"]
+        # which library produced the number: a diagnostic build (make DIAG=1: ablation masks and stamps compiled in) is marked, and the
+        # kernel-variant switches in force are listed (include/rdo_ptq_hip.h: rdo_get_tuning)
+        from hipops import _lib as _L
+        ver = _L.lib().rdo_version().decode()
+        out["build_mode"] = "diag" if "DIAG" in ver else "release"
+        out["config"]["library"] = ver
+        out["config"]["tuning"] = {k: int(_L.lib().rdo_get_tuning(k.encode())) for k in
+                                   ("conv_x6", "xcd", "graph_unroll", "x6p_halo", "wgrad_p3_row", "h2_stagger", "h2_k32", "h2_n48", "wgrad_sub")}
         if res["dp_paths"]:
             out["dp_graph"] = res["dp_paths"] == ["graph"]
             out["config"]["dp_loop"] = "+".join(res["dp_paths"])

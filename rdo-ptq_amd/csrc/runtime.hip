@@ -98,7 +98,11 @@ struct rdo_plan {
 
 extern "C" {
 
+#ifdef RDO_DIAG
+const char* rdo_version(void) { return "rdo-ptq-hip 0.1 (gfx950) DIAG"; }     // diagnostic build: ablation masks / stamps compiled in
+#else
 const char* rdo_version(void) { return "rdo-ptq-hip 0.1 (gfx950)"; }
+#endif
 const char* rdo_last_error(void) { return rdo::g_err.c_str(); }
 
 int rdo_set_tuning(const char* key, int32_t value) {

@@ -8,7 +8,8 @@ import sys
 TAGS = {"conv_fwd_h2h_kernel": "conv_fwd_h2_halo", "conv_fwd_h2h_kernel<4, 2, 2, 3>": "conv_fwd_h2_halo",
         "conv_fwd_h2h_kernel<8, 1, 1, 2>": "conv_fwd_h2_halo64", "conv_wgrad_h2r_kernel": "conv_wgrad_h2_rows", "conv_fwd_h2_kernel": "conv_fwd_h2_256x192",
         "conv_wgrad_h2_kernel": "conv_wgrad_h2_192x192", "conv_fwd_x6v5_kernel": "conv_fwd_x6_128x192", "conv_wgrad_x6w8_kernel<false>": "conv_wgrad_x6_192x192",
-        "ada_step_batch_kernel": "ada_step"}
+        "ada_step_batch_kernel": "ada_step", "conv_fwd_h2k_kernel<4, 2, 4, 6, 0>": "conv_fwd_h2_halo", "conv_fwd_h2k_kernel<8, 1, 2, 3, 0>": "conv_fwd_h2_halo64",
+        "conv_fwd_h2k_kernel<8, 1, 2, 4, 0>": "conv_fwd_h2_halo64", "conv_wgrad_h2r_kernel<1, 2, 2>": "conv_wgrad_h2_rows"}
 
 
 def table(path):
