@@ -108,8 +108,8 @@ __device__ __forceinline__ void tile_to_lds(const f32x16& acc, float* D, int ldd
     for (int r = 0; r < 16; ++r) D[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk) * ldd + 32 * tj + lr] = acc[r];
 }
 
-// rows of this tile that are tokens (< N), columns < hd  ->  global [pixel][ch0 + d]
-__device__ __forceinline__ void tile_to_global(const AttnGeom& g, const f32x16& acc, float* dst, int row_stride, int ch0, int win, int ti,
+// rows of this tile that are tokens (< N), columns < hd  ->  global [pixel][ch0 + d]; pix: the window's token -> pixel table (LDS)
+__device__ __forceinline__ void tile_to_global(const AttnGeom& g, const f32x16& acc, float* dst, int row_stride, int ch0, const int* pix, int ti,
                                                int tj, float mul) {
     const int l = threadIdx.x & 63, lr = l & 31, lk = l >> 5;
     const int d = 32 * tj + lr;
@@ -117,7 +117,7 @@ __device__ __forceinline__ void tile_to_global(const AttnGeom& g, const f32x16& 
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (i < g.N) dst[(long)token_pixel(g, win, i) * row_stride + ch0 + d] = mul * acc[r];
+        if (i < g.N) dst[(long)pix[i] * row_stride + ch0 + d] = mul * acc[r];
     }
 }
 
@@ -125,22 +125,37 @@ __device__ __forceinline__ void zero_lds(float* p, int n) {
     for (int e = threadIdx.x; e < n; e += 256) p[e] = 0.f;
 }
 
-__device__ __forceinline__ void load_tile256(const AttnGeom& g, const float* src, int row_stride, int ch0, int win, float* dst, float mul) {
+__device__ __forceinline__ void load_tile256(const AttnGeom& g, const float* src, int row_stride, int ch0, const int* pix, float* dst, float mul) {
+    // head dims that are multiples of 4 (the Lu2022 models: 32): 16-byte global loads, one token-pixel computation per quad -- with
+    // 4-byte loads a thread issued 8 dependent-address loads per tile (three integer divisions each), and the four tiles of the
+    // backward kernel cost more than its five GEMMs
+    if (((g.hd | row_stride | ch0) & 3) == 0) {
+        typedef float f32x4 __attribute__((ext_vector_type(4)));
+        const int qpt = g.hd >> 2, nq = g.N * qpt;
+        for (int e = threadIdx.x; e < nq; e += 256) {
+            const int tok = e / qpt, dq = e - tok * qpt;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(src + (long)pix[tok] * row_stride + ch0 + 4 * dq);
+            float* d = dst + tok * g.hs + 4 * dq;            // (hs is odd: scalar LDS stores)
+            d[0] = mul * v[0]; d[1] = mul * v[1]; d[2] = mul * v[2]; d[3] = mul * v[3];
+        }
+        return;
+    }
     for (int e = threadIdx.x; e < g.N * g.hd; e += 256) {
         const int tok = e / g.hd, d = e - tok * g.hd;
-        dst[tok * g.hs + d] = mul * src[(long)token_pixel(g, win, tok) * row_stride + ch0 + d];
+        dst[tok * g.hs + d] = mul * src[(long)pix[tok] * row_stride + ch0 + d];
     }
 }
 
 // softmax of row i of S (+ bias, + shift mask) in place; returns nothing, P[i][j >= N] = 0
-__device__ __forceinline__ void softmax_row(const AttnGeom& g, float* S, const float* bias, int win, int head, int i) {
+// reg: the window's token -> shift-mask region table (LDS; read only when shift > 0)
+__device__ __forceinline__ void softmax_row(const AttnGeom& g, float* S, const float* bias, const int* reg, int head, int i) {
     float* row = S + i * SS;
     const float* br = bias + ((long)head * g.N + i) * g.N;
-    const int ri = g.shift > 0 ? token_region(g, win, i) : 0;
+    const int ri = g.shift > 0 ? reg[i] : 0;
     float mx = -3.0e38f;
     for (int j = 0; j < g.N; ++j) {
         float s = row[j] + br[j];
-        if (g.shift > 0 && token_region(g, win, j) != ri) s += -100.0f;
+        if (g.shift > 0 && reg[j] != ri) s += -100.0f;
         row[j] = s;
         mx = fmaxf(mx, s);
     }
@@ -164,18 +179,23 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const float* qkv
     float* S = V + 64 * g.hs;
     const int win = blockIdx.x, head = blockIdx.y;
     const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
+    __shared__ int pix[NMAX], reg[NMAX];                     // token -> pixel (roll + window partition) and -> mask region, computed once
+    if (threadIdx.x < g.N) {
+        pix[threadIdx.x] = token_pixel(g, win, threadIdx.x);
+        reg[threadIdx.x] = g.shift > 0 ? token_region(g, win, threadIdx.x) : 0;
+    }
     zero_lds(lds, 3 * 64 * g.hs);
     __syncthreads();
-    load_tile256(g, qkv, 3 * g.C, head * g.hd, win, Q, g.scale);
-    load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, win, K, 1.f);
-    load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
+    load_tile256(g, qkv, 3 * g.C, head * g.hd, pix, Q, g.scale);
+    load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix, K, 1.f);
+    load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix, V, 1.f);
     __syncthreads();
     const int hk = (g.hd + 1) & ~1;
     tile_to_lds(tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0), S, SS, ti, tj);
     __syncthreads();
     if (threadIdx.x < g.N) {
         const int i = threadIdx.x;
-        softmax_row(g, S, bias, win, head, i);
+        softmax_row(g, S, bias, reg, head, i);
         if (probs) {
             float* pr = probs + (((long)win * g.N + i) * g.N) * g.heads + head;
             for (int j = 0; j < g.N; ++j) pr[(long)j * g.heads] = S[i * SS + j];
@@ -186,7 +206,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const float* qkv
     if (32 * tj < g.hd) {
         const int nk = (g.N + 1) & ~1;
         const f32x16 o = tile_gemm<false, false>(S, SS, V, g.hs, ti, tj, nk, g.hd);
-        tile_to_global(g, o, out, g.C, head * g.hd, win, ti, tj, 1.f);
+        tile_to_global(g, o, out, g.C, head * g.hd, pix, ti, tj, 1.f);
     }
 }
 
@@ -201,12 +221,17 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv
     float* dS = P + 64 * SS;              // [64][65]: dP, then dS
     const int win = blockIdx.x, head = blockIdx.y;
     const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
+    __shared__ int pix[NMAX], reg[NMAX];
+    if (threadIdx.x < g.N) {
+        pix[threadIdx.x] = token_pixel(g, win, threadIdx.x);
+        reg[threadIdx.x] = g.shift > 0 ? token_region(g, win, threadIdx.x) : 0;
+    }
     zero_lds(lds, 4 * 64 * g.hs);
     __syncthreads();
-    load_tile256(g, qkv, 3 * g.C, head * g.hd, win, Q, g.scale);
-    load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, win, K, 1.f);
-    load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, win, V, 1.f);
-    load_tile256(g, dout, g.C, head * g.hd, win, dO, 1.f);
+    load_tile256(g, qkv, 3 * g.C, head * g.hd, pix, Q, g.scale);
+    load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix, K, 1.f);
+    load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix, V, 1.f);
+    load_tile256(g, dout, g.C, head * g.hd, pix, dO, 1.f);
     __syncthreads();
     const int hk = (g.hd + 1) & ~1, nk = (g.N + 1) & ~1;
     tile_to_lds(tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0), P, SS, ti, tj);
@@ -215,7 +240,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv
     if (threadIdx.x < 64) {
         const int i = threadIdx.x;
         if (i < g.N) {
-            softmax_row(g, P, bias, win, head, i);
+            softmax_row(g, P, bias, reg, head, i);
             float D = 0.f;
             for (int j = 0; j < g.N; ++j) D += P[i * SS + j] * dS[i * SS + j];
             for (int j = 0; j < g.N; ++j) dS[i * SS + j] = P[i * SS + j] * (dS[i * SS + j] - D);
@@ -227,9 +252,9 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv
     __syncthreads();
     if (32 * tj < g.hd) {
         // dQ = scale * dS K ; dK = dS^T Qs (Qs carries the scale) ; dV = P^T dO
-        tile_to_global(g, tile_gemm<false, false>(dS, SS, K, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, head * g.hd, win, ti, tj, g.scale);
-        tile_to_global(g, tile_gemm<true, false>(dS, SS, Q, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, g.C + head * g.hd, win, ti, tj, 1.f);
-        tile_to_global(g, tile_gemm<true, false>(P, SS, dO, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, 2 * g.C + head * g.hd, win, ti, tj, 1.f);
+        tile_to_global(g, tile_gemm<false, false>(dS, SS, K, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, head * g.hd, pix, ti, tj, g.scale);
+        tile_to_global(g, tile_gemm<true, false>(dS, SS, Q, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, g.C + head * g.hd, pix, ti, tj, 1.f);
+        tile_to_global(g, tile_gemm<true, false>(P, SS, dO, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, 2 * g.C + head * g.hd, pix, ti, tj, 1.f);
     }
 }
 
