@@ -16,6 +16,7 @@ from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstr
 cfg = dict(height=256, width=256, in_chans=3, embed_dim=192, latent_dim=320, window_size=8, mlp_ratio=2.0, qkv_bias=True,
            qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, use_checkpoint=False)
 units = sys.argv[1:] or ["g_a0", "g_a1", "g_a7", "g_s0", "g_s6"]
+ITERS = tuple(int(v) for v in os.environ.get("LU_ITERS", "4,24").split(","))
 torch.manual_seed(0)
 model = lic.NIC(cfg).cuda().eval()
 wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
@@ -38,7 +39,7 @@ for name in units:
         for m in getattr(qnn.model, n).modules():
             if isinstance(m, (QuantModule, BaseQuantBlock)):
                 m.trained = order.index(n) < order.index(name)
-    for iters in (4, 24):
+    for iters in ITERS:
         for m in unit.modules():
             if isinstance(m, (QuantModule, BaseQuantBlock)):
                 m.trained = False
@@ -54,4 +55,4 @@ for name in units:
            b_range=(20, 2), warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
         torch.cuda.synchronize()
         ts.append(time.time() - t0)
-    print(f"{name}: {(ts[1] - ts[0]) / 20 * 1e3:8.2f} ms/iteration   (setup+4 iters {ts[0]:.2f} s)   peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
+    print(f"{name}: {(ts[1] - ts[0]) / (ITERS[1] - ITERS[0]) * 1e3:8.2f} ms/iteration   (setup+{ITERS[0]} iters {ts[0]:.2f} s)   peak mem {torch.cuda.max_memory_allocated() / 2**30:.1f} GiB", flush=True)
