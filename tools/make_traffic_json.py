@@ -23,8 +23,11 @@ def table(path):
 
 f, w = table(sys.argv[1]), table(sys.argv[2])
 res = {}
-for k, tag in TAGS.items():
-    if k in f and k in w:
+PREFIX = {"conv_fwd_h2k_kernel<4, 2, 4, 6": "conv_fwd_h2_halo", "conv_fwd_h2k_kernel<8, 1, 2,": "conv_fwd_h2_halo64",
+          "conv_wgrad_h2r_kernel<": "conv_wgrad_h2_rows"}           # template kernels: any trailing diagnostic parameters
+for k in f:
+    tag = TAGS.get(k) or next((t for p, t in PREFIX.items() if k.startswith(p)), None)
+    if tag and k in w and tag not in res:
         res[tag] = {"fetch_mib_raw": f[k][1], "write_mib": w[k][1], "kernel": k, "dispatches": f[k][0]}
 json.dump(res, open(sys.argv[3], "w"), indent=1)
 print(json.dumps(res, indent=1))
