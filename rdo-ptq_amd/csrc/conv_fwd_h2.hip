@@ -659,13 +659,29 @@ static int h2_ksplit(const rdo_conv_desc* d) {
 // halo kernel with its slice pairs split over workgroups -- the smallest split that reaches 192 workgroups -- and the second pass of the
 // per-tap kernel.  Against the per-tap kernel's 12-way split the partial sums shrink (6 x 3.1 MB instead of 12 x 3.1 MB for those convs)
 // and the K loop is the halo kernel's.  0: not applicable.
-static int h2k_ksplit(const rdo_conv_desc* d) {
-    if (!(rdo::tuning(rdo::T_X6P_HALO) && rdo::tuning(rdo::T_H2_K32) >= 2 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
+static int h2k_ksplit(const rdo_conv_desc* d, int* shape_out = nullptr) {
+    const int mode = rdo::tuning(rdo::T_H2_K32);
+    if (!(rdo::tuning(rdo::T_X6P_HALO) && mode >= 2 && d->KH == 3 && d->KW == 3 && d->stride == 1 && d->pad == 1 &&
           d->H % 16 == 0 && d->W % 16 == 0 && d->Cin % 32 == 0 && d->Cout % 64 == 0))
         return 0;
-    const long tiles = (long)d->B * d->H * d->W / 256 * (d->Cout / 64);
-    if (tiles >= 160 || tiles < 24) return 0;
+    const long patches = (long)d->B * d->H * d->W / 256;
     const int cpairs = d->Cin / 32;
+    // mode 3: 256 x 48 tiles and the LARGEST even split that keeps every workgroup resident at once (one per CU: no second round)
+    if (mode >= 3 && d->Cout % 48 == 0) {
+        const long tiles = patches * (d->Cout / 48);
+        if (tiles < 200 && tiles >= 24) {
+            int best = 0;
+            for (int ks = 2; ks <= cpairs; ++ks)
+                if (cpairs % ks == 0 && tiles * ks <= 256) best = ks;
+            if (best) {
+                if (shape_out) *shape_out = 3;
+                return best;
+            }
+        }
+    }
+    const long tiles = patches * (d->Cout / 64);
+    if (tiles >= 160 || tiles < 24) return 0;
+    if (shape_out) *shape_out = 2;
     for (int ks = 2; ks <= cpairs; ++ks)
         if (cpairs % ks == 0 && tiles * ks >= 192) return ks;
     return 0;
@@ -787,15 +803,16 @@ static int conv2d_fwd_h2_impl(const rdo_conv_desc* d, const void* x_planes, floa
     RDO_REQUIRE(!tail || halo, "rdo_conv2d_fwd_h2_tail: shape not on the halo kernel (rdo_conv2d_fwd_h2_tail_supported)");
     // few tiles: the K32 halo kernel split over slice pairs + the second pass (h2k_ksplit)
     if (!halo && !tail) {
-        const int ks2 = h2k_ksplit(d);
+        int kshape = 2;
+        const int ks2 = h2k_ksplit(d, &kshape);
         if (ks2 >= 2 && workspace && (long)ks2 * a.M * a.Cout <= workspace_floats) {
             H2Args k = a;
             k.ksplit = ks2;
             k.partial = workspace;
-            if (rdo::h2k_supported(k, 2))
+            if (rdo::h2k_supported(k, kshape))
                 return rdo::dispatch(
-                    [k](hipStream_t s) {
-                        if (int rc = rdo::h2k_launch(k, 2, s)) return rc;
+                    [k, kshape](hipStream_t s) {
+                        if (int rc = rdo::h2k_launch(k, kshape, s)) return rc;
                         long g = rdo::ceil_div((long)k.M * k.Cout / 16, 256);
                         hipLaunchKernelGGL(h2_splitk_epilogue_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(256), 0, s, k);
                         return rdo::check_launch("h2_splitk_epilogue");

@@ -408,7 +408,7 @@ namespace rdo {
 
 bool h2k_supported(const H2Args& a, int shape) {
     return a.Cout % (shape == 1 ? 192 : (shape == 3 ? 48 : 64)) == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 && a.W % 16 == 0 &&
-           a.Cin % 32 == 0 && a.ksplit >= 1 && a.ksplit <= a.Cin / 32 && (a.ksplit == 1) == (a.partial == nullptr) && (shape == 2 || a.ksplit == 1) &&
+           a.Cin % 32 == 0 && a.ksplit >= 1 && a.ksplit <= a.Cin / 32 && (a.ksplit == 1) == (a.partial == nullptr) && (shape >= 2 || a.ksplit == 1) &&
            (long)a.Cin * 9 * a.Cout * 16 < (1L << 31);
 }
 

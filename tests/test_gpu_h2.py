@@ -158,11 +158,16 @@ def test_conv_h2_k32_halo_kernel_equals_k16_halo_kernel(ops, L, B, H, W, Cin, Co
     _k32_vs_k16(ops, L, B, H, W, Cin, Cout, 1)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 32, 32, N, N), (8, 32, 32, N, N), (6, 32, 32, N, N)])
-def test_conv_h2_k32_halo_kernel_with_k_split(ops, L, B, H, W, Cin, Cout):
-    """Few 256 x 64 tiles (the 32^2 convs): the K32 halo kernel split over slice pairs + the second pass (h2_k32 = 2) against the
-    per-tap path these shapes take otherwise (h2_k32 = 0 / 1: 12-way K split of the 16-channel per-tap kernel)."""
-    _k32_vs_k16(ops, L, B, H, W, Cin, Cout, 2)
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 32, 32, N, N), (8, 32, 32, N, N), (6, 32, 32, N, N), (4, 16, 16, N, 4 * N)])
+def test_conv_h2_k32_halo_kernel_with_k_split(ops, L, B, H, W, Cin, Cout, mode):
+    """Few tiles (the 32^2 convs): the K32 halo kernel split over slice pairs + the second pass -- h2_k32 = 2: 256 x 64 tiles, the smallest
+    split that reaches 192 workgroups; 3 (default): 256 x 48 tiles and the largest even split that keeps all workgroups resident at once
+    (4 x 32^2 192 -> 192: 64 tiles x 3 = 192 workgroups of 18 stages, 35.8 -> 21.1 us) -- against the path these shapes take otherwise
+    (12-way K split of the 16-channel per-tap kernel)."""
+    if not ops.conv_h2_supported((B, H, W, Cin), (Cout, 3, 3, Cin), 1, 1):
+        pytest.skip("shape not on the plane path")
+    _k32_vs_k16(ops, L, B, H, W, Cin, Cout, mode)
 
 
 def _k32_vs_k16(ops, L, B, H, W, Cin, Cout, k32_value):
