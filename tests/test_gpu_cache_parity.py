@@ -203,3 +203,38 @@ def test_activation_quantised_cache_building_matches_reference(golden_dir):
     assert float(dev.max()) / float(ref.abs().max()) < 2e-2 and float(dev.mean()) / float(ref.abs().max()) < 1e-3
     # and it is the quantised path that was compared: the quantised input is measurably away from the FP input
     assert float((ref - T(fx["g_a.2/inp_fp"])).abs().max()) > 5e-3
+
+
+def test_fp_cache_memo_gives_the_rows_of_the_per_unit_passes(monkeypatch):
+    """`quantization.utils._FpMemo` (one full-precision forward for the x_fp / target rows of ALL units) against the per-unit truncated
+    passes it replaces (RDO_FP_MEMO=0): bit-identical caches for units across the model, also behind a calibrated prefix, a short last
+    batch included; a unit asked for twice falls back to its own pass."""
+    import lic
+    from helpers import WQ, AQ
+    from quantization import QuantModel
+    from quantization import utils as U
+    torch.manual_seed(4)
+    model = lic.Cheng2020Anchor(N=8).cuda().eval()
+    qnn = QuantModel(model=model, weight_quant_params=WQ, act_quant_params=AQ, is_cheng=True).cuda().eval()
+    cali = torch.rand(10, 3, 64, 64, device="cuda")
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:4])
+    units = U._FpMemo.units_of(qnn)
+    assert len(units) >= 29
+    for u in units[:5]:                              # a "calibrated" prefix: the quantised pass differs from the full-precision one
+        for m in u.modules():
+            if hasattr(m, "trained"):
+                m.trained = True
+    picks = [units[0], units[3], units[7], units[12], units[-1]]
+    monkeypatch.setenv("RDO_FP_MEMO", "0")
+    ref = [U.save_inp_oup_data(qnn, u, cali, True, False, batch_size=4, input_prob=True) for u in picks]
+    monkeypatch.setenv("RDO_FP_MEMO", "1")
+    U._FpMemo.current = U._FpMemo.refused = None
+    got = [U.save_inp_oup_data(qnn, u, cali, True, False, batch_size=4, input_prob=True) for u in picks]
+    assert U._FpMemo.current is not None and id(picks[0]) not in U._FpMemo.current.rows        # built once, rows handed out
+    for ((q0, f0), o0), ((q1, f1), o1) in zip(ref, got):
+        assert torch.equal(q0, q1) and torch.equal(f0, f1) and torch.equal(o0, o1)
+    (q2, f2), o2 = U.save_inp_oup_data(qnn, picks[1], cali, True, False, batch_size=4, input_prob=True)     # second request: own pass
+    assert torch.equal(f2, ref[1][0][1]) and torch.equal(o2, ref[1][1])
+    U._FpMemo.current = None
