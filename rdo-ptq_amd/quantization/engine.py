@@ -36,6 +36,46 @@ from .quantizer import AdaRoundQuantizer, from_rows, to_rows
 UNIT_KINDS = ("layer", "rb", "rbws", "rbu", "rstb")
 
 
+class IdxStream:
+    """Mini-batch index tables drawn from torch's GLOBAL CPU generator exactly as the reference draws them -- one `torch.randperm(n)` per
+    iteration (layer_opt.py:289) -- with the NEXT unit's table drawn ahead of time while the GPU runs the current unit's loop (20 000
+    draws of randperm(256) cost the host ~0.1 s per unit, 2 % of the full schedule, with the GPU idle).
+
+    Exactness: the look-ahead works on a PRIVATE generator started from a copy of the global generator's state; it is adopted only if the
+    next request asks for the same (n, B, iters) AND the global generator's state is still that copy (nobody drew from it or re-seeded it in
+    between) -- the global generator is then moved to the private generator's final state, i.e. exactly where the draws would have left
+    it.  Anything else discards the look-ahead and draws from the global generator as before."""
+    _spec = None
+
+    @classmethod
+    def begin(cls, n, B, iters):
+        g = torch.Generator()
+        state0 = torch.get_rng_state()
+        g.set_state(state0)
+        cls._spec = dict(key=(int(n), int(B), int(iters)), state0=state0, gen=g, rows=[])
+
+    @classmethod
+    def step(cls, k):
+        """draw up to k more rows of the look-ahead (called between the enqueues of `UnitEngine.run`)"""
+        sp = cls._spec
+        if sp is None:
+            return
+        n, B, iters = sp["key"]
+        k = min(int(k), iters - len(sp["rows"]))
+        g = sp["gen"]
+        sp["rows"].extend(torch.randperm(n, generator=g)[:B] for _ in range(k))
+
+    @classmethod
+    def take(cls, n, B, iters):
+        sp, cls._spec = cls._spec, None
+        if sp is not None and sp["key"] == (int(n), int(B), int(iters)) and torch.equal(torch.get_rng_state(), sp["state0"]):
+            g = sp["gen"]
+            sp["rows"].extend(torch.randperm(n, generator=g)[:B] for _ in range(iters - len(sp["rows"])))
+            torch.set_rng_state(g.get_state())
+            return torch.stack(sp["rows"])
+        return torch.stack([torch.randperm(n)[:B] for _ in range(iters)])
+
+
 class _Op:
     """Device state of one trainable QuantModule inside a unit."""
 
@@ -222,7 +262,7 @@ class UnitEngine:
             self.B = n
         if idx_table is None:
             # same CPU-generator stream as the reference: one torch.randperm(n) per iteration (layer_opt.py:289)
-            idx_table = torch.stack([torch.randperm(n)[:self.B] for _ in range(self.iters)])
+            idx_table = IdxStream.take(n, self.B, self.iters)
         idx_table = torch.as_tensor(idx_table).to(torch.int32)
         if tuple(idx_table.shape) != (self.iters, self.B):
             raise ValueError(f"idx_table must be [{self.iters},{self.B}], got {tuple(idx_table.shape)}")
@@ -1048,8 +1088,10 @@ class UnitEngine:
                 self._after_step()
 
     # ------------------------------------------------------------------------------------------------------------------
-    def run(self, n_iters=None):
-        """Enqueue `n_iters` (default: all remaining) calibration iterations on the current stream.  Units on H2 planes read their
+    def run(self, n_iters=None, idle=None):
+        """Enqueue `n_iters` (default: all remaining) calibration iterations on the current stream; `idle()` (optional) is called after
+        every enqueued piece, in front of the next poll -- host work that overlaps the GPU's (recon.py draws the next unit's mini-batch
+        indices there).  Units on H2 planes read their
         overflow word every `H2_POLL` iterations of a long call (a 4-byte read; calls of at most H2_POLL iterations stay fully
         asynchronous, the word is then read by `logs` / `finish`) and restart themselves when it is set (`_recover`)."""
         done = self._done
@@ -1062,6 +1104,8 @@ class UnitEngine:
                 k = target - self._done
                 if self.P and self.H2_POLL > 0:
                     k = min(k, self.H2_POLL)
+                if not (self.P and self.H2_POLL > 0) and idle is not None:
+                    k = min(k, max(64, (target - done) // 16))      # no poll points: still enqueue in pieces so that `idle` gets its turns
                 if self.plan_rd is not None:
                     self._run_rd(k)
                 elif not self.split:
@@ -1069,6 +1113,8 @@ class UnitEngine:
                 else:
                     self._run_dp(k)
                 self._done += k
+                if idle is not None:
+                    idle()                                      # host work while the GPU has the enqueued iterations to do
                 if self._done < target and self._overflowed():
                     self._recover()                  # back to iteration 0 with new scales / on fp32 activations
         return n

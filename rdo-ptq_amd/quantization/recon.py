@@ -194,7 +194,12 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     else:
         eng = UnitEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), **common)
     t2 = _mark()
-    eng.run()
+    # the next unit's index table is drawn while this unit's loop runs on the GPU (engine.IdxStream: adopted only if the next request
+    # matches and nobody touched the CPU generator in between)
+    from .engine import IdxStream
+    IdxStream.begin(eng.cq.shape[0], eng.B, eng.iters)
+    per_turn = max(256, eng.iters // 12)
+    eng.run(idle=lambda: IdxStream.step(per_turn))
     t3 = _mark()
     if timing is not None:
         timing.append(dict(unit=unit_name, kind=kind, cache_s=t1 - t0, record_s=t2 - t1, loop_s=t3 - t2))

@@ -153,3 +153,43 @@ def test_tuning_switches_round_trip():
     assert h.rdo_set_tuning(b"x6p_ablate", 7) != 0 and h.rdo_get_tuning(b"x6p_ablate") == 0
     assert h.rdo_set_tuning(b"wgrad_x6_w8", 0) != 0 and h.rdo_set_tuning(b"fwd_x6_ver", 3) != 0
     assert h.rdo_set_tuning(b"no_such_key", 1) != 0 and h.rdo_get_tuning(b"no_such_key") == -1
+
+
+def test_index_stream_look_ahead_is_the_reference_stream():
+    """engine.IdxStream: the next unit's mini-batch index table drawn ahead on a private generator is adopted only when it IS what the
+    global CPU generator would have produced (layer_opt.py:289: one torch.randperm(n) per iteration) -- same table, same generator state
+    afterwards; a different request or a touched generator discards it."""
+    import torch
+    from quantization.engine import IdxStream
+    n, B, iters = 37, 4, 200
+    direct = lambda: torch.stack([torch.randperm(n)[:B] for _ in range(iters)])
+    torch.manual_seed(123)
+    want1, want2 = direct(), direct()
+    after = torch.get_rng_state()
+    # look-ahead adopted
+    torch.manual_seed(123)
+    got1 = IdxStream.take(n, B, iters)                      # nothing pending: drawn from the global generator
+    IdxStream.begin(n, B, iters)
+    IdxStream.step(50); IdxStream.step(70)                  # partial look-ahead: take() completes it
+    got2 = IdxStream.take(n, B, iters)
+    assert torch.equal(got1, want1) and torch.equal(got2, want2) and torch.equal(torch.get_rng_state(), after)
+    # the generator was used in between: discarded, the stream continues from where the generator really is
+    torch.manual_seed(123)
+    IdxStream.take(n, B, iters)
+    IdxStream.begin(n, B, iters)
+    IdxStream.step(iters)
+    extra = torch.rand(3)
+    ref = direct()
+    torch.manual_seed(123)
+    direct(); torch.rand(3)
+    assert torch.equal(direct(), ref)
+    torch.manual_seed(123)
+    IdxStream.take(n, B, iters); IdxStream.begin(n, B, iters); IdxStream.step(iters); torch.rand(3)
+    assert torch.equal(IdxStream.take(n, B, iters), ref)
+    # a different request: discarded
+    torch.manual_seed(5)
+    IdxStream.begin(n, B, iters); IdxStream.step(10)
+    got = IdxStream.take(n + 1, B, iters)
+    torch.manual_seed(5)
+    assert torch.equal(got, torch.stack([torch.randperm(n + 1)[:B] for _ in range(iters)]))
+    assert IdxStream._spec is None
