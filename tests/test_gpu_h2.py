@@ -392,6 +392,30 @@ def test_wgrad_h2_row_kernel_equals_per_tap_kernel(ops, B, H, W, Cin, Cout):
     assert torch.equal(got[0], got[1])
 
 
+@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, 192, 192), (1, 32, 64, 64, 48), (3, 16, 32, 320, 192), (2, 96, 64, 256, 160)])
+def test_wgrad_h2_row_kernel_stage_variants_give_the_same_slabs(ops, B, H, W, Cin, Cout, variant):
+    """The row kernel's other stage shapes (tuning key wgrad_sub: 2 = two 32-pixel segments per barrier -- odd segment counts multiply zeros
+    for the missing one --, 3 = ring of three, waves 4-7 issue their DMAs at the end of the stage) walk the same pixels in the same order per
+    output element as the shipped one (1): the same bits."""
+    g = torch.Generator(device="cuda").manual_seed(H + W + Cout + 1)
+    x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
+    dy = torch.randn(B, H, W, Cout, device="cuda", generator=g) * 0.1
+    wshape = (Cout, 3, 3, Cin)
+    if not ops.wgrad_h2_supported(tuple(x.shape), wshape, 1, 1):
+        pytest.skip("shape not on the plane path")
+    xp, dyp = ops.split_h2(x), ops.split_h2(dy)
+    got = {}
+    saved = ops.set_tuning("wgrad_sub", 1)
+    try:
+        for v in (1, variant):
+            ops.set_tuning("wgrad_sub", v)
+            got[v] = ops.conv2d_wgrad_h2(xp, tuple(x.shape), dyp, wshape, 1, 1)
+    finally:
+        ops.set_tuning("wgrad_sub", saved)
+    assert torch.equal(got[1], got[variant])
+
+
 @pytest.mark.parametrize("B,H,Cin,Cout,K,s,p,x6", [(4, 64, N, N, 3, 1, 1, True), (4, 32, N, N, 3, 1, 1, True), (4, 16, N, N, 3, 1, 1, False),
                                                    (4, 16, 320, N, 5, 2, 2, False), (4, 32, N, N, 3, 2, 1, False)])
 @pytest.mark.parametrize("act", [0, 1])
