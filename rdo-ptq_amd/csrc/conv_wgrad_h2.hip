@@ -52,7 +52,7 @@ struct WgPArgs {
 #ifdef RDO_DIAG
 #define WG_ABL(bit) (a.ablate & (bit))
 __device__ unsigned long long g_wg_stamps[256 * 4];
-__device__ unsigned long long g_wg_phase[256 * 2 * 8];      // [workgroup][wave 0 / wave 4][phase]: cycles summed over the stages (ablate bit 64)
+__device__ unsigned long long g_wg_phase[256 * 8 * 8];      // [workgroup][wave][phase]: cycles summed over the stages (ablate bit 64)
 #else
 #define WG_ABL(bit) false
 #endif
@@ -290,7 +290,7 @@ constexpr int STAGE3B = OPB + NP * XPLANEB;    // 24 + 10 = 34 KiB
 // the stage, waves 4-7 a third into their MFMAs, and waves 0-3 then idled ~650 cycles per stage at the barrier.  <1, 3, 8>: waves 4-7
 // issue at the END of the stage -- for stage s + 2, a ring of three, counted vmcnt(5) -- so that each half multiplies while the other
 // issues.
-template <int SUB, int RING3, int LSLOT>
+template <int SUB, int RING3, int LSLOT, int PF = 0>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     constexpr int T = 192;
     constexpr int TM = 3, TN = 6;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     int t = lid - chunk * gridDim.y;
     const int cib = t % a.tiles_ci; t /= a.tiles_ci;                     // tiles_ci = Cin / 64 here
     const int tco = t % a.tiles_co; t /= a.tiles_co;
-    const int kh = t;
+    const int kh = __builtin_amdgcn_readfirstlane(t);                   // (the divisions above run on the vector unit: tell the compiler it is uniform)
     const int co0 = tco * T, ci0 = cib * 64;
 
     // stages = 32-pixel segments of output rows; this chunk owns segments [sbeg, send)
@@ -323,64 +323,73 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     const int nsegs = send > sbeg ? send - sbeg : 0;
     const int nsteps = (nsegs + SUB - 1) / SUB;                          // a short last stage multiplies zeros for its missing segment
 
-    const u16* const zero = reinterpret_cast<const u16*>(g_zero_page_w);
-    const int prow8 = lane >> 3, cpos = lane & 7;
+    // DMA lane roles: 16-channel slice (lane >> 4) of the piece's 64 channels, pixel ((lane >> 1) & 7) of its eight, half slice (lane & 1).
+    // Sixteen consecutive lanes read 256 contiguous bytes of one slice: the texture addresser takes such a piece in 16 cycles, against 32
+    // for the pixel-major roles of round 3 whose lane quads straddled two slices (tools/micro/dma_rate.hip).  The LDS image of a piece is
+    // therefore [slice][pixel][32 B]; a transposed fragment read covers 2 x 256 contiguous bytes, so no swizzle is needed.
+    const int prow8 = (lane >> 1) & 7, dsl = lane >> 4, dhalf = lane & 1;
+    // The pieces go through buffer descriptors (`buffer_load_dwordx4 ... lds`): a lane whose offset fails the descriptor's range check
+    // writes ZEROS to LDS (tools/micro/buf_lds.hip), which is the padding -- no zero-page pointer select per lane -- and the per-stage
+    // part of an address is one scalar offset.  A piece costs a v_cndmask (where lanes can be padding), an M0 write and the load.
     // dY pieces of this wave: k = wave + 8 j of the 24 [plane][sub-tile][8-row group] pieces
     constexpr int XP = NP * 5;                                          // X pieces (dY: 24 = three per wave)
-    int yoff[3];
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    constexpr int RSRC3 = 0x00020000;                                   // raw buffer, 32-bit data format
+    typedef __attribute__((address_space(3))) void lds_void;
+    const unsigned ybytes = (unsigned)(a.yplane * 2), xbytes = (unsigned)(a.xplane * 2);
+    __amdgpu_buffer_rsrc_t ry[3], rx[2];
+    unsigned yvoff[3], xvoff[2];
+    int ydst[3], xdst[2];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
         const int k = wave + 8 * j;
         const int plane = k / 12, sub = (k % 12) >> 2, rg = k & 3;
         const int row = 8 * rg + prow8;
-        const int ch = co0 + 64 * sub + 8 * (cpos ^ (2 * ((row >> 1) & 3)));
-        yoff[j] = ch < a.Cout ? (int)(plane * a.yplane) + ((ch >> 4) * a.M + row) * 16 + (ch & 15) : -1;
+        const int ch = co0 + 64 * sub + 16 * dsl + 8 * dhalf;
+        ry[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.yp + plane * a.yplane), 0, ybytes, RSRC3);
+        yvoff[j] = ch < a.Cout ? (unsigned)(((ch >> 4) * a.M + row) * 16 + (ch & 15)) * 2u : OOB;
+        ydst[j] = plane * PLANEB + sub * SUBB + rg * 1024;
     }
-    // X pieces: k = wave + 8 j of the 10 [plane][8-row group] pieces; row r of the image is input pixel wo0 - 1 + r
-    int xoff[2], xrow[2];
-    int xk[2];
+    // X pieces: k = wave + 8 j of the 10 [plane][8-row group] pieces; row r of the image is input pixel wo0 - 1 + r.  The descriptor
+    // starts one pixel BEFORE the plane so that the stage offset (pixel of row 1) is never negative; the lanes of a row left of the image
+    // are padding and never touch that pixel.
+    int xedge[2];                                                       // bit 0: left-most image row, bit 1: right-most, bit 2: always
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int k = wave + 8 * j < XP ? wave + 8 * j : wave;           // (waves 2-7 repeat their one piece: five DMAs per wave and stage)
-        xk[j] = k;
         const int plane = k / 5, rg = k - plane * 5;
         const int row = 8 * rg + prow8;
-        const int ch = ci0 + 8 * (cpos ^ (2 * ((row >> 1) & 3)));
-        xrow[j] = row;
-        xoff[j] = row < PK + 2 ? (int)(plane * a.xplane) + (ch >> 4) * a.Min * 16 + (ch & 15) : -1;
+        const int ch = ci0 + 16 * dsl + 8 * dhalf;
+        rx[j] = __builtin_amdgcn_make_buffer_rsrc((void*)(a.xp + plane * a.xplane - 16), 0, xbytes + 32u, RSRC3);
+        xvoff[j] = row < PK + 2 ? (unsigned)(((ch >> 4) * a.Min + row) * 16 + (ch & 15)) * 2u : OOB;
+        xedge[j] = (row == 0 ? 1 : 0) | (row == PK + 1 ? 2 : 0) | 4;
+        xdst[j] = OPB + plane * XPLANEB + rg * 1024;
     }
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
-    // segment cursor (image, output row, 32-pixel segment of the row), advanced by increments: the three integer divisions per stage
-    // were a measurable part of the loop skeleton
+    // Segment cursor.  Rows are whole segments (Wo % 32 == 0, Wo == W, Ho == H), so the first output pixel of segment `seg` is 32 seg and
+    // both stage offsets are LINEAR in it: dY at pixel 32 seg, X (image row 1) at pixel 32 seg + (kh - 1) W.  Only the padding needs the
+    // position inside the image: a segment counter per row (left / right edge) and a row counter per image (top / bottom edge for kh 0 / 2).
+    // (Phase stamps, tools/wgrad_phases.py: ~60 scalar instructions of cursor and address arithmetic per stage cost every wave ~260 cycles
+    // at the top of the stage, when nobody multiplies.)
     int seg = sbeg;
-    int cb = sbeg / (a.Ho * segs_row);
-    int cho = (sbeg - cb * (a.Ho * segs_row)) / segs_row;
-    int cws = sbeg - (cb * a.Ho + cho) * segs_row;
+    int cho = (sbeg / segs_row) % a.Ho;
+    int cws = sbeg % segs_row;
+    unsigned ysoff = (unsigned)sbeg * (PK * 32u);
+    unsigned xsoff = (unsigned)(sbeg * PK + (kh - 1) * a.W) * 32u;         // (wraps below zero only where every lane is padding)
+    const int row_bad = kh == 0 ? 0 : kh == 2 ? a.Ho - 1 : -1;            // the output row whose input row hi = ho + kh - 1 is outside
     auto dma_seg = [&](char* const dst) {
-        const int b = cb, ho = cho, wo0 = cws * PK;
         const bool live = seg < send;                                    // beyond the chunk: zeros (the stage's MFMAs add nothing)
-        ++seg;
-        if (++cws == segs_row) { cws = 0; if (++cho == a.Ho) { cho = 0; ++cb; } }
+        const int emask = (cws == 0 ? 1 : 0) | (cws == segs_row - 1 ? 2 : 0) | ((!live || cho == row_bad) ? 4 : 0);   // padding of this stage
+        const unsigned ys = ysoff, xs = xsoff;
+        ++seg; ysoff += PK * 32u; xsoff += PK * 32u;
+        if (++cws == segs_row) { cws = 0; if (++cho == a.Ho) cho = 0; }
         if (WG_ABL(1)) return;
-        const int m0 = (b * a.Ho + ho) * a.Wo + wo0;
-        const int hi = ho + kh - 1;
-        const bool rowok = live && (unsigned)hi < (unsigned)a.H;
-        const int xbase = (b * a.H + hi) * a.W + wo0 - 1;
 #pragma unroll
-        for (int j = 0; j < 3; ++j) {
-            const int k = wave + 8 * j;                                  // 24 pieces: three per wave
-            const u16* src = (yoff[j] >= 0 && live) ? a.yp + yoff[j] + (long)m0 * 16 : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + (k / 12) * PLANEB + ((k % 12) >> 2) * SUBB + (k & 3) * 1024), 16, 0, 0);
-        }
+        for (int j = 0; j < 3; ++j)                                      // 24 pieces: three per wave
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(ry[j], (lds_void*)(dst + ydst[j]), 16, live ? yvoff[j] : OOB, ys, 0, 0);
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int k = xk[j];
             if (RING3 == 2 && wave + 8 * j >= XP) break;                 // (no counted wait: the repeated piece is not needed)
-            const int wi = wo0 - 1 + xrow[j];
-            const bool ok = xoff[j] >= 0 && rowok && (unsigned)wi < (unsigned)a.W;
-            const u16* src = ok ? a.xp + xoff[j] + (long)(xbase + xrow[j]) * 16 : zero;
-            __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)(dst + OPB + (k / 5) * XPLANEB + (k % 5) * 1024), 16, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rx[j], (lds_void*)(dst + xdst[j]), 16, (xedge[j] & emask) ? OOB : xvoff[j], xs, 0, 0);
         }
     };
     auto dma_stage = [&](int buf) {
@@ -398,21 +407,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     const int fr = 4 * lc + ((lane >> 2) & 3);
     const int p4 = lane & 3;
     int fa_off[TM], fb_off[TN];
-    {
-        const int fsw = 2 * ((fr >> 1) & 3);
 #pragma unroll
-        for (int i = 0; i < TM; ++i) {
-            const int c = wco0 + 16 * i;
-            const int chunkpos = (2 * ((c & 63) >> 4) + (p4 >> 1)) ^ fsw;
-            fa_off[i] = (c >> 6) * SUBB + fr * 128 + chunkpos * 16 + (p4 & 1) * 8;
-        }
+    for (int i = 0; i < TM; ++i) {
+        const int c = wco0 + 16 * i;
+        fa_off[i] = (c >> 6) * SUBB + (fr >> 3) * 1024 + ((c & 63) >> 4) * 256 + (fr & 7) * 32 + p4 * 8;
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int jt = 6 * (wave & 1) + j;
         const int row = fr + (jt >> 2);                                  // tap kw: input pixel = output pixel + kw - 1 = image row + kw
-        const int chunkpos = (2 * (jt & 3) + (p4 >> 1)) ^ (2 * ((row >> 1) & 3));
-        fb_off[j] = OPB + row * 128 + chunkpos * 16 + (p4 & 1) * 8;
+        fb_off[j] = OPB + (row >> 3) * 1024 + (jt & 3) * 256 + (row & 7) * 32 + p4 * 8;
     }
 
     constexpr int PA[3] = {1, 0, 0};             // (dy2, x1) (dy1, x2) (dy1, x1): small terms first
@@ -427,6 +431,113 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
 #pragma unroll
         for (int r = 0; r < RING3 - 1; ++r) dma_stage(r);
     }
+    if constexpr (PF != 0) {
+        // PF: the fragments of a stage's FIRST third (A: 6 register sets, B: 4) are read one stage ahead, during the previous stage's last
+        // third, so that MFMAs start right behind the barrier instead of ~500 cycles of read issue and latency later (phase stamps: the
+        // MFMA pipe idled from the barrier until the late waves' first fragments arrived, ~750 of ~3000 cycles).  Needs a ring of three:
+        // buffer s + 1 is read in stage s while DMA(s + 2) lands in the third.  The B register set of third T3 alternates with the stage
+        // parity, (T3 + P) & 1, so the look-ahead always targets the set the running third does not use.
+        static_assert(SUB == 1 && RING3 == 3, "look-ahead variant: one segment per stage, ring of three");
+        f16x8 fa[2][NP][TM], fb[2][NP][2];
+        auto rd_a = [&](auto pc, const char* st) {
+            constexpr int P = decltype(pc)::value;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int i = 0; i < TM; ++i) fa[P][p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
+        };
+        auto rd_b = [&](auto setc, const char* st, int third) {
+            constexpr int S = decltype(setc)::value;
+#pragma unroll
+            for (int p = 0; p < NP; ++p)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[S][p][j] = tr_pair(st + p * XPLANEB + fb_off[2 * third + j]);
+        };
+#ifdef RDO_DIAG
+        const unsigned long long st_c0 = clock64(), st_r0 = wall_clock64();
+#endif
+        if (nsteps > 0) {
+            asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                // stage 0 has landed (five DMAs per wave and stage)
+            __builtin_amdgcn_s_barrier();
+            rd_a(std::integral_constant<int, 0>{}, smem);
+            rd_b(std::integral_constant<int, 0>{}, smem, 0);
+        }
+        auto stage = [&](auto pc, const int s, const int buf) {
+            constexpr int P = decltype(pc)::value;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                // my DMAs of stage s + 1 have landed ...
+            __builtin_amdgcn_s_barrier();                                    // ... everybody's have, and nobody reads buffer (s - 1) % 3 any more
+            const int nb = buf >= 1 ? buf - 1 : 2;                           // (s + 2) % 3
+            const int nx = buf == 2 ? 0 : buf + 1;                           // (s + 1) % 3
+            const bool more = s + 2 < nsteps, ahead = s + 1 < nsteps;
+            if (more && !late) dma_stage(nb);
+            const char* st = smem + buf * SLOTB;
+            const char* sn = smem + nx * SLOTB;
+            [&]<int... SL>(std::integer_sequence<int, SL...>) {
+                (([&] {
+                     constexpr int T3 = SL / 3, Q = SL % 3, SET = (T3 + P) & 1;
+                     using NS = std::integral_constant<int, SET ^ 1>;
+                     if constexpr (Q == 0) {
+                         tr_wait();                                          // this third's fragments are there
+                         if constexpr (PF == 1) {
+                             if constexpr (T3 < 2) rd_b(NS{}, st, T3 + 1);
+                             else if (ahead) { rd_a(std::integral_constant<int, P ^ 1>{}, sn); rd_b(NS{}, sn, 0); }
+                         }
+                     }
+                     if constexpr (PF == 1) {
+#pragma unroll
+                         for (int i = 0; i < TM; ++i)
+#pragma unroll
+                             for (int j = 0; j < 2; ++j)
+                                 acc[i][2 * T3 + j] =
+                                     __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[P][PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                     } else {
+                         // PF == 2: the reads of the next third (4 pairs) / of the next stage's first third (10 pairs) go out one pair
+                         // behind each of this third's first MFMAs, in the shadow of the 16-cycle MFMA, instead of in a block in front.
+                         // (In the last stage the look-ahead reads whatever the next ring slot holds; nobody uses it.)
+                         [&]<int... U>(std::integer_sequence<int, U...>) {
+                             (([&] {
+                                  constexpr int i = U / 2, j = U % 2, K = Q * 6 + U;
+                                  acc[i][2 * T3 + j] =
+                                      __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[P][PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                                  if constexpr (T3 < 2) {
+                                      if constexpr (K < 4) fb[SET ^ 1][K / 2][K % 2] = tr_pair(st + (K / 2) * XPLANEB + fb_off[2 * (T3 + 1) + K % 2]);
+                                  } else {
+                                      if constexpr (K < 6) fa[P ^ 1][K / 3][K % 3] = tr_pair(sn + (K / 3) * PLANEB + fa_off[K % 3]);
+                                      else if constexpr (K < 10) fb[SET ^ 1][(K - 6) / 2][(K - 6) % 2] = tr_pair(sn + ((K - 6) / 2) * XPLANEB + fb_off[(K - 6) % 2]);
+                                  }
+                                  __builtin_amdgcn_sched_barrier(0);
+                              }()),
+                              ...);
+                         }
+                         (std::make_integer_sequence<int, 6>{});
+                     }
+                     __builtin_amdgcn_sched_barrier(0);
+                     if constexpr (SL == LSLOT) {
+                         if (more && late) dma_stage(nb);
+                     }
+                     __builtin_amdgcn_sched_barrier(0);
+                 }()),
+                 ...);
+            }
+            (std::make_integer_sequence<int, 9>{});
+        };
+        int buf = 0;
+        for (int s = 0; s < nsteps; s += 2) {
+            stage(std::integral_constant<int, 0>{}, s, buf);
+            buf = buf == 2 ? 0 : buf + 1;
+            if (s + 1 < nsteps) {
+                stage(std::integral_constant<int, 1>{}, s + 1, buf);
+                buf = buf == 2 ? 0 : buf + 1;
+            }
+        }
+        tr_wait();
+#ifdef RDO_DIAG
+        if (tid == 0 && lin < 256) {
+            g_wg_stamps[lin * 4 + 0] = clock64() - st_c0; g_wg_stamps[lin * 4 + 1] = wall_clock64() - st_r0;
+            g_wg_stamps[lin * 4 + 2] = (unsigned long long)nsteps; g_wg_stamps[lin * 4 + 3] = 0;
+        }
+#endif
+    } else {
     f16x8 fa[NP][TM], fb[2][NP][2];
     auto read_b = [&](auto setc, const char* st, int third) {
         constexpr int S = decltype(setc)::value;
@@ -523,15 +634,16 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
         }
         buf = buf + 1 == RING3 ? 0 : buf + 1;
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the clamped tail DMAs still target this workgroup's LDS
 #ifdef RDO_DIAG
     if (tid == 0 && lin < 256) {       // shader-clock cycles and 100 MHz wall ticks of the K loop, stage count in the low bits of slot 1
         g_wg_stamps[lin * 4 + 0] = clock64() - st_c0; g_wg_stamps[lin * 4 + 1] = wall_clock64() - st_r0;
         g_wg_stamps[lin * 4 + 2] = (unsigned long long)(nsteps * SUB); g_wg_stamps[lin * 4 + 3] = 0;
     }
-    if (phase_on && lane == 0 && (wave == 0 || wave == 4) && lin < 256)
-        for (int k = 0; k < 6; ++k) g_wg_phase[(lin * 2 + (wave >> 2)) * 8 + k] = ph[k];
+    if (phase_on && lane == 0 && lin < 256)
+        for (int k = 0; k < 6; ++k) g_wg_phase[(lin * 8 + wave) * 8 + k] = ph[k];
 #endif
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // the clamped tail DMAs still target this workgroup's LDS
 
     const long wsize = (long)a.Cout * 9 * a.Cin;
     float* slab = a.slabs + (long)chunk * wsize;
@@ -600,31 +712,40 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
         const int variant = rdo::tuning(rdo::T_WGRAD_SUB);
         return rdo::dispatch(
             [b, variant](hipStream_t s) {
-                auto go = [&](auto subc, auto ringc, auto slotc) -> int {
-                    constexpr int SUB = decltype(subc)::value, RING = decltype(ringc)::value, LS = decltype(slotc)::value;
+                auto go = [&](auto subc, auto ringc, auto slotc, auto pfc) -> int {
+                    constexpr int SUB = decltype(subc)::value, RING = decltype(ringc)::value, LS = decltype(slotc)::value, PF = decltype(pfc)::value;
                     constexpr size_t lds = (size_t)RING * SUB * STAGE3B;
                     static_assert(lds <= 160 * 1024, "row weight-gradient LDS");
                     static rdo::PerDevice attr;
                     if (!attr.done()) {
-                        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2r_kernel<SUB, RING, LS>),
+                        if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_wgrad_h2r_kernel<SUB, RING, LS, PF>),
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                             return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_wgrad_h2r) failed");
                         attr.mark();
                     }
                     dim3 grid((unsigned)b.nsplit, (unsigned)(3 * b.tiles_co * b.tiles_ci));
-                    hipLaunchKernelGGL((conv_wgrad_h2r_kernel<SUB, RING, LS>), grid, dim3(512), lds, s, b);
+                    hipLaunchKernelGGL((conv_wgrad_h2r_kernel<SUB, RING, LS, PF>), grid, dim3(512), lds, s, b);
                     return rdo::check_launch("conv_wgrad_h2r");
                 };
                 using rdo_i1 = std::integral_constant<int, 1>; using rdo_i2 = std::integral_constant<int, 2>; using rdo_i3 = std::integral_constant<int, 3>;
                 using rdo_i5 = std::integral_constant<int, 5>; using rdo_i8 = std::integral_constant<int, 8>;
+                using rdo_i0 = std::integral_constant<int, 0>;
                 switch (variant) {
-                    case 2: return go(rdo_i2{}, rdo_i2{}, rdo_i2{});
-                    case 3: return go(rdo_i1{}, rdo_i3{}, rdo_i8{});
-                    case 4: return go(rdo_i1{}, rdo_i3{}, rdo_i5{});
-                    case 5: return go(rdo_i1{}, rdo_i2{}, rdo_i5{});
-                    case 6: return go(rdo_i1{}, rdo_i2{}, rdo_i8{});
-                    case 7: return go(rdo_i1{}, rdo_i2{}, std::integral_constant<int, 0>{});
-                    default: return go(rdo_i1{}, rdo_i2{}, rdo_i2{});
+                    case 2: return go(rdo_i2{}, rdo_i2{}, rdo_i2{}, rdo_i0{});
+                    case 3: return go(rdo_i1{}, rdo_i3{}, rdo_i8{}, rdo_i0{});
+                    case 4: return go(rdo_i1{}, rdo_i3{}, rdo_i5{}, rdo_i0{});
+                    case 5: return go(rdo_i1{}, rdo_i2{}, rdo_i5{}, rdo_i0{});
+                    case 6: return go(rdo_i1{}, rdo_i2{}, rdo_i8{}, rdo_i0{});
+                    case 7: return go(rdo_i1{}, rdo_i2{}, rdo_i0{}, rdo_i0{});
+                    case 8: return go(rdo_i1{}, rdo_i3{}, rdo_i5{}, rdo_i1{});
+                    case 9: return go(rdo_i1{}, rdo_i3{}, rdo_i2{}, rdo_i1{});
+                    case 10: return go(rdo_i1{}, rdo_i3{}, rdo_i8{}, rdo_i1{});
+                    case 11: return go(rdo_i1{}, rdo_i3{}, rdo_i0{}, rdo_i1{});
+                    case 12: return go(rdo_i1{}, rdo_i3{}, rdo_i3{}, rdo_i1{});
+                    case 13: return go(rdo_i1{}, rdo_i3{}, rdo_i2{}, rdo_i2{});
+                    case 14: return go(rdo_i1{}, rdo_i3{}, rdo_i5{}, rdo_i2{});
+                    case 15: return go(rdo_i1{}, rdo_i3{}, rdo_i0{}, rdo_i2{});
+                    default: return go(rdo_i1{}, rdo_i2{}, rdo_i2{}, rdo_i0{});
                 }
             },
             stream, "conv_wgrad_h2_rows", flops, bytes);
@@ -649,7 +770,7 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
 #ifdef RDO_DIAG
 // diagnostic build only: per workgroup {K-loop cycles, K-loop 100 MHz ticks, stages, 0} of the last row-kernel launch (tools/h2_stamps.py)
 extern "C" int rdo_diag_wgrad_phases(unsigned long long* out, int n) {
-    if (!out || n <= 0 || n > 256 * 2 * 8) return RDO_EINVAL;
+    if (!out || n <= 0 || n > 256 * 8 * 8) return RDO_EINVAL;
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_wg_phase), (size_t)n * sizeof(unsigned long long)) == hipSuccess ? RDO_OK : RDO_EHIP;
 }
 extern "C" int rdo_diag_wgrad_stamps(unsigned long long* out, int n) {

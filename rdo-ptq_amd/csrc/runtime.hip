@@ -31,7 +31,7 @@ constexpr TuneDef kTune[T_COUNT] = {{"wgrad_x6_w8", "RDO_WGX6_W8", 1}, {"conv_x6
                                     {"tail_grid", "RDO_TAIL_GRID", 1024}, {"x6p_halo", "RDO_X6P_HALO", 1},
                                     {"wgrad_p3_row", "RDO_WGRAD_P3_ROW", 1}, {"thin_mfma", "RDO_THIN_MFMA", 1},
                                     {"h2_stagger", "RDO_H2_STAGGER", 1}, {"ada_w1_min", "RDO_ADA_W1_MIN", 128},
-                                    {"h2_k32", "RDO_H2_K32", 3}, {"wgrad_sub", "RDO_WGRAD_SUB", 1}, {"h2_n48", "RDO_H2_N48", 1}};
+                                    {"h2_k32", "RDO_H2_K32", 3}, {"wgrad_sub", "RDO_WGRAD_SUB", 13}, {"h2_n48", "RDO_H2_N48", 1}};
 std::atomic<int> g_tune[T_COUNT];
 std::once_flag g_tune_once;
 void tune_init() {

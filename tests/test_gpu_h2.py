@@ -392,12 +392,13 @@ def test_wgrad_h2_row_kernel_equals_per_tap_kernel(ops, B, H, W, Cin, Cout):
     assert torch.equal(got[0], got[1])
 
 
-@pytest.mark.parametrize("variant", [2, 3])
+@pytest.mark.parametrize("variant", [2, 3, 9, 13])
 @pytest.mark.parametrize("B,H,W,Cin,Cout", [(4, 128, 128, 192, 192), (1, 32, 64, 64, 48), (3, 16, 32, 320, 192), (2, 96, 64, 256, 160)])
 def test_wgrad_h2_row_kernel_stage_variants_give_the_same_slabs(ops, B, H, W, Cin, Cout, variant):
-    """The row kernel's other stage shapes (tuning key wgrad_sub: 2 = two 32-pixel segments per barrier -- odd segment counts multiply zeros
-    for the missing one --, 3 = ring of three, waves 4-7 issue their DMAs at the end of the stage) walk the same pixels in the same order per
-    output element as the shipped one (1): the same bits."""
+    """The row kernel's stage shapes (tuning key wgrad_sub: 1 = one 32-pixel segment per barrier, ring of two -- the round-3 loop --, 2 = two
+    segments per barrier -- odd segment counts multiply zeros for the missing one --, 3 = ring of three, waves 4-7 issue their DMAs at the end
+    of the stage, 9 = ring of three with the next stage's first fragments read one stage ahead, 13 = the same with the reads interleaved
+    into the MFMAs -- the shipped one) walk the same pixels in the same order per output element: the same bits."""
     g = torch.Generator(device="cuda").manual_seed(H + W + Cout + 1)
     x = torch.randn(B, H, W, Cin, device="cuda", generator=g)
     dy = torch.randn(B, H, W, Cout, device="cuda", generator=g) * 0.1
