@@ -9,10 +9,11 @@
 //     (1.90 GHz in the K loop of the 16-channel kernel);
 //   * A = weights (rows = output channels), B = activations (columns = pixels): a lane's four accumulator values are four consecutive
 //     CHANNELS of one pixel, so the accumulators go to the epilogue's staging tile as 16-byte stores (the 32 x 32 form: 4-byte stores).
-// LDS images, both [row][64 bytes] per plane with row = halo pixel q (activations) or output channel (weights) and the four 16-byte
-// chunks of a row = the four k-groups of the MFMA (8 input channels each; k-groups 0, 1 = first slice, 2, 3 = second slice), stored at
-// chunk position g ^ (2 * ((row >> 2) & 1)): every ds_read_b128 of a fragment -- 16 consecutive rows x 4 k-groups, any start row --
-// touches all 64 banks once.  The swizzle sits on the per-lane SOURCE address of the LDS-DMA pieces (1 KiB = 16 rows x 64 bytes).
+// LDS images, per plane [slice of 16 channels][row][32 bytes] with row = halo pixel q (activations: 324 rows per slice) or output channel
+// (weights: blocks of 16 channels, each [slice][16 channels][32 B] = one 1 KiB DMA piece); the k-groups of the MFMA (8 input channels each)
+// are the two halves of a row's 32 bytes in the two slices.  A ds_read_b128 of a fragment -- 16 consecutive rows, any start row, x 4
+// k-groups -- touches all 64 banks once in each of its four lane groups without a swizzle, and sixteen DMA lanes read 256+ contiguous
+// bytes of one slice (a 1 KiB piece in 16 cycles of the texture addresser; the [row][4 k-groups] image of round 3 took 32).
 // LDS: two halo buffers of 42 KiB (slice pair cs and cs + 1), 1 KiB that swallows the DMA pieces beyond the image, the three-deep weight
 // ring of 24 KiB (BN = 192; 8 KiB for BN = 64): 158 KiB / 110 KiB; the epilogue stages 128 x (BN + 4) floats in the same memory.
 // DMA per wave: per stage its weight pieces of stage s + 2 (three for BN = 192, one for BN = 64) and, in taps 0-5, one of its six pieces of
@@ -26,12 +27,9 @@
 namespace {
 
 typedef float f32x4k __attribute__((ext_vector_type(4)));
-__device__ __attribute__((aligned(64))) unsigned g_zero_page_k[16];    // zero-initialised: source of masked DMA lanes
 #ifdef RDO_DIAG
 __device__ unsigned long long g_h2k_stamps[256 * 4];
 #endif
-
-__device__ __forceinline__ int swz(int row) { return ((row >> 2) & 1) << 1; }
 
 // Unit tail on the four finished channels [n, n + 4) of pixel m (v = conv + bias, the pre-activation): v becomes dL/dpre, the return value
 // is sum d^2.  The arithmetic of tail16 (conv_h2_common.h) / loss_act_quad (fused_tail.hip), operation for operation per element.
@@ -90,7 +88,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wrow = wave / WN, wcol = wave - wrow * WN;
-    const int wm0 = wrow * (TP * 16), wn0 = wcol * (TC * 16);
+    const int wn0 = wcol * (TC * 16);
     const int l16 = lane & 15, kg = lane >> 4;
     const TileId tile = xcd_tile_id(a.xcd_mode);
     const int n0 = tile.n * BN;
@@ -100,36 +98,40 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     const int h0 = (prem / pw_n) * PT, w0 = (prem % pw_n) * PT;
     const int pbase = (pb * a.H + h0) * a.W + w0;            // first pixel of the patch
     const long Min = (long)a.B * a.H * a.W;
-    const u16* const zero = reinterpret_cast<const u16*>(g_zero_page_k);
 
-    // ---- halo loader: pieces wave, wave + 8, ... of the [plane][halo pixel][chunk position] image.  The lane's source offset of a
-    // piece is recomputed when the piece is issued (once per stage at most: ~25 vector instructions) -- six such offsets kept in
-    // registers for the whole K loop were what spilled the 256-register budget of the 256 x 192 tile.
-    auto halo_off = [&](int piece) -> int {                  // element offset into a.xp for slice pair 0, or -1: zero page
+    // ---- LDS-DMA through buffer descriptors (`buffer_load_dwordx4 ... lds`): a lane whose offset fails the range check writes ZEROS,
+    // which is the padding around the image (tools/micro/buf_lds.hip); the per-stage part of an address is a scalar offset.
+    constexpr unsigned OOB = 0xFFFFFFFFu;
+    constexpr int RSRC3 = 0x00020000;                        // raw buffer, 32-bit data format
+    __amdgpu_buffer_rsrc_t rsrc[2];                          // [0] activations, [1] weights
+    rsrc[0] = __builtin_amdgcn_make_buffer_rsrc((void*)a.xp, 0, (unsigned)(a.xplane * 4), RSRC3);   // both planes
+    rsrc[1] = __builtin_amdgcn_make_buffer_rsrc((void*)a.wp, 0, (unsigned)(a.wplane * 4), RSRC3);
+    // ---- halo loader: pieces wave, wave + 8, ... of the [plane][slice][halo pixel][32 B] image: lane e of the image is 16 bytes (half a
+    // slice record) of halo pixel (e % 648) / 2 of block e / 648.  Consecutive lanes walk a halo row (18 pixels = 576 contiguous bytes
+    // of the source): the texture addresser takes such a piece in 16 cycles against 32 for the [pixel][4 k-groups] image of round 3,
+    // whose lane quads straddled the two slices (tools/micro/dma_rate.hip).  The lane's offset of a piece is recomputed when the piece
+    // is issued (once per stage at most: ~20 vector instructions) -- six such offsets kept in registers for the whole K loop were what
+    // spilled the 256-register budget of the 256 x 192 tile.
+    auto halo_off = [&](int piece) -> unsigned {             // byte offset into a.xp for slice pair 0, or OOB: padding
         const int e = piece * 64 + lane;
-        const int pl = e >= HPIX * 4 ? 1 : 0;
-        const int r = e - pl * (HPIX * 4);
-        const int q = r >> 2;
-        const int g = (r & 3) ^ swz(q);                      // k-group that belongs at chunk position r & 3 of row q
+        const int blk = (e * 6473) >> 22;                    // e / 648 for e < 3 072
+        const int r = e - blk * (HPIX * 2);
+        const int q = r >> 1;
         const int hr = (q * 3641) >> 16;                     // q / 18 for q < 1 296
         const int hc = q - hr * HWD;
         const int hi = h0 - 1 + hr, wi = w0 - 1 + hc;
         const bool ok = e < ACHUNKS && (unsigned)hi < (unsigned)a.H && (unsigned)wi < (unsigned)a.W;
-        return ok ? (int)(pl * a.xplane) + (int)(((g >> 1) * Min + ((pb * a.H + hi) * a.W + wi)) * 16) + (g & 1) * 8 : -1;
+        const unsigned off = (unsigned)((blk >> 1) * a.xplane + ((blk & 1) * Min + ((pb * a.H + hi) * a.W + wi)) * 16) * 2u + (r & 1) * 16u;
+        return ok ? off : OOB;
     };
-    // ---- weight loader: pieces wave, wave + 8, ... of the [plane][channel][chunk position] image of a stage.  BN * 4 chunks per plane
-    // are BN / 16 whole pieces, so piece k is plane k / (BN / 16), channels 16 (k % (BN / 16)) ...: a wave-uniform part per piece and ONE
-    // per-lane part (channel within the piece, k-group through the swizzle, which depends on the lane only)
-    int dma_lane;
-    {
-        const int row = lane >> 2;                           // channel within the piece; (16 k' + row) >> 2 has the parity of row >> 2
-        const int g = (lane & 3) ^ swz(row);
-        dma_lane = (g >> 1) * 9 * a.Cout * 16 + row * 16 + (g & 1) * 8;
-    }
-    auto dma_uni = [&](int j) -> int {                       // wave-uniform part of piece wave + 8 j (beyond the image: piece 0 again)
+    // ---- weight loader: pieces wave, wave + 8, ... of the [plane][16 channels][slice][channel][32 B] image of a stage: piece k is plane
+    // k / (BN / 16), channels 16 (k % (BN / 16)) ...: a wave-uniform part per piece and ONE per-lane part (slice = lane >> 5: 9 Cout
+    // records further in the fragment-ordered planes; channel (lane >> 1) & 15; half record lane & 1) -- 512 contiguous bytes per slice
+    const unsigned dma_lane = (unsigned)((lane >> 5) * 9 * a.Cout * 16 + ((lane >> 1) & 15) * 16 + (lane & 1) * 8) * 2u;
+    auto dma_uni = [&](int j) -> unsigned {                  // wave-uniform part of piece wave + 8 j (beyond the image: piece 0 again), bytes
         const int k = wave + 8 * j < BPIECES ? wave + 8 * j : 0;
         const int pl = k / (BN / 16), kk = k - pl * (BN / 16);
-        return (int)(pl * a.wplane) + (n0 + kk * 16) * 16;
+        return (unsigned)(pl * a.wplane + (n0 + kk * 16) * 16) * 2u;
     };
 
     f32x4k acc[TC][TP];
@@ -145,33 +147,32 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
     const int nstages = 9 * cpairs;
 
     typedef __attribute__((address_space(3))) void lds_void;
-    typedef const __attribute__((address_space(1))) void glb_void;
     auto dma_a = [&](int j, int cp_next) {                   // piece j of the wave, halo of slice pair cp_next into buffer cp_next & 1
         const int cn = cp0 + (cp_next < cpairs ? cp_next : cpairs - 1);
         const int piece = wave + 8 * j;
-        const int off = halo_off(piece);
-        const u16* src = off >= 0 ? a.xp + off + (long)cn * Min * 32 : zero;
+        const unsigned off = halo_off(piece);
         char* dst = piece < APIECES ? smem + (cp_next & 1) * ABUF + piece * 1024 : smem + ADUMMY;
-        if constexpr (!(ABL & 1)) __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)dst, 16, 0, 0);
+        if constexpr (!(ABL & 1)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc[0], (lds_void*)dst, 16, off, (unsigned)cn * (unsigned)(Min * 64), 0, 0);
     };
-    const u16* wsrc = a.wp;
+    unsigned wsoff = 0;
     auto dma_b = [&](int j, int nb) {
-        if constexpr (!(ABL & 2))
-            __builtin_amdgcn_global_load_lds((glb_void*)(wsrc + dma_uni(j) + dma_lane),
-                                             (lds_void*)(wave + 8 * j < BPIECES ? smem + BBASE + nb * BSTAGE + (wave + 8 * j) * 1024 : smem + ADUMMY), 16, 0, 0);
+        char* dst = wave + 8 * j < BPIECES ? smem + BBASE + nb * BSTAGE + (wave + 8 * j) * 1024 : smem + ADUMMY;
+        const unsigned so = wsoff + dma_uni(j);
+        if constexpr (!(ABL & 2)) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc[1], (lds_void*)dst, 16, dma_lane, so, 0, 0);
     };
     // stage s = slice pair s / 9, tap s % 9: its weights start at slice 2 (s / 9), tap s % 9 of the fragment-ordered planes
     auto set_wsrc = [&](int stage) {
         const int st = stage < nstages ? stage : nstages - 1;
         const int cp = st / 9, tap = st - cp * 9;
-        wsrc = a.wp + ((long)(2 * (cp0 + cp)) * 9 + tap) * a.Cout * 16;
+        wsoff = (unsigned)(((2 * (cp0 + cp)) * 9 + tap) * a.Cout * 16) * 2u;
     };
 
     // fragment addresses.  Weights: row = wn0 + 16 i + l16 with wn0 and 16 i multiples of 8, so the swizzle depends on the lane only:
     // ONE base register, (plane, tile) are immediate offsets.  Halo: q = (patch row + kh) * 18 + l16 + kw, swizzled per (tile, tap):
     // recomputed every stage from `qlane` (kept opaque to the optimiser there: hoisted out of the slice-pair loop the 9 x TP addresses
     // would cost 36 registers and spill the accumulators).
-    const int fw_base = BBASE + (wn0 + l16) * 64 + ((kg ^ swz(l16)) << 4);
+    const int fw_base = BBASE + (wn0 >> 4) * 1024 + (kg >> 1) * 512 + l16 * 32 + (kg & 1) * 16;
+    const int fx_lane = (kg >> 1) * (HPIX * 32) + (kg & 1) * 16;
     int qlane = (wrow * TP) * HWD + l16;
 
     // prologue: halo of slice pair 0, weights of stages 0 and 1
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
 #pragma unroll
             for (int j = 0; j < TP; ++j) {
                 const int q = qlane + (j + KH) * HWD + KW;
-                fx_off[j] = q * 64 + ((kg ^ swz(q)) << 4);
+                fx_off[j] = q * 32 + fx_lane;
             }
             auto rd_x = [&](int p) {
                 if constexpr (ABL & 8) return;
@@ -409,7 +410,7 @@ namespace rdo {
 bool h2k_supported(const H2Args& a, int shape) {
     return a.Cout % (shape == 1 ? 192 : (shape == 3 ? 48 : 64)) == 0 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.H % 16 == 0 && a.W % 16 == 0 &&
            a.Cin % 32 == 0 && a.ksplit >= 1 && a.ksplit <= a.Cin / 32 && (a.ksplit == 1) == (a.partial == nullptr) && (shape >= 2 || a.ksplit == 1) &&
-           (long)a.Cin * 9 * a.Cout * 16 < (1L << 31);
+           (long)a.Cin * 9 * a.Cout * 16 < (1L << 30) && a.xplane < (1L << 30);      // (one buffer descriptor spans both planes: < 4 GiB)
 }
 
 int h2k_launch(const H2Args& a, int shape, hipStream_t s) {
