@@ -34,6 +34,9 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0    # same guide, "Peak BF16/FP16 MFMA" (dense)
 PEAK_HBM_GBS = 8000.0
 
 
+MEASURED_F16_MFMA_SUSTAINED_TFLOPS = 1709.0   # tools/micro/mfma_power.hip on MI355X, 16x16x32 f16, random operand bits, every CU busy
+
+
 def kernel_peak(tag):
     """Dense MFMA peak for the arithmetic a conv kernel family executes, in ALGORITHMIC (fp32-equivalent) TFLOP/s:
     the *_x6_* kernels issue 6 bf16 MFMA products per fp32 product (exact 3-way operand split), the *_h2_* kernels 3 fp16 products
@@ -525,7 +528,11 @@ def main():
                          "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": traffic,
                          "traffic_source": traffic_src,
                          "launches_per_step": cnt, "avg_launch_ms": round(ms / cnt, 4),
-                         "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3)},
+                         "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
+                         # what the board's power limit lets nothing-but-MFMA code reach on random fp16 operands (tools/micro/mfma_power.hip,
+                         # DESIGN 3): 1709 TFLOP/s of v_mfma_f32_16x16x32_f16 at 1.72 GHz -- informative, `frac` stays against the nominal peak
+                         "power_limited_peak_measured": round(MEASURED_F16_MFMA_SUSTAINED_TFLOPS / 3.0, 1) if "_h2_" in dom else None,
+                         "frac_of_power_limited_peak": round(achieved / (MEASURED_F16_MFMA_SUSTAINED_TFLOPS / 3.0), 4) if "_h2_" in dom else None},
             "kernels": kernels,
         }
         if res["windows"]:
