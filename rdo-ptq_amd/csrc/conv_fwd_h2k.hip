@@ -31,35 +31,30 @@ typedef float f32x4k __attribute__((ext_vector_type(4)));
 __device__ unsigned long long g_h2k_stamps[256 * 4];
 #endif
 
-// Unit tail on the four finished channels [n, n + 4) of pixel m (v = conv + bias, the pre-activation): v becomes dL/dpre, the return value
-// is sum d^2.  The arithmetic of tail16 (conv_h2_common.h) / loss_act_quad (fused_tail.hip), operation for operation per element.
-__device__ __forceinline__ float tail4(const H2Args& a, int m, int n, f32x4& v) {
-    const int b = (int)(((long)m * a.Cout) / a.tail_per_image);
-    const int it = *a.tail_iter;
-    const float* y = a.tail_tgt + (long)a.tail_idx[(long)it * a.tail_B + b] * a.tail_per_image + ((long)m * a.Cout - (long)b * a.tail_per_image) + n;
+// Unit tail on the four finished channels [n, n + 4) of a pixel (v = conv + bias, the pre-activation): v becomes dL/dpre, the return value
+// is sum d^2.  The arithmetic of tail16 (conv_h2_common.h) / loss_act_quad (fused_tail.hip), operation for operation per element.  Its
+// inputs -- the target quad y4 and the residual's two plane quads p0 / p1 -- are fetched by the caller, a whole row of tiles ahead.
+typedef unsigned u32x2k __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float tail4_math(const H2Args& a, f32x4& v, const f32x4& y4, const u32x2k& p0, const u32x2k& p1) {
     const float slope = a.tail_act == 1 ? 0.01f : 0.f;
     const float gs = a.tail_coef * 2.f * a.tail_inv_npix;
     f32x4 r = f32x4{0.f, 0.f, 0.f, 0.f};
     if (a.tail_resp) {                                       // the residual from its planes: (h1 + h2) / s, the sum is exact in fp32
-        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-        const u16* rp = a.tail_resp + ((long)(n >> 4) * a.M + m) * 16 + (n & 15);
-        const u32x2 p0 = *reinterpret_cast<const u32x2*>(rp), p1 = *reinterpret_cast<const u32x2*>(rp + a.oplane);
         r[0] = (h2_lo(p0[0]) + h2_lo(p1[0])) * a.tail_res_inv;
         r[1] = (h2_hi(p0[0]) + h2_hi(p1[0])) * a.tail_res_inv;
         r[2] = (h2_lo(p0[1]) + h2_lo(p1[1])) * a.tail_res_inv;
         r[3] = (h2_hi(p0[1]) + h2_hi(p1[1])) * a.tail_res_inv;
     }
-    const f32x4 y4 = *reinterpret_cast<const f32x4*>(y);
     float dd[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const float p = v[k];
-        float o = p;
-        if (a.tail_act) o = p > 0.f ? p : slope * p;
-        if (a.tail_resp) o += r[k];
+        const bool act = a.tail_act != 0, res = a.tail_resp != nullptr;      // wave-uniform: selects, not branches per element
+        float o = act ? (p > 0.f ? p : slope * p) : p;
+        o = res ? o + r[k] : o;
         dd[k] = o - y4[k];
         const float g = dd[k] * gs;
-        v[k] = a.tail_act ? (p > 0.f ? g : slope * g) : g;
+        v[k] = act ? (p > 0.f ? g : slope * g) : g;
     }
     return (dd[0] * dd[0] + dd[1] * dd[1]) + (dd[2] * dd[2] + dd[3] * dd[3]);
 }
@@ -340,7 +335,33 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
             }
         return;
     }
+    // Loads and stores share ONE counter on this chip (vmcnt, in order): a load issued behind a store is only known to have landed once
+    // the store has been acknowledged, and hipcc has to wait vmcnt(0) for any load whose issue sits behind a run-time branch.  A tile's
+    // "load inputs, compute, store" therefore ran as 24 serial memory round trips per wave (planes + LeakyReLU: 111.9 us against 96.4 with
+    // no activation -- the activation only added BRANCHES around loads that never ran; conv + tail 120).  So: the inputs of a whole row
+    // of tiles (same 16 channels, TP pixel rows) are fetched first, then the row is computed and stored with no load in between.
     const bool need_planes = a.outp != nullptr;
+    const bool has_act = a.epilogue != RDO_EPI_NONE;
+    // the (leaky) rectifiers and their backward masks as selects on wave-uniform flags: `activate`'s switch per ELEMENT compiled to a tree
+    // of branches per element -- ~3 000 basic blocks of epilogue, 19 us on the planes + LeakyReLU launch
+    const bool rect = a.epilogue == RDO_EPI_LRELU || a.epilogue == RDO_EPI_LRELU_BWD || a.epilogue == RDO_EPI_RELU || a.epilogue == RDO_EPI_RELU_BWD;
+    const bool rect_relu = a.epilogue == RDO_EPI_RELU || a.epilogue == RDO_EPI_RELU_BWD;
+    const bool rect_aux = a.epilogue == RDO_EPI_LRELU_BWD || a.epilogue == RDO_EPI_RELU_BWD;      // the mask is the sign of the aux operand
+    const float* yimg = nullptr;                             // unit tail: the target image of this patch, so that the quad of (m, n) is yimg[m Cout + n]
+    if (a.tail_tgt) yimg = a.tail_tgt + ((long)a.tail_idx[(long)(*a.tail_iter) * a.tail_B + pb] - pb) * a.tail_per_image;
+    // The fetches are UNCONDITIONAL: four loads per tile (fp32 aux quad | fp32 residual or target quad | aux or tail-residual plane-0 quad |
+    // tail-residual plane-1 quad), and an input the launch does not have reads the first 16 bytes of the activation planes instead (one
+    // cache line for the whole wave).  A load behind a run-time branch costs hipcc a vmcnt(0) at the join -- which, with stores and loads
+    // on one counter, is a wait for the previous row's stores even when the load never ran.
+    const bool f_a = has_act && a.aux != nullptr;
+    const bool f_ap = has_act && a.aux == nullptr && a.auxp != nullptr;
+    const bool f_y = yimg != nullptr, f_rp = f_y && a.tail_resp != nullptr;
+    const bool f_b = a.add_residual || f_y, f_c = f_ap || f_rp;
+    const float* const dummyf = reinterpret_cast<const float*>(a.xp);
+    const float* const pA = f_a ? a.aux : dummyf;
+    const float* const pB = a.add_residual ? a.residual : (f_y ? yimg : dummyf);
+    const u16* const pC = f_ap ? a.auxp : (f_rp ? a.tail_resp : a.xp);
+    const u16* const pD = f_rp ? a.tail_resp + a.oplane : a.xp;
     float tail_loss = 0.f;
     int bad = 0;
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -349,21 +370,47 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
         const int n = n0 + wn0 + 16 * i + 4 * kg;
         f32x4 b4 = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.bias) b4 = *reinterpret_cast<const f32x4*>(a.bias + n);
+        f32x4 q0[TP], q1[TP];                                // q0: fp32 activation operand (mask / GDN input); q1: fp32 residual or tail target
+        u32x2k rp0[TP], rp1[TP];                             // plane-0 quad of the aux tensor or of the tail residual; its plane-1 quad
+#pragma unroll
+        for (int j = 0; j < TP; ++j) {
+            const int m = pbase + (wrow * TP + j) * a.W + l16;
+            const long o = (long)m * a.Cout + n;
+            const long po = ((long)(n >> 4) * a.M + m) * 16 + (n & 15);
+            q0[j] = *reinterpret_cast<const f32x4*>(pA + (f_a ? o : 0L));
+            q1[j] = *reinterpret_cast<const f32x4*>(pB + (f_b ? o : 0L));
+            rp0[j] = *reinterpret_cast<const u32x2k*>(pC + (f_c ? po : 0L));
+            rp1[j] = *reinterpret_cast<const u32x2k*>(pD + (f_rp ? po : 0L));
+        }
+        // every fetched register passes through an empty asm HERE: hipcc waits for the row's loads once, in front of it, and no longer
+        // connects the values with a (possibly) pending load -- otherwise each tile's first use of q0 / q1 behind the previous tile's
+        // conditional stores is another vmcnt(0), i.e. a wait for those stores
+#pragma unroll
+        for (int j = 0; j < TP; ++j) asm volatile("" : "+v"(q0[j]), "+v"(q1[j]), "+v"(rp0[j]), "+v"(rp1[j]));
+        asm volatile("" : "+v"(b4));
 #pragma unroll
         for (int j = 0; j < TP; ++j) {
             const int m = pbase + (wrow * TP + j) * a.W + l16;
             const long o = (long)m * a.Cout + n;
             f32x4 v = acc[i][j] * a.acc_scale + b4;
             if (a.pre) *reinterpret_cast<f32x4*>(a.pre + o) = v;
-            if (a.epilogue != RDO_EPI_NONE) {
-                const f32x4 x4 = aux_quad(a, m, n, o);
+            if (f_ap)                                        // plane 0 of the aux tensor: same sign as the value, enough for the masks
+                q0[j] = f32x4{h2_lo(rp0[j][0]), h2_hi(rp0[j][0]), h2_lo(rp0[j][1]), h2_hi(rp0[j][1])};
+            if (rect) {
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = activate(a, v[e], x4[e]);
+                for (int e = 0; e < 4; ++e) {
+                    const float t = rect_aux ? q0[j][e] : v[e];
+                    const float lo = rect_relu ? 0.f : 0.01f * v[e];
+                    v[e] = t > 0.f ? v[e] : lo;
+                }
+            } else if (has_act) {                            // GDN / IGDN: aux * v^-1/2 / aux * v^1/2 (the arithmetic of `activate`)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = q0[j][e] * (a.epilogue == RDO_EPI_IGDN ? __fsqrt_rn(v[e]) : __frsqrt_rn(v[e]));
             }
-            if (a.add_residual) v += *reinterpret_cast<const f32x4*>(a.residual + o);
+            if (a.add_residual) v += q1[j];
             if (a.out) *reinterpret_cast<f32x4*>(a.out + o) = v;
             if (need_planes) {
-                if (a.tail_tgt) tail_loss += tail4(a, m, n, v);
+                if (f_y) tail_loss += tail4_math(a, v, q1[j], rp0[j], rp1[j]);
                 u16* dst = a.outp + ((long)(n >> 4) * a.M + m) * 16 + (n & 15);
                 u32x2 hi, lo;
                 unsigned h, l;
