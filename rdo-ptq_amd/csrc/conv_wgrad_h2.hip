@@ -669,7 +669,8 @@ extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d);
 
 extern "C" int rdo_conv2d_wgrad_h2_supported(const rdo_conv_desc* d) {
     if (!d || d->square_input || d->Cin % 16 != 0 || d->Cout % 16 != 0) return 0;
-    if ((double)d->B * d->H * d->W * d->Cin >= 2147483648.0 || (double)d->B * d->Ho * d->Wo * d->Cout >= 2147483648.0) return 0;
+    // (the row kernel's buffer descriptors span one plane plus a 32-byte lead-in: 2 x elements + 32 bytes must fit 32 bits)
+    if ((double)d->B * d->H * d->W * d->Cin >= 2147483648.0 - 64.0 || (double)d->B * d->Ho * d->Wo * d->Cout >= 2147483648.0 - 64.0) return 0;
     return rdo_conv2d_wgrad_uses_bf16x6(d);
 }
 
