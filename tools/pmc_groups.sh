@@ -1,4 +1,5 @@
 # rocprofv3 --pmc passes (one counter group per pass, kernel-trace only) over one command; prints per-kernel means.
+# SQ counters only: passes with TA_* / TCP_* counters did not finish on this pool (each ran into its 300 s limit).
 # usage: bash tools/pmc_groups.sh <tag> <kernel-substring> -- python3 tools/bench_one_h2.py wgrad 128 192 192
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
@@ -15,9 +16,6 @@ GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WA
 SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_VALU_MFMA_BUSY_CYCLES SQ_INST_CYCLES_VMEM_RD
 SQ_LDS_BANK_CONFLICT SQ_LDS_ADDR_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_DATA_FIFO_FULL SQ_LDS_CMD_FIFO_FULL SQ_LDS_UNALIGNED_STALL SQ_INSTS_LDS
 SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_INSTS_VMEM_RD SQ_INSTS_MFMA SQ_INSTS_VALU SQ_INSTS_SALU SQ_INST_LEVEL_VMEM
-TA_TA_BUSY TA_ADDR_STALLED_BY_TC_CYCLES TA_ADDR_STALLED_BY_TD_CYCLES TA_DATA_STALLED_BY_TC_CYCLES TA_FLAT_READ_LDS_WAVEFRONTS TA_TOTAL_WAVEFRONTS
-TCP_PENDING_STALL_CYCLES TCP_TCR_TCP_STALL_CYCLES TCP_TD_TCP_STALL_CYCLES TCP_TCP_TA_DATA_STALL_CYCLES TCP_TCC_READ_REQ TCP_TOTAL_CACHE_ACCESSES TCP_LFIFO_STALL_CYCLES
-TCP_TCC_READ_REQ_LATENCY TCP_TCP_LATENCY TCP_READ_TAGCONFLICT_STALL_CYCLES TCP_RFIFO_STALL_CYCLES TCP_TCP_TA_ADDR_STALL_CYCLES TCP_GATE_EN2
 G
 python3 - "$OUT" "$PAT" <<'PY'
 import csv, glob, os, re, sys
