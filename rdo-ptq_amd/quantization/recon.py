@@ -125,7 +125,11 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
                 include_act_func=True, b_range=(20, 2), warmup=0.0, input_prob=1.0, act_quant=False, lr=4e-5, p=2.0,
                 config=None, args=None, is_block=False):
     if opt_mode != "mse":
-        raise NotImplementedError("only opt_mode='mse' (the mode main2.py uses) is built")
+        # The reference cannot run these modes on a compression model either: its LossFunction returns None for them whenever a coder
+        # tail output is passed (layer_opt.py:146-151, always the case in its loops, so `err.backward()` fails), and GetLayerGrad feeds
+        # the model's output DICT to log_softmax / kl_div (utils.py:316-321: BRECQ's classification code).
+        raise NotImplementedError(f"opt_mode={opt_mode!r}: only 'mse' (the mode main2.py uses) is built -- the Fisher-weighted modes of the "
+                                  "reference are classification left-overs that do not run on its compression models")
     task_p = getattr(args, "task_loss", 2.0) if args is not None else 2.0
     if float(p) != 2.0:
         raise NotImplementedError("rec_loss is built for p = 2 (the value main2.py passes); --task_loss may be any exponent >= 1")
