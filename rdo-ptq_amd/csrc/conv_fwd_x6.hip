@@ -866,7 +866,7 @@ extern "C" int rdo_split_bf16x3(const float* w, int64_t n, void* planes, void* s
 }
 
 // split factor for a shape: enough 128 x 192 x (K/ks) workgroups to fill the chip (>= 256, preferably >= 512), at least
-// 12 K stages (of 16 channels) per split, at most 8 splits; 0 = the shape is too small for this path
+// 12 K stages (of 16 channels) per split, at most 16 splits; 0 = the shape is too small for this path
 extern "C" int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d) {
     if (!d || d->Cin % 16 != 0 || d->Cout < 160) return 0;
     const long M = (long)d->B * d->Ho * d->Wo;
@@ -874,7 +874,7 @@ extern "C" int rdo_conv2d_fwd_bf16x6_ksplit(const rdo_conv_desc* d) {
     const long stages = (long)d->KH * d->KW * (d->Cin / 16);
     // two co-resident workgroups per CU: 512 fill the chip evenly (measured on 128 tiles: ks=4 -> 80 us, ks=3 -> 87 us)
     int best = 0;
-    for (int ks = 1; ks <= 8; ++ks)
+    for (int ks = 1; ks <= 16; ++ks)
         if (tiles * ks >= 256 && stages / ks >= 12) {
             best = ks;
             if (tiles * ks >= 512) break;
