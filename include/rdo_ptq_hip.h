@@ -398,6 +398,9 @@ rdo_plan* rdo_plan_create(void);
 void rdo_plan_destroy(rdo_plan* p);
 int rdo_plan_begin_record(rdo_plan* p);      /* subsequent rdo_* calls on this thread are recorded instead of launched */
 int rdo_plan_end_record(rdo_plan* p);
+/* suspend (on != 0) / resume recording on this thread: calls in between are launched, not recorded (one-time preparation of constants
+ * found while a plan is being recorded); returns 1 when recording was already suspended, else 0 */
+int rdo_plan_suspend_record(int on);
 int rdo_plan_num_ops(const rdo_plan* p);
 int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream);
 /* one iteration of `p` then one of `q` as ONE graph launch (cached per partner): "apply of iteration i + forward/backward of iteration

@@ -226,7 +226,8 @@ inline bool big_tiles(const rdo_conv_desc* d) {
     const long big_tiles_total = (long)d->KH * d->KW * rdo::ceil_div(d->Cout, 192) * rdo::ceil_div(d->Cin, 192);
     // many tiles (the 768 / 1152-channel sub-pixel convs): few pixel splits fill the chip, so short reductions still pay off
     const long min_m = big_tiles_total >= 32 ? 1024 : 4096;
-    if (d->Cout >= 160 && d->Cin >= 160 && M >= min_m && big_tiles_total >= 4) return true;
+    // (three tiles: the 192 -> 576 qkv Linear of the Swin blocks over 16 K tokens -- 138 us on the fp32 small tile)
+    if (d->Cout >= 160 && d->Cin >= 160 && M >= min_m && big_tiles_total >= 3) return true;
     // ... except over >= 16 K pixels (the GDN gamma gradient of the 64^2 and 128^2 units): there the split-bf16 tile with 256 splits
     // beats the fp32 small tile even after the AdaRound step has read 256 slabs of 144 KiB (tools/bench_wgrad_1x1.py: 37 + 12 us
     // against 87 + 9 at 4 x 128^2, 19 + 12 against 27 + 9 at 4 x 64^2)

@@ -154,6 +154,23 @@ void rdo_plan_destroy(rdo_plan* p) {
     delete p;
 }
 
+// Suspend (on != 0) / resume recording on this thread: calls in between are LAUNCHED, not recorded -- one-time preparation of constants
+// (a frozen weight's derived layouts) discovered while a plan is being recorded.  Returns the previous state (1 = was suspended), < 0 on error.
+int rdo_plan_suspend_record(int on) {
+    static thread_local bool suspended = false;
+    rdo::Recorder& r = rdo::recorder();
+    const int was = suspended ? 1 : 0;
+    if (on && !suspended) {
+        if (!r.active) return 0;                         // nothing is recording: nothing to suspend
+        r.active = false;
+        suspended = true;
+    } else if (!on && suspended) {
+        r.active = true;
+        suspended = false;
+    }
+    return was;
+}
+
 int rdo_plan_begin_record(rdo_plan* p) {
     RDO_REQUIRE(p != nullptr, "plan is null");
     RDO_REQUIRE(!rdo::recorder().active, "another plan is already recording on this thread");

@@ -122,6 +122,7 @@ _SIGS = {
     "rdo_plan_destroy": (None, [P]),
     "rdo_plan_begin_record": (C.c_int, [P]),
     "rdo_plan_end_record": (C.c_int, [P]),
+    "rdo_plan_suspend_record": (C.c_int, [C.c_int]),
     "rdo_plan_num_ops": (C.c_int, [P]),
     "rdo_plan_run": (C.c_int, [P, C.c_int, C.c_int, P]),
     "rdo_plan_run_then": (C.c_int, [P, P, C.c_int, P]),

@@ -24,6 +24,17 @@ class Plan:
         finally:
             L.check(L.lib().rdo_plan_end_record(self._h), "rdo_plan_end_record")
 
+    @staticmethod
+    @contextlib.contextmanager
+    def eager():
+        """Inside a `record()` scope: the calls made in this block are launched now, not recorded (no-op outside a recording)."""
+        was = int(L.lib().rdo_plan_suspend_record(1))
+        try:
+            yield
+        finally:
+            if not was:
+                L.lib().rdo_plan_suspend_record(0)
+
     @property
     def num_ops(self):
         return int(L.lib().rdo_plan_num_ops(self._h))

@@ -20,6 +20,7 @@ import torch
 
 from hipops import _lib as L
 from hipops import ops
+from hipops.plan import Plan
 
 from . import dp
 from .engine import UnitEngine, _Op
@@ -53,7 +54,10 @@ class _FpOp:
             # forward without zero insertion where the geometry allows: stride-1 conv with the phase weight + pixel shuffle
             self.tc_phase = ops.TconvPhase.get(self.w.shape[1], *self.tconv, True, self.w.device)
             if self.tc_phase is not None:
-                self.wp = ops.tconv_expand(self.w, self.tc_phase)
+                # (a tail op is built while the engine's plan is being RECORDED: the derived weight must exist before `fill_planes`
+                # splits it, i.e. be computed now and not as a recorded op of every iteration)
+                with Plan.eager():
+                    self.wp = ops.tconv_expand(self.w, self.tc_phase)
                 self.bias_p = None if self.bias is None else self.bias.repeat_interleave(self.tc_phase.S2).contiguous()
         else:
             raise NotImplementedError(f"tail stage of kind '{qm.kind}'")
@@ -65,6 +69,11 @@ class _FpOp:
         elif self.tconv is None:
             # dgrad of a strided conv = transposed conv of dy: stride-1 conv of the zero-inserted dy with this layout
             self.w_bwd = self.w.permute(3, 1, 2, 0).flip(1, 2).contiguous()       # [ci][kh'][kw'][co]
+            # ... or, where that transposed conv's output is stride x its input (k = 3 / s = 2 / p = 1 of models/nic_cvt.py on even
+            # sizes), its phase form: a stride-1 conv of dy itself with the phase weight + pixel shuffle -- no zero insertion, a quarter
+            # of the multiply-adds, and a shape the split-precision kernel takes (decided per problem in `_fp_conv`)
+            self.bw_phase_of = lambda opad: ops.TconvPhase.get(self.K, self.stride, self.pad, opad, False, self.w.device)
+            self.wbp = self.wbp_planes = None
         self.wq_planes = self.wd_planes = None
 
     def wq4(self):
@@ -83,6 +92,8 @@ class _FpOp:
     def fill_planes(self):
         if getattr(self, "wp_planes", None) is not None:
             ops.split_bf16x3(self.wp, self.wp_planes)
+        if getattr(self, "wbp_planes", None) is not None:
+            ops.split_bf16x3(self.wbp, self.wbp_planes)
         if self.wq_planes is not None:
             ops.split_bf16x3(self.w, self.wq_planes)
         if self.wd_planes is not None:
@@ -322,10 +333,21 @@ class TapeEngine(UnitEngine):
                 else:
                     q = p.K - 1 - p.pad
                     opad = H - ((Ho - 1) * p.stride - 2 * p.pad + p.K)
-                    Hu, Wu = (Ho - 1) * p.stride + 1 + 2 * q + opad, (Wo - 1) * p.stride + 1 + 2 * q + opad
-                    du = self._buf(B, Hu, Wu, p.w4[0])
-                    ops.zero_insert(dy, p.stride, q, q, Hu, Wu, out=du)
-                    ops.conv2d_fwd(du, p.w_bwd, None, 1, 0, out=dx)
+                    ph = p.bw_phase_of(opad) if H == Ho * p.stride and W == Wo * p.stride else None
+                    if ph is not None:
+                        if p.wbp is None:                    # [s^2 Cin][K'][K'][Cout] from the weight read as a transposed conv's
+                            with Plan.eager():
+                                p.wbp = ops.tconv_expand(p.w.permute(3, 1, 2, 0).contiguous(), ph)
+                            if ops.uses_bf16x6(tuple(dy.shape), tuple(p.wbp.shape), 1, ph.pad):
+                                p.wbp_planes = torch.empty((3,) + tuple(p.wbp.shape), device=self.dev, dtype=torch.int16)
+                        dp = self._buf(B, Ho, Wo, p.wbp.shape[0])
+                        ops.conv2d_fwd(dy, p.wbp, None, 1, ph.pad, out=dp, wplanes=p.wbp_planes)
+                        self._shuffle(dp, p.stride, dx)
+                    else:
+                        Hu, Wu = (Ho - 1) * p.stride + 1 + 2 * q + opad, (Wo - 1) * p.stride + 1 + 2 * q + opad
+                        du = self._buf(B, Hu, Wu, p.w4[0])
+                        ops.zero_insert(dy, p.stride, q, q, Hu, Wu, out=du)
+                        ops.conv2d_fwd(du, p.w_bwd, None, 1, 0, out=dx)
                 self._grad_commit(x, dx, first)
             self.tape.append(bwd)
             return y

@@ -237,3 +237,59 @@ def test_tape_engine_dp_split_equals_fused(golden_dir, name):
     for n in res[0][0]:
         torch.testing.assert_close(res[0][0][n], res[1][0][n], rtol=0, atol=0)
     torch.testing.assert_close(res[0][1], res[1][1], rtol=1e-6, atol=0)
+
+
+def test_tail_weight_preparation_runs_eagerly_inside_a_recording():
+    """A frozen tail op is built while the engine's plan is being RECORDED; the layouts derived from its weight (the phase weight of a
+    transposed conv) must be computed there and then -- `fill_planes` splits them right after the recording, before any replay -- and
+    must not become ops of the plan."""
+    from hipops import ops
+    from hipops.plan import Plan
+    from quantization import QuantModule
+    from quantization.swin_engine import _FpOp
+    torch.manual_seed(0)
+    qm = QuantModule(torch.nn.ConvTranspose2d(32, 48, 5, stride=2, padding=2, output_padding=1), WQ, AQ).cuda()
+    plan = Plan()
+    with plan.record():
+        p = _FpOp(qm)
+        assert p.tc_phase is not None
+        want = None
+        with Plan.eager():
+            want = ops.tconv_expand(p.w, p.tc_phase)
+        torch.cuda.synchronize()
+        assert torch.equal(p.wp, want)                      # already there: nothing waits for a replay
+    assert plan.num_ops == 0
+    assert float(p.wp.abs().max()) > 0
+
+
+@pytest.mark.parametrize("B,Ho,C", [(4, 64, 192), (2, 16, 32)])
+def test_strided_conv_input_gradient_in_phase_form(B, Ho, C):
+    """dgrad of conv(k = 3, s = 2, p = 1) = stride-1 conv of dy with the phase weight of the transposed conv + pixel shuffle (what the tape
+    engine records for the tail's strided convs; the large shape runs on the split-precision kernel) against zero insertion + dense
+    conv on the fp32 kernel, and both against torch."""
+    from hipops import ops
+    torch.manual_seed(1)
+    K, s, pad = 3, 2, 1
+    w = torch.randn(C, K, K, C, device="cuda") / (C * K * K) ** 0.5          # conv rows [Cout][KH][KW][Cin]
+    dy = torch.randn(B, Ho, Ho, C, device="cuda")
+    H = Ho * s
+    opad = H - ((Ho - 1) * s - 2 * pad + K)
+    ph = ops.TconvPhase.get(K, s, pad, opad, False, dy.device)
+    assert ph is not None
+    wbp = ops.tconv_expand(w.permute(3, 1, 2, 0).contiguous(), ph)
+    planes = ops.split_bf16x3(wbp) if ops.uses_bf16x6(tuple(dy.shape), tuple(wbp.shape), 1, ph.pad) else None
+    assert (planes is not None) == (C == 192)
+    dp = ops.conv2d_fwd(dy, wbp, None, 1, ph.pad, wplanes=planes)
+    dx = ops.pixel_shuffle(dp, s)
+    q = K - 1 - pad
+    Hu = (Ho - 1) * s + 1 + 2 * q + opad
+    du = ops.zero_insert(dy, s, q, q, Hu, Hu)
+    ref = ops.conv2d_fwd(du, w.permute(3, 1, 2, 0).flip(1, 2).contiguous(), None, 1, 0)
+    assert dx.shape == ref.shape == (B, H, H, C)
+    x = torch.zeros(B, C, H, H, device="cuda", dtype=torch.float64, requires_grad=True)
+    y = torch.nn.functional.conv2d(x, w.permute(0, 3, 1, 2).double(), None, s, pad)
+    y.backward(dy.permute(0, 3, 1, 2).double())
+    want = x.grad.permute(0, 2, 3, 1)
+    scale = float(want.abs().max())
+    assert float((dx.double() - want).abs().max()) <= 3e-6 * scale
+    assert float((ref.double() - want).abs().max()) <= 3e-6 * scale
