@@ -146,28 +146,64 @@ __device__ __forceinline__ void load_tile256(const AttnGeom& g, const float* src
     }
 }
 
-// softmax of row i of S (+ bias, + shift mask) in place; returns nothing, P[i][j >= N] = 0
-// reg: the window's token -> shift-mask region table (LDS; read only when shift > 0)
-__device__ __forceinline__ void softmax_row(const AttnGeom& g, float* S, const float* bias, const int* reg, int head, int i) {
+// softmax of the rows of S (+ bias, + shift mask, reg = the window's token -> mask-region table in LDS) in place, by ALL 256 threads of
+// the workgroup: row i = thread / 4, columns j = (thread & 3) + 4 k, k < 16 -- the four threads of a
+// row are neighbours in one wave (maximum and sum by two xor-shuffles), a thread's sixteen values stay in registers between the passes,
+// and the loops have compile-time bounds.  (`softmax_row` on 64 threads walked a row of LDS three times in run-time loops while three
+// quarters of the workgroup waited: the row phase, not the five 64 x 64 x hd products, was most of the attention kernels' time.)
+// `dP` != nullptr (backward): also D = sum_j P dP and dS = P (dP - D), written over dP.  Rows / columns beyond N are zeroed in both.
+__device__ __forceinline__ void softmax_rows256(const AttnGeom& g, float* S, float* dP, const float* bias, const int* reg, int head, float* probs,
+                                                int win) {
+    const int i = threadIdx.x >> 2, part = threadIdx.x & 3;
+    const bool rowok = i < g.N;
     float* row = S + i * SS;
-    const float* br = bias + ((long)head * g.N + i) * g.N;
-    const int ri = g.shift > 0 ? reg[i] : 0;
+    const float* br = bias + ((long)head * g.N + (rowok ? i : 0)) * g.N;
+    const int ri = (g.shift > 0 && rowok) ? reg[i] : 0;
+    float v[16];
     float mx = -3.0e38f;
-    for (int j = 0; j < g.N; ++j) {
-        float s = row[j] + br[j];
-        if (g.shift > 0 && reg[j] != ri) s += -100.0f;
-        row[j] = s;
-        mx = fmaxf(mx, s);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = part + 4 * k;
+        float sv = -3.0e38f;
+        if (rowok && j < g.N) {
+            sv = row[j] + br[j];
+            if (g.shift > 0 && reg[j] != ri) sv += -100.0f;
+        }
+        v[k] = sv;
+        mx = fmaxf(mx, sv);
     }
+    mx = fmaxf(mx, __shfl_xor(mx, 1, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 2, 64));
     float sum = 0.f;
-    for (int j = 0; j < g.N; ++j) {
-        const float e = expf(row[j] - mx);
-        row[j] = e;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = part + 4 * k;
+        const float e = (rowok && j < g.N) ? expf(v[k] - mx) : 0.f;
+        v[k] = e;
         sum += e;
     }
-    const float inv = 1.0f / sum;
-    for (int j = 0; j < g.N; ++j) row[j] *= inv;
-    for (int j = g.N; j < 64; ++j) row[j] = 0.f;
+    sum += __shfl_xor(sum, 1, 64);
+    sum += __shfl_xor(sum, 2, 64);
+    const float inv = rowok ? 1.0f / sum : 0.f;
+    float D = 0.f;
+    float dp[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+        const int j = part + 4 * k;
+        v[k] *= inv;
+        row[j] = v[k];
+        if (dP) {
+            dp[k] = (rowok && j < g.N) ? dP[i * SS + j] : 0.f;
+            D += v[k] * dp[k];
+        }
+        if (probs && rowok && j < g.N) probs[(((long)win * g.N + i) * g.N + j) * g.heads + head] = v[k];
+    }
+    if (dP) {
+        D += __shfl_xor(D, 1, 64);
+        D += __shfl_xor(D, 2, 64);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) dP[i * SS + part + 4 * k] = v[k] * (dp[k] - D);
+    }
 }
 
 __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
@@ -193,14 +229,7 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const float* qkv
     const int hk = (g.hd + 1) & ~1;
     tile_to_lds(tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0), S, SS, ti, tj);
     __syncthreads();
-    if (threadIdx.x < g.N) {
-        const int i = threadIdx.x;
-        softmax_row(g, S, bias, reg, head, i);
-        if (probs) {
-            float* pr = probs + (((long)win * g.N + i) * g.N) * g.heads + head;
-            for (int j = 0; j < g.N; ++j) pr[(long)j * g.heads] = S[i * SS + j];
-        }
-    }
+    softmax_rows256(g, S, nullptr, bias, reg, head, probs, win);
     if (no_pv) return;
     __syncthreads();
     if (32 * tj < g.hd) {
@@ -237,18 +266,7 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv
     tile_to_lds(tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0), P, SS, ti, tj);
     tile_to_lds(tile_gemm<false, true>(dO, g.hs, V, g.hs, ti, tj, hk, 0), dS, SS, ti, tj);      // dP = dO V^T
     __syncthreads();
-    if (threadIdx.x < 64) {
-        const int i = threadIdx.x;
-        if (i < g.N) {
-            softmax_row(g, P, bias, reg, head, i);
-            float D = 0.f;
-            for (int j = 0; j < g.N; ++j) D += P[i * SS + j] * dS[i * SS + j];
-            for (int j = 0; j < g.N; ++j) dS[i * SS + j] = P[i * SS + j] * (dS[i * SS + j] - D);
-            for (int j = g.N; j < 64; ++j) dS[i * SS + j] = 0.f;
-        } else {
-            for (int j = 0; j < 64; ++j) { P[i * SS + j] = 0.f; dS[i * SS + j] = 0.f; }
-        }
-    }
+    softmax_rows256(g, P, dS, bias, reg, head, nullptr, win);
     __syncthreads();
     if (32 * tj < g.hd) {
         // dQ = scale * dS K ; dK = dS^T Qs (Qs carries the scale) ; dV = P^T dO
