@@ -228,6 +228,8 @@ inline bool big_tiles(const rdo_conv_desc* d) {
     const long min_m = big_tiles_total >= 32 ? 1024 : 4096;
     // (three tiles: the 192 -> 576 qkv Linear of the Swin blocks over 16 K tokens -- 138 us on the fp32 small tile)
     if (d->Cout >= 160 && d->Cin >= 160 && M >= min_m && big_tiles_total >= 3) return true;
+    // (two tiles over >= 16 K pixels: the 192 <-> 384 MLP Linears of the Swin blocks, 117 us on the fp32 small tile)
+    if (d->Cout >= 160 && d->Cin >= 160 && M >= 16384 && big_tiles_total == 2) return true;
     // ... except over >= 16 K pixels (the GDN gamma gradient of the 64^2 and 128^2 units): there the split-bf16 tile with 256 splits
     // beats the fp32 small tile even after the AdaRound step has read 256 slabs of 144 KiB (tools/bench_wgrad_1x1.py: 37 + 12 us
     // against 87 + 9 at 4 x 128^2, 19 + 12 against 27 + 9 at 4 x 64^2)
