@@ -183,26 +183,15 @@ class TapeEngine(UnitEngine):
             ops.add(g, buf, out=g)
 
     # -- linear over the token matrix ------------------------------------------------------------------------------------
-    def _linear(self, x, p, need_dx=True, res=None, grad_res=True):
-        """y = x W^T + b (+ res: the residual add rides in the GEMM's epilogue instead of a pass of its own; backward: res receives dy
-        like the first operand of `_add`)."""
+    def _linear(self, x, p, need_dx=True):
         rows, cin = x.numel() // x.shape[-1], x.shape[-1]
         cout = p.w4[0]
         y = self._buf(*x.shape[:-1], cout)
         x4, y4 = x.view(1, 1, rows, cin), y.view(1, 1, rows, cout)
-        self._conv(p, x4, y4, residual=None if res is None else res.view(1, 1, rows, cout))
+        self._conv(p, x4, y4)
 
         def bwd():
-            dy = self.G[id(y)]
-            if res is not None and grad_res:                # the residual branch: as in `_add.bwd`
-                self._aliased.add(id(dy))
-                if id(res) not in self.G:
-                    self.G[id(res)] = dy
-                elif self.G[id(res)] is not dy:
-                    acc = self._buf(*res.shape)
-                    ops.add(self.G[id(res)], dy, out=acc)
-                    self.G[id(res)] = acc
-            dy4 = dy.view(1, 1, rows, cout)
+            dy4 = self.G[id(y)].view(1, 1, rows, cout)
             if isinstance(p, _Op):
                 self._wgrad(p, x4, dy4)
             if need_dx:
@@ -306,11 +295,13 @@ class TapeEngine(UnitEngine):
             bias = blk.attn.position_bias()
             self._keep.append(bias)
             a = self._attention(qkv, desc, bias)
-            t1 = self._linear(a, p["attn.proj"], res=t, grad_res=want_dt)       # t + proj(a)
+            pr = self._linear(a, p["attn.proj"])
+            t1 = self._add(t, pr, grad_a=want_dt)
             n2 = self._layer_norm(t1, ln2)
             f1 = self._linear(n2, p["mlp.fc1"])
             g = self._gelu(f1)
-            t = self._linear(g, p["mlp.fc2"], res=t1)                           # t1 + fc2(g)
+            f2 = self._linear(g, p["mlp.fc2"])
+            t = self._add(t1, f2)
         return self._add(t, x, grad_a=True) if need_dx else self._add_in(t, x)
 
     def _add_in(self, t, x):
