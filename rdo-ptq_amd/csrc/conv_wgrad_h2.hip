@@ -281,15 +281,19 @@ constexpr int XROWS = 40;                      // 34 used; five 8-row DMA pieces
 constexpr int XPLANEB = XROWS * 128;
 constexpr int STAGE3B = OPB + NP * XPLANEB;    // 24 + 10 = 34 KiB
 
-// SUB: 32-pixel segments per stage (per barrier / DMA wait).  SUB = 2 (tuning key "wgrad_sub", the default): the images of two segments
-// per ring slot -- half as many barriers, waits and loop skeletons per MFMA (MFMAs-only ablation of the SUB = 1 kernel: 2094 cycles per
-// stage for 1728 cycles of back-to-back MFMAs); 136 KiB of LDS instead of 68.
-// RING3: LDS ring slots (RING3 - 1 stages of DMA in flight); LSLOT: the MFMA slot (0..8 of the stage's first segment) behind which waves 4-7
-// issue their DMAs.  In-kernel phase stamps (tools/wgrad_phases.py) showed what the loop was bound by: ISSUING an LDS-DMA piece costs the
-// wave ~150 cycles here (five pieces per wave and stage: 640-775 cycles against 864 cycles of its MFMAs), waves 0-3 paid it at the top of
-// the stage, waves 4-7 a third into their MFMAs, and waves 0-3 then idled ~650 cycles per stage at the barrier.  <1, 3, 8>: waves 4-7
-// issue at the END of the stage -- for stage s + 2, a ring of three, counted vmcnt(5) -- so that each half multiplies while the other
-// issues.
+// Template parameters = the stage shapes behind the tuning key "wgrad_sub" (all give the same bits):
+//   SUB    32-pixel segments per stage (per barrier / DMA wait); 2 = two segments per ring slot, half as many barriers (136 KiB of LDS)
+//   RING3  LDS ring slots (RING3 - 1 stages of DMA in flight)
+//   LSLOT  the MFMA slot (0..8) behind which waves 4-7 issue their DMAs (waves 0-3 issue at the top of the stage)
+//   PF     1 / 2: the fragments of the NEXT stage's first third are read one stage ahead (ring of three); 2 = those reads interleaved
+//          one pair per MFMA into the last third.  <1, 3, 2, 2> is the shipped one ("wgrad_sub" = 13).
+// What the in-kernel phase stamps (tools/wgrad_phases.py, all eight waves) and the ablations (tools/wgrad_ablate.py) showed, in the order
+// it was found: (1) issuing an LDS-DMA piece cost a wave ~130-150 cycles when four waves issue together -- the pixel-major lane roles
+// made the texture addresser take 32 cycles per piece (lane quads straddling two slices) and every piece carried ~20 scalar / vector
+// instructions of pointer selection; slice-major pieces through buffer descriptors (below) halve both.  (2) With that gone, waves 0-3 wait
+// ~900 cycles per stage at the barrier for waves 4-7, whose MFMAs share the SIMD's pipe with their partner exactly when both multiply:
+// the look-ahead reads (PF) let both start right behind the barrier.  (3) In a sustained stream the loop runs at 2.1-2.2 GHz: at the
+// board's power limit, like the forward kernel.
 template <int SUB, int RING3, int LSLOT, int PF = 0>
 __global__ __launch_bounds__(512, 2) void conv_wgrad_h2r_kernel(WgPArgs a) {
     constexpr int T = 192;
