@@ -5,6 +5,7 @@ Conventions: every tensor is a contiguous fp32 CUDA tensor; activations are NHWC
 When a plan is being recorded (hipops.plan.Plan.record()), the same calls are captured instead of launched."""
 import ctypes as C
 import math
+import threading
 
 import torch
 
@@ -725,8 +726,7 @@ class h2_flag:
     (rdo_h2_bind_flag).  An output `H2` that carries its own `.flag` raises that one instead (`_bind_out`).  A raised word holds the
     fp32 bit pattern of the largest FINITE |x * scale| that did not fit in word 0 (`overflow_magnitude`) and a non-finite mark in word 1.  Blocks nest; leaving restores the previous
     binding."""
-    _stack = []
-    _bound = None
+    _tls = threading.local()          # rdo_h2_bind_flag is thread_local in the library (csrc/runtime.hip): so is this cache of it
 
     def __init__(self, word):
         if word is not None and not (word.is_cuda and word.dtype == torch.int32 and word.numel() >= 2):
@@ -734,26 +734,36 @@ class h2_flag:
         self.word = word
 
     @staticmethod
+    def _state():
+        st = h2_flag._tls
+        if not hasattr(st, "stack"):
+            st.stack, st.bound = [], None
+        return st
+
+    @staticmethod
     def bind(word):
-        if word is not h2_flag._bound:
+        st = h2_flag._state()
+        if word is not st.bound:
             L.check(L.lib().rdo_h2_bind_flag(None if word is None else _ptr(word)), "rdo_h2_bind_flag")
-            h2_flag._bound = word
+            st.bound = word
 
     def __enter__(self):
-        h2_flag._stack.append(self.word)
+        h2_flag._state().stack.append(self.word)
         h2_flag.bind(self.word)
         return self.word
 
     def __exit__(self, *exc):
-        h2_flag._stack.pop()
-        h2_flag.bind(h2_flag._stack[-1] if h2_flag._stack else None)
+        st = h2_flag._state()
+        st.stack.pop()
+        h2_flag.bind(st.stack[-1] if st.stack else None)
         return False
 
 
 def _bind_out(planes):
     """the overflow word the next producer raises: the output tensor's own, else the enclosing h2_flag block's, else the default"""
     own = getattr(planes, "flag", None)
-    h2_flag.bind(own if own is not None else (h2_flag._stack[-1] if h2_flag._stack else None))
+    st = h2_flag._state()
+    h2_flag.bind(own if own is not None else (st.stack[-1] if st.stack else None))
 
 
 def overflow_magnitude(word_value):

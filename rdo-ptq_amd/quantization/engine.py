@@ -294,6 +294,7 @@ class UnitEngine:
         self._ovf_slot = {}                    # plane tensor name -> its pair
         self.h2_restarts = 0                   # times the unit was restarted after an overflow (0 in every measured run so far)
         self._done = 0
+        self._ovf_checked = -1                 # position (`_done`) at which the rank-synchronised overflow verdict was last formed
         with ops.h2_flag(self._ovf[0:2]):
             self._build_ops()
             self._alloc()
@@ -764,6 +765,13 @@ class UnitEngine:
         finally:
             self._set_weights(soft=True)
         self._clear_probe()
+        if self.world > 1:
+            # every rank probes its own shard: agree on the magnitudes (MAX) so that all ranks record the same scales, take the same
+            # "all-zero tensor" decision below and -- after an overflow, whose words are MAX-reduced too -- re-derive the same new scales
+            a = amax.to(self.dev)
+            a = torch.where(torch.isfinite(a), a, torch.full_like(a, float("inf")))
+            torch.distributed.all_reduce(a, op=torch.distributed.ReduceOp.MAX, group=self.group)
+            amax = a.cpu()
         if not torch.isfinite(amax).all():
             raise RuntimeError("calibration engine: non-finite activations in the probe iteration")
         if bool((amax <= 0).any()):
@@ -836,23 +844,36 @@ class UnitEngine:
         self._clear_probe()
         self._ovf.zero_()
         self._done = 0
+        self._ovf_checked = -1
         self._dp_graph = self._rd_graph = None
         self._record()
         for op in self.ops.values():
             op.refresh_planes()
 
     def _check_overflow(self):
-        """Called where results leave the engine (logs, finish): an overflow not yet seen by the polls of `run` is handled here."""
-        guard = 0
+        """Where results leave the engine: an overflow not yet seen by the polls of `run` is handled here.  COLLECTIVE under data
+        parallelism (the MAX all-reduce of `_overflowed`), so it must only be reached at rank-invariant points: it is run once per
+        position of the unit (`sync_overflow`, called by recon.py behind `run()` on every rank, and by `finish`) and the verdict is
+        cached -- `logs` / `logs_terms` called afterwards, on any subset of the ranks, issue no overflow collective.
+        Restart ladder (`_recover`): H2_RESTARTS restarts on re-derived scales, then one on fp32 activations (`use_h2 = False`, no
+        planes left, `_overflowed` is False by construction).  An overflow word raised with no plane tensor alive would be a library
+        fault."""
+        if self._ovf_checked == self._done:
+            return
         while self._overflowed():
-            guard += 1
-            if guard > 2:
-                raise RuntimeError("calibration engine: H2 overflow persists after the fp32 restart (library fault)")
+            if not self.use_h2:
+                raise RuntimeError("calibration engine: an H2 overflow word is raised on the fp32-activation path (library fault)")
             target = self._done
             with ops.h2_flag(self._ovf[0:2]):
                 self._recover()
             self.run(target)
             torch.cuda.synchronize()
+        self._ovf_checked = self._done
+
+    def sync_overflow(self):
+        """The rank-synchronised fp16-range verdict for the iterations run so far (see `_check_overflow`): call it on EVERY rank at the
+        same point of the schedule before any rank-dependent use of `logs*()`."""
+        self._check_overflow()
 
     def _forward_backward(self):
         o, t, x = self.ops, self.t, self.x_in

@@ -121,9 +121,20 @@ def _unit_modules(unit):
     raise NotImplementedError(f"reconstruction of {type(unit).__name__} is not built yet")
 
 
-def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, weight=0.01, opt_mode="mse", asym=False,
-                include_act_func=True, b_range=(20, 2), warmup=0.0, input_prob=1.0, act_quant=False, lr=4e-5, p=2.0,
-                config=None, args=None, is_block=False):
+def reconstruct(model, unit, unit_name, cali_data, *a, **kw):
+    """`_reconstruct` with the one piece of cross-unit state tidied up on failure: the full-precision cache memo of the schedule
+    (quantization/utils.py::_FpMemo) is dropped when a unit raises, so a schedule that dies half-way pins no device memory."""
+    try:
+        return _reconstruct(model, unit, unit_name, cali_data, *a, **kw)
+    except BaseException:
+        from .utils import _FpMemo
+        _FpMemo.clear()
+        raise
+
+
+def _reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, weight=0.01, opt_mode="mse", asym=False,
+                 include_act_func=True, b_range=(20, 2), warmup=0.0, input_prob=1.0, act_quant=False, lr=4e-5, p=2.0,
+                 config=None, args=None, is_block=False):
     if opt_mode != "mse":
         # The reference cannot run these modes on a compression model either: its LossFunction returns None for them whenever a coder
         # tail output is passed (layer_opt.py:146-151, always the case in its loops, so `err.backward()` fails), and GetLayerGrad feeds
@@ -207,9 +218,15 @@ def reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, w
     t3 = _mark()
     if timing is not None:
         timing.append(dict(unit=unit_name, kind=kind, cache_s=t1 - t0, record_s=t2 - t1, loop_s=t3 - t2))
-    if logging.getLogger().isEnabledFor(logging.INFO) and iters >= 500:
+    # rank-invariant from here on: the overflow verdict of the unit (a MAX all-reduce under data parallelism) is formed ONCE, here, on
+    # every rank; `logs_terms` is a collective as well when world > 1 (mean of the ranks' data terms), so with several ranks every rank
+    # computes the log rows whether or not its own logger prints them -- the log level may differ from rank to rank, the sequence of
+    # collectives must not
+    eng.sync_overflow()
+    want_log = logging.getLogger().isEnabledFor(logging.INFO)
+    if iters >= 500 and (want_log or world_size > 1):
         rec, task, rd, b = eng.logs_terms()
-        for c in range(500, iters + 1, 500):
+        for c in (range(500, iters + 1, 500) if want_log else ()):
             logging.info("Total loss:\t{:.3f} ( task:{:.3f}, rec:{:.3f}, round:{:.3f})\tb={:.2f}\tcount={}".format(
                 float(rec[c - 1] + task[c - 1] + rd[c - 1]), float(task[c - 1]), float(rec[c - 1]), float(rd[c - 1]),
                 float(b[c - 1]), c))

@@ -113,21 +113,47 @@ class GetLayerInpOut:
 # size fits RDO_FP_MEMO_GIB (default 64) and half of the free device memory; a unit's rows are released when it takes them; any change of
 # model, calibration tensor or batch size drops the memo.  RDO_FP_MEMO=0 turns it off.
 class _FpMemo:
+    """One memo at a time.  What makes a hand-out safe (each a way the rows of the one full forward could differ from the unit's own
+    truncated pass, in which case the unit simply gets no rows and runs its own pass):
+      * a unit called more or less than ONCE in some batch (a shared / looped module: its rows would interleave) is dropped;
+      * a captured tensor that any LATER op of the full forward modified in place (`_version` moved: the truncated pass stops at the
+        unit and never runs that op) is dropped;
+      * units with `ignore_reconstruction` are never asked for (main2.py:231,241) and are not captured.
+    Identity: the memo holds a weak reference to the model and a STRONG one to the calibration tensor it was built from -- the tensor's
+    storage cannot be freed and re-issued under the same `data_ptr()` while the memo lives, and a dead model drops the memo.
+    `clear()` releases it explicitly (recon.reconstruct calls it when a unit fails; a schedule that stops early may call it too)."""
     current = None
     refused = None          # key of the last memo that could not be built (too large / the model's forward failed): not retried per unit
 
-    def __init__(self, key):
-        self.key, self.rows = key, {}
+    def __init__(self, model, cali_data, batch_size):
+        import weakref
+        self.model_ref = weakref.ref(model)
+        self.cali = cali_data                  # strong: pins the storage behind data_ptr()
+        self.sig = self._sig(cali_data, batch_size)
+        self.rows = {}
+
+    @staticmethod
+    def _sig(cali_data, batch_size):
+        return (cali_data.data_ptr(), cali_data._version, tuple(cali_data.shape), tuple(cali_data.stride()), int(batch_size))
+
+    def matches(self, model, cali_data, batch_size):
+        return self.model_ref() is model and self.sig == self._sig(cali_data, batch_size)
+
+    @classmethod
+    def clear(cls):
+        cls.current = cls.refused = None
 
     @staticmethod
     def units_of(model):
-        """the reconstruction units in the order main2.py's recon_model visits them (main2.py:227-253)"""
+        """the reconstruction units in the order main2.py's recon_model visits them (main2.py:227-253); units the schedule skips
+        (`ignore_reconstruction`, main2.py:231,241) are left out"""
         out = []
 
         def walk(m):
             for _, c in m.named_children():
                 if isinstance(c, (QuantModule, BaseQuantBlock)):
-                    out.append(c)
+                    if not getattr(c, "ignore_reconstruction", False):
+                        out.append(c)
                 else:
                     walk(c)
         walk(model.model if isinstance(getattr(model, "model", None), torch.nn.Module) else model)
@@ -136,16 +162,19 @@ class _FpMemo:
     @classmethod
     def get(cls, model, layer, cali_data, batch_size, device):
         import os
+        import weakref
         if os.environ.get("RDO_FP_MEMO", "1") == "0":
             return None
-        key = (id(model), cali_data.data_ptr(), cali_data._version, tuple(cali_data.shape), int(batch_size))
         memo = cls.current
-        if memo is None or memo.key != key:
-            if cls.refused == key:
+        if memo is not None and memo.model_ref() is None:
+            memo = cls.current = None                            # the model it belonged to is gone
+        if memo is None or not memo.matches(model, cali_data, batch_size):
+            r = cls.refused
+            if r is not None and r[0]() is model and r[1] == cls._sig(cali_data, batch_size):
                 return None
-            memo = cls.current = cls._build(model, cali_data, batch_size, device, key)
+            memo = cls.current = cls._build(model, cali_data, batch_size, device)
             if memo is None:
-                cls.refused = key
+                cls.refused = (weakref.ref(model), cls._sig(cali_data, batch_size))
                 return None
             cls.refused = None
         got = memo.rows.pop(id(layer), None)
@@ -154,14 +183,26 @@ class _FpMemo:
         return got
 
     @classmethod
-    def _build(cls, model, cali_data, batch_size, device, key):
+    def _build(cls, model, cali_data, batch_size, device):
         import os
         units = cls.units_of(model)
         if len(units) < 2:
             return None
         store = {id(u): ([], []) for u in units}
-        hooks = [u.register_forward_hook(lambda m, i, o: (store[id(m)][0].append(i[0].detach()), store[id(m)][1].append(o.detach())) and None)
-                 for u in units]
+        calls = {id(u): 0 for u in units}
+        bad = set()
+
+        def hook(m, i, o):
+            k = id(m)
+            calls[k] += 1
+            if not (torch.is_tensor(o) and len(i) > 0 and torch.is_tensor(i[0])):
+                bad.add(k)
+                return None
+            a, b = i[0].detach(), o.detach()
+            store[k][0].append((a, a._version))
+            store[k][1].append((b, b._version))
+            return None
+        hooks = [u.register_forward_hook(hook) for u in units]
         was_training = model.training
         states = [(m, m.use_weight_quant, m.use_act_quant) for m in model.modules() if isinstance(m, (QuantModule, BaseQuantBlock))]
         budget = min(float(os.environ.get("RDO_FP_MEMO_GIB", "64")) * 2 ** 30, 0.5 * torch.cuda.mem_get_info(device)[0])
@@ -172,9 +213,19 @@ class _FpMemo:
             with torch.no_grad():
                 n = cali_data.size(0)
                 for i in range(0, n, batch_size):
+                    for k in calls:
+                        calls[k] = 0
                     model(cali_data[i:i + batch_size].to(device))
+                    for k, c in calls.items():
+                        if c != 1:                               # shared / looped / unreached module: its rows are not one per image
+                            bad.add(k)
+                    for k, (a, b) in store.items():              # a later op of this forward wrote into a captured tensor in place
+                        if k not in bad and any(t._version != v for t, v in (a[-1:] + b[-1:])):
+                            bad.add(k)
+                    for k in bad:
+                        store[k][0].clear(); store[k][1].clear()
                     if i == 0:                                   # extrapolate from the first batch
-                        per = sum(t.numel() * t.element_size() for a, b in store.values() for t in a + b) / min(batch_size, n)
+                        per = sum(t.numel() * t.element_size() for a, b in store.values() for t, _ in a + b) / min(batch_size, n)
                         if per * n > budget:
                             ok = False
                             break
@@ -188,13 +239,14 @@ class _FpMemo:
             model.train(was_training)
         if not ok:
             return None
-        memo = cls(key)
+        memo = cls(model, cali_data, batch_size)
+        nb = (cali_data.size(0) + batch_size - 1) // batch_size
         for u in units:
             a, b = store.pop(id(u))
-            if a and len(a) == len(b):
-                memo.rows[id(u)] = (torch.cat(a), torch.cat(b))
+            if id(u) not in bad and len(a) == nb and len(b) == nb:
+                memo.rows[id(u)] = (torch.cat([t for t, _ in a]), torch.cat([t for t, _ in b]))
             del a, b
-        return memo
+        return memo if memo.rows else None
 
 
 def save_inp_oup_data(model: QuantModel, layer: Union[QuantModule, BaseQuantBlock], cali_data: torch.Tensor,

@@ -226,7 +226,10 @@ def test_fp_cache_memo_gives_the_rows_of_the_per_unit_passes(monkeypatch):
         for m in u.modules():
             if hasattr(m, "trained"):
                 m.trained = True
-    picks = [units[0], units[3], units[7], units[12], units[-1]]
+    byname = {n: m for n, m in qnn.model.named_modules()}
+    named = [byname[n] for n in ("h_a.2", "h_a.8", "h_s.0", "h_s.4", "entropy_parameters.0", "entropy_parameters.4", "context_prediction")]
+    assert all(any(u is m for u in units) for m in named)        # hyper-analysis / hyper-synthesis / entropy-parameter units too
+    picks = [units[0], units[3], units[7], units[12], units[-1]] + [m for m in named if all(m is not q for q in (units[0], units[3], units[7], units[12], units[-1]))]
     monkeypatch.setenv("RDO_FP_MEMO", "0")
     ref = [U.save_inp_oup_data(qnn, u, cali, True, False, batch_size=4, input_prob=True) for u in picks]
     monkeypatch.setenv("RDO_FP_MEMO", "1")
@@ -238,3 +241,60 @@ def test_fp_cache_memo_gives_the_rows_of_the_per_unit_passes(monkeypatch):
     (q2, f2), o2 = U.save_inp_oup_data(qnn, picks[1], cali, True, False, batch_size=4, input_prob=True)     # second request: own pass
     assert torch.equal(f2, ref[1][0][1]) and torch.equal(o2, ref[1][1])
     U._FpMemo.current = None
+
+
+def test_fp_cache_memo_refuses_rows_it_cannot_vouch_for(monkeypatch):
+    """The three ways the rows of the one full forward could differ from a unit's own truncated pass: a unit that the
+    model calls TWICE per forward (its rows would interleave), a unit whose captured output a LATER op of the full forward modifies in
+    place (the truncated pass stops before that op), and a unit the schedule skips (`ignore_reconstruction`).  Each must get no rows from
+    the memo -- its caches then come from its own pass and equal the RDO_FP_MEMO=0 ones bit for bit -- while the other units keep theirs."""
+    import torch.nn as nn
+    from helpers import WQ, AQ
+    from quantization import QuantModel
+    from quantization import utils as U
+
+    class Net(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.a = nn.Conv2d(3, 8, 3, padding=1)
+            self.shared = nn.Conv2d(8, 8, 3, padding=1)
+            self.b = nn.Conv2d(8, 8, 3, padding=1)
+            self.c = nn.Conv2d(8, 8, 3, padding=1)
+            self.d = nn.Conv2d(8, 4, 3, padding=1)
+
+        def forward(self, x):
+            h = self.a(x)
+            h = self.shared(self.shared(h))          # called twice per forward
+            h = self.b(h)
+            h.mul_(0.5)                              # in place on b's output, AFTER b's hook has fired
+            h = self.c(h)
+            return self.d(h)
+    torch.manual_seed(9)
+    qnn = QuantModel(model=Net().cuda().eval(), weight_quant_params=WQ, act_quant_params=AQ).cuda().eval()
+    cali = torch.rand(6, 3, 32, 32, device="cuda")
+    qnn.set_quant_state(True, False)
+    with torch.no_grad():
+        qnn(cali[:4])
+    m = qnn.model
+    m.c.ignore_reconstruction = True
+    assert [u for u in U._FpMemo.units_of(qnn)] == [m.a, m.shared, m.b, m.d]
+    m.a.trained = True
+    monkeypatch.setenv("RDO_FP_MEMO", "0")
+    ref = {n: U.save_inp_oup_data(qnn, getattr(m, n), cali, True, False, batch_size=4, input_prob=True) for n in ("a", "shared", "b", "d")}
+    monkeypatch.setenv("RDO_FP_MEMO", "1")
+    U._FpMemo.clear()
+    (q, f), o = U.save_inp_oup_data(qnn, m.a, cali, True, False, batch_size=4, input_prob=True)
+    memo = U._FpMemo.current
+    assert memo is not None and set(memo.rows) == {id(m.d)}, "only `d` may keep rows: `shared` runs twice, `b`'s output is overwritten in place"
+    assert torch.equal(f, ref["a"][0][1]) and torch.equal(o, ref["a"][1])
+    for n in ("shared", "b", "d"):
+        (q, f), o = U.save_inp_oup_data(qnn, getattr(m, n), cali, True, False, batch_size=4, input_prob=True)
+        assert torch.equal(q, ref[n][0][0]) and torch.equal(f, ref[n][0][1]) and torch.equal(o, ref[n][1]), n
+    assert U._FpMemo.current is None                 # every row handed out -> released
+    # identity: a different model object, or a dead one, never reuses the memo; clear() drops it
+    U.save_inp_oup_data(qnn, m.a, cali, True, False, batch_size=4, input_prob=True)
+    assert U._FpMemo.current is not None and U._FpMemo.current.matches(qnn, cali, 4)
+    assert not U._FpMemo.current.matches(qnn, cali.clone(), 4) and not U._FpMemo.current.matches(qnn, cali, 2)
+    U._FpMemo.clear()
+    assert U._FpMemo.current is None
+
