@@ -23,18 +23,28 @@ sys.path.insert(0, ROOT)
 
 def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2, log=print, quality=True, arch="anchor", w_bits=8,
                  a_bits=8, per_unit_log=True):
-    """arch: "anchor" | "attn" (Cheng2020-attn, BASELINE config 3); w_bits / a_bits: weight grid and dynamic activation grid."""
+    """arch: "anchor" | "attn" (Cheng2020-attn, BASELINE config 3) | "lu2022" (BASELINE config 4: NIC embed 192 / latent 320, the 25
+    units of main2.py's recon_model on the tape engine); w_bits / a_bits: weight grid and dynamic activation grid."""
     import math
     import bench
     from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstruction, layer_reconstruction
     from test_datasets import evaluate_images
     dev = torch.device("cuda:0")
-    model = bench.seeded_model(192, 1005, dev, arch=arch)
+    lu = arch == "lu2022"
+    if lu:
+        eval_hw = (256, 256)       # the NIC is built for one resolution (window masks, token counts)
     g = torch.Generator().manual_seed(1005)
-    with torch.no_grad():      # variance-preserving conv weights: the signal (and the quantisation error) reaches the output
-        for name, p_ in model.named_parameters():
-            if p_.dim() == 4 and "entropy_bottleneck" not in name:
-                p_.copy_(((torch.rand(p_.shape, generator=g) - 0.5) * 2 * (3.0 / p_[0].numel()) ** 0.5).to(dev))
+    if lu:
+        import lic
+        torch.manual_seed(1005)
+        model = lic.NIC(dict(height=256, width=256, in_chans=3, embed_dim=192, latent_dim=320, window_size=8, mlp_ratio=2.0, qkv_bias=True,
+                             qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, use_checkpoint=False)).to(dev).eval()
+    else:
+        model = bench.seeded_model(192, 1005, dev, arch=arch)
+        with torch.no_grad():      # variance-preserving conv weights: the signal (and the quantisation error) reaches the output
+            for name, p_ in model.named_parameters():
+                if p_.dim() == 4 and "entropy_bottleneck" not in name:
+                    p_.copy_(((torch.rand(p_.shape, generator=g) - 0.5) * 2 * (3.0 / p_[0].numel()) ** 0.5).to(dev))
     cali = torch.rand(images, 3, 256, 256, generator=g).to(dev)
     test_imgs = [torch.rand(1, 3, eval_hw[0], eval_hw[1], generator=g) for _ in range(n_eval)]
     probe = torch.rand(4, 3, 256, 256, generator=g).to(dev)
@@ -55,7 +65,8 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
     aq = {"n_bits": a_bits, "channel_wise": True, "scale_method": "max", "leaf_param": False}
     if a_bits != 8:
         aq["dynamic_bits"] = a_bits           # the reference's dynamic activation quantiser hard-wires 8 bits (quantizer.py:81)
-    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=True).to(dev).eval()
+    qnn = QuantModel(model=model, weight_quant_params=wq, act_quant_params=aq, is_cheng=not lu).to(dev).eval()
+    last = (lambda: qnn.model.g_s7) if lu else (lambda: qnn.model.g_s[-1][0])        # main2.py:258-263
     qnn.set_first_last_layer_to_8bit()
     qnn.disable_network_output_quantization()
     qnn.set_quant_state(True, False)
@@ -64,7 +75,7 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
     if quality:
         res["w8_rtn"] = evaluate_images(qnn.eval(), test_imgs) + (fidelity(qnn),)
     timing = []
-    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020", timing=timing)
+    args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Lu2022" if lu else "Cheng2020", timing=timing)
     kwargs = dict(cali_data=cali, batch_size=batch, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
                   warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
     engines = []
@@ -80,7 +91,7 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
             else:
                 recon_model(module, prefix + name + ".")
     qnn.set_quant_state(True, False)
-    qnn.model.g_s[-1][0].set_quant_state(True, False)
+    last().set_quant_state(True, False)
     torch.cuda.synchronize()
     t0 = time.time()
     recon_model(qnn.model)
@@ -104,18 +115,18 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
             done += int(((h == 0) | (h == 1)).sum())
             tot += h.numel()
         rec, task, rnd, b = e.logs_terms()
-        units.append(dict(unit=name, kind=e.kind, loop_s=round(t["loop_s"], 3), cache_s=round(t["cache_s"], 3), record_s=round(t["record_s"], 3),
+        units.append(dict(unit=name, kind=e.kind, loop_ms_per_iter=round(t["loop_s"] / iters * 1e3, 4), loop_s=round(t["loop_s"], 3), cache_s=round(t["cache_s"], 3), record_s=round(t["record_s"], 3),
                           hard_frac=done / tot, loss_first=float(rec[0] + task[0] + rnd[0]), loss_last=float(rec[-1] + task[-1] + rnd[-1]),
                           rec_first=float(rec[0]), rec_last=float(rec[-1]), round_last=float(rnd[-1])))
         if per_unit_log:
-            log(f"  {name:24s} {e.kind:5s} loop {t['loop_s']:7.2f} s  cache {t['cache_s']:5.2f} s  record {t['record_s']:5.2f} s  "
+            log(f"  {name:24s} {e.kind:5s} loop {t['loop_s']:7.2f} s = {t['loop_s'] / iters * 1e3:7.3f} ms/it  cache {t['cache_s']:5.2f} s  record {t['record_s']:5.2f} s  "
                 f"soft targets in {{0,1}}: {100 * done / tot:6.2f} %  rec {float(rec[0]):.4e} -> {float(rec[-1]):.4e}  round {float(rnd[-1]):.3e}")
     res["units"] = units
     if quality:
         qnn.set_quant_state(True, False)
         res["w8"] = evaluate_images(qnn.eval(), test_imgs) + (fidelity(qnn),)
         qnn.set_quant_state(True, True)
-        qnn.model.g_s[-1][0].set_quant_state(True, False)
+        last().set_quant_state(True, False)
         res["w8a8"] = evaluate_images(qnn.eval(), test_imgs) + (fidelity(qnn),)
         log(f"FP32      PSNR {res['fp32'][0]:.3f} dB  bpp {res['fp32'][1]:.4f}")
         for k, lab in (("w8_rtn", "W8 RTN   "), ("w8", "W8 cal.  "), ("w8a8", "W8A8 cal.")):
@@ -132,7 +143,9 @@ if __name__ == "__main__":
     ap.add_argument("--iters", type=int, default=20000)
     ap.add_argument("--batch", type=int, default=4)
     ap.add_argument("--json", default=None)
+    ap.add_argument("--arch", default="anchor", choices=["anchor", "attn", "lu2022"])
+    ap.add_argument("--no-quality", action="store_true")
     a = ap.parse_args()
-    r = run_schedule(a.images, a.iters, a.batch)
+    r = run_schedule(a.images, a.iters, a.batch, arch=a.arch, quality=not a.no_quality)
     if a.json:
         json.dump(r, open(a.json, "w"), indent=1)
