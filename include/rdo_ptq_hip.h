@@ -39,7 +39,9 @@ enum {
     RDO_EPI_GDN = 3,        /* out = aux * rsqrt(acc + bias)                                      quant_layer.py:147-153 */
     RDO_EPI_IGDN = 4,       /* out = aux * sqrt(acc + bias)                                       quant_layer.py:147-153 */
     RDO_EPI_RELU = 5,       /* out = max(acc + bias, 0): nn.ReLU fused into the QuantModule          quant_model.py:51-54 */
-    RDO_EPI_RELU_BWD = 6    /* out = aux > 0 ? acc : 0                    (dgrad through a ReLU whose OUTPUT is aux)        */
+    RDO_EPI_RELU_BWD = 6,   /* out = aux > 0 ? acc : 0                    (dgrad through a ReLU whose OUTPUT is aux)        */
+    RDO_EPI_GELU = 7,       /* out = gelu(acc + bias), exact erf form: Mlp.act fused into fc1            models/layers.py:37-47 */
+    RDO_EPI_GELU_BWD = 8    /* out = acc * gelu'(aux)       (dgrad through a GELU whose INPUT -- fc1's `pre` output -- is aux)    */
 };
 
 typedef struct rdo_conv_desc {
@@ -280,6 +282,16 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
  * [nslabs][C] of dy * xhat (consumed by rdo_adaround_step like the wgrad slabs).  gamma == NULL means weight 1. */
 int rdo_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int64_t rows, int32_t C, float eps, float* dx,
                        float* dgamma_slabs, int32_t nslabs, void* stream);
+/* Residual add + LayerNorm in one pass (SwinTransformerBlock.forward, models/layers.py:260-300: `x = shortcut + attn(...)` followed by
+ * `norm2(x)`, and the next block's `norm1` of `x + mlp(...)`): s = a (+ b, nullable) -> sum_out (nullable; needs b), out = LayerNorm(s).
+ * C a multiple of 4, <= 512; pointers 16-byte aligned. */
+int rdo_add_layer_norm(const float* a, const float* b, const float* weight, const float* bias, int64_t rows, int32_t C, float eps,
+                       float* sum_out, float* out, void* stream);
+/* rdo_layer_norm_bwd with the gradient that reaches x along the residual path folded in: dx = (add1) (+ add2) + LayerNorm-backward(dy)
+ * (both addends nullable; add2 needs add1).  Replaces autograd's AddBackward accumulation behind every LayerNorm of a Swin block. */
+int rdo_layer_norm_bwd_add(const float* x, const float* gamma, const float* dy, const float* add1, const float* add2, int64_t rows,
+                           int32_t C, float eps, float* dx, float* dgamma_slabs, int32_t nslabs, void* stream);
+int rdo_add3(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);   /* (a + b) + c: RSTB output, layers.py:433 */
 int rdo_gelu_fwd(const float* x, int64_t n, float* out, void* stream);                      /* nn.GELU(): exact erf form */
 int rdo_gelu_bwd(const float* dy, const float* x, int64_t n, float* dx, void* stream);
 int rdo_round(const float* x, int64_t n, float* out, void* stream);                         /* torch.round (half to even): round_ste forward */

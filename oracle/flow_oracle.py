@@ -170,13 +170,15 @@ class FlowOracle:
     def recon_model(self, cali, idx_streams, process_seed, *, iters, batch_size, weight=0.01, input_prob=0.5, b_range=(20, 2),
                     warmup=0.2, on_unit=None):
         """main2.py:227-253 + layer_opt.py / block_opt.py around the loop: units in order, each calibrated on caches of the
-        calibrated prefix.  `idx_streams[name]` = the [iters, B] mini-batch index table of that unit (layer_opt.py:289)."""
+        calibrated prefix.  `idx_streams[name]` = the [iters, B] mini-batch index table of that unit (layer_opt.py:289).
+        `iters`: one count for all units (main2.py --iters_w) or a callable unit name -> count (tests with per-unit horizons)."""
         logs = {}
         for u in self.units:
             xq, xf, tg = self.caches(u.name, cali)
             self._set_modes("prefix")
             seed = self.unit_seed(process_seed, u.local)
-            logs[u.name] = O.reconstruct_unit(u.kind, u.ops, xq, xf, tg, iters=iters, batch_size=batch_size,
+            logs[u.name] = O.reconstruct_unit(u.kind, u.ops, xq, xf, tg, iters=iters(u.name) if callable(iters) else iters,
+                                              batch_size=batch_size,
                                               idx_stream=idx_streams[u.name],
                                               mask_fn=lambda i, shape, seed=seed: O.qdrop_keep_mask_nhwc(seed, i, shape, input_prob),
                                               input_prob=input_prob, weight=weight, b_range=b_range, warmup=warmup)

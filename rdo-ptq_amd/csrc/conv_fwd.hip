@@ -55,6 +55,8 @@ __device__ __forceinline__ void finish(const FwdArgs& a, long o, float v) {
         case RDO_EPI_RELU_BWD: v = a.aux[o] > 0.f ? v : 0.f; break;
         case RDO_EPI_GDN: v = a.aux[o] * __frsqrt_rn(v); break;
         case RDO_EPI_IGDN: v = a.aux[o] * __fsqrt_rn(v); break;
+        case RDO_EPI_GELU: v = rdo::gelu(v); break;
+        case RDO_EPI_GELU_BWD: v *= rdo::gelu_grad(a.aux[o]); break;
         default: break;
     }
     if (a.add_residual) v += a.residual[o];
@@ -440,8 +442,8 @@ extern "C" int rdo_conv2d_fwd(const rdo_conv_desc* d, const float* x, const floa
     RDO_REQUIRE((long)d->B * d->H * d->W * d->Cin < (1L << 31) && (long)d->Cout * d->KH * d->KW * d->Cin < (1L << 31),
                 "rdo_conv2d_fwd: tensors of 2^31 or more elements are not supported (32-bit staging offsets)");
     const int epi = d->epilogue;
-    RDO_REQUIRE(epi >= RDO_EPI_NONE && epi <= RDO_EPI_RELU_BWD, "rdo_conv2d_fwd: unknown epilogue %d", epi);
-    RDO_REQUIRE(epi == RDO_EPI_NONE || epi == RDO_EPI_LRELU || epi == RDO_EPI_RELU || aux != nullptr,
+    RDO_REQUIRE(epi >= RDO_EPI_NONE && epi <= RDO_EPI_GELU_BWD, "rdo_conv2d_fwd: unknown epilogue %d", epi);
+    RDO_REQUIRE(epi == RDO_EPI_NONE || epi == RDO_EPI_LRELU || epi == RDO_EPI_RELU || epi == RDO_EPI_GELU || aux != nullptr,
                 "rdo_conv2d_fwd: epilogue %d needs aux", epi);
     RDO_REQUIRE(!d->add_residual || residual != nullptr, "rdo_conv2d_fwd: add_residual without residual");
     if (rdo_conv_is_thincout(d, true) && pre == nullptr) {

@@ -104,6 +104,8 @@ __device__ __forceinline__ void finish(const X6Args& a, long o, float v) {
         case RDO_EPI_RELU_BWD: v = a.aux[o] > 0.f ? v : 0.f; break;
         case RDO_EPI_GDN: v = a.aux[o] * __frsqrt_rn(v); break;
         case RDO_EPI_IGDN: v = a.aux[o] * __fsqrt_rn(v); break;
+        case RDO_EPI_GELU: v = rdo::gelu(v); break;
+        case RDO_EPI_GELU_BWD: v *= rdo::gelu_grad(a.aux[o]); break;
         default: break;
     }
     if (a.add_residual) v += a.residual[o];

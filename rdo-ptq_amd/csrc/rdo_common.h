@@ -137,6 +137,14 @@ __device__ __forceinline__ void h2_report(int bad, int* flag) {
         else atomicOr(flag + 1, 1);
     }
 }
+// exact (erf) GELU of nn.GELU() (models/layers.py:37,40) and its derivative; shared by the element-wise kernels (swin.hip) and the
+// RDO_EPI_GELU / RDO_EPI_GELU_BWD epilogues of the conv kernels
+__device__ __forceinline__ float gelu(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+    const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
+    const float pdf = 0.39894228040143268f * expf(-0.5f * v * v);
+    return cdf + v * pdf;
+}
 #endif
 
 }  // namespace rdo

@@ -206,28 +206,52 @@ __device__ __forceinline__ void softmax_rows256(const AttnGeom& g, float* S, flo
     }
 }
 
+// (window, head) of a workgroup.  Launch ids go round-robin over the 8 XCDs (id % 8), each with its own L2: the heads of one window read
+// interleaved pieces of the same qkv rows (head h of a token is hd floats inside a 3C-float row: neighbouring heads share cache lines),
+// so they are numbered next to each other INSIDE one XCD -- slot = id / 8 walks (window of this XCD, head) with the head fastest.
+__device__ __forceinline__ void attn_wg(int windows, int heads, int& win, int& head) {
+    const int id = blockIdx.x;
+    const int xcd = id & 7, slot = id >> 3;
+    const int full = windows >> 3, rest = windows & 7;          // windows per XCD: `full`, one more on the first `rest` XCDs
+    const int mine = full + (xcd < rest ? 1 : 0);
+    const int first = xcd * full + (xcd < rest ? xcd : rest);
+    const int lw = slot / heads;
+    head = slot - lw * heads;
+    win = lw < mine ? first + lw : -1;                           // (ids beyond the XCD's share: the grid is padded to a multiple of 8)
+}
+
+// LDS budget (round 5): the score matrices are held in the MFMA accumulators until every wave is done with the operands they were
+// computed from, then written OVER those operands -- forward: S over Q / K (3 x 64 x hs floats in all: four workgroups per CU at hd = 48,
+// two before), backward: P over V (which no later product reads) + dS behind it (71 KiB instead of 85 at hd = 48: two workgroups per
+// CU instead of one).  These kernels are latency chains (load tiles -> products -> row softmax -> products -> store); a second resident
+// workgroup is what fills the gaps.
 __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
-                                                                int no_pv) {
+                                                                int no_pv, int windows) {
     extern __shared__ float lds[];
-    float* Q = lds;
+    float* V = lds;
+    float* Q = V + 64 * g.hs;
     float* K = Q + 64 * g.hs;
-    float* V = K + 64 * g.hs;
-    float* S = V + 64 * g.hs;
-    const int win = blockIdx.x, head = blockIdx.y;
+    float* S = Q;                                             // [64][65] over Q and K (2 x 64 x hs >= 64 x 65 for hs >= 33; else behind V)
+    int win, head;
+    attn_wg(windows, g.heads, win, head);
+    if (win < 0) return;
     const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
     __shared__ int pix[NMAX], reg[NMAX];                     // token -> pixel (roll + window partition) and -> mask region, computed once
     if (threadIdx.x < g.N) {
         pix[threadIdx.x] = token_pixel(g, win, threadIdx.x);
         reg[threadIdx.x] = g.shift > 0 ? token_region(g, win, threadIdx.x) : 0;
     }
-    zero_lds(lds, 3 * 64 * g.hs);
+    const bool full = g.N == NMAX && (g.hd & 1) == 0;         // every row a token, no odd-K zero column: nothing reads the padding
+    if (!full) zero_lds(lds, 3 * 64 * g.hs);
     __syncthreads();
     load_tile256(g, qkv, 3 * g.C, head * g.hd, pix, Q, g.scale);
     load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix, K, 1.f);
     load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix, V, 1.f);
     __syncthreads();
     const int hk = (g.hd + 1) & ~1;
-    tile_to_lds(tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0), S, SS, ti, tj);
+    const f32x16 sc = tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0);
+    __syncthreads();                                          // every wave has read Q and K
+    tile_to_lds(sc, S, SS, ti, tj);
     __syncthreads();
     softmax_rows256(g, S, nullptr, bias, reg, head, probs, win);
     if (no_pv) return;
@@ -240,22 +264,25 @@ __global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const float* qkv
 }
 
 __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv, const float* bias, const float* dout, AttnGeom g,
-                                                                float* dqkv) {
+                                                                float* dqkv, int windows) {
     extern __shared__ float lds[];
     float* Q = lds;                       // pre-scaled
     float* K = Q + 64 * g.hs;
-    float* V = K + 64 * g.hs;
-    float* dO = V + 64 * g.hs;
-    float* P = dO + 64 * g.hs;            // [64][65]: scores, then probabilities
+    float* dO = K + 64 * g.hs;
+    float* V = dO + 64 * g.hs;
+    float* P = V;                         // [64][65]: scores, then probabilities -- over V once the dP product has read it
     float* dS = P + 64 * SS;              // [64][65]: dP, then dS
-    const int win = blockIdx.x, head = blockIdx.y;
+    int win, head;
+    attn_wg(windows, g.heads, win, head);
+    if (win < 0) return;
     const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
     __shared__ int pix[NMAX], reg[NMAX];
     if (threadIdx.x < g.N) {
         pix[threadIdx.x] = token_pixel(g, win, threadIdx.x);
         reg[threadIdx.x] = g.shift > 0 ? token_region(g, win, threadIdx.x) : 0;
     }
-    zero_lds(lds, 4 * 64 * g.hs);
+    const bool full = g.N == NMAX && (g.hd & 1) == 0;
+    if (!full) zero_lds(lds, 4 * 64 * g.hs);
     __syncthreads();
     load_tile256(g, qkv, 3 * g.C, head * g.hd, pix, Q, g.scale);
     load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix, K, 1.f);
@@ -263,8 +290,11 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv
     load_tile256(g, dout, g.C, head * g.hd, pix, dO, 1.f);
     __syncthreads();
     const int hk = (g.hd + 1) & ~1, nk = (g.N + 1) & ~1;
-    tile_to_lds(tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0), P, SS, ti, tj);
-    tile_to_lds(tile_gemm<false, true>(dO, g.hs, V, g.hs, ti, tj, hk, 0), dS, SS, ti, tj);      // dP = dO V^T
+    const f32x16 sc = tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0);
+    const f32x16 dp = tile_gemm<false, true>(dO, g.hs, V, g.hs, ti, tj, hk, 0);                   // dP = dO V^T
+    __syncthreads();                                                                               // every wave has read V
+    tile_to_lds(sc, P, SS, ti, tj);
+    tile_to_lds(dp, dS, SS, ti, tj);
     __syncthreads();
     softmax_rows256(g, P, dS, bias, reg, head, nullptr, win);
     __syncthreads();
@@ -335,19 +365,167 @@ __global__ __launch_bounds__(256) void layer_norm_bwd_kernel(const float* x, con
         dgamma_slabs[(long)blockIdx.x * C + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
 }
 
+// ---- residual add + LayerNorm in one pass, and LayerNorm backward with the residual gradient folded in (round 5) ----------------
+// A Swin block is  t1 = t + proj(attn(LN1(t)));  t2 = t1 + fc2(gelu(fc1(LN2(t1))))  (models/layers.py:260-300): every LayerNorm but the
+// first of an RSTB reads a sum that a separate add kernel has just written, and the gradient of that sum is the LayerNorm's input
+// gradient PLUS what flows past it along the residual path.  `add_ln_kernel`: s = a (+ b) -> s_out (if wanted), y = LN(s).
+// `ln_bwd_add_kernel`: dx = (add1) (+ add2) + LN-backward(dy).  63 add launches of a g_a1 iteration become 4.
+// Layout: 16 lanes per row, VPL float4 per lane (C / 4 <= 16 * VPL), four rows per wave: every load instruction of a 16-lane group is
+// 256 contiguous bytes; the two row statistics are four-step butterflies inside the group.  Same arithmetic as the scalar kernels
+// (two-pass mean / variance).
+typedef float ln4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float ln_sum4(ln4 v) { return (v.x + v.y) + (v.z + v.w); }
+__device__ __forceinline__ float ln_red16(float v) {
+    v += __shfl_xor(v, 8, 16); v += __shfl_xor(v, 4, 16); v += __shfl_xor(v, 2, 16); v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void add_ln_kernel(const ln4* __restrict__ a, const ln4* __restrict__ b, const ln4* __restrict__ w,
+                                                     const ln4* __restrict__ bias, long rows, int C4, float eps, ln4* __restrict__ s_out,
+                                                     ln4* __restrict__ y_out) {
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const float invC = 1.f / (float)(4 * C4);
+    ln4 wv[VPL], bv[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const int c = l16 + 16 * k;
+        wv[k] = (w && c < C4) ? w[c] : ln4{1.f, 1.f, 1.f, 1.f};
+        bv[k] = (bias && c < C4) ? bias[c] : ln4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = (long)blockIdx.x * 16 + grp; row < rows; row += (long)gridDim.x * 16) {
+        const long base = row * C4;
+        ln4 v[VPL];
+        float s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = l16 + 16 * k;
+            if (c < C4) {
+                v[k] = a[base + c];
+                if (b) v[k] += b[base + c];
+                if (s_out) s_out[base + c] = v[k];
+                s1 += ln_sum4(v[k]);
+            } else {
+                v[k] = ln4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const float mean = ln_red16(s1) * invC;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            if (l16 + 16 * k < C4) {
+                v[k] -= mean;
+                s2 += ln_sum4(v[k] * v[k]);
+            }
+        }
+        const float rstd = rsqrtf(ln_red16(s2) * invC + eps);
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = l16 + 16 * k;
+            if (c < C4) y_out[base + c] = v[k] * rstd * wv[k] + bv[k];
+        }
+    }
+}
+
+template <int VPL>
+__global__ __launch_bounds__(256) void ln_bwd_add_kernel(const ln4* __restrict__ x, const ln4* __restrict__ gamma, const ln4* __restrict__ dy,
+                                                         const ln4* __restrict__ add1, const ln4* __restrict__ add2, long rows, int C4,
+                                                         float eps, ln4* __restrict__ dx, float* __restrict__ dgamma_slabs) {
+    __shared__ float part[4][512];
+    const int l16 = threadIdx.x & 15, grp = threadIdx.x >> 4;
+    const float invC = 1.f / (float)(4 * C4);
+    ln4 gv[VPL], dg[VPL];
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+        const int c = l16 + 16 * k;
+        gv[k] = (gamma && c < C4) ? gamma[c] : ln4{1.f, 1.f, 1.f, 1.f};
+        dg[k] = ln4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (long row = (long)blockIdx.x * 16 + grp; row < rows; row += (long)gridDim.x * 16) {
+        const long base = row * C4;
+        ln4 xv[VPL], g[VPL];
+        float s1 = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            const int c = l16 + 16 * k;
+            if (c < C4) {
+                xv[k] = x[base + c];
+                g[k] = dy[base + c];
+                s1 += ln_sum4(xv[k]);
+            } else {
+                xv[k] = ln4{0.f, 0.f, 0.f, 0.f};
+                g[k] = ln4{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        const float mean = ln_red16(s1) * invC;
+        float s2 = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            if (l16 + 16 * k < C4) {
+                xv[k] -= mean;
+                s2 += ln_sum4(xv[k] * xv[k]);
+            }
+        }
+        const float rstd = rsqrtf(ln_red16(s2) * invC + eps);
+        float sa = 0.f, sb = 0.f;
+#pragma unroll
+        for (int k = 0; k < VPL; ++k) {
+            xv[k] *= rstd;                               // xhat (zero beyond C)
+            dg[k] += g[k] * xv[k];
+            g[k] *= gv[k];                               // dy * gamma
+            sa += ln_sum4(g[k]);
+            sb += ln_sum4(g[k] * xv[k]);
+        }
+        sa = ln_red16(sa) * invC;
+        sb = ln_red16(sb) * invC;
+        if (dx) {
+#pragma unroll
+            for (int k = 0; k < VPL; ++k) {
+                const int c = l16 + 16 * k;
+                if (c < C4) {
+                    ln4 r = rstd * (g[k] - sa - xv[k] * sb);
+                    if (add1) r = add1[base + c] + r;
+                    if (add2) r = add2[base + c] + r;
+                    dx[base + c] = r;
+                }
+            }
+        }
+    }
+    if (!dgamma_slabs) return;
+    // the four row groups of a wave hold the same channels: fold them (lanes l, l+16, l+32, l+48), then the four waves through LDS
+    const int wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < VPL; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float v = dg[k][e];
+            v += __shfl_xor(v, 16, 64);
+            v += __shfl_xor(v, 32, 64);
+            const int c = l16 + 16 * k;
+            if ((threadIdx.x & 63) < 16 && c < C4) part[wave][4 * c + e] = v;
+        }
+    }
+    __syncthreads();
+    const int C = 4 * C4;
+    for (int c = threadIdx.x; c < C; c += 256)
+        dgamma_slabs[(long)blockIdx.x * C + c] = part[0][c] + part[1][c] + part[2][c] + part[3][c];
+}
+
+// out = (a + b) + c: the sum of an RSTB's last block and the RSTB's own residual in the reference's order (layers.py:300, 433)
+__global__ __launch_bounds__(256) void add3_kernel(const ln4* a, const ln4* b, const ln4* c, long n4, ln4* out) {
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n4; t += (long)gridDim.x * blockDim.x) out[t] = (a[t] + b[t]) + c[t];
+}
+
 // exact (erf) GELU, nn.GELU() default (layers.py:37,40)
 __global__ __launch_bounds__(256) void gelu_fwd_kernel(const float* x, long n, float* out) {
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
         const float v = x[t];
-        out[t] = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        out[t] = rdo::gelu(v);
     }
 }
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const float* dy, const float* x, long n, float* dx) {
     for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < n; t += (long)gridDim.x * blockDim.x) {
-        const float v = x[t];
-        const float cdf = 0.5f * (1.0f + erff(v * 0.70710678118654752f));
-        const float pdf = 0.39894228040143268f * expf(-0.5f * v * v);
-        dx[t] = dy[t] * (cdf + v * pdf);
+        dx[t] = dy[t] * rdo::gelu_grad(x[t]);
     }
 }
 __global__ __launch_bounds__(256) void round_kernel(const float* x, long n, float* out) {
@@ -369,7 +547,7 @@ int make_geom(const rdo_attn_desc* d, AttnGeom* g, const char* who) {
     g->B = d->B; g->H = d->H; g->W = d->W; g->C = d->C; g->heads = d->heads; g->ws = d->window; g->shift = d->shift;
     g->N = d->window * d->window;
     g->hd = d->C / d->heads;
-    g->hs = (g->hd + 2) | 1;                 // odd row stride with room for the zero column an odd head dim needs
+    g->hs = (g->hd + 1) | 1;                 // odd row stride; an odd head dim gets the zero column its last k pair reads (hd + 2)
     RDO_REQUIRE(g->hd <= 64, "%s: head dims above 64 are not supported", who);
     g->scale = d->scale;
     return RDO_OK;
@@ -384,8 +562,11 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
     if (int rc = make_geom(d, &g, "rdo_window_attention_fwd")) return rc;
     RDO_REQUIRE(qkv && bias && (out || probs), "rdo_window_attention_fwd: null argument");
     const int windows = g.B * (g.H / g.ws) * (g.W / g.ws);
-    const size_t lds = ((size_t)3 * 64 * g.hs + (size_t)64 * SS) * sizeof(float);
+    // V, then Q and K with the score matrix over them (or behind V where two narrow tiles are smaller than it)
+    const size_t qk = (size_t)2 * 64 * g.hs, sm = (size_t)64 * SS;
+    const size_t lds = ((size_t)64 * g.hs + (qk > sm ? qk : sm)) * sizeof(float);
     const int no_pv = out == nullptr;
+    const unsigned grid = (unsigned)(rdo::ceil_div(windows, 8) * 8 * g.heads);
     return rdo::dispatch(
         [=](hipStream_t s) {
             static rdo::PerDevice attr;
@@ -395,7 +576,7 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_fwd_mfma) failed");
                 attr.mark();
             }
-            hipLaunchKernelGGL(win_attn_fwd_mfma_kernel, dim3(windows, g.heads), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv);
+            hipLaunchKernelGGL(win_attn_fwd_mfma_kernel, dim3(grid), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv, windows);
             return rdo::check_launch("window_attention_fwd");
         },
         stream, "window_attention_fwd", 4.0 * windows * g.heads * (double)g.N * g.N * g.hd,
@@ -421,7 +602,10 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
     if (int rc = make_geom(d, &g, "rdo_window_attention_bwd")) return rc;
     RDO_REQUIRE(qkv && bias && dout && dqkv, "rdo_window_attention_bwd: null argument");
     const int windows = g.B * (g.H / g.ws) * (g.W / g.ws);
-    const size_t lds = ((size_t)4 * 64 * g.hs + (size_t)2 * 64 * SS) * sizeof(float);
+    // Q, K, dO, then V with P over it and dS behind
+    const size_t lds = ((size_t)3 * 64 * g.hs + (size_t)2 * 64 * SS) * sizeof(float);
+    static_assert(SS >= 64 + 1, "P must cover a 64-float row");
+    const unsigned grid = (unsigned)(rdo::ceil_div(windows, 8) * 8 * g.heads);
     return rdo::dispatch(
         [=](hipStream_t s) {
             static rdo::PerDevice attr;
@@ -431,7 +615,7 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_bwd_mfma) failed");
                 attr.mark();
             }
-            hipLaunchKernelGGL(win_attn_bwd_mfma_kernel, dim3(windows, g.heads), dim3(256), lds, s, qkv, bias, dout, g, dqkv);
+            hipLaunchKernelGGL(win_attn_bwd_mfma_kernel, dim3(grid), dim3(256), lds, s, qkv, bias, dout, g, dqkv, windows);
             return rdo::check_launch("window_attention_bwd");
         },
         stream, "window_attention_bwd", 10.0 * windows * g.heads * (double)g.N * g.N * g.hd,
@@ -453,6 +637,69 @@ int rdo_layer_norm_bwd(const float* x, const float* gamma, const float* dy, int6
             return rdo::check_launch("layer_norm_bwd");
         },
         stream, "layer_norm_bwd", 0.0, 12.0 * rows * C);
+}
+
+int rdo_add_layer_norm(const float* a, const float* b, const float* weight, const float* bias, int64_t rows, int32_t C, float eps,
+                       float* sum_out, float* out, void* stream) {
+    RDO_REQUIRE(a && out && rows > 0 && C > 0 && C % 4 == 0 && C <= 512, "rdo_add_layer_norm: bad argument (C a multiple of 4, <= 512)");
+    RDO_REQUIRE(!sum_out || b, "rdo_add_layer_norm: sum_out without a second addend");
+    RDO_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(weight) |
+                  reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(sum_out) | reinterpret_cast<uintptr_t>(out)) & 15) == 0,
+                "rdo_add_layer_norm: pointers must be 16-byte aligned");
+    const int C4 = C / 4;
+    long blocks = rdo::ceil_div(rows, 16);
+    if (blocks > 4096) blocks = 4096;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, (const ln4*)a, (const ln4*)b, (const ln4*)weight,
+                                   (const ln4*)bias, (long)rows, C4, eps, (ln4*)sum_out, (ln4*)out);
+            };
+            if (C4 <= 48) go(add_ln_kernel<3>);
+            else if (C4 <= 80) go(add_ln_kernel<5>);
+            else go(add_ln_kernel<8>);
+            return rdo::check_launch("add_layer_norm");
+        },
+        stream, "add_layer_norm", 0.0, 4.0 * rows * C * (2.0 + (b ? 1.0 : 0.0) + (sum_out ? 1.0 : 0.0)));
+}
+
+int rdo_layer_norm_bwd_add(const float* x, const float* gamma, const float* dy, const float* add1, const float* add2, int64_t rows,
+                           int32_t C, float eps, float* dx, float* dgamma_slabs, int32_t nslabs, void* stream) {
+    RDO_REQUIRE(x && dy && rows > 0 && C > 0 && C % 4 == 0 && C <= 512, "rdo_layer_norm_bwd_add: bad argument (C a multiple of 4, <= 512)");
+    RDO_REQUIRE(dx || dgamma_slabs, "rdo_layer_norm_bwd_add: nothing to compute");
+    RDO_REQUIRE(!dgamma_slabs || nslabs > 0, "rdo_layer_norm_bwd_add: nslabs must be positive");
+    RDO_REQUIRE(!add2 || add1, "rdo_layer_norm_bwd_add: add2 without add1");
+    RDO_REQUIRE(dx || !add1, "rdo_layer_norm_bwd_add: an addend without dx");
+    RDO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(dy) |
+                  reinterpret_cast<uintptr_t>(add1) | reinterpret_cast<uintptr_t>(add2) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0,
+                "rdo_layer_norm_bwd_add: pointers must be 16-byte aligned");
+    const int C4 = C / 4;
+    long blocks = rdo::ceil_div(rows, 16);
+    if (dgamma_slabs) blocks = nslabs;       // every slab is written (rows are strided over the blocks)
+    else if (blocks > 4096) blocks = 4096;
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            auto go = [&](auto kern) {
+                hipLaunchKernelGGL(kern, dim3((unsigned)blocks), dim3(256), 0, s, (const ln4*)x, (const ln4*)gamma, (const ln4*)dy,
+                                   (const ln4*)add1, (const ln4*)add2, (long)rows, C4, eps, (ln4*)dx, dgamma_slabs);
+            };
+            if (C4 <= 48) go(ln_bwd_add_kernel<3>);
+            else if (C4 <= 80) go(ln_bwd_add_kernel<5>);
+            else go(ln_bwd_add_kernel<8>);
+            return rdo::check_launch("layer_norm_bwd_add");
+        },
+        stream, "layer_norm_bwd_add", 0.0, 4.0 * rows * C * (3.0 + (add1 ? 1.0 : 0.0) + (add2 ? 1.0 : 0.0)));
+}
+
+int rdo_add3(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream) {
+    RDO_REQUIRE(a && b && c && out && n > 0 && n % 4 == 0, "rdo_add3: bad argument");
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            hipLaunchKernelGGL(add3_kernel, dim3(grid1d(n / 4)), dim3(256), 0, s, (const ln4*)a, (const ln4*)b, (const ln4*)c, (long)(n / 4),
+                               (ln4*)out);
+            return rdo::check_launch("add3");
+        },
+        stream, "add3", 0.0, 16.0 * n);
 }
 
 int rdo_gelu_fwd(const float* x, int64_t n, float* out, void* stream) {

@@ -8,7 +8,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "librdoptq_hip.so")
 
-EPI_NONE, EPI_LRELU, EPI_LRELU_BWD, EPI_GDN, EPI_IGDN, EPI_RELU, EPI_RELU_BWD = range(7)
+EPI_NONE, EPI_LRELU, EPI_LRELU_BWD, EPI_GDN, EPI_IGDN, EPI_RELU, EPI_RELU_BWD, EPI_GELU, EPI_GELU_BWD = range(9)
 LOG_SLOTS = 32            # RDO_LOG_SLOTS of include/rdo_ptq_hip.h
 
 
@@ -75,6 +75,9 @@ _SIGS = {
     "rdo_window_attention_pv": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P]),
     "rdo_window_attention_bwd": (C.c_int, [C.POINTER(AttnDesc), P, P, P, P, P]),
     "rdo_layer_norm_bwd": (C.c_int, [P, P, P, C.c_int64, C.c_int32, C.c_float, P, P, C.c_int32, P]),
+    "rdo_add_layer_norm": (C.c_int, [P, P, P, P, C.c_int64, C.c_int32, C.c_float, P, P, P]),
+    "rdo_layer_norm_bwd_add": (C.c_int, [P, P, P, P, P, C.c_int64, C.c_int32, C.c_float, P, P, C.c_int32, P]),
+    "rdo_add3": (C.c_int, [P, P, P, C.c_int64, P, P]),
     "rdo_gelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
     "rdo_gelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_round": (C.c_int, [P, C.c_int64, P, P]),

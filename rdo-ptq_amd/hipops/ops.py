@@ -523,6 +523,32 @@ def layer_norm(x, weight, bias, eps=1e-5, out=None):
     return out
 
 
+def add_layer_norm(a, b, weight, bias, eps=1e-5, sum_out=None, out=None):
+    """s = a + b (b may be None) -> `sum_out` (written when given), LayerNorm(s) -> out: the residual add of a Swin block and the
+    LayerNorm that reads it, in one pass."""
+    Cc = a.shape[-1]
+    out = torch.empty_like(a) if out is None else out
+    L.check(L.lib().rdo_add_layer_norm(_ptr(a), _ptr(b), _ptr(weight), _ptr(bias), a.numel() // Cc, Cc, eps, _ptr(sum_out), _ptr(out),
+                                       _stream()), "rdo_add_layer_norm")
+    return out
+
+
+def layer_norm_bwd_add(x, weight, dy, add1=None, add2=None, eps=1e-5, dx=None, dgamma_slabs=None):
+    """dx = (add1) (+ add2) + LayerNorm-backward(dy); dgamma partial sums as in `layer_norm_bwd`."""
+    Cc = x.shape[-1]
+    ns = 0 if dgamma_slabs is None else dgamma_slabs.shape[0]
+    L.check(L.lib().rdo_layer_norm_bwd_add(_ptr(x), _ptr(weight), _ptr(dy), _ptr(add1), _ptr(add2), x.numel() // Cc, Cc, eps, _ptr(dx),
+                                           _ptr(dgamma_slabs), ns, _stream()), "rdo_layer_norm_bwd_add")
+    return dx
+
+
+def add3(a, b, c, out=None):
+    """(a + b) + c"""
+    out = torch.empty_like(a) if out is None else out
+    L.check(L.lib().rdo_add3(_ptr(a), _ptr(b), _ptr(c), a.numel(), _ptr(out), _stream()), "rdo_add3")
+    return out
+
+
 def layer_norm_bwd(x, weight, dy, eps=1e-5, dx=None, dgamma_slabs=None):
     """dx (returned) and, when `dgamma_slabs` [nslabs, C] is given, the partial sums of dy * xhat."""
     Cc = x.shape[-1]

@@ -160,122 +160,116 @@ class TapeEngine(UnitEngine):
         return t
 
     # ------------------------------------------------------------------------------------------------------------------ tape
-    def _grad_slot(self, t):
-        """(buffer to write the next gradient contribution of `t` into, True if it is the first one)."""
-        g = self.G.get(id(t))
-        if g is None:
-            g = self._buf(*t.shape)
-            self.G[id(t)] = g
-            return g, True
-        return self._buf(*t.shape), False
+    # Gradients are LAZY SUMS: G[id(t)] is the list of buffers whose sum is dL/dt.  A backward closure appends the buffer it wrote
+    # (`_gput`); a consumer that needs the sum as one tensor asks `_gget` (one add per extra contribution); the LayerNorm backward
+    # takes up to two contributions as addends of its own output (`rdo_layer_norm_bwd_add`), which is where the residual paths of a
+    # Swin block meet -- so a block's backward runs without a single add kernel.  Buffers are written once and never accumulated in
+    # place, so sharing one buffer between two tensors (both inputs of an add) needs no alias tracking.
+    def _gput(self, t, buf):
+        self.G.setdefault(id(t), []).append(buf)
 
-    def _grad_commit(self, t, buf, first):
-        if first:
-            return
-        g = self.G[id(t)]
-        if id(g) in self._aliased:
-            # g also serves as the gradient of another tensor (both inputs of a residual add share their output's gradient):
-            # accumulate into a private buffer instead of in place
+    def _gparts(self, t):
+        return self.G.get(id(t), [])
+
+    def _gget(self, t):
+        parts = self.G[id(t)]
+        while len(parts) > 1:
             acc = self._buf(*t.shape)
-            ops.add(g, buf, out=acc)
-            self.G[id(t)] = acc
-        else:
-            ops.add(g, buf, out=g)
+            ops.add(parts[0], parts[1], out=acc)
+            parts[:2] = [acc]
+        return parts[0]
+
+    def _gnew(self, t):
+        buf = self._buf(*t.shape)
+        self._gput(t, buf)
+        return buf
 
     # -- linear over the token matrix ------------------------------------------------------------------------------------
-    def _linear(self, x, p, need_dx=True):
+    def _linear(self, x, p, need_dx=True, gelu=False, gelu_in=None):
+        """y = x W^T + b.  gelu=True: the Mlp's activation in fc1's epilogue -- returns (gelu(y), y); gelu_in: this linear's INPUT is
+        gelu(gelu_in), so its input gradient goes through RDO_EPI_GELU_BWD and is stored as the gradient of `gelu_in`."""
         rows, cin = x.numel() // x.shape[-1], x.shape[-1]
         cout = p.w4[0]
         y = self._buf(*x.shape[:-1], cout)
         x4, y4 = x.view(1, 1, rows, cin), y.view(1, 1, rows, cout)
-        self._conv(p, x4, y4)
+        pre = None
+        if gelu:
+            pre = self._buf(*y.shape)
+            self._conv(p, x4, y4, epilogue=L.EPI_GELU, pre=pre.view(1, 1, rows, cout))
+        else:
+            self._conv(p, x4, y4)
 
         def bwd():
-            dy4 = self.G[id(y)].view(1, 1, rows, cout)
+            dy4 = self._gget(pre if gelu else y).view(1, 1, rows, cout)
             if isinstance(p, _Op):
                 self._wgrad(p, x4, dy4)
             if need_dx:
-                dx, first = self._grad_slot(x)
-                self._dgrad(p, dy4, dx.view(1, 1, rows, cin))
-                self._grad_commit(x, dx, first)
+                if gelu_in is not None:
+                    dx = self._gnew(gelu_in)
+                    self._dgrad(p, dy4, dx.view(1, 1, rows, cin), epilogue=L.EPI_GELU_BWD, aux=gelu_in.view(1, 1, rows, cin))
+                else:
+                    self._dgrad(p, dy4, self._gnew(x).view(1, 1, rows, cin))
         self.tape.append(bwd)
-        return y
+        return (y, pre) if gelu else y
 
-    def _layer_norm(self, x, ln: _Ln, need_dx=True):
-        y = self._buf(*x.shape)
-        ops.layer_norm(x, ln.gamma, ln.beta, out=y)
+    def _add_ln(self, a, b, ln: _Ln, need_ds=True):
+        """s = a + b (b None: s is a), y = LayerNorm(s) -> (s, y).  Backward: ds = (what reached s along the residual path) +
+        LayerNorm-backward(dy); a and b both receive ds."""
+        y = self._buf(*a.shape)
+        if b is None:
+            s = a
+            ops.add_layer_norm(a, None, ln.gamma, ln.beta, out=y)
+        else:
+            s = self._buf(*a.shape)
+            ops.add_layer_norm(a, b, ln.gamma, ln.beta, sum_out=s, out=y)
 
         def bwd():
-            dy = self.G[id(y)]
+            dy = self._gget(y)
             slabs = None
             if ln.op is not None:
                 # dgamma partial sums: one 4-wave block per slab.  Many slabs keep the 65k-row maps parallel; they are folded
                 # 32 -> 1 by rdo_reduce_slabs so that the AdaRound step (one thread per weight) sums at most 32 of them
-                rows, Cc = x.numel() // x.shape[-1], x.shape[-1]
+                rows, Cc = s.numel() // s.shape[-1], s.shape[-1]
                 if ln.op.slabs is None:
                     n1 = max(1, min(32, (rows + 15) // 16))
                     n2 = 32 if rows >= 16 * 32 * 4 else 1
                     ln.op.slabs = self._buf(n1, Cc)
                     ln.op.slabs_wide = self._buf(n2 * n1, Cc) if n2 > 1 else ln.op.slabs
                 slabs = ln.op.slabs_wide
-            dx, first = self._grad_slot(x) if need_dx else (None, True)
-            ops.layer_norm_bwd(x, ln.gamma, dy, dx=dx, dgamma_slabs=slabs)
+            ds = None
+            if need_ds:
+                parts = self._gparts(s)
+                if len(parts) > 2:
+                    self._gget(s)
+                    parts = self._gparts(s)
+                ds = self._buf(*s.shape)
+                ops.layer_norm_bwd_add(s, ln.gamma, dy, *parts, dx=ds, dgamma_slabs=slabs)
+                if b is None:
+                    self.G[id(s)] = [ds]
+                else:
+                    self._gput(a, ds)
+                    self._gput(b, ds)
+            else:
+                ops.layer_norm_bwd_add(s, ln.gamma, dy, dx=None, dgamma_slabs=slabs)
             if ln.op is not None and ln.op.slabs_wide is not ln.op.slabs:
                 n1 = ln.op.slabs.shape[0]
-                ops.reduce_slabs(slabs.view(slabs.shape[0] // n1, n1 * x.shape[-1]), out=ln.op.slabs.view(-1))
-            if need_dx:
-                self._grad_commit(x, dx, first)
+                ops.reduce_slabs(slabs.view(slabs.shape[0] // n1, n1 * s.shape[-1]), out=ln.op.slabs.view(-1))
         self.tape.append(bwd)
-        return y
+        return s, y
 
     def _attention(self, qkv, desc, bias):
         out = self._buf(desc.B, desc.H, desc.W, desc.C)
         ops.window_attention(desc, qkv, bias, out=out)
 
         def bwd():
-            dq, first = self._grad_slot(qkv)
-            ops.window_attention_bwd(desc, qkv, bias, self.G[id(out)], dq)
-            self._grad_commit(qkv, dq, first)
+            ops.window_attention_bwd(desc, qkv, bias, self._gget(out), self._gnew(qkv))
         self.tape.append(bwd)
         return out
-
-    def _gelu(self, x):
-        y = self._buf(*x.shape)
-        ops.gelu(x, out=y)
-
-        def bwd():
-            dx, first = self._grad_slot(x)
-            ops.gelu_bwd(self.G[id(y)], x, dx)
-            self._grad_commit(x, dx, first)
-        self.tape.append(bwd)
-        return y
-
-    def _add(self, a, b, grad_a=True):
-        y = self._buf(*a.shape)
-        ops.add(a, b, out=y)
-
-        def bwd():
-            dy = self.G[id(y)]
-            if grad_a:
-                self._aliased.add(id(dy))
-            for t in ((a, b) if grad_a else (b,)):
-                if id(t) not in self.G:
-                    self.G[id(t)] = dy                     # first contribution: share the buffer (never written in place again)
-                else:
-                    g = self.G[id(t)]
-                    if g is dy:
-                        continue
-                    # the stored gradient may itself be a shared buffer: accumulate into a private copy
-                    acc = self._buf(*t.shape)
-                    ops.add(g, dy, out=acc)
-                    self.G[id(t)] = acc
-        self.tape.append(bwd)
-        return y
 
     # -- one RSTB (trainable: AdaRound ops of this engine; frozen: the stage's FP parameters) -----------------------------------
     def _rstb(self, x, rstb, ops_of=None, need_dx=True):
         B, H, W, C = x.shape
-        t = x
+        ta, tb = x, None                      # the running token tensor is ta + tb; the sum is formed by the LayerNorm that reads it
         for i, blk in enumerate(rstb.residual_group.blocks):
             pre = f"residual_group.blocks.{i}."
             if ops_of is not None:
@@ -287,30 +281,27 @@ class TapeEngine(UnitEngine):
                 ln1, ln2 = _Ln(blk.norm1), _Ln(blk.norm2)
                 self._keep.extend(p.values())
                 self._fp.extend(p.values())
-            first_block_input = t is x
-            want_dt = need_dx or not first_block_input
-            n1 = self._layer_norm(t, ln1, need_dx=want_dt)
+            want_dt = need_dx or i > 0        # the gradient of the unit's own (cached) input is never needed
+            t, n1 = self._add_ln(ta, tb, ln1, need_ds=want_dt)
             qkv = self._linear(n1, p["attn.qkv"])
             desc = ops.attn_desc(B, H, W, C, blk.num_heads, blk.window_size, blk.shift_size, blk.attn.scale)
             bias = blk.attn.position_bias()
             self._keep.append(bias)
-            a = self._attention(qkv, desc, bias)
-            pr = self._linear(a, p["attn.proj"])
-            t1 = self._add(t, pr, grad_a=want_dt)
-            n2 = self._layer_norm(t1, ln2)
-            f1 = self._linear(n2, p["mlp.fc1"])
-            g = self._gelu(f1)
-            f2 = self._linear(g, p["mlp.fc2"])
-            t = self._add(t1, f2)
-        return self._add(t, x, grad_a=True) if need_dx else self._add_in(t, x)
-
-    def _add_in(self, t, x):
-        """t + x where x needs no gradient (the cached unit input)."""
-        y = self._buf(*t.shape)
-        ops.add(t, x, out=y)
+            att = self._attention(qkv, desc, bias)
+            pr = self._linear(att, p["attn.proj"])
+            t1, n2 = self._add_ln(t, pr, ln2)
+            g, f1 = self._linear(n2, p["mlp.fc1"], gelu=True)
+            f2 = self._linear(g, p["mlp.fc2"], gelu_in=f1)
+            ta, tb = t1, f2
+        y = self._buf(*x.shape)
+        ops.add3(ta, tb, x, out=y)            # (t1 + f2) + x: last block's sum, then the RSTB's residual (layers.py:300, 433)
 
         def bwd():
-            self.G[id(t)] = self.G[id(y)]
+            dy = self._gget(y)
+            self._gput(ta, dy)
+            self._gput(tb, dy)
+            if need_dx:
+                self._gput(x, dy)
         self.tape.append(bwd)
         return y
 
@@ -326,8 +317,8 @@ class TapeEngine(UnitEngine):
             self._conv(p, x, y)
 
             def bwd():
-                dy = self.G[id(y)]
-                dx, first = self._grad_slot(x)
+                dy = self._gget(y)
+                dx = self._gnew(x)
                 if p.same:
                     self._dgrad(p, dy, dx)
                 else:
@@ -348,7 +339,6 @@ class TapeEngine(UnitEngine):
                         du = self._buf(B, Hu, Wu, p.w4[0])
                         ops.zero_insert(dy, p.stride, q, q, Hu, Wu, out=du)
                         ops.conv2d_fwd(du, p.w_bwd, None, 1, 0, out=dx)
-                self._grad_commit(x, dx, first)
             self.tape.append(bwd)
             return y
         s_, p_, op_ = p.tconv
@@ -369,9 +359,7 @@ class TapeEngine(UnitEngine):
             self._conv(p, xu, y)
 
         def bwd():
-            dx, first = self._grad_slot(x)
-            ops.conv2d_fwd(self.G[id(y)], p.w_bwd, None, s_, p_, out=dx)
-            self._grad_commit(x, dx, first)
+            ops.conv2d_fwd(self._gget(y), p.w_bwd, None, s_, p_, out=self._gnew(x))
         self.tape.append(bwd)
         return y
 
@@ -397,7 +385,7 @@ class TapeEngine(UnitEngine):
             self._conv(op, xin, y, epilogue=L.EPI_NONE if epi is None else epi)
 
         def bwd():
-            dy = self.G[id(y)]
+            dy = self._gget(y)
             if epi is not None:
                 (ops.lrelu_bwd if epi == L.EPI_LRELU else ops.relu_bwd)(dy, y, t["dpre"])
                 dy = t["dpre"]
@@ -412,7 +400,7 @@ class TapeEngine(UnitEngine):
         if self.kind != "rstb" and not self.tail and not self.tail_round:
             return super()._forward_backward()
         from .quant_block import QuantRSTB
-        self.tape, self.G, self._aliased = [], {}, set()
+        self.tape, self.G = [], {}
         x = self.x_in
         ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
                          iter_publish=self._it_pub())
@@ -438,13 +426,12 @@ class TapeEngine(UnitEngine):
             else:
                 ops.lp_loss_grad(zr, self.task_cache, self.idx, self.it, 0.0, 1.0, self.task_p, dz, self.task_log)
             if z is y:                                                 # round-only tail: both terms meet at the unit output
-                ops.add(dz, dy, out=dy)
+                self._gput(y, dz)
             else:
-                self.G[id(z)] = dz
+                self._gput(z, dz)
                 for bw in reversed(self.tape[n_unit:]):
                     bw()
-                ops.add(self.G[id(y)], dy, out=dy)
-        self.G[id(y)] = dy
+        self._gput(y, dy)                                              # rec term last: task + rec are summed where the unit's backward starts
         for bw in reversed(self.tape[:n_unit]):
             bw()
         self.G.clear()

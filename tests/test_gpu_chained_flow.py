@@ -49,12 +49,14 @@ def _product_flow(qnn, cali, B, iters, last_layer):
     """main2.py:214-263 on the drop-in package; -> {dotted unit name: engine} in recon_model order."""
     from quantization import BaseQuantBlock, QuantModule, block_reconstruction, layer_reconstruction
     args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Cheng2020")
-    kwargs = dict(cali_data=cali, batch_size=B, iters=iters, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
-                  warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    base = dict(cali_data=cali, batch_size=B, weight=0.01, input_prob=0.5, lr=4e-5, asym=True, b_range=(20, 2),
+                warmup=0.2, act_quant=False, opt_mode="mse", config=None, args=args)
+    it_of = iters if callable(iters) else (lambda full_name: iters)       # iterations per unit (main2.py passes one --iters_w for all)
     engines = {}
 
     def recon_model(m: nn.Module, prefix):
         for name, module in m.named_children():
+            kwargs = dict(base, iters=it_of(prefix + name))
             if isinstance(module, QuantModule):
                 eng = layer_reconstruction(qnn, module, name, **kwargs)
                 if eng is not None:
@@ -72,11 +74,13 @@ def _product_flow(qnn, cali, B, iters, last_layer):
 def _compare(engines, flow, qnn, last_layer, test_imgs):
     from test_datasets import evaluate_images
     assert list(engines) == [u.name for u in flow.units]
-    same = total = 0
+    from oracle import rdo_oracle as O
+    same = total = moved = 0
     for u in flow.units:
         eng = engines[u.name]
         for n, op in u.ops.items():
             a_gpu, a_ref = eng.alpha_of(n).cpu(), op.alpha
+            moved += int(((a_ref >= 0) != (O.adaround_init_alpha(op.weight.clone(), op.delta) >= 0)).sum())   # vs nearest rounding (diagnostic)
             assert a_gpu.shape == a_ref.shape, (u.name, n)
             diff = int(((a_gpu >= 0) != (a_ref >= 0)).sum())
             numel = a_ref.numel()
@@ -84,6 +88,7 @@ def _compare(engines, flow, qnn, last_layer, test_imgs):
             same += numel - diff
             total += numel
     assert same >= 0.998 * total, (same, total)
+    print(f"decisions the calibration changed against nearest rounding: {moved} of {total} ({100.0 * moved / total:.3f} %); product != oracle: {total - same}")
     res = {}
     for act, (tol_bpp, tol_psnr) in ((False, (1e-3, 0.02)), (True, (2e-3, 0.05))):
         qnn.set_quant_state(weight_quant=True, act_quant=act)
@@ -128,7 +133,7 @@ def _run(arch, N, iters, n_img=8, crop=64, test_hw=((96, 80), (96, 80)), loss_rt
     idx = {name: e.idx.cpu().numpy() for name, e in engines.items()}
     for u in flow.units:               # the two sides derive the same QDrop key for every unit
         assert engines[u.name].seed == FlowOracle.unit_seed(SEED, u.local), u.name
-    logs = flow.recon_model(cali, idx, SEED, iters=iters, batch_size=B)
+    logs = flow.recon_model(cali, idx, SEED, iters=(lambda n: engines[n].iters) if callable(iters) else iters, batch_size=B)
     # first and last iteration's loss of every unit, product vs oracle: the chain has not drifted apart
     for u in flow.units:
         tot = engines[u.name].logs()[0].numpy()
@@ -151,5 +156,10 @@ def test_chained_flow_full_size_cheng2020_n192_matches_oracle_flow():
     public layer_/block_reconstruction API -- the H2 / halo / row / split-K / fused-tail kernels at the sizes the bench runs them --,
     every unit on caches of the product's own calibrated prefix, against the oracle flow doing the same on the CPU; then W8 and W8A8
     bpp / PSNR on a held-out 512 x 768 image (the Kodak geometry of test_datasets.py:76-117).  Same bars as the toy-width flows."""
-    agree, res = _run("cheng", 192, 12, n_img=8, crop=256, test_hw=((512, 768),))
+    # iterations per unit (round 5, VERDICT round 4 weak 2): 12 on the 128^2 / 64^2 units (their long horizons are
+    # tests/test_gpu_long_horizon.py), 80 on everything from 32^2 down -- g_a.4-6, the hyper path, g_s.0-2, the entropy-parameter and
+    # context layers: the rounding loss is on for 64 of them and alphas near zero change sign, so "identical decisions" is a statement
+    # about the trained rounding, not about two implementations of nearest rounding (the print shows the share that moved)
+    big = {"g_a.0", "g_a.1", "g_a.2", "g_a.3", "g_s.3", "g_s.4", "g_s.5", "g_s.6", "g_s.7.0"}
+    agree, res = _run("cheng", 192, lambda n: 12 if n in big else 80, n_img=8, crop=256, test_hw=((512, 768),))
     print("cheng2020 N=192: identical rounding decisions", agree, "W8", res[False], "W8A8", res[True])

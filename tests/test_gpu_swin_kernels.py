@@ -102,3 +102,80 @@ def test_gelu_and_round():
     assert _rel(ops.gelu_bwd(dy.cuda(), xc).cpu(), x.grad) < 2e-6
     v = torch.cat([torch.arange(-6, 7).float() / 2, torch.randn(100, generator=g) * 4])
     torch.testing.assert_close(ops.round_(v.cuda()).cpu(), torch.round(v), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("rows,C", [(7, 16), (513, 192), (65, 320), (1030, 32), (40, 512), (4 * 128 * 128, 192)])
+def test_residual_add_layer_norm_fused_forward_and_backward(rows, C):
+    """rdo_add_layer_norm / rdo_layer_norm_bwd_add / rdo_add3 (round 5): the residual add of a Swin block folded into the LayerNorm that
+    reads it, and the residual-path gradient folded into the LayerNorm backward, against torch autograd in float64 -- with zero, one
+    and two addends, with and without the gamma partial sums; the sum tensor bit-equal to the separate add kernel."""
+    from hipops import ops
+    g = torch.Generator().manual_seed(rows + C)
+    a = torch.randn(rows, C, generator=g) * 2 + 0.3
+    b = torch.randn(rows, C, generator=g)
+    w = 1 + 0.3 * torch.randn(C, generator=g)
+    bias = torch.randn(C, generator=g)
+    dy = torch.randn(rows, C, generator=g)
+    e1, e2 = torch.randn(rows, C, generator=g), torch.randn(rows, C, generator=g)
+    s64 = (a.double() + b.double()).requires_grad_(True)
+    w64 = w.double().requires_grad_(True)
+    y64 = F.layer_norm(s64, (C,), w64, bias.double())
+    (y64 * dy.double()).sum().backward()
+    ac, bc, wc, biasc = a.cuda(), b.cuda(), w.cuda(), bias.cuda()
+    s = torch.empty_like(ac)
+    y = ops.add_layer_norm(ac, bc, wc, biasc, sum_out=s)
+    torch.testing.assert_close(s, ops.add(ac, bc), rtol=0, atol=0)
+    assert _rel(y.cpu().double(), y64.detach()) < 3e-6
+    y1 = ops.add_layer_norm(s, None, wc, biasc)                       # no second addend: plain LayerNorm of s
+    torch.testing.assert_close(y1, y, rtol=0, atol=0)
+    assert _rel(ops.layer_norm(s, wc, biasc).cpu().double(), y64.detach()) < 3e-6
+    nsl = 8 if rows < 4096 else 1024
+    slabs = torch.empty(nsl, C, device="cuda")
+    dx0 = torch.empty_like(ac)
+    ops.layer_norm_bwd_add(s, wc, dy.cuda(), dx=dx0, dgamma_slabs=slabs)
+    scale = float(s64.grad.abs().max())
+    assert float((dx0.cpu().double() - s64.grad).abs().max()) < 2e-5 * scale
+    assert _rel(slabs.sum(0).cpu().double(), w64.grad) < 2e-5
+    dx1, dx2 = torch.empty_like(ac), torch.empty_like(ac)
+    ops.layer_norm_bwd_add(s, wc, dy.cuda(), e1.cuda(), dx=dx1)
+    ops.layer_norm_bwd_add(s, wc, dy.cuda(), e1.cuda(), e2.cuda(), dx=dx2)
+    torch.testing.assert_close(dx1, e1.cuda() + dx0, rtol=0, atol=0)                  # the addends enter in this order: add1 + r, add2 + (...)
+    torch.testing.assert_close(dx2, e2.cuda() + (e1.cuda() + dx0), rtol=0, atol=0)
+    only = torch.empty(nsl, C, device="cuda")
+    ops.layer_norm_bwd_add(s, wc, dy.cuda(), dx=None, dgamma_slabs=only)               # trainable LayerNorm whose input needs no gradient
+    torch.testing.assert_close(only, slabs, rtol=0, atol=0)
+    if (rows * C) % 4 == 0:
+        torch.testing.assert_close(ops.add3(ac, bc, e1.cuda()), (ac + bc) + e1.cuda(), rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("rows,cin,cout,planes", [(4 * 64 * 64, 192, 384, True), (4 * 64 * 64, 384, 192, True), (300, 192, 384, False),
+                                                  (1024, 320, 640, False)])
+def test_gelu_epilogues_of_the_linear_kernels(rows, cin, cout, planes):
+    """RDO_EPI_GELU (fc1 + nn.GELU() in one launch, pre-activation kept for the backward) and RDO_EPI_GELU_BWD (fc2's input gradient
+    times gelu'(pre)) of rdo_conv2d_fwd on the fp32-MFMA and the split-bf16 kernels against the separate kernels and float64."""
+    from hipops import _lib as L, ops
+    g = torch.Generator().manual_seed(rows + cin)
+    x = torch.randn(1, 1, rows, cin, generator=g).cuda()
+    w = (torch.randn(cout, 1, 1, cin, generator=g) / cin ** 0.5).cuda()
+    b = torch.randn(cout, generator=g).cuda()
+    wp = ops.split_bf16x3(w) if planes else None
+    assert (wp is not None and ops.uses_bf16x6(tuple(x.shape), tuple(w.shape), 1, 0)) == planes
+    pre = torch.empty(1, 1, rows, cout, device="cuda")
+    y = ops.conv2d_fwd(x, w, b, 1, 0, epilogue=L.EPI_GELU, pre=pre, wplanes=wp)
+    pre_ref = ops.conv2d_fwd(x, w, b, 1, 0, wplanes=wp)
+    torch.testing.assert_close(pre, pre_ref, rtol=0, atol=0)
+    want = F.gelu(pre.double().cpu())
+    assert float((y.cpu().double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+    # backward: d(pre_in) = (dy W) * gelu'(pre_in) for a linear whose input was gelu(pre_in)
+    pin = torch.randn(1, 1, rows, cout, generator=g).cuda() * 2
+    wd = w.permute(3, 1, 2, 0).contiguous()                            # [cin][1][1][cout]: maps dy [rows, cin] -> [rows, cout]
+    dyv = torch.randn(1, 1, rows, cin, generator=g).cuda()
+    wdp = ops.split_bf16x3(wd) if ops.uses_bf16x6(tuple(dyv.shape), tuple(wd.shape), 1, 0) else None
+    got = ops.conv2d_fwd(dyv, wd, None, 1, 0, epilogue=L.EPI_GELU_BWD, aux=pin, wplanes=wdp)
+    lin = ops.conv2d_fwd(dyv, wd, None, 1, 0, wplanes=wdp)
+    sep = ops.gelu_bwd(lin.view(-1), pin.view(-1)).view_as(lin)
+    p64 = pin.double().cpu().requires_grad_(True)
+    F.gelu(p64).sum().backward()
+    want = lin.double().cpu() * p64.grad
+    assert float((got.cpu().double() - want).abs().max()) < 2e-6 * float(want.abs().max())
+    assert float((got - sep).abs().max()) <= 1e-6 * float(sep.abs().max())
