@@ -292,6 +292,14 @@ int rdo_add_layer_norm(const float* a, const float* b, const float* weight, cons
 int rdo_layer_norm_bwd_add(const float* x, const float* gamma, const float* dy, const float* add1, const float* add2, int64_t rows,
                            int32_t C, float eps, float* dx, float* dgamma_slabs, int32_t nslabs, void* stream);
 int rdo_add3(const float* a, const float* b, const float* c, int64_t n, float* out, void* stream);   /* (a + b) + c: RSTB output, layers.py:433 */
+/* Token-matrix Linear  out[M][N] = x[M][K] W^T + bias  (F.linear of the Swin blocks, models/layers.py:44-47,147,163; quant_layer.py:119;
+ * its input gradient is the same entry on the planes of W^T) on fp16 two-way-split MFMA with a PER-TOKEN dynamic power-of-two scale
+ * taken inside the kernel: no probed scale, no overflow flag (csrc/linear_h2.hip).  `wplanes`: rdo_split_h2_linear of W [N][K] * wscale
+ * (2 * N * K halfs, fragment order).  rdo_linear_h2_supported: M % 64 == 0, K % 192 == 0, N % 192 == 0. */
+int rdo_linear_h2_supported(int64_t M, int32_t K, int32_t N);
+int rdo_split_h2_linear(const float* w, int32_t N, int32_t K, float scale, void* planes, void* stream);
+int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias, float* out,
+                  void* stream);
 int rdo_gelu_fwd(const float* x, int64_t n, float* out, void* stream);                      /* nn.GELU(): exact erf form */
 int rdo_gelu_bwd(const float* dy, const float* x, int64_t n, float* dx, void* stream);
 int rdo_round(const float* x, int64_t n, float* out, void* stream);                         /* torch.round (half to even): round_ste forward */

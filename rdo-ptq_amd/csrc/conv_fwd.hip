@@ -45,7 +45,10 @@ struct FwdArgs {
 
 __device__ __forceinline__ int swz(int row, int q) { return (q ^ ((row >> 1) & 7)) << 2; }
 
-// bias has been added: pre-activation copy, activation, residual, store
+// bias has been added: pre-activation copy, activation, residual, store.  HEAVY: the instantiations that also carry the GELU epilogues
+// (erff / expf polynomials: compiled into every kernel they cost the plain launches registers and 10-50 % of their time, measured on
+// the Lu2022 linears) -- the two tiles the Swin linears select and the split-K second pass
+template <bool HEAVY>
 __device__ __forceinline__ void finish(const FwdArgs& a, long o, float v) {
     if (a.pre) a.pre[o] = v;
     switch (a.epilogue) {
@@ -55,15 +58,15 @@ __device__ __forceinline__ void finish(const FwdArgs& a, long o, float v) {
         case RDO_EPI_RELU_BWD: v = a.aux[o] > 0.f ? v : 0.f; break;
         case RDO_EPI_GDN: v = a.aux[o] * __frsqrt_rn(v); break;
         case RDO_EPI_IGDN: v = a.aux[o] * __fsqrt_rn(v); break;
-        case RDO_EPI_GELU: v = rdo::gelu(v); break;
-        case RDO_EPI_GELU_BWD: v *= rdo::gelu_grad(a.aux[o]); break;
+        case RDO_EPI_GELU: if constexpr (HEAVY) v = rdo::gelu(v); break;
+        case RDO_EPI_GELU_BWD: if constexpr (HEAVY) v *= rdo::gelu_grad(a.aux[o]); break;
         default: break;
     }
     if (a.add_residual) v += a.residual[o];
     a.out[o] = v;
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool HEAVY = false>
 __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
     constexpr int WM = BM / WAVES_M, WN = BN / WAVES_N;
     constexpr int TM = WM / 32, TN = WN / 32;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(256) void conv_fwd_kernel(FwdArgs a) {
                 if (a.partial) {
                     a.partial[(long)blockIdx.z * a.M * a.Cout + o] = acc[i][j][r];
                 } else {
-                    finish(a, o, acc[i][j][r] + bv);
+                    finish<HEAVY>(a, o, acc[i][j][r] + bv);
                 }
             }
         }
@@ -263,14 +266,14 @@ __global__ __launch_bounds__(256) void conv_splitk_epilogue_kernel(FwdArgs a) {
         float v = 0.f;
         for (int z = 0; z < a.ksplit; ++z) v += a.partial[(long)z * total + o];
         if (a.bias) v += a.bias[o % a.Cout];
-        finish(a, o, v);
+        finish<true>(a, o, v);
     }
 }
 
-template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC>
+template <int BM, int BN, int WAVES_M, int WAVES_N, bool VEC, bool HEAVY = false>
 int launch(const FwdArgs& a, hipStream_t s) {
     constexpr size_t lds = (size_t)2 * (BM + BN) * BK * sizeof(float);
-    auto kern = conv_fwd_kernel<BM, BN, WAVES_M, WAVES_N, VEC>;
+    auto kern = conv_fwd_kernel<BM, BN, WAVES_M, WAVES_N, VEC, HEAVY>;
     static rdo::PerDevice attr_set;
     if (!attr_set.done()) {
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
@@ -327,6 +330,13 @@ Choice choose(const FwdArgs& a, long ws_floats) {
 
 template <bool VEC>
 int launch_choice(const FwdArgs& a, int tile, hipStream_t s) {
+    if (a.epilogue >= RDO_EPI_GELU && !(a.ksplit > 1 && !a.partial_only)) {      // (a split-K launch applies its epilogue in the second pass)
+        if constexpr (VEC) {
+            if (tile == 3) return launch<64, 192, 2, 2, true, true>(a, s);
+            if (tile == 4) return launch<64, 64, 2, 2, true, true>(a, s);
+        }
+        return rdo::set_error(RDO_EINVAL, "rdo_conv2d_fwd: the GELU epilogues are built for the 64-row tiles with Cin %% 4 == 0 (Linear layers)");
+    }
     switch (tile) {
         case 0: return launch<128, 192, 2, 2, VEC>(a, s);
         case 1: return launch<128, 64, 2, 2, VEC>(a, s);

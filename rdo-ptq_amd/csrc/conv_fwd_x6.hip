@@ -95,6 +95,8 @@ __device__ __forceinline__ TileId xcd_tile_id(int mode) {
     return t;
 }
 
+// HEAVY: with the GELU epilogues (see conv_fwd.hip: kept out of the plain instantiations)
+template <bool HEAVY>
 __device__ __forceinline__ void finish(const X6Args& a, long o, float v) {
     if (a.pre) a.pre[o] = v;
     switch (a.epilogue) {
@@ -104,8 +106,8 @@ __device__ __forceinline__ void finish(const X6Args& a, long o, float v) {
         case RDO_EPI_RELU_BWD: v = a.aux[o] > 0.f ? v : 0.f; break;
         case RDO_EPI_GDN: v = a.aux[o] * __frsqrt_rn(v); break;
         case RDO_EPI_IGDN: v = a.aux[o] * __fsqrt_rn(v); break;
-        case RDO_EPI_GELU: v = rdo::gelu(v); break;
-        case RDO_EPI_GELU_BWD: v *= rdo::gelu_grad(a.aux[o]); break;
+        case RDO_EPI_GELU: if constexpr (HEAVY) v = rdo::gelu(v); break;
+        case RDO_EPI_GELU_BWD: if constexpr (HEAVY) v *= rdo::gelu_grad(a.aux[o]); break;
         default: break;
     }
     if (a.add_residual) v += a.residual[o];
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
                 if (m >= a.M) continue;
                 const long o = (long)m * a.Cout + n;
                 if (a.partial) a.partial[(long)tile.z * a.M * a.Cout + o] = acc[i][j][r];
-                else finish(a, o, acc[i][j][r] + bv);
+                else finish<false>(a, o, acc[i][j][r] + bv);
             }
     }
 }
@@ -375,6 +377,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v3_kernel(X6Args a) {
 // place), (2) writes stage t+2's image into buffer t&1 (A: split + ds_write, B: LDS-DMA) and (3) loads stage t+3's A quads.
 // Slot order (A plane, B plane): (2,0) (0,2) (1,0) (1,1) (0,1) (0,0); fa2 is re-read after slot 0, fb2 after slot 1, fa1 after
 // slot 3, fb1 after slot 4, and next stage's fa0/fb0 go to the alternate register set at the top of the stage.
+template <bool HEAVY>
 __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
     constexpr int BM = 128, BN = 192, KS = 16;
     constexpr int TM = 2, TN = 3;
@@ -587,7 +590,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v5_kernel(X6Args a) {
                 if (m >= a.M) continue;
                 const long o = (long)m * a.Cout + n;
                 if (a.partial) a.partial[(long)tile.z * a.M * a.Cout + o] = acc[i][j][r];
-                else finish(a, o, acc[i][j][r] + bv);
+                else finish<HEAVY>(a, o, acc[i][j][r] + bv);
             }
     }
 }
@@ -807,7 +810,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6v6_kernel(X6Args a) {
                 if (m >= a.M) continue;
                 const long o = (long)m * a.Cout + n;
                 if (a.partial) a.partial[(long)tile.z * a.M * a.Cout + o] = acc[i][j][r];
-                else finish(a, o, acc[i][j][r] + bv);
+                else finish<false>(a, o, acc[i][j][r] + bv);
             }
     }
 }
@@ -819,7 +822,7 @@ __global__ __launch_bounds__(256) void x6_splitk_epilogue_kernel(X6Args a) {
         float v = 0.f;
         for (int z = 0; z < a.ksplit; ++z) v += a.partial[(long)z * total + o];
         if (a.bias) v += a.bias[o % a.Cout];
-        finish(a, o, v);
+        finish<true>(a, o, v);
     }
 }
 
@@ -918,7 +921,7 @@ static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* w
             constexpr int ver = 5;
 #endif
             // v6 (the three kw taps share one activation image) takes the stride-1 3-wide kernels whose tiles are whole image rows
-            const bool v6_ok = a.stride == 1 && a.KW == 3 && a.pad == 1 && a.Cin % 16 == 0 && a.M % 128 == 0 && a.W >= 16 &&
+            const bool v6_ok = a.epilogue < RDO_EPI_GELU && a.stride == 1 && a.KW == 3 && a.pad == 1 && a.Cin % 16 == 0 && a.M % 128 == 0 && a.W >= 16 &&
                                (a.W % 128 == 0 || (128 % a.W == 0 && (a.H * a.W) % 128 == 0)) &&
                                a.ksplit <= (a.Cin / 16) * a.KH;
             if (ver_env >= 6 && v6_ok) {
@@ -945,7 +948,7 @@ static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* w
 #ifdef RDO_DIAG
             const void* kern = ver == 3 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<false>)
                              : ver == 4 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<true>)
-                                        : reinterpret_cast<const void*>(conv_fwd_x6v5_kernel);
+                                        : reinterpret_cast<const void*>(conv_fwd_x6v5_kernel<false>);
             static rdo::PerDevice attr[3];
             if (!attr[ver - 3].done()) {
                 if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
@@ -954,16 +957,19 @@ static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* w
             }
             if (ver == 3) hipLaunchKernelGGL(conv_fwd_x6v3_kernel<false>, grid, dim3(256), lds, s, a);
             else if (ver == 4) hipLaunchKernelGGL(conv_fwd_x6v3_kernel<true>, grid, dim3(256), lds, s, a);
-            else hipLaunchKernelGGL(conv_fwd_x6v5_kernel, grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL(conv_fwd_x6v5_kernel<false>, grid, dim3(256), lds, s, a);
 #else
-            static rdo::PerDevice attr5;
-            if (!attr5.done()) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(conv_fwd_x6v5_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) !=
-                    hipSuccess)
+            // the GELU epilogues of an unsplit launch: their own instantiation (a split launch applies them in its second pass)
+            const bool heavy = a.epilogue >= RDO_EPI_GELU && a.ksplit == 1;
+            static rdo::PerDevice attr5[2];
+            if (!attr5[heavy].done()) {
+                const void* k5 = heavy ? reinterpret_cast<const void*>(conv_fwd_x6v5_kernel<true>) : reinterpret_cast<const void*>(conv_fwd_x6v5_kernel<false>);
+                if (hipFuncSetAttribute(k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(conv_fwd_x6 v5) failed");
-                attr5.mark();
+                attr5[heavy].mark();
             }
-            hipLaunchKernelGGL(conv_fwd_x6v5_kernel, grid, dim3(256), lds, s, a);
+            if (heavy) hipLaunchKernelGGL(conv_fwd_x6v5_kernel<true>, grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL(conv_fwd_x6v5_kernel<false>, grid, dim3(256), lds, s, a);
 #endif
             if (int rc = rdo::check_launch("conv_fwd_x6")) return rc;
             if (a.ksplit > 1 && !a.partial_only) {

@@ -1,0 +1,239 @@
+// Token-matrix Linear on fp16 two-way-split MFMA with a per-token dynamic scale (round 5; the Lu2022 path).
+//
+//   Y[M][N] = X[M][K] W^T (+ bias)        X fp32 in HBM (tokens x channels, the NHWC image of a [B,H,W,C] map), W [N][K]
+//
+// replaces F.linear of the Swin blocks (models/layers.py:147,163 qkv / proj, :44-47 fc1 / fc2; quant_layer.py:119 for the wrapped ones) and
+// its input gradient (dX = dY W: the same kernel on W^T) for the LARGE token matrices -- the 64^2 and 128^2 maps, 16 K / 64 K tokens of
+// 192 channels -- which the calibration engine ran on the split-bf16 conv kernel as 1x1 convolutions: six MFMA products per fp32
+// product, activations split in that kernel's loader, 150 us for the 14.5-GFLOP qkv Linear of a 128^2 map (95 TFLOP/s).
+//
+// Arithmetic: the H2 form of conv_fwd_h2k.hip (x s = h1 + h2 in fp16, THREE products h1 g1 + h1 g2 + h2 g1 on v_mfma_f32_16x16x32_f16,
+// fp32 accumulate, rdo_common.h) -- but the tape engine's tensors have no probed static scales, and gradients span many octaves
+// from tensor to tensor.  A Linear reduces over a token's OWN channels only, so the scale can be per token: a workgroup loads the
+// whole [64 tokens][192 channels] panel of a K block before any product, takes each token's largest magnitude, and splits
+// x * 2^(7 - floor(log2 amax)): every token's values land in [2^-?, 2^8), nothing can overflow, no probe iteration, no flag, and a
+// token of tiny gradients keeps full relative precision.  The accumulator of a token is rescaled by the (exact, power-of-two) ratio
+// of two K blocks' scales when K spans several blocks.
+//
+// Structure: one workgroup = 64 tokens x all N output channels, 4 waves; wave w owns output channels [48 w, 48 w + 48) of each
+// 192-channel chunk and all 64 tokens (3 x 4 accumulator tiles of 16 x 16).  A = weights (rows = output channels), B = activations
+// (columns = tokens): a lane's four accumulator values are four consecutive channels of one token -> 16-byte stores straight from the
+// accumulators, one scale per lane and tile.  The activation panel is STATIONARY in LDS ([plane][16-channel slice][token][32 B]:
+// every ds_read_b128 fragment read is 2 x 512 contiguous bytes, conflict-free); weight fragments never touch LDS: the planes are
+// stored in fragment order (rdo_split_h2_linear: [plane][K/32][N/16][lane][8 halfs], 1 KiB per fragment) and each wave loads its own
+// three fragments per plane and K step with one coalesced global_load_dwordx4 each, one K step ahead -- no barrier inside the K loop.
+// LDS 48.5 KiB: three workgroups per CU, so one workgroup's panel load (HBM) hides under the others' products.
+#include "rdo_common.h"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BM = 64;            // tokens per workgroup
+constexpr int KB = 192;           // channels per K block (one LDS panel)
+constexpr int NC = 192;           // output channels per chunk (4 waves x 48)
+constexpr int SLICES = KB / 16;   // 12
+constexpr int PLANE = SLICES * BM * 32;   // bytes per plane of the panel: 24 KiB
+constexpr int LDS_BYTES = 2 * PLANE + 2 * BM * 4;   // + two scale rows (current / previous K block)
+
+struct LinArgs {
+    const float* x;        // [M][K]
+    const unsigned short* wp;   // [2][K/32][N/16][64][8] fp16 bit patterns of W * wscale
+    const float* bias;     // [N] or null
+    float* out;            // [M][N]
+    int M, K, N;
+    float inv_wscale;      // 1 / wscale
+};
+
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
+__global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* scl = reinterpret_cast<float*>(smem + 2 * PLANE);          // [2][BM]: 1 / scale of the token for K block (kb & 1)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l16 = lane & 15, kg = lane >> 4;
+    const long m0 = (long)blockIdx.x * BM;
+    const int nkb = a.K / KB, nchunks = a.N / NC, nblk = a.N / 16, ksteps = a.K / 32;
+
+    // ---- panel loader: 16 lanes per token, three float4 per lane (channels 4 (l16 + 16 k) ...), 16 tokens per pass, 4 passes
+    auto load_panel = [&](int kb) {
+        const int row_in_pass = tid >> 4;
+#pragma unroll
+        for (int pass = 0; pass < BM / 16; ++pass) {
+            const int r = pass * 16 + row_in_pass;
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.x + (m0 + r) * a.K + (long)kb * KB);
+            f32x4 v[3];
+            float amax = 0.f;
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                v[k] = src[l16 + 16 * k];
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[k][0]), fabsf(v[k][1])), fmaxf(fabsf(v[k][2]), fabsf(v[k][3]))));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 8, 16));
+            amax = fmaxf(amax, __shfl_xor(amax, 4, 16));
+            amax = fmaxf(amax, __shfl_xor(amax, 2, 16));
+            amax = fmaxf(amax, __shfl_xor(amax, 1, 16));
+            // scale 2^(7 - floor(log2 amax)): the token's largest value lands in [2^7, 2^8).  Zero / denormal / non-finite rows: scale 1
+            // (zeros stay zeros; inf / NaN propagate through fp16 as they would through fp32)
+            const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFF) - 127;
+            const bool plain = e < -100 || e > 100;
+            const float s = plain ? 1.f : pow2f(7 - e);
+            if (l16 == 0) scl[(kb & 1) * BM + r] = plain ? 1.f : pow2f(e - 7);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int c4 = l16 + 16 * k;                              // float4 index inside the K block: slice c4 / 4, 8-byte piece c4 % 4
+                const f32x4 xs = v[k] * s;
+                const f16x4 hi = __builtin_convertvector(xs, f16x4);
+                const f16x4 lo = __builtin_convertvector(xs - __builtin_convertvector(hi, f32x4), f16x4);
+                char* dst = smem + (c4 >> 2) * (BM * 32) + r * 32 + (c4 & 3) * 8;
+                *reinterpret_cast<f16x4*>(dst) = hi;
+                *reinterpret_cast<f16x4*>(dst + PLANE) = lo;
+            }
+        }
+    };
+
+    // ---- weight fragments: plane p, K step ks, 16-channel block b -> 1 KiB at ((p * ksteps + ks) * nblk + b) * 512 halfs; lane -> 16 bytes
+    const u32x4* wbase = reinterpret_cast<const u32x4*>(a.wp) + lane;
+    auto load_w = [&](f16x8 (&fw)[2][3], int ks, int chunk) {
+        const long b0 = (long)chunk * (NC / 16) + wave * 3;
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+                fw[p][i] = __builtin_bit_cast(f16x8, wbase[(((long)p * ksteps + ks) * nblk + b0 + i) * 64]);
+    };
+    // activation fragments of K step ks (inside the panel): token tile j, plane p
+    const int fx_lane = (kg >> 1) * (BM * 32) + l16 * 32 + (kg & 1) * 16;
+    auto read_x = [&](f16x8 (&fx)[2][4], int ksl) {
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                fx[p][j] = *reinterpret_cast<const f16x8*>(smem + p * PLANE + (2 * ksl) * (BM * 32) + j * (16 * 32) + fx_lane);
+    };
+
+    f32x4 acc[3][4];
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int kb = 0; kb < nkb; ++kb) {
+            if (chunk == 0 || nkb > 1) {                      // (one K block: the panel of chunk 0 serves every chunk)
+                if (kb > 0 || chunk > 0) __syncthreads();     // every wave is done with the previous panel
+                load_panel(kb);
+                __syncthreads();
+                if (kb > 0) {                                  // accumulators carry the previous block's token scale: exact power-of-two ratio
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float ratio = scl[((kb - 1) & 1) * BM + 16 * j + l16] / scl[(kb & 1) * BM + 16 * j + l16];
+#pragma unroll
+                        for (int i = 0; i < 3; ++i) acc[i][j] *= ratio;
+                    }
+                }
+            }
+            f16x8 fw[2][2][3];
+            load_w(fw[0], kb * (KB / 32), chunk);
+#pragma unroll
+            for (int ksl = 0; ksl < KB / 32; ++ksl) {
+                if (ksl + 1 < KB / 32) load_w(fw[(ksl + 1) & 1], kb * (KB / 32) + ksl + 1, chunk);
+                f16x8 fx[2][4];
+                read_x(fx, ksl);
+                const int c = ksl & 1;
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][1][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_lo x_hi (small first)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[1][j], acc[i][j], 0, 0, 0);    // w_hi x_lo
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_hi x_hi
+                    }
+            }
+        }
+        // ---- epilogue of the chunk: y = acc / (token scale * weight scale) + bias, four consecutive channels of one token per lane
+        const float* inv_s = scl + ((nkb - 1) & 1) * BM;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int tok = 16 * j + l16;
+            const float f = inv_s[tok] * a.inv_wscale;
+            float* orow = a.out + (m0 + tok) * a.N + chunk * NC + wave * 48 + 4 * kg;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                f32x4 y = acc[i][j] * f;
+                if (a.bias) y += *reinterpret_cast<const f32x4*>(a.bias + chunk * NC + wave * 48 + 16 * i + 4 * kg);
+                *reinterpret_cast<f32x4*>(orow + 16 * i) = y;
+            }
+        }
+    }
+}
+
+// W [N][K] fp32 -> fragment-ordered fp16 planes of W * scale.  One thread per (plane-independent) 8-half record.
+__global__ __launch_bounds__(256) void split_h2_linear_kernel(const float* w, int N, int K, float scale, unsigned short* planes) {
+    const int ksteps = K / 32, nblk = N / 16;
+    const long recs = (long)ksteps * nblk * 64;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < recs; t += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(t & 63);
+        const long fb = t >> 6;                         // ks * nblk + b
+        const int b = (int)(fb % nblk), ks = (int)(fb / nblk);
+        const int row = 16 * b + (lane & 15), k0 = 32 * ks + 8 * (lane >> 4);
+        const float* src = w + (long)row * K + k0;
+        f16x8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float v = src[e] * scale;
+            const _Float16 h = (_Float16)v;
+            hi[e] = h;
+            lo[e] = (_Float16)(v - (float)h);
+        }
+        *reinterpret_cast<f16x8*>(planes + t * 8) = hi;
+        *reinterpret_cast<f16x8*>(planes + (recs + t) * 8) = lo;
+    }
+}
+
+bool pow2(float s) {
+    if (!(s > 0.f) || s != s || s > 3.0e38f) return false;
+    int e;
+    return frexpf(s, &e) == 0.5f;
+}
+
+}  // namespace
+
+extern "C" int rdo_linear_h2_supported(int64_t M, int32_t K, int32_t N) {
+    return M > 0 && M % BM == 0 && K > 0 && K % KB == 0 && N > 0 && N % NC == 0 && (double)M * (K > N ? K : N) * 4.0 < 4.0e9;
+}
+
+extern "C" int rdo_split_h2_linear(const float* w, int32_t N, int32_t K, float scale, void* planes, void* stream) {
+    RDO_REQUIRE(w && planes && N > 0 && K > 0 && N % 16 == 0 && K % 32 == 0, "rdo_split_h2_linear: bad argument (N %% 16, K %% 32)");
+    RDO_REQUIRE(pow2(scale), "rdo_split_h2_linear: scale %g is not a power of two", (double)scale);
+    const long recs = (long)(K / 32) * (N / 16) * 64;
+    unsigned short* p = reinterpret_cast<unsigned short*>(planes);
+    return rdo::dispatch(
+        [=](hipStream_t s) {
+            long g = rdo::ceil_div(recs, 256);
+            hipLaunchKernelGGL(split_h2_linear_kernel, dim3((unsigned)(g > 1024 ? 1024 : g)), dim3(256), 0, s, w, N, K, scale, p);
+            return rdo::check_launch("split_h2_linear");
+        },
+        stream, "split_h2_linear", 0.0, 8.0 * (double)N * K);
+}
+
+extern "C" int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias, float* out,
+                             void* stream) {
+    RDO_REQUIRE(x && wplanes && out, "rdo_linear_h2: null argument");
+    RDO_REQUIRE(rdo_linear_h2_supported(M, K, N), "rdo_linear_h2: shape %ld x %d -> %d is not supported (M %% 64, K %% 192, N %% 192)", (long)M, K, N);
+    RDO_REQUIRE(pow2(wscale), "rdo_linear_h2: weight scale %g is not a power of two", (double)wscale);
+    RDO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wplanes) | reinterpret_cast<uintptr_t>(bias) |
+                  reinterpret_cast<uintptr_t>(out)) & 15) == 0, "rdo_linear_h2: pointers must be 16-byte aligned");
+    LinArgs a;
+    a.x = x; a.wp = reinterpret_cast<const unsigned short*>(wplanes); a.bias = bias; a.out = out;
+    a.M = (int)M; a.K = K; a.N = N; a.inv_wscale = 1.0f / wscale;
+    const double flops = 2.0 * (double)M * K * N;
+    return rdo::dispatch(
+        [a](hipStream_t s) {
+            hipLaunchKernelGGL(linear_h2_kernel, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, s, a);
+            return rdo::check_launch("linear_h2");
+        },
+        stream, "linear_h2", flops, 4.0 * ((double)M * K + (double)M * N + (double)K * N));
+}

@@ -523,6 +523,34 @@ def layer_norm(x, weight, bias, eps=1e-5, out=None):
     return out
 
 
+def linear_h2_supported(rows, cin, cout):
+    return bool(L.lib().rdo_linear_h2_supported(int(rows), int(cin), int(cout)))
+
+
+def split_h2_linear(w, scale=None, planes=None):
+    """W [N][K] (any shape whose first dim is N, rest flattened to K) -> H2 planes in the fragment order of rdo_linear_h2; the scale
+    defaults to a power of two that puts max |W| at 2^7 (a device synchronisation: set-up only -- pass `scale` inside recorded plans)."""
+    N = w.shape[0]
+    K = w.numel() // N
+    if scale is None:
+        scale = pow2_scale(w.abs().max())
+    if planes is None:
+        planes = H2(torch.empty((2, K // 32, N // 16, 64, 8), device=w.device, dtype=torch.int16), scale)
+    L.check(L.lib().rdo_split_h2_linear(_ptr(w), N, K, float(planes.scale), _ptr(planes), _stream()), "rdo_split_h2_linear")
+    return planes
+
+
+def linear_h2(x, planes, bias=None, out=None):
+    """out [rows, N] = x [rows, K] W^T + bias on the per-token-scaled fp16-split kernel; `planes` from split_h2_linear."""
+    K = x.shape[-1]
+    rows = x.numel() // K
+    N = planes.t.shape[2] * 16
+    if out is None:
+        out = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=torch.float32)
+    L.check(L.lib().rdo_linear_h2(_ptr(x), rows, K, N, _ptr(planes), float(planes.scale), _ptr(bias), _ptr(out), _stream()), "rdo_linear_h2")
+    return out
+
+
 def add_layer_norm(a, b, weight, bias, eps=1e-5, sum_out=None, out=None):
     """s = a + b (b may be None) -> `sum_out` (written when given), LayerNorm(s) -> out: the residual add of a Swin block and the
     LayerNorm that reads it, in one pass."""

@@ -14,6 +14,7 @@ the tensor they belong to; a second contribution to the same tensor goes through
 
 Tokens stay in natural pixel order ([B, H, W, C] == [B, L, C]); Linears run on the conv kernels as 1x1 convolutions (bf16x6
 split-precision path for the large ones), the attention core / LayerNorm / GELU on csrc/swin.hip."""
+import os
 from collections import OrderedDict
 
 import torch
@@ -165,6 +166,16 @@ class TapeEngine(UnitEngine):
     # takes up to two contributions as addends of its own output (`rdo_layer_norm_bwd_add`), which is where the residual paths of a
     # Swin block meet -- so a block's backward runs without a single add kernel.  Buffers are written once and never accumulated in
     # place, so sharing one buffer between two tensors (both inputs of an add) needs no alias tracking.
+    # A/B switches (whole runs).  RDO_SWIN_FUSE_GELU: 1 (default) = the Mlp's GELU / its derivative in the epilogue of fc1 / of fc2's input
+    # gradient WHERE that conv is split over K -- its second pass touches every output element anyway; 2 = in every launch; 0 = never.
+    # Measured on g_a1 at full size (profiles/r05c_lu2022_g_a1_trace.md): inside the main GEMM kernels the erf / exp polynomials run in
+    # the epilogue of a 128 x 192 tile while the matrix pipe idles -- 126 us against 56 + 19 (GEMM + separate GELU kernel) per launch
+    # on the split-bf16 kernel, 23 against 15.5 + 5 on the fp32 one -- so fusing everywhere LOSES 0.4 ms per iteration.
+    # RDO_SWIN_FUSE_LN=0 -> separate add kernels around the plain LayerNorm kernels
+    fuse_gelu = int(os.environ.get("RDO_SWIN_FUSE_GELU", "1"))
+    fuse_ln = os.environ.get("RDO_SWIN_FUSE_LN", "1") != "0"
+    fuse_ln_fwd = os.environ.get("RDO_SWIN_FUSE_LN_FWD", "1") != "0"
+
     def _gput(self, t, buf):
         self.G.setdefault(id(t), []).append(buf)
 
@@ -193,9 +204,15 @@ class TapeEngine(UnitEngine):
         y = self._buf(*x.shape[:-1], cout)
         x4, y4 = x.view(1, 1, rows, cin), y.view(1, 1, rows, cout)
         pre = None
-        if gelu:
+        fuse_here = lambda xs, w4, has_planes: self.fuse_gelu == 2 or (
+            self.fuse_gelu == 1 and ops.conv_fwd_ksplit(tuple(xs), tuple(w4), 1, 0, has_planes, self.dev)[0] >= 2)
+        if gelu and fuse_here(x4.shape, p.w4, ops.uses_bf16x6(tuple(x4.shape), p.w4, 1, 0)):
             pre = self._buf(*y.shape)
             self._conv(p, x4, y4, epilogue=L.EPI_GELU, pre=pre.view(1, 1, rows, cout))
+        elif gelu:
+            pre = self._buf(*y.shape)
+            self._conv(p, x4, pre.view(1, 1, rows, cout))
+            ops.gelu(pre, out=y)
         else:
             self._conv(p, x4, y4)
 
@@ -204,9 +221,14 @@ class TapeEngine(UnitEngine):
             if isinstance(p, _Op):
                 self._wgrad(p, x4, dy4)
             if need_dx:
-                if gelu_in is not None:
+                wd4 = tuple(p.wd4().shape)
+                if gelu_in is not None and fuse_here(dy4.shape, wd4, ops.uses_bf16x6(tuple(dy4.shape), wd4, 1, 0)):
                     dx = self._gnew(gelu_in)
                     self._dgrad(p, dy4, dx.view(1, 1, rows, cin), epilogue=L.EPI_GELU_BWD, aux=gelu_in.view(1, 1, rows, cin))
+                elif gelu_in is not None:
+                    dg = self._buf(*x.shape)
+                    self._dgrad(p, dy4, dg.view(1, 1, rows, cin))
+                    ops.gelu_bwd(dg, gelu_in, self._gnew(gelu_in))
                 else:
                     self._dgrad(p, dy4, self._gnew(x).view(1, 1, rows, cin))
         self.tape.append(bwd)
@@ -216,11 +238,14 @@ class TapeEngine(UnitEngine):
         """s = a + b (b None: s is a), y = LayerNorm(s) -> (s, y).  Backward: ds = (what reached s along the residual path) +
         LayerNorm-backward(dy); a and b both receive ds."""
         y = self._buf(*a.shape)
-        if b is None:
-            s = a
+        s = a if b is None else self._buf(*a.shape)
+        if not (self.fuse_ln and self.fuse_ln_fwd):
+            if b is not None:
+                ops.add(a, b, out=s)
+            ops.layer_norm(s, ln.gamma, ln.beta, out=y)
+        elif b is None:
             ops.add_layer_norm(a, None, ln.gamma, ln.beta, out=y)
         else:
-            s = self._buf(*a.shape)
             ops.add_layer_norm(a, b, ln.gamma, ln.beta, sum_out=s, out=y)
 
         def bwd():
@@ -243,14 +268,23 @@ class TapeEngine(UnitEngine):
                     self._gget(s)
                     parts = self._gparts(s)
                 ds = self._buf(*s.shape)
-                ops.layer_norm_bwd_add(s, ln.gamma, dy, *parts, dx=ds, dgamma_slabs=slabs)
+                if self.fuse_ln:
+                    ops.layer_norm_bwd_add(s, ln.gamma, dy, *parts, dx=ds, dgamma_slabs=slabs)
+                else:
+                    ops.layer_norm_bwd(s, ln.gamma, dy, dx=ds, dgamma_slabs=slabs)
+                    for extra in parts:
+                        nxt = self._buf(*s.shape)
+                        ops.add(extra, ds, out=nxt)
+                        ds = nxt
                 if b is None:
                     self.G[id(s)] = [ds]
                 else:
                     self._gput(a, ds)
                     self._gput(b, ds)
-            else:
+            elif self.fuse_ln:
                 ops.layer_norm_bwd_add(s, ln.gamma, dy, dx=None, dgamma_slabs=slabs)
+            else:
+                ops.layer_norm_bwd(s, ln.gamma, dy, dx=None, dgamma_slabs=slabs)
             if ln.op is not None and ln.op.slabs_wide is not ln.op.slabs:
                 n1 = ln.op.slabs.shape[0]
                 ops.reduce_slabs(slabs.view(slabs.shape[0] // n1, n1 * s.shape[-1]), out=ln.op.slabs.view(-1))
@@ -420,6 +454,7 @@ class TapeEngine(UnitEngine):
             if self.tail_round:
                 zr = self._buf(*z.shape)
                 ops.round_(z, out=zr)                                  # round_ste: identity gradient
+                self.z_rounded = zr                                    # (inspection: the latents the task term saw in the last iteration)
             dz = self._buf(*z.shape)
             if self.task_p == 2.0:
                 ops.lp2_loss_grad(zr, self.task_cache, self.idx, self.it, 1.0, dz, self.task_log)

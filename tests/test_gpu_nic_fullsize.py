@@ -141,12 +141,38 @@ def test_lu2022_full_size_units_match_oracle(nic_full, name):
                      force_dp_split=True, weight=0.01, b_range=(20, 2), warmup=0.2, input_prob=0.5, **tape)
     eng2.plan_a.run(1, graph=False)
     torch.cuda.synchronize()
-    worst = 0.0
+    if tail_round:
+        # round_ste makes the task term's gradient 2 (round(z) - target) / n DISCONTINUOUS in z: one latent within fp32 noise of x.5 that
+        # rounds the other way on the GPU moves every gradient of the unit by ~1 % (the target is the rounded FP latent, so only the few
+        # elements where the quantised prefix changed a rounding contribute at all).  The gradient comparison therefore hands the
+        # oracle the latents the ENGINE rounded to in this iteration (an input: the backward pass is what is compared) and bounds the
+        # number of such events separately.
+        zr_gpu = eng2.z_rounded.permute(0, 3, 1, 2).contiguous().cpu()
+        nic2 = S.NicOracle({k: v.clone() for k, v in state.items()}, CFG)
+        unit2 = nic2.stages[name]
+        ops2, fwd2 = (unit2.ops, (lambda ops_, x: unit2(x))) if isinstance(unit2, S.RstbOracle) else ({"layer": unit2}, "layer")
+        rest = nic2.coder(name[:3])[nic2.coder(name[:3]).index(name) + 1:]
+        seen = {}
+
+        def tail_fixed(t):
+            z = nic2.run(rest, t)
+            seen["flips"] = int((torch.round(z.detach()) != zr_gpu).sum())
+            return z + (zr_gpu - z).detach()
+        grads = []
+        O.reconstruct_unit(fwd2, ops2, inp_q, inp_fp, out_fp, iters=1, batch_size=B, idx_stream=idx[:1],
+                           mask_fn=lambda i, shape: O.qdrop_keep_mask_nhwc(seed, i, shape, 0.5), tail=tail_fixed,
+                           fp_net_out=nic.tail_of(name)(out_fp), input_prob=0.5, weight=0.0, b_range=(20, 2), warmup=0.2,
+                           grad_hook=lambda gs: grads.extend(g.clone() for g in gs))      # (weight 0: no rounding term in a 1-iteration run)
+        print(f"{name}: latents rounded differently by the two sides in iteration 0: {seen['flips']} of {zr_gpu.numel()}")
+        assert seen["flips"] <= 3
+    worst, bad = 0.0, []
     for (k, op), g_o in zip(eng2.ops.items(), grads):
         g = _logical(op, op.dalpha).cpu()
         assert g.shape == g_o.shape, k
         rel = float((g - g_o).abs().max() / (g_o.abs().max() + 1e-30))
         worst = max(worst, rel)
-        assert rel < 2e-5, (k, rel, float(g_o.abs().max()))
+        if not rel < 2e-5:
+            bad.append((k, rel, float(g_o.abs().max())))
+    assert not bad, bad
     print(f"{name}: loss rel {float(np.max(np.abs(total.numpy() - np.array(log.total)) / np.abs(np.array(log.total)))):.2e}, "
           f"worst first-iteration gradient rel {worst:.2e}")

@@ -167,9 +167,9 @@ def test_gelu_epilogues_of_the_linear_kernels(rows, cin, cout, planes):
     want = F.gelu(pre.double().cpu())
     assert float((y.cpu().double() - want).abs().max()) < 2e-6 * float(want.abs().max())
     # backward: d(pre_in) = (dy W) * gelu'(pre_in) for a linear whose input was gelu(pre_in)
-    pin = torch.randn(1, 1, rows, cout, generator=g).cuda() * 2
-    wd = w.permute(3, 1, 2, 0).contiguous()                            # [cin][1][1][cout]: maps dy [rows, cin] -> [rows, cout]
-    dyv = torch.randn(1, 1, rows, cin, generator=g).cuda()
+    pin = torch.randn(1, 1, rows, cin, generator=g).cuda() * 2          # the GELU's input: this linear's input was gelu(pin)
+    wd = w.permute(3, 1, 2, 0).contiguous()                            # [cin][1][1][cout]: maps dy [rows, cout] -> dx [rows, cin]
+    dyv = torch.randn(1, 1, rows, cout, generator=g).cuda()
     wdp = ops.split_bf16x3(wd) if ops.uses_bf16x6(tuple(dyv.shape), tuple(wd.shape), 1, 0) else None
     got = ops.conv2d_fwd(dyv, wd, None, 1, 0, epilogue=L.EPI_GELU_BWD, aux=pin, wplanes=wdp)
     lin = ops.conv2d_fwd(dyv, wd, None, 1, 0, wplanes=wdp)
