@@ -55,23 +55,39 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
     float* scl = reinterpret_cast<float*>(smem + 2 * PLANE);          // [2][BM]: 1 / scale of the token for K block (kb & 1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
-    const long m0 = (long)blockIdx.x * BM;
     const int nkb = a.K / KB, nchunks = a.N / NC, nblk = a.N / 16, ksteps = a.K / 32;
+    int wg_tile, wg_chunk;
+    {
+        const int ntiles = a.M / BM;
+        const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+        const int full = ntiles >> 3, rest = ntiles & 7;
+        const int mine = full + (xcd < rest ? 1 : 0), first = xcd * full + (xcd < rest ? xcd : rest);
+        const int lt = slot / nchunks;
+        wg_chunk = slot - lt * nchunks;
+        if (lt >= mine) return;                               // (grid padded to a multiple of 8 tiles)
+        wg_tile = first + lt;
+    }
+    const long m0 = (long)wg_tile * BM;
 
     // ---- panel loader: 16 lanes per token, three float4 per lane (channels 4 (l16 + 16 k) ...), 16 tokens per pass, 4 passes
+    // All twelve loads of a thread are issued before the first is used: ONE memory round trip per panel (pass by pass -- load, reduce,
+    // split, store -- a workgroup spent four dependent HBM latencies before its first product: 25 us per workgroup for 2 us of MFMAs).
     auto load_panel = [&](int kb) {
         const int row_in_pass = tid >> 4;
+        f32x4 v[BM / 16][3];
+#pragma unroll
+        for (int pass = 0; pass < BM / 16; ++pass) {
+            const f32x4* src = reinterpret_cast<const f32x4*>(a.x + (m0 + pass * 16 + row_in_pass) * a.K + (long)kb * KB);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) v[pass][k] = src[l16 + 16 * k];
+        }
 #pragma unroll
         for (int pass = 0; pass < BM / 16; ++pass) {
             const int r = pass * 16 + row_in_pass;
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.x + (m0 + r) * a.K + (long)kb * KB);
-            f32x4 v[3];
             float amax = 0.f;
 #pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                v[k] = src[l16 + 16 * k];
-                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[k][0]), fabsf(v[k][1])), fmaxf(fabsf(v[k][2]), fabsf(v[k][3]))));
-            }
+            for (int k = 0; k < 3; ++k)
+                amax = fmaxf(amax, fmaxf(fmaxf(fabsf(v[pass][k][0]), fabsf(v[pass][k][1])), fmaxf(fabsf(v[pass][k][2]), fabsf(v[pass][k][3]))));
             amax = fmaxf(amax, __shfl_xor(amax, 8, 16));
             amax = fmaxf(amax, __shfl_xor(amax, 4, 16));
             amax = fmaxf(amax, __shfl_xor(amax, 2, 16));
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int c4 = l16 + 16 * k;                              // float4 index inside the K block: slice c4 / 4, 8-byte piece c4 % 4
-                const f32x4 xs = v[k] * s;
+                const f32x4 xs = v[pass][k] * s;
                 const f16x4 hi = __builtin_convertvector(xs, f16x4);
                 const f16x4 lo = __builtin_convertvector(xs - __builtin_convertvector(hi, f32x4), f16x4);
                 char* dst = smem + (c4 >> 2) * (BM * 32) + r * 32 + (c4 & 3) * 8;
@@ -115,45 +131,53 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
                 fx[p][j] = *reinterpret_cast<const f16x8*>(smem + p * PLANE + (2 * ksl) * (BM * 32) + j * (16 * 32) + fx_lane);
     };
 
+    // ---- (token tile, chunk) of this workgroup.  Launch ids go round-robin over the 8 XCDs; the chunks of one token tile read the same
+    // panel, so they are neighbours INSIDE an XCD (slot = id / 8 walks (tile of this XCD, chunk), chunk fastest): the panel comes from
+    // HBM once and from that XCD's L2 for the other chunks.  One chunk per workgroup: 3 x as many, shorter workgroups for the qkv
+    // Linear (1024 workgroups on 768 resident slots left a third of the chip idle for the last round).
     f32x4 acc[3][4];
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
+    {
+        const int chunk = wg_chunk;
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
         for (int kb = 0; kb < nkb; ++kb) {
-            if (chunk == 0 || nkb > 1) {                      // (one K block: the panel of chunk 0 serves every chunk)
-                if (kb > 0 || chunk > 0) __syncthreads();     // every wave is done with the previous panel
-                load_panel(kb);
-                __syncthreads();
-                if (kb > 0) {                                  // accumulators carry the previous block's token scale: exact power-of-two ratio
+            if (kb > 0) __syncthreads();                       // every wave is done with the previous panel
+            load_panel(kb);
+            f16x8 fw[2][2][3];
+            load_w(fw[0], kb * (KB / 32), chunk);              // (in flight across the barrier)
+            __syncthreads();
+            if (kb > 0) {                                      // accumulators carry the previous block's token scale: exact power-of-two ratio
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float ratio = scl[((kb - 1) & 1) * BM + 16 * j + l16] / scl[(kb & 1) * BM + 16 * j + l16];
+                for (int j = 0; j < 4; ++j) {
+                    const float ratio = scl[((kb - 1) & 1) * BM + 16 * j + l16] / scl[(kb & 1) * BM + 16 * j + l16];
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) acc[i][j] *= ratio;
-                    }
+                    for (int i = 0; i < 3; ++i) acc[i][j] *= ratio;
                 }
             }
-            f16x8 fw[2][2][3];
-            load_w(fw[0], kb * (KB / 32), chunk);
 #pragma unroll
             for (int ksl = 0; ksl < KB / 32; ++ksl) {
                 if (ksl + 1 < KB / 32) load_w(fw[(ksl + 1) & 1], kb * (KB / 32) + ksl + 1, chunk);
                 f16x8 fx[2][4];
                 read_x(fx, ksl);
                 const int c = ksl & 1;
+                // product-major: twelve independent accumulators between two MFMAs on the same one (small products first)
 #pragma unroll
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][1][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_lo x_hi (small first)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[1][j], acc[i][j], 0, 0, 0);    // w_hi x_lo
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_hi x_hi
-                    }
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][1][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_lo x_hi
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[1][j], acc[i][j], 0, 0, 0);    // w_hi x_lo
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_hi x_hi
             }
         }
-        // ---- epilogue of the chunk: y = acc / (token scale * weight scale) + bias, four consecutive channels of one token per lane
+        // ---- epilogue: y = acc / (token scale * weight scale) + bias, four consecutive channels of one token per lane
         const float* inv_s = scl + ((nkb - 1) & 1) * BM;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -232,7 +256,8 @@ extern "C" int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, co
     const double flops = 2.0 * (double)M * K * N;
     return rdo::dispatch(
         [a](hipStream_t s) {
-            hipLaunchKernelGGL(linear_h2_kernel, dim3((unsigned)(a.M / BM)), dim3(256), LDS_BYTES, s, a);
+            const unsigned grid = (unsigned)(rdo::ceil_div(a.M / BM, 8) * 8 * (a.N / NC));
+            hipLaunchKernelGGL(linear_h2_kernel, dim3(grid), dim3(256), LDS_BYTES, s, a);
             return rdo::check_launch("linear_h2");
         },
         stream, "linear_h2", flops, 4.0 * ((double)M * K + (double)M * N + (double)K * N));

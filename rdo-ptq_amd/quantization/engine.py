@@ -169,6 +169,21 @@ class _Op:
         # exact bf16 three-way splits of the kernel-layout weights, (re)made after every update for the convs that run on
         # the split-bf16 MFMA path (large problems only; decided by the library from the activation shape)
         self.wq_planes = self.wd_planes = None
+        self.lin_fwd = self.lin_bwd = None     # fragment-ordered fp16 planes of a Linear for rdo_linear_h2 (large token matrices)
+
+    def lin_planes(self, fwd: bool):
+        """Planes of this Linear's soft weight (fwd) / of its transpose (input gradient) for rdo_linear_h2: allocated on first use -- while
+        the plan is being recorded --, filled by `refresh_planes` (eagerly after the recording, then inside the plan behind every step)."""
+        if self.qm.kind != "linear":
+            raise RuntimeError("lin_planes: not a Linear")
+        co, _, _, ci = self.w4
+        if fwd:
+            if self.lin_fwd is None:
+                self.lin_fwd = ops.H2(torch.empty((2, ci // 32, co // 16, 64, 8), device=self.w.device, dtype=torch.int16), self.wscale)
+            return self.lin_fwd
+        if self.lin_bwd is None:
+            self.lin_bwd = ops.H2(torch.empty((2, co // 32, ci // 16, 64, 8), device=self.w.device, dtype=torch.int16), self.wscale)
+        return self.lin_bwd
 
     def enable_planes(self, fwd: bool, dgrad: bool, h2: bool = False):
         """Allocate the plane buffers (called while the plan is being recorded: no kernel may run here; the engine fills them
@@ -196,6 +211,10 @@ class _Op:
             ops.split_h2_conv(self.wp, planes=self.wp_h2)
 
     def refresh_planes(self):
+        if self.lin_fwd is not None:
+            ops.split_h2_linear(self.wq4(), planes=self.lin_fwd)
+        if self.lin_bwd is not None:
+            ops.split_h2_linear(self.wd4(), planes=self.lin_bwd)
         if self.wp_planes is not None:
             ops.split_bf16x3(self.wp, self.wp_planes)
         if self.wp_h2 is not None:
@@ -466,6 +485,10 @@ class UnitEngine:
         for op in self.ops.values():
             if op.tc_phase is not None:
                 op.expand_phase()
+            if op.lin_fwd is not None:                     # Linears on rdo_linear_h2: fragment-ordered planes of the new soft weights
+                ops.split_h2_linear(op.wq4(), planes=op.lin_fwd)
+            if op.lin_bwd is not None:
+                ops.split_h2_linear(op.wd4(), planes=op.lin_bwd)
 
     def _loss(self, pred, grad):
         if self.rd is not None:
@@ -838,7 +861,7 @@ class UnitEngine:
         for op in self.ops.values():
             ops.adaround_init_alpha(op.desc, op.w, op.delta, op.alpha)
             op.m.zero_(); op.v.zero_()
-            op.wq_planes = op.wd_planes = op.wp_h2 = op.wp_planes = None
+            op.wq_planes = op.wd_planes = op.wp_h2 = op.wp_planes = op.lin_fwd = op.lin_bwd = None
         self._set_weights(soft=True)
         self.P, self._ovf_slot = {}, {}
         self._clear_probe()

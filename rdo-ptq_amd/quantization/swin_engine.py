@@ -76,6 +76,22 @@ class _FpOp:
             self.bw_phase_of = lambda opad: ops.TconvPhase.get(self.K, self.stride, self.pad, opad, False, self.w.device)
             self.wbp = self.wbp_planes = None
         self.wq_planes = self.wd_planes = None
+        self.lin_fwd = self.lin_bwd = None
+
+    def lin_planes(self, fwd: bool):
+        """Frozen Linear for rdo_linear_h2: planes of W (fwd) / W^T (input gradient), allocated here (possibly inside a recording),
+        filled by `fill_planes` once the recording is over.  Scale: a power of two from the weight's own magnitude (a torch reduction:
+        not a recorded op)."""
+        co, _, _, ci = self.w4
+        if getattr(self, "_lin_scale", None) is None:
+            self._lin_scale = ops.pow2_scale(self.w.abs().max())
+        if fwd:
+            if self.lin_fwd is None:
+                self.lin_fwd = ops.H2(torch.empty((2, ci // 32, co // 16, 64, 8), device=self.w.device, dtype=torch.int16), self._lin_scale)
+            return self.lin_fwd
+        if self.lin_bwd is None:
+            self.lin_bwd = ops.H2(torch.empty((2, co // 32, ci // 16, 64, 8), device=self.w.device, dtype=torch.int16), self._lin_scale)
+        return self.lin_bwd
 
     def wq4(self):
         return self.w
@@ -91,6 +107,10 @@ class _FpOp:
             self.wd_planes = torch.empty((3,) + tuple(self.wd.shape), device=self.wd.device, dtype=torch.int16)
 
     def fill_planes(self):
+        if self.lin_fwd is not None:
+            ops.split_h2_linear(self.w, planes=self.lin_fwd)
+        if self.lin_bwd is not None:
+            ops.split_h2_linear(self.wd, planes=self.lin_bwd)
         if getattr(self, "wp_planes", None) is not None:
             ops.split_bf16x3(self.wp, self.wp_planes)
         if getattr(self, "wbp_planes", None) is not None:
@@ -174,6 +194,8 @@ class TapeEngine(UnitEngine):
     # RDO_SWIN_FUSE_LN=0 -> separate add kernels around the plain LayerNorm kernels
     fuse_gelu = int(os.environ.get("RDO_SWIN_FUSE_GELU", "1"))
     fuse_ln = os.environ.get("RDO_SWIN_FUSE_LN", "1") != "0"
+    # RDO_SWIN_LIN_H2=0: the Linears of the large token matrices back on the split-bf16 1x1-conv kernel (six products, csrc/conv_fwd_x6.hip)
+    lin_h2 = os.environ.get("RDO_SWIN_LIN_H2", "1") != "0"
     fuse_ln_fwd = os.environ.get("RDO_SWIN_FUSE_LN_FWD", "1") != "0"
 
     def _gput(self, t, buf):
@@ -204,9 +226,18 @@ class TapeEngine(UnitEngine):
         y = self._buf(*x.shape[:-1], cout)
         x4, y4 = x.view(1, 1, rows, cin), y.view(1, 1, rows, cout)
         pre = None
+        lin_f = self.lin_h2 and ops.linear_h2_supported(rows, cin, cout)          # large token matrices: per-token-scaled fp16-split kernel
+        lin_b = self.lin_h2 and ops.linear_h2_supported(rows, cout, cin)
+        bias_of = lambda: p.bias
         fuse_here = lambda xs, w4, has_planes: self.fuse_gelu == 2 or (
             self.fuse_gelu == 1 and ops.conv_fwd_ksplit(tuple(xs), tuple(w4), 1, 0, has_planes, self.dev)[0] >= 2)
-        if gelu and fuse_here(x4.shape, p.w4, ops.uses_bf16x6(tuple(x4.shape), p.w4, 1, 0)):
+        if lin_f:
+            if gelu:
+                pre = self._buf(*y.shape)
+            ops.linear_h2(x, p.lin_planes(True), bias_of(), out=pre if gelu else y)
+            if gelu:
+                ops.gelu(pre, out=y)
+        elif gelu and fuse_here(x4.shape, p.w4, ops.uses_bf16x6(tuple(x4.shape), p.w4, 1, 0)):
             pre = self._buf(*y.shape)
             self._conv(p, x4, y4, epilogue=L.EPI_GELU, pre=pre.view(1, 1, rows, cout))
         elif gelu:
@@ -220,7 +251,15 @@ class TapeEngine(UnitEngine):
             dy4 = self._gget(pre if gelu else y).view(1, 1, rows, cout)
             if isinstance(p, _Op):
                 self._wgrad(p, x4, dy4)
-            if need_dx:
+            if need_dx and lin_b:
+                dy = dy4.view(rows, cout)
+                if gelu_in is not None:
+                    dg = self._buf(*x.shape)
+                    ops.linear_h2(dy, p.lin_planes(False), None, out=dg)
+                    ops.gelu_bwd(dg, gelu_in, self._gnew(gelu_in))
+                else:
+                    ops.linear_h2(dy, p.lin_planes(False), None, out=self._gnew(x))
+            elif need_dx:
                 wd4 = tuple(p.wd4().shape)
                 if gelu_in is not None and fuse_here(dy4.shape, wd4, ops.uses_bf16x6(tuple(dy4.shape), wd4, 1, 0)):
                     dx = self._gnew(gelu_in)

@@ -179,3 +179,36 @@ def test_gelu_epilogues_of_the_linear_kernels(rows, cin, cout, planes):
     want = lin.double().cpu() * p64.grad
     assert float((got.cpu().double() - want).abs().max()) < 2e-6 * float(want.abs().max())
     assert float((got - sep).abs().max()) <= 1e-6 * float(sep.abs().max())
+
+
+@pytest.mark.parametrize("rows,K,N", [(64, 192, 192), (4 * 64 * 64, 192, 576), (4 * 128 * 128, 384, 192), (16384, 576, 192), (640, 192, 384)])
+@pytest.mark.parametrize("kind", ["act", "grad", "zero_rows"])
+def test_linear_h2_per_token_scale_matches_float64(rows, K, N, kind):
+    """rdo_linear_h2 (csrc/linear_h2.hip): Y = X W^T + b on fp16 two-way-split MFMA with a per-token dynamic power-of-two scale, against
+    float64 -- for activation-like inputs, for gradient-like inputs (1e-6 and below, magnitudes differing by e^(+-9) from token to token:
+    a per-TENSOR scale would drop the small tokens into fp16's denormals), and with all-zero tokens.  The error is measured per token
+    against that token's own largest output (what a per-token scale promises): 2e-6, the level of the split-bf16 six-product kernel."""
+    from hipops import ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = torch.randn(rows, K, generator=g)
+    if kind == "grad":
+        x = x * 1e-6 * torch.exp(3 * torch.randn(rows, 1, generator=g))
+    if kind == "zero_rows":
+        x[::3] = 0.0
+        x[1, :] = 0.0
+        x[1, 5] = 1e-30
+    w = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    assert ops.linear_h2_supported(rows, K, N) and not ops.linear_h2_supported(rows + 1, K, N) and not ops.linear_h2_supported(rows, K + 32, N)
+    planes = ops.split_h2_linear(w.cuda())
+    want = x.double() @ w.double().t()
+    tok = want.abs().amax(1, keepdim=True)
+    live = tok.squeeze(1) > 0
+    y0 = ops.linear_h2(x.cuda(), planes, None).cpu().double()                  # the form the input gradients take: no bias
+    assert float(((y0 - want).abs()[live] / tok[live]).max()) < 2e-6
+    assert float(y0[~live].abs().max() if (~live).any() else 0.0) == 0.0       # a token of zeros gives exact zeros
+    if kind != "grad":                                                        # (a bias next to 1e-8 outputs would measure fp32's own rounding)
+        y = ops.linear_h2(x.cuda(), planes, b.cuda()).cpu().double()
+        ref = want + b.double()
+        assert float(((y - ref).abs() / ref.abs().amax(1, keepdim=True)).max()) < 2e-6
+        assert bool((y[~live] == b.double()).all())                           # ... and with a bias exactly the bias
