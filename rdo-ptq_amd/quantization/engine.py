@@ -1178,16 +1178,19 @@ class UnitEngine:
             self.plan_b.run_then(self.plan_a, graph=graph)
 
     def _run_dp(self, n):
-        """n data-parallel iterations.  Default: the HOST drives plan A -> all-reduce -> plan B (each plan a graph replay, the
-        collective enqueued by torch.distributed in between).  Opt-in `RDO_DP_GRAPH=1` with the RCCL backend: the whole iteration --
-        the recorded kernels of the three plans AND the collectives -- is captured once into ONE graph (torch.cuda.graph) and
-        replayed with no host work in between.  The ranks AGREE on the outcome of the capture (MIN all-reduce of an "ok" flag) before
-        anyone replays: a rank never replays a graph with collectives while another runs the host loop.  `self.dp_path` says
-        which loop ran ("graph" / "host"); every rank logs it."""
+        """n data-parallel iterations.  With the RCCL backend (round 5: the DEFAULT; `RDO_DP_GRAPH=0` keeps the host loop) the whole
+        iteration -- the recorded kernels of the three plans AND the collectives -- is captured once per unit into ONE graph
+        (torch.cuda.graph) and replayed with no host work in between: the host-driven loop (plan A -> all-reduce -> plan B, each plan
+        a graph replay, the collective enqueued by torch.distributed in between) costs two to three enqueues per unit-iteration, which
+        the sixteen <= 50-us units cannot hide (+13 % on one rank against +5 % captured, `extra.dp_overhead_one_rank` of the bench
+        line re-measures both on every run).  The ranks AGREE on the outcome of the capture (MIN all-reduce of an "ok" flag) before
+        anyone replays: a rank never replays a graph with collectives while another runs the host loop; a unit whose capture fails
+        on any rank runs the host loop on every rank.  Other backends (gloo in the CPU / one-GPU tests): host loop.  `self.dp_path`
+        says which loop ran ("graph" / "host"); every rank logs it, the bench line carries it per unit."""
         import logging
         dist = torch.distributed
         comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
-        want = self.use_graph and os.environ.get("RDO_DP_GRAPH", "0") == "1" and (not comm or dist.get_backend(self.group) == "nccl")
+        want = self.use_graph and os.environ.get("RDO_DP_GRAPH", "1") == "1" and comm and dist.get_backend(self.group) == "nccl"
         if want and self._dp_graph is None and not self._dp_graph_failed and n > 1:
             ok = 1
             try:
