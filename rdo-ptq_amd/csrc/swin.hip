@@ -102,6 +102,39 @@ __device__ __forceinline__ f32x16 tile_gemm(const float* A, int lda, const float
     return acc;
 }
 
+// NG independent products over the same K, stepped together: the operand loads of four k pairs of EVERY product are issued before
+// the first MFMA of the group (the one-product loop above compiles to  2 x ds_read_b32 -> s_waitcnt lgkmcnt(0) -> v_mfma  per k pair:
+// the LDS latency fully exposed behind every 64-cycle MFMA), and consecutive MFMAs go to different accumulators.
+// `ld(g, k, a, b)`: operands of product g for reduction index k (the lane's own k = s + lk is passed in).
+template <int NG, typename LD>
+__device__ __forceinline__ void tile_gemm_multi(f32x16 (&acc)[NG], int K, LD ld) {
+    const int lk = (threadIdx.x & 63) >> 5;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
+    int s = 0;
+    for (; s + 8 <= K; s += 8) {
+        float a[NG][4], b[NG][4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) ld(g, s + 2 * u + lk, a[g][u], b[g][u]);
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[g][u], b[g][u], acc[g], 0, 0, 0);
+    }
+    for (; s < K; s += 2) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            float a, b;
+            ld(g, s + lk, a, b);
+            acc[g] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[g], 0, 0, 0);
+        }
+    }
+}
+
 __device__ __forceinline__ void tile_to_lds(const f32x16& acc, float* D, int ldd, int ti, int tj) {
     const int l = threadIdx.x & 63, lr = l & 31, lk = l >> 5;
 #pragma unroll
@@ -206,65 +239,139 @@ __device__ __forceinline__ void softmax_rows256(const AttnGeom& g, float* S, flo
     }
 }
 
-// (window, head) of a workgroup.  Launch ids go round-robin over the 8 XCDs (id % 8), each with its own L2: the heads of one window read
-// interleaved pieces of the same qkv rows (head h of a token is hd floats inside a 3C-float row: neighbouring heads share cache lines),
-// so they are numbered next to each other INSIDE one XCD -- slot = id / 8 walks (window of this XCD, head) with the head fastest.
-__device__ __forceinline__ void attn_wg(int windows, int heads, int& win, int& head) {
-    const int id = blockIdx.x;
+// (window, head) of work item `id`.  Launch ids go round-robin over the 8 XCDs (id % 8), each with its own L2: the heads of one window
+// read interleaved pieces of the same qkv rows (head h of a token is hd floats inside a 3C-float row: neighbouring heads share cache
+// lines), so they are numbered next to each other INSIDE one XCD -- slot = id / 8 walks (window of this XCD, head) with the head
+// fastest.  Window counts that are not a multiple of 8 (toy shapes): plain order.
+__device__ __forceinline__ void attn_item(int id, int windows, int heads, int& win, int& head) {
+    if (windows & 7) {
+        win = id / heads;
+        head = id - win * heads;
+        return;
+    }
     const int xcd = id & 7, slot = id >> 3;
-    const int full = windows >> 3, rest = windows & 7;          // windows per XCD: `full`, one more on the first `rest` XCDs
-    const int mine = full + (xcd < rest ? 1 : 0);
-    const int first = xcd * full + (xcd < rest ? xcd : rest);
     const int lw = slot / heads;
     head = slot - lw * heads;
-    win = lw < mine ? first + lw : -1;                           // (ids beyond the XCD's share: the grid is padded to a multiple of 8)
+    win = xcd * (windows >> 3) + lw;
 }
 
-// LDS budget (round 5): the score matrices are held in the MFMA accumulators until every wave is done with the operands they were
-// computed from, then written OVER those operands -- forward: S over Q / K (3 x 64 x hs floats in all: four workgroups per CU at hd = 48,
-// two before), backward: P over V (which no later product reads) + dS behind it (71 KiB instead of 85 at hd = 48: two workgroups per
-// CU instead of one).  These kernels are latency chains (load tiles -> products -> row softmax -> products -> store); a second resident
-// workgroup is what fills the gaps.
-__global__ __launch_bounds__(256) void win_attn_fwd_mfma_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
-                                                                int no_pv, int windows) {
+// One tile (Q, K, V or dO of a (window, head) pair) travels global -> registers -> LDS in two steps, so that the loads of the NEXT work
+// item are in flight while the current one is multiplied (`fetch` right behind the barrier that publishes the current tiles, `stash`
+// at the top of the next item).  Vector form only: head dim and channel offsets multiples of 4 (every Lu2022 shape).
+typedef float af4 __attribute__((ext_vector_type(4)));
+// TILE_IT = ceil(tokens x hd / 4 / 256): quads per thread and tile (hd <= 16: 1, <= 32: 2, <= 48: 3, <= 64: 4) -- a template parameter, the
+// prefetch registers of a kernel are 3 or 4 tiles x TILE_IT x 4
+template <int TILE_IT>
+__device__ __forceinline__ void tile_fetch(const AttnGeom& g, const float* src, int row_stride, int ch0, const int* pix, af4 (&r)[TILE_IT]) {
+    const int qpt = g.hd >> 2, nq = g.N * qpt;
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        if (e < nq) {
+            const int tok = e / qpt, dq = e - tok * qpt;
+            r[it] = *reinterpret_cast<const af4*>(src + (long)pix[tok] * row_stride + ch0 + 4 * dq);
+        }
+    }
+}
+template <int TILE_IT>
+__device__ __forceinline__ void tile_stash(const AttnGeom& g, const af4 (&r)[TILE_IT], float* dst, float mul) {
+    const int qpt = g.hd >> 2, nq = g.N * qpt;
+#pragma unroll
+    for (int it = 0; it < TILE_IT; ++it) {
+        const int e = threadIdx.x + 256 * it;
+        if (e < nq) {
+            const int tok = e / qpt, dq = e - tok * qpt;
+            float* d = dst + tok * g.hs + 4 * dq;              // (hs is odd: scalar LDS stores)
+            d[0] = mul * r[it][0]; d[1] = mul * r[it][1]; d[2] = mul * r[it][2]; d[3] = mul * r[it][3];
+        }
+    }
+}
+
+// Round 5.  (1) LDS budget: the score matrices are held in the MFMA accumulators until every wave is done with the operands they were
+// computed from, then written OVER those operands -- forward: S over Q / K (3 x 64 x hs floats in all: four workgroups per CU at
+// hd = 48, two before), backward: P over V (which no later product reads) + dS behind it (71 KiB instead of 85 at hd = 48: two
+// workgroups per CU instead of one).  (2) PERSISTENT workgroups: the kernels are latency chains (load tiles -> products -> row softmax ->
+// products -> store); with one (window, head) per workgroup all resident workgroups load, then multiply, then store at the same time
+// (29 us per pair for 4.4 us of MFMAs on the 128^2 maps).  A workgroup now walks items id, id + grid, ... (same XCD) and fetches the
+// next item's tiles into registers right after publishing the current ones: HBM latency and the loads themselves run under the
+// products.  PF = false (head dims that are not multiples of 4): tiles loaded in place, no prefetch.
+template <bool PF, int TILE_IT>
+__global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
+                                                                int no_pv, int windows, int nitems) {
     extern __shared__ float lds[];
     float* V = lds;
     float* Q = V + 64 * g.hs;
     float* K = Q + 64 * g.hs;
     float* S = Q;                                             // [64][65] over Q and K (2 x 64 x hs >= 64 x 65 for hs >= 33; else behind V)
-    int win, head;
-    attn_wg(windows, g.heads, win, head);
-    if (win < 0) return;
+    __shared__ int pix[2][NMAX], reg[2][NMAX];               // token -> pixel (roll + window partition) and -> mask region, per item
     const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
-    __shared__ int pix[NMAX], reg[NMAX];                     // token -> pixel (roll + window partition) and -> mask region, computed once
-    if (threadIdx.x < g.N) {
-        pix[threadIdx.x] = token_pixel(g, win, threadIdx.x);
-        reg[threadIdx.x] = g.shift > 0 ? token_region(g, win, threadIdx.x) : 0;
-    }
+    const int lr = threadIdx.x & 31, ai = 32 * ti + lr, bj = 32 * tj + lr, hs = g.hs;
     const bool full = g.N == NMAX && (g.hd & 1) == 0;         // every row a token, no odd-K zero column: nothing reads the padding
-    if (!full) zero_lds(lds, 3 * 64 * g.hs);
+    const int hk = (g.hd + 1) & ~1, nk = (g.N + 1) & ~1;
+    auto tables = [&](int b, int win) {
+        if (threadIdx.x < g.N) {
+            pix[b][threadIdx.x] = token_pixel(g, win, threadIdx.x);
+            reg[b][threadIdx.x] = g.shift > 0 ? token_region(g, win, threadIdx.x) : 0;
+        }
+    };
+    af4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT];
+    auto fetch = [&](int b, int head) {
+        tile_fetch(g, qkv, 3 * g.C, head * g.hd, pix[b], rq);
+        tile_fetch(g, qkv, 3 * g.C, g.C + head * g.hd, pix[b], rk);
+        tile_fetch(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix[b], rv);
+    };
+    int id = blockIdx.x, buf = 0, win, head;
+    attn_item(id, windows, g.heads, win, head);
+    tables(0, win);
     __syncthreads();
-    load_tile256(g, qkv, 3 * g.C, head * g.hd, pix, Q, g.scale);
-    load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix, K, 1.f);
-    load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix, V, 1.f);
-    __syncthreads();
-    const int hk = (g.hd + 1) & ~1;
-    const f32x16 sc = tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0);
-    __syncthreads();                                          // every wave has read Q and K
-    tile_to_lds(sc, S, SS, ti, tj);
-    __syncthreads();
-    softmax_rows256(g, S, nullptr, bias, reg, head, probs, win);
-    if (no_pv) return;
-    __syncthreads();
-    if (32 * tj < g.hd) {
-        const int nk = (g.N + 1) & ~1;
-        const f32x16 o = tile_gemm<false, false>(S, SS, V, g.hs, ti, tj, nk, g.hd);
-        tile_to_global(g, o, out, g.C, head * g.hd, pix, ti, tj, 1.f);
+    if (PF) fetch(0, head);
+    for (;;) {
+        if (!full) {
+            zero_lds(lds, 3 * 64 * g.hs);
+            __syncthreads();
+        }
+        if (PF) {
+            tile_stash(g, rq, Q, g.scale);
+            tile_stash(g, rk, K, 1.f);
+            tile_stash(g, rv, V, 1.f);
+        } else {
+            load_tile256(g, qkv, 3 * g.C, head * g.hd, pix[buf], Q, g.scale);
+            load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix[buf], K, 1.f);
+            load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix[buf], V, 1.f);
+        }
+        const int nid = id + gridDim.x;
+        const bool more = nid < nitems;
+        int nwin = 0, nhead = 0;
+        if (more) {
+            attn_item(nid, windows, g.heads, nwin, nhead);
+            tables(buf ^ 1, nwin);
+        }
+        __syncthreads();                                      // tiles of this item and tables of the next are visible
+        if (PF && more) fetch(buf ^ 1, nhead);               // in flight while this item is multiplied
+        f32x16 sc[1];
+        tile_gemm_multi<1>(sc, hk, [&](int, int k, float& a, float& b) { a = Q[ai * hs + k]; b = K[bj * hs + k]; });
+        __syncthreads();                                      // every wave has read Q and K
+        tile_to_lds(sc[0], S, SS, ti, tj);
+        __syncthreads();
+        softmax_rows256(g, S, nullptr, bias, reg[buf], head, probs, win);
+        if (!no_pv) {
+            __syncthreads();
+            if (32 * tj < g.hd) {
+                const bool bok = bj < g.hd;
+                f32x16 o[1];
+                tile_gemm_multi<1>(o, nk, [&](int, int k, float& a, float& b) { a = S[ai * SS + k]; b = bok ? V[k * hs + bj] : 0.f; });
+                tile_to_global(g, o[0], out, g.C, head * g.hd, pix[buf], ti, tj, 1.f);
+            }
+        }
+        if (!more) break;
+        __syncthreads();                                      // every wave is done with this item's LDS images
+        id = nid; win = nwin; head = nhead; buf ^= 1;
     }
 }
 
-__global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv, const float* bias, const float* dout, AttnGeom g,
-                                                                float* dqkv, int windows) {
+template <bool PF, int TILE_IT>
+__global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* qkv, const float* bias, const float* dout, AttnGeom g,
+                                                                float* dqkv, int windows, int nitems) {
     extern __shared__ float lds[];
     float* Q = lds;                       // pre-scaled
     float* K = Q + 64 * g.hs;
@@ -272,37 +379,81 @@ __global__ __launch_bounds__(256) void win_attn_bwd_mfma_kernel(const float* qkv
     float* V = dO + 64 * g.hs;
     float* P = V;                         // [64][65]: scores, then probabilities -- over V once the dP product has read it
     float* dS = P + 64 * SS;              // [64][65]: dP, then dS
-    int win, head;
-    attn_wg(windows, g.heads, win, head);
-    if (win < 0) return;
+    __shared__ int pix[2][NMAX], reg[2][NMAX];
     const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
-    __shared__ int pix[NMAX], reg[NMAX];
-    if (threadIdx.x < g.N) {
-        pix[threadIdx.x] = token_pixel(g, win, threadIdx.x);
-        reg[threadIdx.x] = g.shift > 0 ? token_region(g, win, threadIdx.x) : 0;
-    }
+    const int lr = threadIdx.x & 31, ai = 32 * ti + lr, bj = 32 * tj + lr, hs = g.hs;
     const bool full = g.N == NMAX && (g.hd & 1) == 0;
-    if (!full) zero_lds(lds, 4 * 64 * g.hs);
-    __syncthreads();
-    load_tile256(g, qkv, 3 * g.C, head * g.hd, pix, Q, g.scale);
-    load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix, K, 1.f);
-    load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix, V, 1.f);
-    load_tile256(g, dout, g.C, head * g.hd, pix, dO, 1.f);
-    __syncthreads();
     const int hk = (g.hd + 1) & ~1, nk = (g.N + 1) & ~1;
-    const f32x16 sc = tile_gemm<false, true>(Q, g.hs, K, g.hs, ti, tj, hk, 0);
-    const f32x16 dp = tile_gemm<false, true>(dO, g.hs, V, g.hs, ti, tj, hk, 0);                   // dP = dO V^T
-    __syncthreads();                                                                               // every wave has read V
-    tile_to_lds(sc, P, SS, ti, tj);
-    tile_to_lds(dp, dS, SS, ti, tj);
+    auto tables = [&](int b, int win) {
+        if (threadIdx.x < g.N) {
+            pix[b][threadIdx.x] = token_pixel(g, win, threadIdx.x);
+            reg[b][threadIdx.x] = g.shift > 0 ? token_region(g, win, threadIdx.x) : 0;
+        }
+    };
+    af4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT], ro[TILE_IT];
+    auto fetch = [&](int b, int head) {
+        tile_fetch(g, qkv, 3 * g.C, head * g.hd, pix[b], rq);
+        tile_fetch(g, qkv, 3 * g.C, g.C + head * g.hd, pix[b], rk);
+        tile_fetch(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix[b], rv);
+        tile_fetch(g, dout, g.C, head * g.hd, pix[b], ro);
+    };
+    int id = blockIdx.x, buf = 0, win, head;
+    attn_item(id, windows, g.heads, win, head);
+    tables(0, win);
     __syncthreads();
-    softmax_rows256(g, P, dS, bias, reg, head, nullptr, win);
-    __syncthreads();
-    if (32 * tj < g.hd) {
-        // dQ = scale * dS K ; dK = dS^T Qs (Qs carries the scale) ; dV = P^T dO
-        tile_to_global(g, tile_gemm<false, false>(dS, SS, K, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, head * g.hd, pix, ti, tj, g.scale);
-        tile_to_global(g, tile_gemm<true, false>(dS, SS, Q, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, g.C + head * g.hd, pix, ti, tj, 1.f);
-        tile_to_global(g, tile_gemm<true, false>(P, SS, dO, g.hs, ti, tj, nk, g.hd), dqkv, 3 * g.C, 2 * g.C + head * g.hd, pix, ti, tj, 1.f);
+    if (PF) fetch(0, head);
+    for (;;) {
+        if (!full) {
+            zero_lds(lds, 4 * 64 * g.hs);
+            __syncthreads();
+        }
+        if (PF) {
+            tile_stash(g, rq, Q, g.scale);
+            tile_stash(g, rk, K, 1.f);
+            tile_stash(g, rv, V, 1.f);
+            tile_stash(g, ro, dO, 1.f);
+        } else {
+            load_tile256(g, qkv, 3 * g.C, head * g.hd, pix[buf], Q, g.scale);
+            load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix[buf], K, 1.f);
+            load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix[buf], V, 1.f);
+            load_tile256(g, dout, g.C, head * g.hd, pix[buf], dO, 1.f);
+        }
+        const int nid = id + gridDim.x;
+        const bool more = nid < nitems;
+        int nwin = 0, nhead = 0;
+        if (more) {
+            attn_item(nid, windows, g.heads, nwin, nhead);
+            tables(buf ^ 1, nwin);
+        }
+        __syncthreads();
+        if (PF && more) fetch(buf ^ 1, nhead);
+        f32x16 sd[2];                                                                              // scores Q K^T and dP = dO V^T, stepped together
+        tile_gemm_multi<2>(sd, hk, [&](int gi, int k, float& a, float& b) {
+            if (gi == 0) { a = Q[ai * hs + k]; b = K[bj * hs + k]; }
+            else { a = dO[ai * hs + k]; b = V[bj * hs + k]; }
+        });
+        __syncthreads();                                                                           // every wave has read V
+        tile_to_lds(sd[0], P, SS, ti, tj);
+        tile_to_lds(sd[1], dS, SS, ti, tj);
+        __syncthreads();
+        softmax_rows256(g, P, dS, bias, reg[buf], head, nullptr, win);
+        __syncthreads();
+        if (32 * tj < g.hd) {
+            // dQ = scale * dS K ; dK = dS^T Qs (Qs carries the scale) ; dV = P^T dO -- three independent accumulators, stepped together
+            const bool bok = bj < g.hd;
+            f32x16 d3[3];
+            tile_gemm_multi<3>(d3, nk, [&](int gi, int k, float& a, float& b) {
+                if (gi == 0) { a = dS[ai * SS + k]; b = bok ? K[k * hs + bj] : 0.f; }
+                else if (gi == 1) { a = dS[k * SS + ai]; b = bok ? Q[k * hs + bj] : 0.f; }
+                else { a = P[k * SS + ai]; b = bok ? dO[k * hs + bj] : 0.f; }
+            });
+            tile_to_global(g, d3[0], dqkv, 3 * g.C, head * g.hd, pix[buf], ti, tj, g.scale);
+            tile_to_global(g, d3[1], dqkv, 3 * g.C, g.C + head * g.hd, pix[buf], ti, tj, 1.f);
+            tile_to_global(g, d3[2], dqkv, 3 * g.C, 2 * g.C + head * g.hd, pix[buf], ti, tj, 1.f);
+        }
+        if (!more) break;
+        __syncthreads();
+        id = nid; win = nwin; head = nhead; buf ^= 1;
     }
 }
 
@@ -566,18 +717,30 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
     const size_t qk = (size_t)2 * 64 * g.hs, sm = (size_t)64 * SS;
     const size_t lds = ((size_t)64 * g.hs + (qk > sm ? qk : sm)) * sizeof(float);
     const int no_pv = out == nullptr;
-    const unsigned grid = (unsigned)(rdo::ceil_div(windows, 8) * 8 * g.heads);
+    const int nitems = windows * g.heads;
+    const bool pf = ((g.hd | g.C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv)) & 15) == 0;
+    // persistent workgroups: as many as are resident at once (LDS-bound), a multiple of 8 so that a workgroup's items stay on one XCD
+    const long resident = (long)256 * (160 * 1024 / (long)(lds + 1024));
+    long grid = nitems < resident ? nitems : resident / 8 * 8;
+    if (grid < 1) grid = 1;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            static rdo::PerDevice attr;
-            if (!attr.done()) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_fwd_mfma_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
-                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_fwd_mfma) failed");
-                attr.mark();
-            }
-            hipLaunchKernelGGL(win_attn_fwd_mfma_kernel, dim3(grid), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv, windows);
-            return rdo::check_launch("window_attention_fwd");
+            auto go = [&](auto kern, int slot) -> int {
+                static rdo::PerDevice attr[5];
+                if (!attr[slot].done()) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess)
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_fwd_mfma) failed");
+                    attr[slot].mark();
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv, windows, nitems);
+                return rdo::check_launch("window_attention_fwd");
+            };
+            if (!pf) return go(win_attn_fwd_mfma_kernel<false, 1>, 0);
+            const int it = (int)rdo::ceil_div((long)g.N * (g.hd >> 2), 256);
+            if (it <= 1) return go(win_attn_fwd_mfma_kernel<true, 1>, 1);
+            if (it == 2) return go(win_attn_fwd_mfma_kernel<true, 2>, 2);
+            if (it == 3) return go(win_attn_fwd_mfma_kernel<true, 3>, 3);
+            return go(win_attn_fwd_mfma_kernel<true, 4>, 4);
         },
         stream, "window_attention_fwd", 4.0 * windows * g.heads * (double)g.N * g.N * g.hd,
         4.0 * ((double)g.B * g.H * g.W * g.C * 4));
@@ -605,18 +768,29 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
     // Q, K, dO, then V with P over it and dS behind
     const size_t lds = ((size_t)3 * 64 * g.hs + (size_t)2 * 64 * SS) * sizeof(float);
     static_assert(SS >= 64 + 1, "P must cover a 64-float row");
-    const unsigned grid = (unsigned)(rdo::ceil_div(windows, 8) * 8 * g.heads);
+    const int nitems = windows * g.heads;
+    const bool pf = ((g.hd | g.C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0;
+    const long resident = (long)256 * (160 * 1024 / (long)(lds + 1024));
+    long grid = nitems < resident ? nitems : resident / 8 * 8;
+    if (grid < 1) grid = 1;
     return rdo::dispatch(
         [=](hipStream_t s) {
-            static rdo::PerDevice attr;
-            if (!attr.done()) {
-                if (hipFuncSetAttribute(reinterpret_cast<const void*>(win_attn_bwd_mfma_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess)
-                    return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_bwd_mfma) failed");
-                attr.mark();
-            }
-            hipLaunchKernelGGL(win_attn_bwd_mfma_kernel, dim3(grid), dim3(256), lds, s, qkv, bias, dout, g, dqkv, windows);
-            return rdo::check_launch("window_attention_bwd");
+            auto go = [&](auto kern, int slot) -> int {
+                static rdo::PerDevice attr[5];
+                if (!attr[slot].done()) {
+                    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024) != hipSuccess)
+                        return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_bwd_mfma) failed");
+                    attr[slot].mark();
+                }
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, dout, g, dqkv, windows, nitems);
+                return rdo::check_launch("window_attention_bwd");
+            };
+            if (!pf) return go(win_attn_bwd_mfma_kernel<false, 1>, 0);
+            const int it = (int)rdo::ceil_div((long)g.N * (g.hd >> 2), 256);
+            if (it <= 1) return go(win_attn_bwd_mfma_kernel<true, 1>, 1);
+            if (it == 2) return go(win_attn_bwd_mfma_kernel<true, 2>, 2);
+            if (it == 3) return go(win_attn_bwd_mfma_kernel<true, 3>, 3);
+            return go(win_attn_bwd_mfma_kernel<true, 4>, 4);
         },
         stream, "window_attention_bwd", 10.0 * windows * g.heads * (double)g.N * g.N * g.hd,
         4.0 * ((double)g.B * g.H * g.W * g.C * 8));

@@ -158,6 +158,76 @@ class FactorizedLikelihoodFn(torch.autograd.Function):
         return g_zhat + _nchw(dz * f), None, None
 
 
+class LinearFn(torch.autograd.Function):
+    """y = x W^T + b over the last dimension (F.linear of the Swin blocks, quant_layer.py:119); `pack` = ops.WeightPack of W as a 1x1
+    conv weight [Cout, 1, 1, Cin] with the bias.  Forward and input gradient on the conv kernels (split precision where they apply)."""
+
+    @staticmethod
+    def forward(ctx, x, pack):
+        cin, cout = x.shape[-1], pack.w.shape[0]
+        x4 = x.reshape(1, 1, -1, cin).contiguous()
+        y = ops.conv2d_fwd_pack(x4, pack, 1, 0)
+        ctx.pack, ctx.xshape = pack, tuple(x.shape)
+        return y.reshape(*x.shape[:-1], cout)
+
+    @staticmethod
+    def backward(ctx, g):
+        cout = ctx.pack.w.shape[0]
+        g4 = g.reshape(1, 1, -1, cout).contiguous()
+        dx = ops.conv2d_fwd_pack(g4, ctx.pack.flipped(), 1, 0)            # [Cin][1][1][Cout]
+        return dx.reshape(ctx.xshape), None
+
+
+class LayerNormFn(torch.autograd.Function):
+    """F.layer_norm over the last dimension with constant weight / bias (quant_layer.py:44-49,121): rdo_layer_norm / rdo_layer_norm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc, weight)
+        ctx.eps = eps
+        return ops.layer_norm(xc, weight, bias, eps)
+
+    @staticmethod
+    def backward(ctx, g):
+        xc, weight = ctx.saved_tensors
+        dx = torch.empty_like(xc)
+        ops.layer_norm_bwd(xc, weight, g.contiguous(), ctx.eps, dx=dx)
+        return dx, None, None, None
+
+
+class WindowAttentionFn(torch.autograd.Function):
+    """The (shifted-)window attention core on qkv [B, H, W, 3C] in natural pixel order (models/layers.py:138-170 with the roll / window
+    partition / mask of :271-294 folded in): rdo_window_attention_fwd / _bwd (probabilities recomputed in the backward)."""
+
+    @staticmethod
+    def forward(ctx, qkv, desc, bias):
+        qc = qkv.contiguous()
+        ctx.desc = desc
+        ctx.save_for_backward(qc, bias)
+        return ops.window_attention(desc, qc, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        qc, bias = ctx.saved_tensors
+        return ops.window_attention_bwd(ctx.desc, qc, bias, g.contiguous()).reshape(qc.shape), None, None
+
+
+class GeluFn(torch.autograd.Function):
+    """nn.GELU() (exact erf form): rdo_gelu_fwd / rdo_gelu_bwd."""
+
+    @staticmethod
+    def forward(ctx, x):
+        xc = x.contiguous()
+        ctx.save_for_backward(xc)
+        return ops.gelu(xc)
+
+    @staticmethod
+    def backward(ctx, g):
+        (xc,) = ctx.saved_tensors
+        return ops.gelu_bwd(g.contiguous(), xc)
+
+
 def round_ste(x):
     return x + (torch.round(x) - x).detach()
 

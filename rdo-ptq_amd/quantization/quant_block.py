@@ -134,6 +134,18 @@ class QuantSC(BaseQuantBlock):
 
 
 # ----------------------------------------------------------------------------- Lu2022: Swin transformer wrappers
+def _tracked(t):
+    """torch's tape wants a gradient with respect to this tensor (the R + lambda*D task loss runs the modules BEHIND a unit under
+    autograd: hipops.autograd Functions instead of the bare kernels)"""
+    return torch.is_grad_enabled() and t.requires_grad
+
+
+def _GeluFn():
+    from hipops.autograd import GeluFn
+    return GeluFn
+
+
+
 class PatchEmbed(nn.Module):
     def forward(self, x):
         return x.flatten(2).transpose(1, 2)
@@ -155,8 +167,10 @@ class QuantMlp(BaseQuantBlock):
 
     def forward(self, x):
         x = self.fc1(x)
-        x = ops.gelu(x.contiguous()) if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none" \
-            else self.act(x)
+        if isinstance(self.act, nn.GELU) and getattr(self.act, "approximate", "none") == "none":
+            x = _GeluFn().apply(x) if _tracked(x) else ops.gelu(x.contiguous())
+        else:
+            x = self.act(x)
         return self.fc2(self._aq(x))
 
 
@@ -195,6 +209,9 @@ class QuantWindowAttention(BaseQuantBlock):
             nb = self.act_quantizer.dynamic_bits
             probs = ops.actquant_perchannel(probs, n_bits=nb)            # per head, as ActQuantizer on [B_, heads, N, N]
             o = ActQuantizer(ops.window_attention_pv(d, qkv, probs).view(B, H * W, C), nb)
+        elif _tracked(qkv):
+            from hipops.autograd import WindowAttentionFn
+            o = WindowAttentionFn.apply(qkv.view(B, H, W, 3 * C), d, bias).view(B, H * W, C)
         else:
             o = ops.window_attention(d, qkv, bias).view(B, H * W, C)
         return self.proj(o)
@@ -233,6 +250,10 @@ class QuantSwinTransformerBlock(BaseQuantBlock):
         B, L, C = x.shape
         x = x.contiguous()
         a = self.attn.attend(self.norm1(x), B, H, W, self.window_size, self.shift_size)
+        if _tracked(x) or _tracked(a):                 # torch's tape is driving (the R + lambda*D tail of the calibration loop): its own adds
+            x = x + a
+            x = x + self.mlp(self.norm2(x))
+            return self._aq(x)
         x = ops.add(x, a.contiguous())
         x = ops.add(x, self.mlp(self.norm2(x)).contiguous())
         return self._aq(x)
@@ -275,6 +296,8 @@ class QuantRSTB(BaseQuantBlock):
         xn = _nhwc(x)                                            # [B, H, W, C]: the token matrix, no copy for channels_last
         B, _, _, C = xn.shape
         t = self.residual_group(xn.view(B, H * W, C), (H, W))
+        if _tracked(t) or _tracked(xn):
+            return self._aq(_nchw_view(t.reshape(B, H, W, C) + xn))
         out = _nchw_view(ops.add(t.contiguous().view(B, H, W, C), xn))
         return self._aq(out)
 

@@ -212,10 +212,23 @@ class QuantModule(nn.Module):
         epi = self.fused_epilogue() if self.se_module is None else None
         fuse = epi is not None
         epi = L.EPI_NONE if epi is None else epi
-        if self.kind not in ("conv", "tconv", "gdn"):
-            raise NotImplementedError(f"QuantModule({self.kind}): no autograd forward (conv / transposed conv / GDN / pixel shuffle only)")
+        if self.kind == "layernorm":
+            weight, bias = self._weights()
+            ns = tuple(self.fwd_kwargs["normalized_shape"])
+            if len(ns) != 1 or ns[0] != input.shape[-1]:
+                raise NotImplementedError("LayerNorm over more than the last dimension is not on the supported path")
+            out = A.LayerNormFn.apply(input, None if weight is None else weight.detach().contiguous(),
+                                      None if bias is None else bias.detach().contiguous(), float(self.fwd_kwargs.get("eps", 1e-5)))
+            out = self.activation_function(out)
+            if not self.disable_act_quant and self.use_act_quant and self.trained:
+                out = self.act_quantizer(out, True)
+            return out
+        if self.kind not in ("conv", "tconv", "gdn", "linear"):
+            raise NotImplementedError(f"QuantModule({self.kind}): no autograd forward")
         pack = self.weight_pack()
-        if self.kind == "conv":
+        if self.kind == "linear":
+            out = A.LinearFn.apply(input, pack)
+        elif self.kind == "conv":
             stride, pad = self.conv_geometry()
             out = A.Conv2dFn.apply(input, pack, pack.bias, stride, pad, epi)
         elif self.kind == "tconv":

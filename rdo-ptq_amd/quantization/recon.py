@@ -177,7 +177,8 @@ def _reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, 
     tail_round = "g_a" in unit_name
     task_cache = None
     model.set_quant_state(False, False)
-    if module_list or tail_round:
+    rd_mode = getattr(args, "loss_mode", "lp") == "rd"
+    if (module_list or tail_round) and not rd_mode:          # (the R + lambda*D task term does not use the lp target)
         task_cache = _nhwc(fp_out(module_list, out_fp, tail_round))
     set_mode(model, act_quant)
     if not is_block and ("g_s7" in unit_name or "7" in unit_name):
@@ -200,10 +201,14 @@ def _reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, 
                   lr=1e-3, seed=unit_seed(unit_name), include_act_func=include_act_func, batch_offset=rank * batch_size,
                   task_p=float(task_p))
     if rd is not None:
-        if kind == "rstb" or task_cache is not None:
-            raise NotImplementedError("loss_mode='rd' is built for the Sequential-indexed coders (Cheng2020 / Minnen2018)")
+        # The rate-distortion task term replaces the lp term through the rest of the sub-coder: the whole wrapped model behind the unit
+        # runs under torch's tape (hipops.autograd; Swin blocks included), so the Lu2022 units need no recorded FP tail here
         common["rd"] = rd
-    if kind == "rstb" or task_cache is not None:
+        if kind == "rstb":
+            eng = TapeEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), **common)
+        else:
+            eng = UnitEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), **common)
+    elif kind == "rstb" or task_cache is not None:
         eng = TapeEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), tail=module_list, tail_round=tail_round,
                          task_cache=task_cache, **common)
     else:

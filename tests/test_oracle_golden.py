@@ -358,3 +358,23 @@ def test_nic_quantised_forward_stagewise(golden_dir, tag):
                 h = T(ref)                                   # continue from the reference's tensor: no error build-up
             if coder == "g_a":
                 h = T(fx[f"{tag}/y_hat"])
+
+
+def test_nic_whole_model_oracle_matches_reference_forward(golden_dir):
+    """`swin_oracle.NicModelOracle` (the whole NIC forward with the entropy models: the checker of the R + lambda*D task loss on the Lu2022
+    coders) against models/nic_cvt.py:NIC.forward of the reference on the golden weights: x_hat and both likelihood tensors."""
+    from oracle import swin_oracle as S
+    fx = np.load(os.path.join(golden_dir, "recon_nic.npz"))
+    state = {k[len("state/"):]: T(fx[k]) for k in fx.files if k.startswith("state/")}
+    mo = S.NicModelOracle(state, NIC_CFG, masked_context=True)           # the full-precision model applies the context mask
+    x = T(fx["cali"])[:fx["fp/x_hat"].shape[0]]
+    with torch.no_grad():
+        o = mo.forward(x)
+    np.testing.assert_allclose(o["x_hat"].numpy(), fx["fp/x_hat"], rtol=1e-4, atol=1e-4)
+    np.testing.assert_allclose(o["likelihoods"]["y"].numpy(), fx["fp/lik_y"], rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(o["likelihoods"]["z"].numpy(), fx["fp/lik_z"], rtol=1e-4, atol=1e-6)
+    # substitution leaves everything in front of the stage alone and replaces its output
+    with torch.no_grad():
+        y1 = mo.nic.run(["g_a0", "g_a1"], x)
+        o2 = mo.forward(x, substitute=("g_a1", y1))
+    np.testing.assert_allclose(o2["x_hat"].numpy(), o["x_hat"].numpy(), rtol=0, atol=0)

@@ -29,7 +29,7 @@ cali = torch.rand(n_img, 3, 256, 256, device="cuda")
 qnn.set_quant_state(True, False)
 with torch.no_grad():
     qnn(cali[:B])
-args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Lu2022")
+args = types.SimpleNamespace(lmbda=0.0483, task_loss=2.0, arch="Lu2022", loss_mode=os.environ.get("LU_LOSS_MODE", "lp"))   # LU_LOSS_MODE=rd: R + lambda*D task term
 for name in units:
     unit = getattr(qnn.model, name)
     fn = layer_reconstruction if isinstance(unit, QuantModule) else block_reconstruction

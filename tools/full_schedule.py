@@ -145,7 +145,9 @@ if __name__ == "__main__":
     ap.add_argument("--json", default=None)
     ap.add_argument("--arch", default="anchor", choices=["anchor", "attn", "lu2022"])
     ap.add_argument("--no-quality", action="store_true")
+    ap.add_argument("--w-bits", type=int, default=8)
+    ap.add_argument("--a-bits", type=int, default=8)
     a = ap.parse_args()
-    r = run_schedule(a.images, a.iters, a.batch, arch=a.arch, quality=not a.no_quality)
+    r = run_schedule(a.images, a.iters, a.batch, arch=a.arch, quality=not a.no_quality, w_bits=a.w_bits, a_bits=a.a_bits)
     if a.json:
         json.dump(r, open(a.json, "w"), indent=1)
