@@ -645,7 +645,7 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs
             for key, fn in (("config3_attn_w10", bench_configs.attn_w10), ("config4_lu2022_g_a1", bench_configs.lu2022_unit),
-                            ("config5_mbt2018_w8a8_eval", bench_configs.mbt2018_eval)):
+                            ("config4_lu2022_schedule", bench_configs.lu2022_schedule), ("config5_mbt2018_w8a8_eval", bench_configs.mbt2018_eval)):
                 try:
                     torch.cuda.empty_cache()
                     extra[key] = fn(log=log)

@@ -78,6 +78,20 @@ def lu2022_unit(name="g_a1", log=print):
             "images_per_s": round(B / ms * 1e3, 1)}
 
 
+def lu2022_schedule(images=8, iters=30, batch=4, log=print):
+    """BASELINE config 4 as a SCHEDULE (missing 2): all 28 reconstruction units of the full-size Lu2022 model (g_a0..g_s7,
+    the context conv and the three entropy-parameter convs: main2.py:227-253 on models/nic_cvt.py) through the public API for a few
+    iterations each; ms per step (one iteration of every unit) from the loop share of the wall, the slowest units by name."""
+    from full_schedule import run_schedule
+    r = run_schedule(images=images, iters=iters, batch=batch, log=log, quality=False, arch="lu2022", per_unit_log=False)
+    slow = sorted(r["units"], key=lambda u: -u["loop_ms_per_iter"])[:6]
+    return {"workload": f"Lu2022 (embed 192, latent 320), {r['n_units']} units, {images} images 256x256, batch {batch}, {iters} iterations per unit "
+                        "(graph capture inside the loop time)",
+            "units": r["n_units"], "ms_per_step": round(r["loop_s"] / iters * 1e3, 3),
+            "images_per_s": round(r["n_units"] * batch * iters / r["loop_s"], 1), "wall_s": round(r["recon_model_wall_s"], 2),
+            "slowest_units_ms_per_iteration": {u["unit"]: u["loop_ms_per_iter"] for u in slow}}
+
+
 def mbt2018_eval(hw=(512, 768), n=6, log=print):
     """BASELINE config 5 on one GPU: W8A8 evaluation (pad, forward through the wrapped model incl. the masked context conv and the
     entropy models, crop, PSNR / bpp) of Minnen2018 with the autoregressive context model at full width on Kodak-sized images."""
@@ -109,7 +123,7 @@ def mbt2018_eval(hw=(512, 768), n=6, log=print):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attn", "lu2022", "mbt2018"]
-    fns = {"attn": attn_w10, "lu2022": lu2022_unit, "mbt2018": mbt2018_eval}
+    which = sys.argv[1:] or ["attn", "lu2022", "lu2022_schedule", "mbt2018"]
+    fns = {"attn": attn_w10, "lu2022": lu2022_unit, "lu2022_schedule": lu2022_schedule, "mbt2018": mbt2018_eval}
     for w in which:
         print(w, fns[w]())
