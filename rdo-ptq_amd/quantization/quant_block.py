@@ -134,12 +134,6 @@ class QuantSC(BaseQuantBlock):
 
 
 # ----------------------------------------------------------------------------- Lu2022: Swin transformer wrappers
-def _tracked(t):
-    """torch's tape wants a gradient with respect to this tensor (the R + lambda*D task loss runs the modules BEHIND a unit under
-    autograd: hipops.autograd Functions instead of the bare kernels)"""
-    return torch.is_grad_enabled() and t.requires_grad
-
-
 def _GeluFn():
     from hipops.autograd import GeluFn
     return GeluFn
@@ -250,7 +244,7 @@ class QuantSwinTransformerBlock(BaseQuantBlock):
         B, L, C = x.shape
         x = x.contiguous()
         a = self.attn.attend(self.norm1(x), B, H, W, self.window_size, self.shift_size)
-        if _tracked(x) or _tracked(a):                 # torch's tape is driving (the R + lambda*D tail of the calibration loop): its own adds
+        if _tracked(x, a):                             # torch's tape is driving (the R + lambda*D tail of the calibration loop): its own adds
             x = x + a
             x = x + self.mlp(self.norm2(x))
             return self._aq(x)
@@ -296,7 +290,7 @@ class QuantRSTB(BaseQuantBlock):
         xn = _nhwc(x)                                            # [B, H, W, C]: the token matrix, no copy for channels_last
         B, _, _, C = xn.shape
         t = self.residual_group(xn.view(B, H * W, C), (H, W))
-        if _tracked(t) or _tracked(xn):
+        if _tracked(t, xn):
             return self._aq(_nchw_view(t.reshape(B, H, W, C) + xn))
         out = _nchw_view(ops.add(t.contiguous().view(B, H, W, C), xn))
         return self._aq(out)
