@@ -298,8 +298,8 @@ int rdo_add3(const float* a, const float* b, const float* c, int64_t n, float* o
  * (2 * N * K halfs, fragment order).  rdo_linear_h2_supported: M % 64 == 0, K % 192 == 0, N % 192 == 0. */
 int rdo_linear_h2_supported(int64_t M, int32_t K, int32_t N);
 int rdo_split_h2_linear(const float* w, int32_t N, int32_t K, float scale, void* planes, void* stream);
-int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias, float* out,
-                  void* stream);
+int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias,
+                  int32_t square_input /* x enters squared: the GDN norm pool beta' + gamma' . x^2, quant_layer.py:147 */, float* out, void* stream);
 int rdo_gelu_fwd(const float* x, int64_t n, float* out, void* stream);                      /* nn.GELU(): exact erf form */
 int rdo_gelu_bwd(const float* dy, const float* x, int64_t n, float* dx, void* stream);
 int rdo_round(const float* x, int64_t n, float* out, void* stream);                         /* torch.round (half to even): round_ste forward */

@@ -15,8 +15,8 @@
 // token of tiny gradients keeps full relative precision.  The accumulator of a token is rescaled by the (exact, power-of-two) ratio
 // of two K blocks' scales when K spans several blocks.
 //
-// Structure: one workgroup = 64 tokens x all N output channels, 4 waves; wave w owns output channels [48 w, 48 w + 48) of each
-// 192-channel chunk and all 64 tokens (3 x 4 accumulator tiles of 16 x 16).  A = weights (rows = output channels), B = activations
+// Structure: one workgroup = 64 tokens x one 192-channel chunk of the outputs, 4 waves; wave w owns output channels [48 w, 48 w + 48) of
+// the chunk and all 64 tokens (3 x 4 accumulator tiles of 16 x 16).  A = weights (rows = output channels), B = activations
 // (columns = tokens): a lane's four accumulator values are four consecutive channels of one token -> 16-byte stores straight from the
 // accumulators, one scale per lane and tile.  The activation panel is STATIONARY in LDS ([plane][16-channel slice][token][32 B]:
 // every ds_read_b128 fragment read is 2 x 512 contiguous bytes, conflict-free); weight fragments never touch LDS: the planes are
@@ -46,6 +46,7 @@ struct LinArgs {
     float* out;            // [M][N]
     int M, K, N;
     float inv_wscale;      // 1 / wscale
+    int square;            // the input enters squared (GDN norm pool: beta' + gamma' . x^2, quant_layer.py:147)
 };
 
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
@@ -80,6 +81,12 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
             const f32x4* src = reinterpret_cast<const f32x4*>(a.x + (m0 + pass * 16 + row_in_pass) * a.K + (long)kb * KB);
 #pragma unroll
             for (int k = 0; k < 3; ++k) v[pass][k] = src[l16 + 16 * k];
+        }
+        if (a.square) {
+#pragma unroll
+            for (int pass = 0; pass < BM / 16; ++pass)
+#pragma unroll
+                for (int k = 0; k < 3; ++k) v[pass][k] *= v[pass][k];
         }
 #pragma unroll
         for (int pass = 0; pass < BM / 16; ++pass) {
@@ -243,8 +250,8 @@ extern "C" int rdo_split_h2_linear(const float* w, int32_t N, int32_t K, float s
         stream, "split_h2_linear", 0.0, 8.0 * (double)N * K);
 }
 
-extern "C" int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias, float* out,
-                             void* stream) {
+extern "C" int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias,
+                             int32_t square_input, float* out, void* stream) {
     RDO_REQUIRE(x && wplanes && out, "rdo_linear_h2: null argument");
     RDO_REQUIRE(rdo_linear_h2_supported(M, K, N), "rdo_linear_h2: shape %ld x %d -> %d is not supported (M %% 64, K %% 192, N %% 192)", (long)M, K, N);
     RDO_REQUIRE(pow2(wscale), "rdo_linear_h2: weight scale %g is not a power of two", (double)wscale);
@@ -252,7 +259,7 @@ extern "C" int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, co
                   reinterpret_cast<uintptr_t>(out)) & 15) == 0, "rdo_linear_h2: pointers must be 16-byte aligned");
     LinArgs a;
     a.x = x; a.wp = reinterpret_cast<const unsigned short*>(wplanes); a.bias = bias; a.out = out;
-    a.M = (int)M; a.K = K; a.N = N; a.inv_wscale = 1.0f / wscale;
+    a.M = (int)M; a.K = K; a.N = N; a.inv_wscale = 1.0f / wscale; a.square = square_input ? 1 : 0;
     const double flops = 2.0 * (double)M * K * N;
     return rdo::dispatch(
         [a](hipStream_t s) {

@@ -540,14 +540,16 @@ def split_h2_linear(w, scale=None, planes=None):
     return planes
 
 
-def linear_h2(x, planes, bias=None, out=None):
-    """out [rows, N] = x [rows, K] W^T + bias on the per-token-scaled fp16-split kernel; `planes` from split_h2_linear."""
+def linear_h2(x, planes, bias=None, out=None, square_input=False):
+    """out [rows, N] = x [rows, K] W^T + bias (x^2 instead of x with `square_input`: the GDN norm pool) on the per-token-scaled
+    fp16-split kernel; `planes` from split_h2_linear."""
     K = x.shape[-1]
     rows = x.numel() // K
     N = planes.t.shape[2] * 16
     if out is None:
         out = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=torch.float32)
-    L.check(L.lib().rdo_linear_h2(_ptr(x), rows, K, N, _ptr(planes), float(planes.scale), _ptr(bias), _ptr(out), _stream()), "rdo_linear_h2")
+    L.check(L.lib().rdo_linear_h2(_ptr(x), rows, K, N, _ptr(planes), float(planes.scale), _ptr(bias), int(bool(square_input)), _ptr(out), _stream()),
+            "rdo_linear_h2")
     return out
 
 

@@ -174,8 +174,8 @@ class _Op:
     def lin_planes(self, fwd: bool):
         """Planes of this Linear's soft weight (fwd) / of its transpose (input gradient) for rdo_linear_h2: allocated on first use -- while
         the plan is being recorded --, filled by `refresh_planes` (eagerly after the recording, then inside the plan behind every step)."""
-        if self.qm.kind != "linear":
-            raise RuntimeError("lin_planes: not a Linear")
+        if self.qm.kind not in ("linear", "gdn"):
+            raise RuntimeError("lin_planes: a Linear or the 1x1 pool of a GDN")
         co, _, _, ci = self.w4
         if fwd:
             if self.lin_fwd is None:
@@ -460,6 +460,33 @@ class UnitEngine:
         return ops.conv2d_fwd(dy, op.wd4(), None, 1, op.K - 1 - op.pad, epilogue=epilogue, aux=aux, out=out,
                               wplanes=op.wd_planes)
 
+    # ---- the two 1x1 GEMMs of a GDN / IGDN (norm pool beta' + gamma' . x^2 and, backward, t . gamma'): token-matrix Linears over the
+    # channels.  From LIN_GDN_MIN_ROWS pixels on they run on rdo_linear_h2 (per-pixel dynamic scale, three fp16 products) instead of the
+    # conv kernels (split-bf16 six products at 128^2, fp32 MFMA tiles below).  RDO_GDN_LIN_H2=0 switches it off.
+    LIN_GDN_MIN_ROWS = int(os.environ.get("RDO_GDN_LIN_MIN_ROWS", 4096))
+    lin_gdn = os.environ.get("RDO_GDN_LIN_H2", "1") != "0"
+
+    def _gdn_lin_ok(self, g, x):
+        C = x.shape[-1]
+        rows = x.numel() // C
+        return (self.lin_gdn and not self._probing and rows >= self.LIN_GDN_MIN_ROWS and g.w4[0] == C and ops.linear_h2_supported(rows, C, C))
+
+    def _gdn_pool(self, g, x, norm):
+        """norm = beta' + gamma' . x^2"""
+        if self._gdn_lin_ok(g, x):
+            C = x.shape[-1]
+            return ops.linear_h2(x.view(-1, C), g.lin_planes(True), g.beta, out=norm.view(-1, C), square_input=True)
+        return self._conv(g, x, norm, square=True)
+
+    def _gdn_acc(self, g, tbuf, acc):
+        """acc = t . gamma'   (wd = gamma'^T as [C][1][1][C])"""
+        if self._gdn_lin_ok(g, tbuf):
+            C = tbuf.shape[-1]
+            return ops.linear_h2(tbuf.view(-1, C), g.lin_planes(False), None, out=acc.view(-1, C))
+        if ops.uses_bf16x6(tuple(tbuf.shape), tuple(g.wd4().shape), 1, 0):
+            g.enable_planes(False, True)
+        return ops.conv2d_fwd(tbuf, g.wd4(), None, 1, 0, out=acc, wplanes=g.wd_planes)
+
     def _tconv_forward(self, op, x, y, epilogue=L.EPI_NONE):
         """y [B, sH, sW, Cout] <- (activation of) the transposed conv of x with the soft weights: stride-1 conv with the phase weight,
         then the pixel shuffle (LeakyReLU / ReLU commute with it)."""
@@ -670,7 +697,8 @@ class UnitEngine:
             cname, dname = "c2", "dc2"
             x_h2 = x.shape[-1] % 16 == 0 and self._conv_ok_h2(c1, xs) and ops.wgrad_h2_supported(xs, c1.w4, c1.stride, c1.pad)
         hs = tuple(t["h1"].shape)
-        g_h2 = self._conv_ok_h2(g, hs, dgrad=True)
+        # gamma'^T GEMM: on rdo_linear_h2 over the fp32 t where that applies (then t is not written as planes at all), else on the plane kernel
+        g_h2 = self._conv_ok_h2(g, hs, dgrad=True) and not self._gdn_lin_ok(g, t["h1"])
         h1p, dcp = self._h2("h1", t["h1"]), self._h2(dname, t["h1"])
         tp = self._h2("t", t["h1"]) if g_h2 else None
         xp = self._h2("x", x) if x_h2 else None
@@ -703,7 +731,7 @@ class UnitEngine:
                 self._conv(o["skip"], x, t["sk"])
                 res = t["sk"]
         self._conv_h2(cv, h1p, hs, out=t[cname])
-        self._conv(g, t[cname], t["norm"], square=True)
+        self._gdn_pool(g, t[cname], t["norm"])
         self._task_is_rec = True
         ops.loss_gdn_bwd(t[cname], t["norm"], res, self.co, self.idx, self.it, 2.0, rbu, self.loss_log, t["dout"], t=t["t"], t_planes=tp)
         if rbu:
@@ -718,10 +746,8 @@ class UnitEngine:
             self._wgrad(o["skip"], x, t["dout"])
         if g_h2:
             self._gdn_backward_h2(g, t["dout"], t[cname], t["norm"], tp, t["acc"], dcp)
-        else:                                             # gamma'^T GEMM on the fp32 t (small shapes), dx still as planes only
-            if ops.uses_bf16x6(hs, tuple(g.wd4().shape), 1, 0):
-                g.enable_planes(False, True)
-            ops.conv2d_fwd(t["t"], g.wd4(), None, 1, 0, out=t["acc"], wplanes=g.wd_planes)
+        else:                                             # gamma'^T GEMM on the fp32 t, dx still as planes only
+            self._gdn_acc(g, t["t"], t["acc"])
             ops.gdn_bwd_dx_h2(t["dout"], t[cname], t["norm"], t["acc"], g.inverse, dx_planes=dcp)
         self._wgrad(g, t[cname], t["t"], square=True)
         self._wgrad_h2(cv, h1p, hs, dcp)
@@ -912,7 +938,7 @@ class UnitEngine:
             # a GDN / IGDN that is its own unit (sequential Minnen2018-style coders): only gamma is trained, no dx needed
             op = o["layer"]
             if self.fused:
-                self._conv(op, x, t["norm"], square=True)                                        # norm pool only
+                self._gdn_pool(op, x, t["norm"])                                                 # norm pool only
                 self._tail_gdn(x, t["norm"], None, op.inverse, t["dy"], t["t"])
             else:
                 self._conv(op, x, t["y"], epilogue=L.EPI_IGDN if op.inverse else L.EPI_GDN, aux=x, pre=t["norm"], square=True)
@@ -998,7 +1024,7 @@ class UnitEngine:
                 self._conv(o["skip"], x, t["sk"])
                 res = t["sk"]
             if self.fused:
-                self._conv(g, t["c2"], t["norm"], square=True)
+                self._gdn_pool(g, t["c2"], t["norm"])
                 self._tail_gdn(t["c2"], t["norm"], res, False, t["dout"], t["t"])
             else:
                 self._conv(g, t["c2"], t["out"], epilogue=L.EPI_GDN, aux=t["c2"], residual=res, pre=t["norm"], square=True)
@@ -1019,7 +1045,7 @@ class UnitEngine:
             self._conv(up, x, t["up"])
             self._shuffle(t["up"], r, t["ups"])
             if self.fused:
-                self._conv(g, t["c"], t["norm"], square=True)
+                self._gdn_pool(g, t["c"], t["norm"])
                 self._tail_gdn(t["c"], t["norm"], t["ups"], True, t["dout"], t["t"])
             else:
                 self._conv(g, t["c"], t["out"], epilogue=L.EPI_IGDN, aux=t["c"], residual=t["ups"], pre=t["norm"], square=True)
@@ -1036,9 +1062,7 @@ class UnitEngine:
     def _gdn_backward(self, g, dout, xin, norm, tbuf, acc, dx, inverse):
         if not self.fused:                                           # the fused tail has already written t
             ops.gdn_bwd_t(dout, xin, norm, inverse, tbuf)
-        if ops.uses_bf16x6(tuple(tbuf.shape), tuple(g.wd4().shape), 1, 0):
-            g.enable_planes(False, True)
-        ops.conv2d_fwd(tbuf, g.wd4(), None, 1, 0, out=acc, wplanes=g.wd_planes)   # t . gamma'  (wd = gamma'^T as [C][1][1][C])
+        self._gdn_acc(g, tbuf, acc)                                   # t . gamma'
         if xin.numel() % 4 == 0:
             ops.gdn_bwd_dx_h2(dout, xin, norm, acc, inverse, dx=dx)   # 16-byte accesses
         else:

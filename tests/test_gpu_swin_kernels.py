@@ -207,6 +207,11 @@ def test_linear_h2_per_token_scale_matches_float64(rows, K, N, kind):
     y0 = ops.linear_h2(x.cuda(), planes, None).cpu().double()                  # the form the input gradients take: no bias
     assert float(((y0 - want).abs()[live] / tok[live]).max()) < 2e-6
     assert float(y0[~live].abs().max() if (~live).any() else 0.0) == 0.0       # a token of zeros gives exact zeros
+    if kind == "act":                                                         # the GDN norm pool: beta' + gamma' . x^2 (squared input, positive weights)
+        wp, bp = w.abs(), b.abs() + 0.1
+        ysq = ops.linear_h2(x.cuda(), ops.split_h2_linear(wp.cuda()), bp.cuda(), square_input=True).cpu().double()
+        ref = (x.double() ** 2) @ wp.double().t() + bp.double()
+        assert float(((ysq - ref).abs() / ref.abs().amax(1, keepdim=True)).max()) < 2e-6
     if kind != "grad":                                                        # (a bias next to 1e-8 outputs would measure fp32's own rounding)
         y = ops.linear_h2(x.cuda(), planes, b.cuda()).cpu().double()
         ref = want + b.double()
