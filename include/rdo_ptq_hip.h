@@ -300,6 +300,10 @@ int rdo_linear_h2_supported(int64_t M, int32_t K, int32_t N);
 int rdo_split_h2_linear(const float* w, int32_t N, int32_t K, float scale, void* planes, void* stream);
 int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias,
                   int32_t square_input /* x enters squared: the GDN norm pool beta' + gamma' . x^2, quant_layer.py:147 */, float* out, void* stream);
+/* ... with an epilogue: RDO_EPI_GELU (out = gelu(y), `pre` = y: Mlp.fc1 + nn.GELU(), models/layers.py:44-47) or RDO_EPI_GELU_BWD
+ * (out = y * gelu'(aux): the input gradient of fc2 taken through that GELU, aux = fc1's `pre`). */
+int rdo_linear_h2_epi(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias,
+                      int32_t square_input, int32_t epilogue, float* pre, const float* aux, float* out, void* stream);
 int rdo_gelu_fwd(const float* x, int64_t n, float* out, void* stream);                      /* nn.GELU(): exact erf form */
 int rdo_gelu_bwd(const float* dy, const float* x, int64_t n, float* dx, void* stream);
 int rdo_round(const float* x, int64_t n, float* out, void* stream);                         /* torch.round (half to even): round_ste forward */

@@ -81,6 +81,7 @@ _SIGS = {
     "rdo_linear_h2_supported": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
     "rdo_split_h2_linear": (C.c_int, [P, C.c_int32, C.c_int32, C.c_float, P, P]),
     "rdo_linear_h2": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, C.c_float, P, C.c_int32, P, P]),
+    "rdo_linear_h2_epi": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, C.c_float, P, C.c_int32, C.c_int32, P, P, P, P]),
     "rdo_gelu_fwd": (C.c_int, [P, C.c_int64, P, P]),
     "rdo_gelu_bwd": (C.c_int, [P, P, C.c_int64, P, P]),
     "rdo_round": (C.c_int, [P, C.c_int64, P, P]),

@@ -540,16 +540,21 @@ def split_h2_linear(w, scale=None, planes=None):
     return planes
 
 
-def linear_h2(x, planes, bias=None, out=None, square_input=False):
+def linear_h2(x, planes, bias=None, out=None, square_input=False, epilogue=L.EPI_NONE, pre=None, aux=None):
     """out [rows, N] = x [rows, K] W^T + bias (x^2 instead of x with `square_input`: the GDN norm pool) on the per-token-scaled
-    fp16-split kernel; `planes` from split_h2_linear."""
+    fp16-split kernel; `planes` from split_h2_linear.  epilogue: EPI_GELU (out = gelu(y), `pre` receives y) or EPI_GELU_BWD
+    (out = y * gelu'(aux))."""
     K = x.shape[-1]
     rows = x.numel() // K
     N = planes.t.shape[2] * 16
     if out is None:
         out = torch.empty(tuple(x.shape[:-1]) + (N,), device=x.device, dtype=torch.float32)
-    L.check(L.lib().rdo_linear_h2(_ptr(x), rows, K, N, _ptr(planes), float(planes.scale), _ptr(bias), int(bool(square_input)), _ptr(out), _stream()),
-            "rdo_linear_h2")
+    if epilogue == L.EPI_NONE:
+        L.check(L.lib().rdo_linear_h2(_ptr(x), rows, K, N, _ptr(planes), float(planes.scale), _ptr(bias), int(bool(square_input)), _ptr(out), _stream()),
+                "rdo_linear_h2")
+    else:
+        L.check(L.lib().rdo_linear_h2_epi(_ptr(x), rows, K, N, _ptr(planes), float(planes.scale), _ptr(bias), int(bool(square_input)), int(epilogue),
+                                          _ptr(pre), _ptr(aux), _ptr(out), _stream()), "rdo_linear_h2_epi")
     return out
 
 

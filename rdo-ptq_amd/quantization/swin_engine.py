@@ -196,6 +196,7 @@ class TapeEngine(UnitEngine):
     fuse_ln = os.environ.get("RDO_SWIN_FUSE_LN", "1") != "0"
     # RDO_SWIN_LIN_H2=0: the Linears of the large token matrices back on the split-bf16 1x1-conv kernel (six products, csrc/conv_fwd_x6.hip)
     lin_h2 = os.environ.get("RDO_SWIN_LIN_H2", "1") != "0"
+    lin_gelu = os.environ.get("RDO_SWIN_LIN_GELU", "1") != "0"      # GELU / its derivative in rdo_linear_h2's epilogue (0: separate kernels)
     fuse_ln_fwd = os.environ.get("RDO_SWIN_FUSE_LN_FWD", "1") != "0"
 
     def _gput(self, t, buf):
@@ -232,11 +233,15 @@ class TapeEngine(UnitEngine):
         fuse_here = lambda xs, w4, has_planes: self.fuse_gelu == 2 or (
             self.fuse_gelu == 1 and ops.conv_fwd_ksplit(tuple(xs), tuple(w4), 1, 0, has_planes, self.dev)[0] >= 2)
         if lin_f:
-            if gelu:
+            if gelu and self.lin_gelu:                         # Mlp.fc1 + GELU in the kernel's epilogue (the pre-activation is kept for the backward)
                 pre = self._buf(*y.shape)
-            ops.linear_h2(x, p.lin_planes(True), bias_of(), out=pre if gelu else y)
-            if gelu:
+                ops.linear_h2(x, p.lin_planes(True), bias_of(), out=y, epilogue=L.EPI_GELU, pre=pre)
+            elif gelu:
+                pre = self._buf(*y.shape)
+                ops.linear_h2(x, p.lin_planes(True), bias_of(), out=pre)
                 ops.gelu(pre, out=y)
+            else:
+                ops.linear_h2(x, p.lin_planes(True), bias_of(), out=y)
         elif gelu and fuse_here(x4.shape, p.w4, ops.uses_bf16x6(tuple(x4.shape), p.w4, 1, 0)):
             pre = self._buf(*y.shape)
             self._conv(p, x4, y4, epilogue=L.EPI_GELU, pre=pre.view(1, 1, rows, cout))
@@ -253,7 +258,9 @@ class TapeEngine(UnitEngine):
                 self._wgrad(p, x4, dy4)
             if need_dx and lin_b:
                 dy = dy4.view(rows, cout)
-                if gelu_in is not None:
+                if gelu_in is not None and self.lin_gelu:      # fc2's input gradient times gelu'(fc1's pre-activation), in the epilogue
+                    ops.linear_h2(dy, p.lin_planes(False), None, out=self._gnew(gelu_in), epilogue=L.EPI_GELU_BWD, aux=gelu_in)
+                elif gelu_in is not None:
                     dg = self._buf(*x.shape)
                     ops.linear_h2(dy, p.lin_planes(False), None, out=dg)
                     ops.gelu_bwd(dg, gelu_in, self._gnew(gelu_in))

@@ -217,3 +217,26 @@ def test_linear_h2_per_token_scale_matches_float64(rows, K, N, kind):
         ref = want + b.double()
         assert float(((y - ref).abs() / ref.abs().amax(1, keepdim=True)).max()) < 2e-6
         assert bool((y[~live] == b.double()).all())                           # ... and with a bias exactly the bias
+
+
+@pytest.mark.parametrize("rows,K,N", [(4 * 64 * 64, 192, 384), (64, 192, 192), (4 * 128 * 128, 384, 192), (256, 192, 576)])
+def test_linear_h2_gelu_epilogues(rows, K, N):
+    """RDO_EPI_GELU (out = gelu(x W^T + b), pre-activation kept) and RDO_EPI_GELU_BWD (out = (dy W) * gelu'(aux)) of rdo_linear_h2 against
+    the plain kernel followed by the separate GELU kernels: the linear part bit for bit, the activation to fp32 rounding."""
+    from hipops import _lib as L, ops
+    g = torch.Generator().manual_seed(rows + K + N)
+    x = torch.randn(rows, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    planes = ops.split_h2_linear(w)
+    pre = torch.empty(rows, N, device="cuda")
+    y = ops.linear_h2(x, planes, b, epilogue=L.EPI_GELU, pre=pre)
+    plain = ops.linear_h2(x, planes, b)
+    torch.testing.assert_close(pre, plain, rtol=0, atol=0)
+    sep = ops.gelu(plain.view(-1)).view_as(plain)
+    assert float((y - sep).abs().max()) <= 1e-6 * float(sep.abs().max())
+    aux = (torch.randn(rows, N, generator=g) * 2).cuda()
+    got = ops.linear_h2(x, planes, None, epilogue=L.EPI_GELU_BWD, aux=aux)
+    lin = ops.linear_h2(x, planes, None)
+    sep = ops.gelu_bwd(lin.view(-1), aux.view(-1)).view_as(lin)
+    assert float((got - sep).abs().max()) <= 1e-6 * float(sep.abs().max())
