@@ -578,6 +578,10 @@ def main():
                                    f"{a.images} calib images {a.crop}x{a.crop} per GPU, batch {a.batch} per GPU",
                        "units": n_units, "batch_per_gpu": a.batch, "images_per_gpu": a.images,
                        "parallelism": f"dp{world}", "hipgraph": not a.no_graph,
+                       "scaling_note": "weak scaling: every rank calibrates its own shard of `images_per_gpu` images with mini-batch `batch_per_gpu` "
+                                       "(global mini-batch = n_gpus x 4) and the per-unit alpha-gradient bucket is all-reduced every iteration; STRONG "
+                                       "scaling of the reference's global mini-batch of 4 is not measured (quantization/recon.py refuses a batch that does "
+                                       "not split evenly over the ranks: 4 over 8 GPUs)",
                        "gemm_arithmetic": "fp32-EQUIVALENT, not fp32: the convs of every block unit from 32^2 up run on fp16 MFMA with a two-way fp16 "
                                           "split of the power-of-two-scaled operands (3 products, fp32 accumulate, 22 significant operand bits; "
                                           "operands pre-split by their producers = H2 tensors), other large convs on bf16 MFMA with the exact "
