@@ -17,6 +17,9 @@ from . import _lib as L
 from . import ops
 
 
+LIN_H2_MIN_ROWS = 4096      # token count from which the tape's Linears take rdo_linear_h2 (below it the conv kernels' split-K forms win)
+
+
 def _nhwc(x):
     return x.permute(0, 2, 3, 1).contiguous()
 
@@ -166,15 +169,23 @@ class LinearFn(torch.autograd.Function):
     def forward(ctx, x, pack):
         cin, cout = x.shape[-1], pack.w.shape[0]
         x4 = x.reshape(1, 1, -1, cin).contiguous()
-        y = ops.conv2d_fwd_pack(x4, pack, 1, 0)
+        rows = x4.shape[2]
+        if rows >= LIN_H2_MIN_ROWS and ops.linear_h2_supported(rows, cin, cout):     # large token matrices: rdo_linear_h2 (three fp16 products)
+            y = ops.linear_h2(x4.view(rows, cin), pack.lin_planes(), pack.bias)
+        else:
+            y = ops.conv2d_fwd_pack(x4, pack, 1, 0)
         ctx.pack, ctx.xshape = pack, tuple(x.shape)
         return y.reshape(*x.shape[:-1], cout)
 
     @staticmethod
     def backward(ctx, g):
-        cout = ctx.pack.w.shape[0]
+        cout, cin = ctx.pack.w.shape[0], ctx.xshape[-1]
         g4 = g.reshape(1, 1, -1, cout).contiguous()
-        dx = ops.conv2d_fwd_pack(g4, ctx.pack.flipped(), 1, 0)            # [Cin][1][1][Cout]
+        rows = g4.shape[2]
+        if rows >= LIN_H2_MIN_ROWS and ops.linear_h2_supported(rows, cout, cin):
+            dx = ops.linear_h2(g4.view(rows, cout), ctx.pack.lin_planes(transposed=True), None)
+        else:
+            dx = ops.conv2d_fwd_pack(g4, ctx.pack.flipped(), 1, 0)        # [Cin][1][1][Cout]
         return dx.reshape(ctx.xshape), None
 
 

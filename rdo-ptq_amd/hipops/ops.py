@@ -481,6 +481,14 @@ class WeightPack:
         """Pack of `w` read with input and output channels exchanged, [Cin][KH][KW][Cout] (taps as they lie)."""
         return self.get("transposed", lambda: WeightPack(self.w.permute(3, 1, 2, 0)))
 
+    def lin_planes(self, transposed=False):
+        """Fragment-ordered fp16 planes of a Linear's weight [N, 1, 1, K] (or of its transpose: the input-gradient Linear) for
+        rdo_linear_h2; the power-of-two scale comes from the weight's own magnitude (a synchronising reduction, once per pack)."""
+        def make():
+            w2 = self.w.reshape(self.w.shape[0], -1)
+            return split_h2_linear(w2.t().contiguous() if transposed else w2)
+        return self.get(("lin", bool(transposed)), make)
+
     def phase(self, ph):
         """(pack of the phase weight, phase bias) of the transposed conv with this weight as `to_rows(W, tconv=True)`."""
         def make():
