@@ -64,15 +64,27 @@ def _logical(op, g):
     return g.permute(0, 3, 1, 2)
 
 
+LONG = {"h_a1": 300, "h_s1": 300, "g_a7": 120}
+
+
+@pytest.mark.parametrize("name", list(LONG))
+def test_lu2022_full_size_long_horizon(nic_full, name):
+    """The same comparison over a realistic stretch of the schedule for three full-width units whose oracle iteration is cheap (an RSTB
+    of h_a with a tail, a transposed conv of h_s with a tail, the 320-channel RSTB of g_a with its round_ste-only tail): 300 / 120
+    iterations, warm-up boundary inside, b decaying, Adam's moments carried -- losses at every 25th iteration and the final hard
+    rounding decisions (>= 99 % per tensor equal to the oracle's; the run itself moves several per cent against nearest rounding)."""
+    test_lu2022_full_size_units_match_oracle(nic_full, name, iters=LONG[name], long=True)
+
+
 @pytest.mark.parametrize("name", list(ITERS))
-def test_lu2022_full_size_units_match_oracle(nic_full, name):
+def test_lu2022_full_size_units_match_oracle(nic_full, name, iters=None, long=False):
     import copy
     from oracle import rdo_oracle as O, swin_oracle as S
     from quantization import BaseQuantBlock, QuantModel, QuantModule, block_reconstruction, layer_reconstruction
     from quantization.recon import unit_seed
     from quantization.swin_engine import TapeEngine
     model, state, cali = nic_full
-    iters = ITERS[name]
+    iters = ITERS[name] if iters is None else iters
     torch.set_num_threads(max(1, min(torch.get_num_threads(), len(os.sched_getaffinity(0)))))
     torch.manual_seed(1005)                                   # recon.unit_seed mixes the process seed into the QDrop stream
     qnn = QuantModel(model=copy.deepcopy(model).cuda().eval(), weight_quant_params=WQ, act_quant_params=AQ).cuda().eval()
@@ -122,6 +134,19 @@ def test_lu2022_full_size_units_match_oracle(nic_full, name):
     # a round_ste flip moves the task term by (2|d| + 1) / (B H' W'): allow three of them
     tc = getattr(eng, "task_cache", None)
     atol = 3.0 * 3.0 / (B * tc.shape[1] * tc.shape[2]) if (tail_round and tc is not None) else 1e-7
+    if long:
+        pick = list(range(0, iters, 25)) + [iters - 1]
+        # (round_ste flips accumulate over a long run: each moves the task term by ~(2|d| + 1) / n -- allow a handful)
+        np.testing.assert_allclose(total.numpy()[pick], np.array(log.total)[pick], rtol=1e-3, atol=4 * atol)
+        moved = same = tot = 0
+        for k, op in ops_o.items():
+            a_gpu, a_ref = eng.alpha_of(k).cpu(), op.alpha
+            a0 = O.adaround_init_alpha(op.weight.clone(), op.delta)
+            flips = float(((a_gpu >= 0) != (a_ref >= 0)).float().mean())
+            assert flips < 1e-2, (k, flips)
+            moved += int(((a_ref >= 0) != (a0 >= 0)).sum()); same += int(((a_gpu >= 0) == (a_ref >= 0)).sum()); tot += a_ref.numel()
+        print(f"{name}: {iters} iterations, decisions moved against nearest rounding {moved / tot:.4f}, product == oracle {same / tot:.6f}")
+        return
     np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=3e-4, atol=atol)
     for k, op in ops_o.items():
         a_gpu, a_ref = eng.alpha_of(k).cpu(), op.alpha
