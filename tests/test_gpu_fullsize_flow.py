@@ -72,9 +72,17 @@ def test_small_layer_units_n192_match_oracle(cheng192, name):
     eng.run()
     torch.cuda.synchronize()
     total, rt, rd = eng.logs()
+    a_gpu, a_ref = eng.alpha_of("layer").cpu(), op.alpha
+    if iters > 50:
+        pick = list(range(0, iters, 25)) + [iters - 1]
+        np.testing.assert_allclose(total.numpy()[pick], np.array(log.total)[pick], rtol=1e-3, atol=1e-7)
+        flips = float(((a_gpu >= 0) != (a_ref >= 0)).float().mean())
+        moved = float(((a_ref >= 0) != (O.adaround_init_alpha(op.weight.clone(), op.delta) >= 0)).float().mean())
+        print(f"{name}: {iters} iterations, decisions moved against nearest rounding {moved:.4f}, product != oracle {flips:.6f}")
+        assert flips < 5e-3 and log.round[-1] > 0.0
+        return
     np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=3e-4, atol=1e-7)
     np.testing.assert_allclose(rd.numpy(), np.array(log.round), rtol=2e-4, atol=1e-7)
-    a_gpu, a_ref = eng.alpha_of("layer").cpu(), op.alpha
     assert a_gpu.shape == a_ref.shape
     # Adam normalises the gradient: an element whose gradient is at the fp32 noise level may move by up to lr per step in either
     # implementation, so bound the FRACTION of such elements and the hard rounding decisions
@@ -114,8 +122,15 @@ ATTN_UNITS = [("g_a.3.conv_a.0.conv.0", "relu"), ("g_a.3.conv_a.0.conv.2", "relu
               ("g_a.8.conv_a.1.conv.2", "relu"), ("g_a.8.conv_b.2.conv.0", "relu")]
 
 
+@pytest.mark.parametrize("name,act", [("g_a.3.conv_a.0.conv.2", "relu"), ("g_a.3.conv_b.3", None)])
+def test_attention_block_layer_units_n192_w10_long_horizon(attn192, name, act):
+    """The same units over 300 iterations (round 5): warm-up boundary at 60, b decaying, Adam's moments carried, on the 10-bit grid --
+    losses at every 25th iteration to 1e-3, final hard rounding decisions >= 99.5 % equal to the oracle's."""
+    test_attention_block_layer_units_n192_w10_match_oracle(attn192, name, act, iters=300)
+
+
 @pytest.mark.parametrize("name,act", ATTN_UNITS)
-def test_attention_block_layer_units_n192_w10_match_oracle(attn192, name, act):
+def test_attention_block_layer_units_n192_w10_match_oracle(attn192, name, act, iters=10):
     """BASELINE config 3 at full width, unit level: the 1x1 (192 -> 96 -> 192) and 3x3 (96 -> 96) convs of the attention blocks as
     ReLU-fused layer units with 10-bit channel-wise weights, HIP engine against oracle.reconstruct_unit on the same caches, index
     stream and QDrop masks."""
@@ -131,7 +146,7 @@ def test_attention_block_layer_units_n192_w10_match_oracle(attn192, name, act):
         out = torch.relu(out)
     g = torch.Generator().manual_seed(11)
     inp_q = inp + 1e-3 * torch.randn(inp.shape, generator=g)
-    iters, B = 10, 4
+    B = 4
     idx = np.stack([np.random.RandomState(i).permutation(4) for i in range(iters)])
     wq10 = {"n_bits": 10, "channel_wise": True, "scale_method": "max"}
     op = QOp("conv", mod.weight.detach().clone(), mod.bias.detach().clone(), stride=mod.stride[0], padding=mod.padding[0], act=act, n_bits=10)
@@ -155,9 +170,17 @@ def test_attention_block_layer_units_n192_w10_match_oracle(attn192, name, act):
     eng.run()
     torch.cuda.synchronize()
     total, rt, rd = eng.logs()
+    a_gpu, a_ref = eng.alpha_of("layer").cpu(), op.alpha
+    if iters > 50:
+        pick = list(range(0, iters, 25)) + [iters - 1]
+        np.testing.assert_allclose(total.numpy()[pick], np.array(log.total)[pick], rtol=1e-3, atol=1e-7)
+        flips = float(((a_gpu >= 0) != (a_ref >= 0)).float().mean())
+        moved = float(((a_ref >= 0) != (O.adaround_init_alpha(op.weight.clone(), op.delta) >= 0)).float().mean())
+        print(f"{name}: {iters} iterations, decisions moved against nearest rounding {moved:.4f}, product != oracle {flips:.6f}")
+        assert flips < 5e-3 and log.round[-1] > 0.0
+        return
     np.testing.assert_allclose(total.numpy(), np.array(log.total), rtol=3e-4, atol=1e-7)
     np.testing.assert_allclose(rd.numpy(), np.array(log.round), rtol=2e-4, atol=1e-7)
-    a_gpu, a_ref = eng.alpha_of("layer").cpu(), op.alpha
     far = ((a_gpu - a_ref).abs() > 2e-3).float().mean()
     flips = ((a_gpu >= 0) != (a_ref >= 0)).float().mean()
     assert float(far) < 2e-3 and float(flips) < 5e-3, (float(far), float(flips))
