@@ -171,7 +171,11 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
             }
 #pragma unroll
             for (int ksl = 0; ksl < KB / 32; ++ksl) {
+                // the next K step's weight fragments are requested HERE, a whole step (36 MFMAs) ahead of their first use: left to itself
+                // hipcc sinks each of the six loads to a few instructions in front of the MFMA that needs it (`global_load; s_waitcnt
+                // vmcnt(1); v_mfma` -- the L2 latency exposed six times per step)
                 if (ksl + 1 < KB / 32) load_w(fw[(ksl + 1) & 1], kb * (KB / 32) + ksl + 1, chunk);
+                __builtin_amdgcn_sched_barrier(0);
                 f16x8 fx[2][4];
                 read_x(fx, ksl);
                 const int c = ksl & 1;
@@ -188,6 +192,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
                 for (int i = 0; i < 3; ++i)
 #pragma unroll
                     for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_hi x_hi
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         // ---- epilogue: y = acc / (token scale * weight scale) + bias, four consecutive channels of one token per lane
