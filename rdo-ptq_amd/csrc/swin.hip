@@ -264,13 +264,14 @@ typedef float af4 __attribute__((ext_vector_type(4)));
 template <int TILE_IT>
 __device__ __forceinline__ void tile_fetch(const AttnGeom& g, const float* src, int row_stride, int ch0, const int* pix, af4 (&r)[TILE_IT]) {
     const int qpt = g.hd >> 2, nq = g.N * qpt;
+    // UNCONDITIONAL loads (a lane past the tile re-reads its last quad): a load behind a per-lane branch is a basic block of its own, and
+    // hipcc waits vmcnt(0) at every join -- twelve serial memory round trips per prefetch instead of one
 #pragma unroll
     for (int it = 0; it < TILE_IT; ++it) {
-        const int e = threadIdx.x + 256 * it;
-        if (e < nq) {
-            const int tok = e / qpt, dq = e - tok * qpt;
-            r[it] = *reinterpret_cast<const af4*>(src + (long)pix[tok] * row_stride + ch0 + 4 * dq);
-        }
+        const int e0 = threadIdx.x + 256 * it;
+        const int e = e0 < nq ? e0 : nq - 1;
+        const int tok = e / qpt, dq = e - tok * qpt;
+        r[it] = *reinterpret_cast<const af4*>(src + (long)pix[tok] * row_stride + ch0 + 4 * dq);
     }
 }
 template <int TILE_IT>
