@@ -49,6 +49,9 @@ struct LinArgs {
     int M, K, N;
     float inv_wscale;      // 1 / wscale
     int square;            // the input enters squared (GDN norm pool: beta' + gamma' . x^2, quant_layer.py:147)
+#ifdef RDO_DIAG
+    int diag;              // ablation bits (diagnostic build only): 1 no output stores, 2 no MFMAs, 4 no panel loads
+#endif
     int epi;               // 0: none; 1: out = gelu(y), pre = y (Mlp.fc1 + nn.GELU, layers.py:44-47); 2: out = y * gelu'(aux) (input gradient through that GELU)
     float* pre;            // epi 1: pre-activation [M][N]
     const float* aux;      // epi 2: the GELU's input [M][N]
@@ -86,7 +89,12 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
         for (int pass = 0; pass < BM / 16; ++pass) {
             const f32x4* src = reinterpret_cast<const f32x4*>(a.x + (m0 + pass * 16 + row_in_pass) * a.K + (long)kb * KB);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) v[pass][k] = src[l16 + 16 * k];
+            for (int k = 0; k < 3; ++k) {
+#ifdef RDO_DIAG
+                if (a.diag & 4) { v[pass][k] = f32x4{1.f, 2.f, 3.f, 4.f}; continue; }
+#endif
+                v[pass][k] = src[l16 + 16 * k];
+            }
         }
         if (a.square) {
 #pragma unroll
@@ -176,6 +184,9 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
                 // vmcnt(1); v_mfma` -- the L2 latency exposed six times per step)
                 if (ksl + 1 < KB / 32) load_w(fw[(ksl + 1) & 1], kb * (KB / 32) + ksl + 1, chunk);
                 __builtin_amdgcn_sched_barrier(0);
+#ifdef RDO_DIAG
+                if (a.diag & 2) continue;
+#endif
                 f16x8 fx[2][4];
                 read_x(fx, ksl);
                 const int c = ksl & 1;
@@ -215,43 +226,81 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) y[e] *= rdo::gelu_grad(u[e]);
                 }
+#ifdef RDO_DIAG
+                if ((a.diag & 1) && y[0] != 12345.678f) continue;
+#endif
                 *reinterpret_cast<f32x4*>(a.out + o + 16 * i) = y;
             }
         }
     }
 }
 
-// ---- persistent form (default): a workgroup walks token tiles t, t + grid, ... and handles ALL output chunks of a tile from one panel.
-// The panel of the NEXT step (next K block of the tile, or the next tile) is fetched into registers right behind the barrier that
-// publishes the current one, so HBM latency and the loads run under the products and the output stores: two workgroups per CU
-// (registers), 512 resident, 1024 tiles of a 128^2 map = two each -- no partial last round, one panel load per tile instead of one per
-// chunk.  K spanning several blocks (fc2, the qkv input gradient) is supported with one output chunk (N = 192); one K block with any
-// number of chunks: every Linear shape of the Lu2022 blocks.
-// EPI: 0 plain, 1 GELU (+ pre-activation output), 2 GELU_BWD -- compile-time, so the erf / exp code (and its registers) stays out of the
-// plain instantiation; MULTIK: K spans several panels (one output chunk).
-template <int EPI, bool MULTIK>
-__global__ __launch_bounds__(256, 2) void linear_h2p_kernel(LinArgs a) {
+// ---- weight-stationary form (default where it applies): the WEIGHTS live in registers, tokens stream through LDS.
+// tools/linear_h2_ablate.py on the kernel above (192 -> 576 over 64 K tokens, 65 us): with panel loads, MFMAs and stores all switched off it
+// still takes 24 us -- every workgroup pulls its chunk's 147 KB of weight fragments from L2 for 64 tokens (452 MB through the vector
+// memory path for 200 MB of tensor traffic) -- and the marginal cost of loads (+8), MFMAs (+19) and stores (+14) adds up exactly to the
+// full time: a launch is only four rounds of workgroups that start together, so their phases never interleave.
+// A (64-token, 192-channel chunk) product needs 192 x 192 weights = 144 KiB as planes: that FITS the register file of a CU.  One
+// workgroup per CU, 8 waves = 4 channel groups x 2 token halves; a wave keeps the fragments of ITS channels for the whole K in registers
+// (NT x 16 channels x K: 48 x 192 for K = 192, 16 x K for K = 384 / 576 -- 144 VGPRs either way), loaded once per launch, and walks
+// token tiles: the raw fp32 panel of the next step is in registers (24 VGPRs, fetched a whole step ahead), split into the OTHER of two
+// LDS panels while the current one is multiplied, one barrier per panel.  Panel loads, products and output stores of consecutive tiles
+// overlap inside one workgroup; the weight traffic of a launch is 256 x 288 KB instead of 147 KB per 64 tokens.
+// The workgroups of one token-tile group (one per output chunk) sit in one XCD and run in step: the panel comes from HBM once.
+// EPI as above (compile-time); NKB = K / 192 (the K blocks of a tile are walked with the accumulators rescaled in between).
+template <int NT, int NKB, int EPI>
+__global__ __launch_bounds__(512, 1) void linear_h2w_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* scl = reinterpret_cast<float*>(smem + 2 * PLANE);
+    constexpr int BUF = 2 * PLANE;                           // one panel: two planes
+    constexpr int KS = (KB / 32) * NKB;                      // K steps of the whole reduction
+    constexpr int NCW = 64 * NT;                             // output channels per workgroup (4 channel groups x NT x 16)
+    float* scl = reinterpret_cast<float*>(smem + 2 * BUF);   // [4][BM]: 1 / token scale of panel (p & 3)
+    float* bsm = scl + 4 * BM;                               // [NCW]: the chunk's bias (zeros without one)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = wave & 3, th = wave >> 2;
     const int l16 = lane & 15, kg = lane >> 4;
-    const int nkb = a.K / KB, nchunks = a.N / NC, nblk = a.N / 16, ksteps = a.K / 32;
+    const int nchunks = a.N / NCW, nblk = a.N / 16;
     const int ntiles = a.M / BM;
-    const int row_in_pass = tid >> 4;
+    // (XCD, slot) -> (tile group, chunk): the chunks of a group are neighbours inside an XCD
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, slots = gridDim.x >> 3;
+    const int groups = slots / nchunks;
+    const int grp = slot / nchunks, chunk = slot - grp * nchunks;
+    const int full = ntiles >> 3, rest = ntiles & 7;
+    const int mine = full + (xcd < rest ? 1 : 0), first = xcd * full + (xcd < rest ? xcd : rest);
+    if (grp >= groups || grp >= mine) return;
 
-    f32x4 v[BM / 16][3];
+    const int row_in_pass = tid >> 4;                        // 32 tokens per pass, two passes
+    f32x4 v[2][3];
+    // The prefetch loads are inline asm, invisible to the compiler's wait-count bookkeeping, and waited for by hand: the counter is shared
+    // with the output stores, a loop header is reached from the prologue (nothing behind the loads) and from the back edge (the epilogue's
+    // stores behind them), and the compiler has to emit ONE immediate that is right for both -- `vmcnt(5) ... vmcnt(0)`, i.e. every step
+    // waited for the previous tile's stores to be acknowledged.
     auto fetch = [&](int tile, int kb) {
 #pragma unroll
-        for (int pass = 0; pass < BM / 16; ++pass) {
-            const f32x4* src = reinterpret_cast<const f32x4*>(a.x + ((long)tile * BM + pass * 16 + row_in_pass) * a.K + (long)kb * KB);
-#pragma unroll
-            for (int k = 0; k < 3; ++k) v[pass][k] = src[l16 + 16 * k];
+        for (int pass = 0; pass < 2; ++pass) {
+            const float* src = a.x + ((long)tile * BM + pass * 32 + row_in_pass) * a.K + (long)kb * KB + 4 * l16;
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v[pass][0]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(v[pass][1]) : "v"(src) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(v[pass][2]) : "v"(src) : "memory");
         }
     };
-    auto stash = [&](int kb) {
+    // behind = vector-memory instructions issued after the loads that have to be back (the counter retires in order): -1 = all of them
+    auto landed = [&](int behind) {
+        if (behind < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (behind == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (behind == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else if (behind == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
 #pragma unroll
-        for (int pass = 0; pass < BM / 16; ++pass) {
-            const int r = pass * 16 + row_in_pass;
+        for (int pass = 0; pass < 2; ++pass)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) asm volatile("" : "+v"(v[pass][k]));
+    };
+    auto stash = [&](int p) {                                // registers -> planes of panel p (LDS buffer p & 1, scale row p & 3)
+        char* buf = smem + (p & 1) * BUF;
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            const int r = pass * 32 + row_in_pass;
             if (a.square) {
 #pragma unroll
                 for (int k = 0; k < 3; ++k) v[pass][k] *= v[pass][k];
@@ -266,130 +315,145 @@ __global__ __launch_bounds__(256, 2) void linear_h2p_kernel(LinArgs a) {
             amax = fmaxf(amax, __shfl_xor(amax, 1, 16));
             const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFF) - 127;
             const bool plain = e < -100 || e > 100;
-            const float s = plain ? 1.f : pow2f(7 - e);
-            if (l16 == 0) scl[(kb & 1) * BM + r] = plain ? 1.f : pow2f(e - 7);
+            const float sc = plain ? 1.f : pow2f(7 - e);
+            if (l16 == 0) scl[(p & 3) * BM + r] = plain ? 1.f : pow2f(e - 7);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int c4 = l16 + 16 * k;
-                const f32x4 xs = v[pass][k] * s;
+                const f32x4 xs = v[pass][k] * sc;
                 const f16x4 hi = __builtin_convertvector(xs, f16x4);
                 const f16x4 lo = __builtin_convertvector(xs - __builtin_convertvector(hi, f32x4), f16x4);
-                char* dst = smem + (c4 >> 2) * (BM * 32) + r * 32 + (c4 & 3) * 8;
+                char* dst = buf + (c4 >> 2) * (BM * 32) + r * 32 + (c4 & 3) * 8;
                 *reinterpret_cast<f16x4*>(dst) = hi;
                 *reinterpret_cast<f16x4*>(dst + PLANE) = lo;
             }
         }
     };
-    const u32x4* wbase = reinterpret_cast<const u32x4*>(a.wp) + lane;
-    auto load_w = [&](f16x8 (&fw)[2][3], int ks, int chunk) {
-        const long b0 = (long)chunk * (NC / 16) + wave * 3;
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                fw[p][i] = __builtin_bit_cast(f16x8, wbase[(((long)p * ksteps + ks) * nblk + b0 + i) * 64]);
-    };
-    const int fx_lane = (kg >> 1) * (BM * 32) + l16 * 32 + (kg & 1) * 16;
-    auto read_x = [&](f16x8 (&fx)[2][4], int ksl) {
-#pragma unroll
-        for (int p = 0; p < 2; ++p)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                fx[p][j] = *reinterpret_cast<const f16x8*>(smem + p * PLANE + (2 * ksl) * (BM * 32) + j * (16 * 32) + fx_lane);
-    };
-    f32x4 acc[3][4];
-    auto zero_acc = [&]() {
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    };
-    auto kloop = [&](int kb, int chunk) {
-        f16x8 fw[2][2][3];
-        load_w(fw[0], kb * (KB / 32), chunk);
-#pragma unroll
-        for (int ksl = 0; ksl < KB / 32; ++ksl) {
-            if (ksl + 1 < KB / 32) load_w(fw[(ksl + 1) & 1], kb * (KB / 32) + ksl + 1, chunk);
-            f16x8 fx[2][4];
-            read_x(fx, ksl);
-            const int c = ksl & 1;
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][1][i], fx[0][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[1][j], acc[i][j], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[c][0][i], fx[0][j], acc[i][j], 0, 0, 0);
-        }
-    };
-    auto epilogue = [&](int tile, int chunk) {
-        const float* inv_s = scl + ((nkb - 1) & 1) * BM;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int tok = 16 * j + l16;
-            const float f = inv_s[tok] * a.inv_wscale;
-            const long o = ((long)tile * BM + tok) * a.N + chunk * NC + wave * 48 + 4 * kg;
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                f32x4 y = acc[i][j] * f;
-                if (a.bias) y += *reinterpret_cast<const f32x4*>(a.bias + chunk * NC + wave * 48 + 16 * i + 4 * kg);
-                if constexpr (EPI == 1) {
-                    *reinterpret_cast<f32x4*>(a.pre + o + 16 * i) = y;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] = rdo::gelu(y[e]);
-                } else if constexpr (EPI == 2) {
-                    const f32x4 u = *reinterpret_cast<const f32x4*>(a.aux + o + 16 * i);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) y[e] *= rdo::gelu_grad(u[e]);
-                }
-                *reinterpret_cast<f32x4*>(a.out + o + 16 * i) = y;
-            }
-        }
-    };
 
-    int tile = blockIdx.x;
-    if (tile >= ntiles) return;
-    fetch(tile, 0);
-    bool first = true;
-    for (; tile < ntiles; tile += gridDim.x) {
-        for (int kb = 0; kb < nkb; ++kb) {
-            if (!first) __syncthreads();                       // every wave is done with the previous panel (and has read its scales)
-            first = false;
-            stash(kb);
-            // the next step's panel: next K block of this tile, else the first block of the next tile
-            const int ntile = kb + 1 < nkb ? tile : tile + (int)gridDim.x;
-            const int nkbi = kb + 1 < nkb ? kb + 1 : 0;
-            if (ntile < ntiles) fetch(ntile, nkbi);
-            __syncthreads();
-            if constexpr (!MULTIK) {
-#pragma clang loop unroll(disable)
-                for (int chunk = 0; chunk < nchunks; ++chunk) {
-                    int c = chunk;
-                    asm volatile("" : "+s"(c));              // (opaque: the optimiser otherwise keeps one induction pointer per weight fragment
-                                                             //  and K step of the chunk loop alive -- 113 spilled registers)
-                    zero_acc();
-                    kloop(0, c);
-                    epilogue(tile, c);
+    int tl = grp;                                            // tile index inside this XCD's share
+    fetch(first + tl, 0);
+    // (the bias goes through LDS: a global load in the epilogue costs an `s_waitcnt vmcnt(0)` there, which also drains the panel prefetch)
+    if (tid < NCW) bsm[tid] = a.bias ? a.bias[chunk * NCW + tid] : 0.f;
+    // the wave's weight fragments, whole K: [plane][K step][16-channel tile]
+    f16x8 fw[2][KS][NT];
+    {
+        const u32x4* wbase = reinterpret_cast<const u32x4*>(a.wp) + lane;
+        const long b0 = (long)chunk * (NCW / 16) + cg * NT;
+        u32x4 raw[2][KS][NT];
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) raw[p][ks][i] = wbase[(((long)p * KS + ks) * nblk + b0 + i) * 64];
+        // (opaque: left to itself the compiler RE-LOADS half of the fragments inside every step -- a load from a constant address is
+        //  cheaper to rematerialise than to keep -- and the in-order vmcnt waits of those 18 loads also drain the panel prefetch)
+#pragma unroll
+        for (int p = 0; p < 2; ++p)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    asm volatile("" : "+v"(raw[p][ks][i]));
+                    fw[p][ks][i] = __builtin_bit_cast(f16x8, raw[p][ks][i]);
                 }
-            } else {
-                if (kb == 0) {
-                    zero_acc();
-                } else {                                       // accumulators carry the previous block's token scale: exact power-of-two ratio
+    }
+    const int fx_lane = (kg >> 1) * (BM * 32) + (32 * th + l16) * 32 + (kg & 1) * 16;
+    f32x4 acc[NT][2];
+    int p = 0;                                               // panel counter of this workgroup
+    landed(-1);
+    stash(0);
+    {
+        const int ntl = NKB > 1 ? tl : tl + groups;
+        fetch(first + (ntl < mine ? ntl : tl), NKB > 1 ? 1 : 0);
+    }
+    __syncthreads();
+    constexpr int NST = 2 * NT * (EPI ? 2 : 1);              // vector-memory instructions of an epilogue
+    static_assert(NST == 2 || NST == 6 || NST == 12, "landed()");
+    bool first_step = true;
+    for (; tl < mine; tl += groups) {
+        const int tile = first + tl;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const float ratio = scl[((kb - 1) & 1) * BM + 16 * j + l16] / scl[(kb & 1) * BM + 16 * j + l16];
+        for (int kb = 0; kb < NKB; ++kb, ++p) {
+            // the panel after this one (already in registers) goes into the other LDS buffer -- every wave left it at the last barrier --
+            // and the one after that is requested: a whole step of products between a load and its use
+            // UNCONDITIONALLY (past the end: a valid tile again, never used): behind a branch the compiler has to assume the loads of the
+            // skipped path are still in flight and puts `s_waitcnt vmcnt(0)` -- a wait for the previous tile's output stores -- in front of
+            // the new requests
+            {
+                // the loads of panel p + 1 were issued in the previous step; behind them only that step's epilogue, if it had one
+                if (kb == 0 && !first_step) landed(NST);
+                else landed(0);
+                first_step = false;
+                stash(p + 1);
+                int t2 = tl, k2 = kb + 2;
+                if (k2 >= NKB) { t2 += groups; k2 -= NKB; }
+                if (k2 >= NKB) { t2 += groups; k2 -= NKB; }      // (NKB = 1: two tiles on)
+                fetch(first + (t2 < mine ? t2 : tl), k2);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const char* buf = smem + (p & 1) * BUF;
+            if (kb == 0) {
 #pragma unroll
-                        for (int i = 0; i < 3; ++i) acc[i][j] *= ratio;
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            } else {                                             // accumulators carry the previous block's token scale: exact power-of-two ratio
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int tok = 32 * th + 16 * j + l16;
+                    const float ratio = scl[((p - 1) & 3) * BM + tok] / scl[(p & 3) * BM + tok];
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[i][j] *= ratio;
+                }
+            }
+#pragma unroll
+            for (int ksl = 0; ksl < KB / 32; ++ksl) {
+                f16x8 fx[2][2];
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        fx[pl][j] = *reinterpret_cast<const f16x8*>(buf + pl * PLANE + (2 * ksl) * (BM * 32) + j * (16 * 32) + fx_lane);
+                const int ks = kb * (KB / 32) + ksl;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[1][ks][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_lo x_hi
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][ks][i], fx[1][j], acc[i][j], 0, 0, 0);    // w_hi x_lo
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(fw[0][ks][i], fx[0][j], acc[i][j], 0, 0, 0);    // w_hi x_hi
+            }
+            if (kb == NKB - 1) {                                 // epilogue: four consecutive channels of one token per lane
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int tok = 32 * th + 16 * j + l16;
+                    const float f = scl[(p & 3) * BM + tok] * a.inv_wscale;
+                    const int ch = chunk * NCW + cg * (16 * NT) + 4 * kg;
+                    const long o = ((long)tile * BM + tok) * a.N + ch;
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) {
+                        f32x4 y = acc[i][j] * f;
+                        y += *reinterpret_cast<const f32x4*>(bsm + cg * (16 * NT) + 4 * kg + 16 * i);
+                        if constexpr (EPI == 1) {
+                            *reinterpret_cast<f32x4*>(a.pre + o + 16 * i) = y;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] = rdo::gelu(y[e]);
+                        } else if constexpr (EPI == 2) {
+                            const f32x4 u = *reinterpret_cast<const f32x4*>(a.aux + o + 16 * i);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) y[e] *= rdo::gelu_grad(u[e]);
+                        }
+                        *reinterpret_cast<f32x4*>(a.out + o + 16 * i) = y;
                     }
                 }
-                kloop(kb, 0);
-                if (kb == nkb - 1) epilogue(tile, 0);
             }
+            __syncthreads();                                     // panel p + 1 is published, panel p is free
         }
     }
 }
@@ -429,13 +493,34 @@ extern "C" int rdo_linear_h2_supported(int64_t M, int32_t K, int32_t N) {
     return M > 0 && M % BM == 0 && K > 0 && K % KB == 0 && N > 0 && N % NC == 0 && (double)M * (K > N ? K : N) * 4.0 < 4.0e9;
 }
 
-// tuning: 0 (default) = one (token tile, chunk) per workgroup, three workgroups per CU; 1 = persistent workgroups with register prefetch
-// (linear_h2p_kernel: two per CU, all chunks of a tile from one panel) -- measured SLOWER on every Lu2022 shape (tools/bench_linear_h2.py:
-// 80 against 68 us for the 192 -> 576 Linear over 64 K tokens, 33 against 20.5 over 16 K): a third resident workgroup and three times
-// as many, shorter workgroups hide more latency than a software prefetch at lower occupancy.  Kept for A/B runs.
-static int lin_persistent() {
-    static const int v = [] { const char* e = getenv("RDO_LIN_H2_PERSISTENT"); return e ? atoi(e) : 0; }();
+// tuning: 1 (default) = the weight-stationary kernel for one K block (K = 192) when every workgroup gets at least four token tiles (the
+// 128^2 maps: 192 -> 576 over 64 K tokens 67 -> 63 us, -> 384 48 -> 38.5, -> 192 29 -> 26; over 16 K tokens the one-time weight load and the
+// tile quantisation lose: 23.6 against 20.0), 2 = also for K = 384 / 576 (16 channels x K per wave: LDS-read-bound, measured 60 / 102 us
+// against 44 / 61 -- kept for A/B runs), 0 = always one (token tile, chunk) per workgroup with the weights streamed from L2
+static int lin_stationary() {
+    static const int v = [] { const char* e = getenv("RDO_LIN_H2_STATIONARY"); return e ? atoi(e) : 1; }();
     return v;
+}
+static int cu_count() {
+    static const int v = [] {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 8) n = 256;
+        return n & ~7;
+    }();
+    return v;
+}
+
+template <int NT, int NKB, int EPI>
+static int launch_w(const LinArgs& a, int slots, hipStream_t s) {
+    constexpr int lds = 4 * PLANE + 4 * BM * 4 + 64 * NT * 4;   // two panels, four scale rows, the chunk's bias
+    static rdo::PerDevice attr;
+    if (!attr.done()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_h2w_kernel<NT, NKB, EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(linear_h2w) failed");
+        attr.mark();
+    }
+    hipLaunchKernelGGL((linear_h2w_kernel<NT, NKB, EPI>), dim3((unsigned)(8 * slots)), dim3(512), lds, s, a);
+    return rdo::check_launch("linear_h2w");
 }
 
 extern "C" int rdo_split_h2_linear(const float* w, int32_t N, int32_t K, float scale, void* planes, void* stream) {
@@ -476,20 +561,25 @@ extern "C" int rdo_linear_h2_epi(const float* x, int64_t M, int32_t K, int32_t N
     a.M = (int)M; a.K = K; a.N = N; a.inv_wscale = 1.0f / wscale; a.square = square_input ? 1 : 0;
     a.epi = epilogue == RDO_EPI_GELU ? 1 : (epilogue == RDO_EPI_GELU_BWD ? 2 : 0);
     a.pre = pre; a.aux = aux;
+#ifdef RDO_DIAG
+    { const char* e = getenv("RDO_LIN_DIAG"); a.diag = e ? atoi(e) : 0; }
+#endif
     const double flops = 2.0 * (double)M * K * N;
-    // the persistent kernel takes one K block with any number of chunks, or several K blocks with one chunk; epilogues only there
-    const bool pers = lin_persistent() && (K == KB || N == NC);
+    const int nkb = K / KB;
+    const int slots = cu_count() / 8;
+    bool stat = false;
+    if (lin_stationary() && nkb == 1 && N / NC <= slots) stat = (M / BM) / (8 * (slots / (N / NC))) >= 4;
+    else if (lin_stationary() == 2 && (nkb == 2 || nkb == 3) && a.epi == 0 && N / 64 <= slots) stat = true;
     return rdo::dispatch(
-        [a, pers](hipStream_t s) {
-            if (pers) {
-                const int ntiles = a.M / BM;
-                const int grid = ntiles < 512 ? ntiles : 512;        // two workgroups per CU (register budget)
-                const bool mk = a.K != KB;
-                auto go = [&](auto kern) { hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), LDS_BYTES, s, a); };
-                if (a.epi == 0) { if (mk) go(linear_h2p_kernel<0, true>); else go(linear_h2p_kernel<0, false>); }
-                else if (a.epi == 1) { if (mk) go(linear_h2p_kernel<1, true>); else go(linear_h2p_kernel<1, false>); }
-                else { if (mk) go(linear_h2p_kernel<2, true>); else go(linear_h2p_kernel<2, false>); }
-                return rdo::check_launch("linear_h2p");
+        [a, stat, nkb, slots](hipStream_t s) {
+            if (stat) {
+                if (nkb == 1) {
+                    if (a.epi == 0) return launch_w<3, 1, 0>(a, slots, s);
+                    if (a.epi == 1) return launch_w<3, 1, 1>(a, slots, s);
+                    return launch_w<3, 1, 2>(a, slots, s);
+                }
+                if (nkb == 2) return launch_w<1, 2, 0>(a, slots, s);
+                return launch_w<1, 3, 0>(a, slots, s);
             }
             const unsigned grid = (unsigned)(rdo::ceil_div(a.M / BM, 8) * 8 * (a.N / NC));
             if (a.epi == 0) hipLaunchKernelGGL(linear_h2_kernel<0>, dim3(grid), dim3(256), LDS_BYTES, s, a);

@@ -181,7 +181,9 @@ def test_gelu_epilogues_of_the_linear_kernels(rows, cin, cout, planes):
     assert float((got - sep).abs().max()) <= 1e-6 * float(sep.abs().max())
 
 
-@pytest.mark.parametrize("rows,K,N", [(64, 192, 192), (4 * 64 * 64, 192, 576), (4 * 128 * 128, 384, 192), (16384, 576, 192), (640, 192, 384)])
+@pytest.mark.parametrize("rows,K,N", [(64, 192, 192), (4 * 64 * 64, 192, 576), (4 * 128 * 128, 384, 192), (16384, 576, 192), (640, 192, 384),
+                                      # the weight-stationary kernel (>= 4 token tiles per workgroup; a tile count the XCDs do not share evenly)
+                                      (4 * 128 * 128 + 192, 192, 192), (24576, 192, 576), (32768 + 64, 192, 384)])
 @pytest.mark.parametrize("kind", ["act", "grad", "zero_rows"])
 def test_linear_h2_per_token_scale_matches_float64(rows, K, N, kind):
     """rdo_linear_h2 (csrc/linear_h2.hip): Y = X W^T + b on fp16 two-way-split MFMA with a per-token dynamic power-of-two scale, against
@@ -219,7 +221,8 @@ def test_linear_h2_per_token_scale_matches_float64(rows, K, N, kind):
         assert bool((y[~live] == b.double()).all())                           # ... and with a bias exactly the bias
 
 
-@pytest.mark.parametrize("rows,K,N", [(4 * 64 * 64, 192, 384), (64, 192, 192), (4 * 128 * 128, 384, 192), (256, 192, 576)])
+@pytest.mark.parametrize("rows,K,N", [(4 * 64 * 64, 192, 384), (64, 192, 192), (4 * 128 * 128, 384, 192), (256, 192, 576),
+                                      (4 * 128 * 128, 192, 384), (4 * 128 * 128 + 64, 192, 192)])      # the weight-stationary kernel
 def test_linear_h2_gelu_epilogues(rows, K, N):
     """RDO_EPI_GELU (out = gelu(x W^T + b), pre-activation kept) and RDO_EPI_GELU_BWD (out = (dy W) * gelu'(aux)) of rdo_linear_h2 against
     the plain kernel followed by the separate GELU kernels: the linear part bit for bit, the activation to fp32 rounding."""
