@@ -16,7 +16,15 @@ constexpr int NMAX = 64;
 struct AttnGeom {
     int B, H, W, C, heads, ws, shift, N, hd, hs;   // hs: LDS row stride (odd)
     float scale;
+#ifdef RDO_DIAG
+    int diag;                                      // ablation bits (diagnostic build, RDO_ATTN_DIAG): 1 no stores, 2 no products, 4 no loads, 8 no softmax
+#endif
 };
+#ifdef RDO_DIAG
+#define ATTN_ABL(bit) (g.diag & (bit))
+#else
+#define ATTN_ABL(bit) false
+#endif
 
 __device__ __forceinline__ int token_pixel(const AttnGeom& g, int win, int tok) {
     const int nww = g.W / g.ws, nwh = g.H / g.ws;
@@ -80,6 +88,7 @@ __global__ __launch_bounds__(64) void win_attn_pv_kernel(const float* qkv, const
 // (a first VALU version -- one wave per pair, score row in registers -- took 0.4 / 1.9 ms per launch on the 128^2 maps of the
 // full-size model, 71 % of a Lu2022 iteration; see profiles/r01_lu2022.md)
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float af4 __attribute__((ext_vector_type(4)));
 constexpr int SS = 65;
 
 // C[i][j] += sum_k A(i,k) * B(k,j) for the wave's tile; TA: A stored [k][i]; TB: B stored [j][k] (else [k][j]).
@@ -106,11 +115,12 @@ __device__ __forceinline__ f32x16 tile_gemm(const float* A, int lda, const float
 // the first MFMA of the group (the one-product loop above compiles to  2 x ds_read_b32 -> s_waitcnt lgkmcnt(0) -> v_mfma  per k pair:
 // the LDS latency fully exposed behind every 64-cycle MFMA), and consecutive MFMAs go to different accumulators.
 // `ld(g, k, a, b)`: operands of product g for reduction index k (the lane's own k = s + lk is passed in).
-template <int NG, typename LD>
+// KEEP0: accumulator 0 arrives pre-loaded (the score product starts from bias + shift mask, `score_init`).
+template <int NG, bool KEEP0 = false, typename LD>
 __device__ __forceinline__ void tile_gemm_multi(f32x16 (&acc)[NG], int K, LD ld) {
     const int lk = (threadIdx.x & 63) >> 5;
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
+    for (int g = KEEP0 ? 1 : 0; g < NG; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[g][r] = 0.f;
     int s = 0;
@@ -141,16 +151,88 @@ __device__ __forceinline__ void tile_to_lds(const f32x16& acc, float* D, int ldd
     for (int r = 0; r < 16; ++r) D[(32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk) * ldd + 32 * tj + lr] = acc[r];
 }
 
-// rows of this tile that are tokens (< N), columns < hd  ->  global [pixel][ch0 + d]; pix: the window's token -> pixel table (LDS)
-__device__ __forceinline__ void tile_to_global(const AttnGeom& g, const f32x16& acc, float* dst, int row_stride, int ch0, const int* pix, int ti,
-                                               int tj, float mul) {
+// Second-stage products, computed TRANSPOSED (O^T = V^T P^T, dQ^T = K^T dS^T, ...: rows = head channels, columns = tokens, reduction over
+// the window's 64 tokens) on v_mfma_f32_16x16x4_f32: wave w owns token block w (16 tokens) and ALL channel blocks of every product.  A
+// lane's four accumulator values are then four CONSECUTIVE channels of one token -- one 16-byte store (the backward kernel spent a
+// quarter of its time issuing 48 dword stores per thread and item: tools/attn_ablate.py).  With 32 x 32 tiles a head of 24 channels kept two of the four
+// waves idle for the whole stage and the other two multiplied 32-wide tiles a quarter full; 48 channels wasted a quarter of the stage.
+// K slots: lane group kq = lane >> 4 takes k = 16 kq + s (s = 0..15) -- any assignment common to A and B is valid, and this one makes
+// every operand read conflict-free ([k][16 consecutive] and [16 consecutive][k] both map the 64 lanes to 64 distinct banks for the odd
+// row strides used here).  Always 64 deep: rows past N are zeros in every LDS image.
+// lda(g, k, d) = A_g[d][k] (channel d, zero for d >= hd), ldb(g, k, t) = B_g[k][t] (token t)
+typedef float f32x4s __attribute__((ext_vector_type(4)));
+template <int NG, int NDB, typename LDA, typename LDB>
+__device__ __forceinline__ void stage2_gemm(f32x4s (&acc)[NG][NDB], LDA lda, LDB ldb) {
+    const int l = threadIdx.x & 63, l16 = l & 15, kq = l >> 4, tok = 16 * (threadIdx.x >> 6) + l16;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int db = 0; db < NDB; ++db) acc[g][db] = f32x4s{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+    for (int s = 0; s < 16; s += 2) {
+        float a[2][NG][NDB], b[2][NG];
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < NG; ++g) {
+                b[u][g] = ldb(g, 16 * kq + s + u, tok);
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) a[u][g][db] = lda(g, 16 * kq + s + u, 16 * db + l16);
+            }
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int db = 0; db < NDB; ++db) acc[g][db] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u][g][db], b[u][g], acc[g][db], 0, 0, 0);
+    }
+}
+// a lane's four accumulator values of channel block db = channels 16 db + 4 kq .. + 3 of token 16 w + l16: one 16-byte store
+template <int NDB>
+__device__ __forceinline__ void stage2_store(const AttnGeom& g, const f32x4s (&acc)[NDB], float* dst, int row_stride, int ch0, const int* pix, float mul) {
+    const int l = threadIdx.x & 63, l16 = l & 15, kq = l >> 4, tok = 16 * (threadIdx.x >> 6) + l16;
+    if (tok >= g.N) return;
+    if (ATTN_ABL(1) && acc[0][0] != 12345.678f) return;
+    float* row = dst + (long)pix[tok] * row_stride + ch0;
+    const bool vec = ((g.hd | row_stride | ch0) & 3) == 0;
+#pragma unroll
+    for (int db = 0; db < NDB; ++db) {
+        const int d0 = 16 * db + 4 * kq;
+        if (vec) {
+            if (d0 < g.hd) *reinterpret_cast<af4*>(row + d0) = af4{mul * acc[db][0], mul * acc[db][1], mul * acc[db][2], mul * acc[db][3]};
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (d0 + e < g.hd) row[d0 + e] = mul * acc[db][e];
+        }
+    }
+}
+
+// accumulator image of  bias[head][i][j] (+ -100 where the shift mask separates i and j)  for the wave's score tile: the score product
+// starts from it, so the sixteen (L2) loads of a lane are in flight under the tile stash and the products instead of inside the row phase
+__device__ __forceinline__ void score_init(const AttnGeom& g, const float* bias, const int* reg, int head, int ti, int tj, f32x16& acc) {
     const int l = threadIdx.x & 63, lr = l & 31, lk = l >> 5;
-    const int d = 32 * tj + lr;
-    if (d >= g.hd) return;
+    const int j = 32 * tj + lr, jc = j < g.N ? j : g.N - 1;
+    const int i0 = 32 * ti + 4 * lk;                                   // the lane's rows: i0 + (r & 3) + 8 (r >> 2)
+    if (g.N == NMAX) {                                                 // every row and column a token: one base pointer, constant row offsets
+        const float* b0 = bias + ((long)head * NMAX + i0) * NMAX + j;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = b0[((r & 3) + 8 * (r >> 2)) * NMAX];
+        if (g.shift > 0) {
+            const int rj = reg[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (reg[i0 + (r & 3) + 8 * (r >> 2)] != rj) acc[r] += -100.0f;
+        }
+        return;
+    }
+    const int rj = g.shift > 0 ? reg[jc] : 0;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        const int i = 32 * ti + (r & 3) + 8 * (r >> 2) + 4 * lk;
-        if (i < g.N) dst[(long)pix[i] * row_stride + ch0 + d] = mul * acc[r];
+        const int i = i0 + (r & 3) + 8 * (r >> 2), ic = i < g.N ? i : g.N - 1;
+        float v = bias[((long)head * g.N + ic) * g.N + jc];
+        if (g.shift > 0 && reg[ic] != rj) v += -100.0f;
+        acc[r] = v;
     }
 }
 
@@ -185,23 +267,18 @@ __device__ __forceinline__ void load_tile256(const AttnGeom& g, const float* src
 // and the loops have compile-time bounds.  (`softmax_row` on 64 threads walked a row of LDS three times in run-time loops while three
 // quarters of the workgroup waited: the row phase, not the five 64 x 64 x hd products, was most of the attention kernels' time.)
 // `dP` != nullptr (backward): also D = sum_j P dP and dS = P (dP - D), written over dP.  Rows / columns beyond N are zeroed in both.
-__device__ __forceinline__ void softmax_rows256(const AttnGeom& g, float* S, float* dP, const float* bias, const int* reg, int head, float* probs,
-                                                int win) {
+// (bias and shift mask are inside S already: the score product started from them, `score_init`)
+__device__ __forceinline__ void softmax_rows256(const AttnGeom& g, float* S, float* dP, int head, float* probs, int win) {
     const int i = threadIdx.x >> 2, part = threadIdx.x & 3;
     const bool rowok = i < g.N;
     float* row = S + i * SS;
-    const float* br = bias + ((long)head * g.N + (rowok ? i : 0)) * g.N;
-    const int ri = (g.shift > 0 && rowok) ? reg[i] : 0;
     float v[16];
     float mx = -3.0e38f;
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int j = part + 4 * k;
         float sv = -3.0e38f;
-        if (rowok && j < g.N) {
-            sv = row[j] + br[j];
-            if (g.shift > 0 && reg[j] != ri) sv += -100.0f;
-        }
+        if (rowok && j < g.N) sv = row[j];
         v[k] = sv;
         mx = fmaxf(mx, sv);
     }
@@ -258,7 +335,6 @@ __device__ __forceinline__ void attn_item(int id, int windows, int heads, int& w
 // One tile (Q, K, V or dO of a (window, head) pair) travels global -> registers -> LDS in two steps, so that the loads of the NEXT work
 // item are in flight while the current one is multiplied (`fetch` right behind the barrier that publishes the current tiles, `stash`
 // at the top of the next item).  Vector form only: head dim and channel offsets multiples of 4 (every Lu2022 shape).
-typedef float af4 __attribute__((ext_vector_type(4)));
 // TILE_IT = ceil(tokens x hd / 4 / 256): quads per thread and tile (hd <= 16: 1, <= 32: 2, <= 48: 3, <= 64: 4) -- a template parameter, the
 // prefetch registers of a kernel are 3 or 4 tiles x TILE_IT x 4
 template <int TILE_IT>
@@ -271,6 +347,7 @@ __device__ __forceinline__ void tile_fetch(const AttnGeom& g, const float* src, 
         const int e0 = threadIdx.x + 256 * it;
         const int e = e0 < nq ? e0 : nq - 1;
         const int tok = e / qpt, dq = e - tok * qpt;
+        if (ATTN_ABL(4)) { r[it] = af4{0.1f, 0.2f, -0.1f, 0.3f}; continue; }
         r[it] = *reinterpret_cast<const af4*>(src + (long)pix[tok] * row_stride + ch0 + 4 * dq);
     }
 }
@@ -298,7 +375,8 @@ __device__ __forceinline__ void tile_stash(const AttnGeom& g, const af4 (&r)[TIL
 // products.  PF = false (head dims that are not multiples of 4): tiles loaded in place, no prefetch.
 template <bool PF, int TILE_IT>
 __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
-                                                                int no_pv, int windows, int nitems) {
+                                                                int no_pv, int windows, int nitems, int stagger) {
+    constexpr int NDB = PF ? TILE_IT : 4;                     // 16-channel blocks of a head (TILE_IT = ceil(hd / 16) on the vector path)
     extern __shared__ float lds[];
     float* V = lds;
     float* Q = V + 64 * g.hs;
@@ -308,7 +386,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
     const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
     const int lr = threadIdx.x & 31, ai = 32 * ti + lr, bj = 32 * tj + lr, hs = g.hs;
     const bool full = g.N == NMAX && (g.hd & 1) == 0;         // every row a token, no odd-K zero column: nothing reads the padding
-    const int hk = (g.hd + 1) & ~1, nk = (g.N + 1) & ~1;
+    const int hk = (g.hd + 1) & ~1;
     auto tables = [&](int b, int win) {
         if (threadIdx.x < g.N) {
             pix[b][threadIdx.x] = token_pixel(g, win, threadIdx.x);
@@ -326,6 +404,11 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
     tables(0, win);
     __syncthreads();
     if (PF) fetch(0, head);
+    if (stagger > 0) {                                        // residency slot of this workgroup on its CU (guess: ids go over 8 XCDs x 32 CUs first)
+        const int st = stagger & 0xFFFF, key = stagger >> 16;
+        const int slot = key == 0 ? (blockIdx.x >> 8) : (int)((blockIdx.x >> 3) % (unsigned)(key + 1));
+        for (int k = slot * st; k > 0; k -= 100) __builtin_amdgcn_s_sleep(100);
+    }
     for (;;) {
         if (!full) {
             zero_lds(lds, 3 * 64 * g.hs);
@@ -340,6 +423,8 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
             load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix[buf], K, 1.f);
             load_tile256(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix[buf], V, 1.f);
         }
+        f32x16 sc[1];
+        score_init(g, bias, reg[buf], head, ti, tj, sc[0]);  // (behind the stash: the prefetch registers are free; its loads land under the barrier)
         const int nid = id + gridDim.x;
         const bool more = nid < nitems;
         int nwin = 0, nhead = 0;
@@ -349,20 +434,17 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
         }
         __syncthreads();                                      // tiles of this item and tables of the next are visible
         if (PF && more) fetch(buf ^ 1, nhead);               // in flight while this item is multiplied
-        f32x16 sc[1];
-        tile_gemm_multi<1>(sc, hk, [&](int, int k, float& a, float& b) { a = Q[ai * hs + k]; b = K[bj * hs + k]; });
+        tile_gemm_multi<1, true>(sc, ATTN_ABL(2) ? 0 : hk, [&](int, int k, float& a, float& b) { a = Q[ai * hs + k]; b = K[bj * hs + k]; });
         __syncthreads();                                      // every wave has read Q and K
         tile_to_lds(sc[0], S, SS, ti, tj);
         __syncthreads();
-        softmax_rows256(g, S, nullptr, bias, reg[buf], head, probs, win);
+        if (!ATTN_ABL(8)) softmax_rows256(g, S, nullptr, head, probs, win);
         if (!no_pv) {
             __syncthreads();
-            if (32 * tj < g.hd) {
-                const bool bok = bj < g.hd;
-                f32x16 o[1];
-                tile_gemm_multi<1>(o, nk, [&](int, int k, float& a, float& b) { a = S[ai * SS + k]; b = bok ? V[k * hs + bj] : 0.f; });
-                tile_to_global(g, o[0], out, g.C, head * g.hd, pix[buf], ti, tj, 1.f);
-            }
+            f32x4s o[1][NDB];                                 // O^T = V^T P^T: rows = channels, columns = tokens
+            if (!ATTN_ABL(2))
+                stage2_gemm<1, NDB>(o, [&](int, int k, int d) { return d < g.hd ? V[k * hs + d] : 0.f; }, [&](int, int k, int t) { return S[t * SS + k]; });
+            stage2_store<NDB>(g, o[0], out, g.C, head * g.hd, pix[buf], 1.f);
         }
         if (!more) break;
         __syncthreads();                                      // every wave is done with this item's LDS images
@@ -372,7 +454,8 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
 
 template <bool PF, int TILE_IT>
 __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* qkv, const float* bias, const float* dout, AttnGeom g,
-                                                                float* dqkv, int windows, int nitems) {
+                                                                float* dqkv, int windows, int nitems, int stagger) {
+    constexpr int NDB = PF ? TILE_IT : 4;
     extern __shared__ float lds[];
     float* Q = lds;                       // pre-scaled
     float* K = Q + 64 * g.hs;
@@ -384,7 +467,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* 
     const int w = threadIdx.x >> 6, ti = w >> 1, tj = w & 1;
     const int lr = threadIdx.x & 31, ai = 32 * ti + lr, bj = 32 * tj + lr, hs = g.hs;
     const bool full = g.N == NMAX && (g.hd & 1) == 0;
-    const int hk = (g.hd + 1) & ~1, nk = (g.N + 1) & ~1;
+    const int hk = (g.hd + 1) & ~1;
     auto tables = [&](int b, int win) {
         if (threadIdx.x < g.N) {
             pix[b][threadIdx.x] = token_pixel(g, win, threadIdx.x);
@@ -403,7 +486,14 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* 
     tables(0, win);
     __syncthreads();
     if (PF) fetch(0, head);
+    if (stagger > 0) {                                        // residency slot of this workgroup on its CU (guess: ids go over 8 XCDs x 32 CUs first)
+        const int st = stagger & 0xFFFF, key = stagger >> 16;
+        const int slot = key == 0 ? (blockIdx.x >> 8) : (int)((blockIdx.x >> 3) % (unsigned)(key + 1));
+        for (int k = slot * st; k > 0; k -= 100) __builtin_amdgcn_s_sleep(100);
+    }
     for (;;) {
+        f32x16 sd[2];                                                                              // scores Q K^T (from bias + mask) and dP = dO V^T, stepped together
+        score_init(g, bias, reg[buf], head, ti, tj, sd[0]);
         if (!full) {
             zero_lds(lds, 4 * 64 * g.hs);
             __syncthreads();
@@ -428,8 +518,7 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* 
         }
         __syncthreads();
         if (PF && more) fetch(buf ^ 1, nhead);
-        f32x16 sd[2];                                                                              // scores Q K^T and dP = dO V^T, stepped together
-        tile_gemm_multi<2>(sd, hk, [&](int gi, int k, float& a, float& b) {
+        tile_gemm_multi<2, true>(sd, ATTN_ABL(2) ? 0 : hk, [&](int gi, int k, float& a, float& b) {
             if (gi == 0) { a = Q[ai * hs + k]; b = K[bj * hs + k]; }
             else { a = dO[ai * hs + k]; b = V[bj * hs + k]; }
         });
@@ -437,20 +526,19 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* 
         tile_to_lds(sd[0], P, SS, ti, tj);
         tile_to_lds(sd[1], dS, SS, ti, tj);
         __syncthreads();
-        softmax_rows256(g, P, dS, bias, reg[buf], head, nullptr, win);
+        if (!ATTN_ABL(8)) softmax_rows256(g, P, dS, head, nullptr, win);
         __syncthreads();
-        if (32 * tj < g.hd) {
-            // dQ = scale * dS K ; dK = dS^T Qs (Qs carries the scale) ; dV = P^T dO -- three independent accumulators, stepped together
-            const bool bok = bj < g.hd;
-            f32x16 d3[3];
-            tile_gemm_multi<3>(d3, nk, [&](int gi, int k, float& a, float& b) {
-                if (gi == 0) { a = dS[ai * SS + k]; b = bok ? K[k * hs + bj] : 0.f; }
-                else if (gi == 1) { a = dS[k * SS + ai]; b = bok ? Q[k * hs + bj] : 0.f; }
-                else { a = P[k * SS + ai]; b = bok ? dO[k * hs + bj] : 0.f; }
-            });
-            tile_to_global(g, d3[0], dqkv, 3 * g.C, head * g.hd, pix[buf], ti, tj, g.scale);
-            tile_to_global(g, d3[1], dqkv, 3 * g.C, g.C + head * g.hd, pix[buf], ti, tj, 1.f);
-            tile_to_global(g, d3[2], dqkv, 3 * g.C, 2 * g.C + head * g.hd, pix[buf], ti, tj, 1.f);
+        {
+            // transposed (rows = channels, columns = tokens): dQ^T = scale * K^T dS^T ; dK^T = Qs^T dS (Qs carries the scale) ; dV^T = dO^T P --
+            // three independent products, stepped together
+            f32x4s d3[3][NDB];
+            if (!ATTN_ABL(2))
+                stage2_gemm<3, NDB>(d3,
+                    [&](int gi, int k, int d) { return d < g.hd ? (gi == 0 ? K : (gi == 1 ? Q : dO))[k * hs + d] : 0.f; },
+                    [&](int gi, int k, int t) { return gi == 0 ? dS[t * SS + k] : (gi == 1 ? dS : P)[k * SS + t]; });
+            stage2_store<NDB>(g, d3[0], dqkv, 3 * g.C, head * g.hd, pix[buf], g.scale);
+            stage2_store<NDB>(g, d3[1], dqkv, 3 * g.C, g.C + head * g.hd, pix[buf], 1.f);
+            stage2_store<NDB>(g, d3[2], dqkv, 3 * g.C, 2 * g.C + head * g.hd, pix[buf], 1.f);
         }
         if (!more) break;
         __syncthreads();
@@ -702,10 +790,46 @@ int make_geom(const rdo_attn_desc* d, AttnGeom* g, const char* who) {
     g->hs = (g->hd + 1) | 1;                 // odd row stride; an odd head dim gets the zero column its last k pair reads (hd + 2)
     RDO_REQUIRE(g->hd <= 64, "%s: head dims above 64 are not supported", who);
     g->scale = d->scale;
+#ifdef RDO_DIAG
+    { const char* e = getenv("RDO_ATTN_DIAG"); g->diag = e ? atoi(e) : 0; }
+#endif
     return RDO_OK;
 }
 
 }  // namespace
+
+// persistent grid of an attention kernel: as many workgroups as are RESIDENT at once -- registers count as well as LDS (the forward
+// kernels fit four times into a CU's LDS at hd = 48 but three times into its register file: a grid of 1024 ran as 768 + a second round
+// of 256 on a third of the chip) -- a multiple of 8 so that a workgroup's items stay on one XCD
+template <typename K>
+static long attn_grid(K kern, size_t lds, int nitems, int slot, bool bwd) {
+    struct Memo { size_t lds; int dev; long resident; };
+    static thread_local Memo memo[2][5] = {};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    Memo& m = memo[bwd ? 1 : 0][slot];
+    if (m.resident == 0 || m.lds != lds || m.dev != dev) {
+        int per_cu = 0, cus = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(kern), 256, lds) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+#ifdef RDO_DIAG
+        if (const char* e = getenv("RDO_ATTN_MAXOCC")) per_cu = atoi(e) < per_cu ? atoi(e) : per_cu;
+#endif
+        m = Memo{lds, dev, (long)per_cu * cus / 8 * 8};
+    }
+    return nitems < m.resident ? nitems : m.resident;
+}
+
+// co-resident workgroups start in step and stay in step (same work, same contention): every phase of one collides with the same phase
+// of the other -- tools/attn_ablate.py: the costs of loads, products, softmax rows and stores ADD UP to the kernel time.  Workgroups of
+// the second (third) residency slot of a CU (launch ids are dealt round-robin over the XCDs, then over a XCD's CUs) start late by
+// `stagger` x 64 cycles per slot: their product phase then runs under the other's row / store phases.  Tuning only: a wrong guess
+// about the placement costs the delay once.
+static int attn_stagger(bool bwd) {
+    static const int v[2] = {[] { const char* e = getenv("RDO_ATTN_STAGGER_FWD"); return e ? atoi(e) : 0; }(),
+                             [] { const char* e = getenv("RDO_ATTN_STAGGER_BWD"); return e ? atoi(e) : 0; }()};
+    return v[bwd ? 1 : 0];
+}
 
 extern "C" {
 
@@ -720,10 +844,7 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
     const int no_pv = out == nullptr;
     const int nitems = windows * g.heads;
     const bool pf = ((g.hd | g.C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv)) & 15) == 0;
-    // persistent workgroups: as many as are resident at once (LDS-bound), a multiple of 8 so that a workgroup's items stay on one XCD
-    const long resident = (long)256 * (160 * 1024 / (long)(lds + 1024));
-    long grid = nitems < resident ? nitems : resident / 8 * 8;
-    if (grid < 1) grid = 1;
+    const int stagger = attn_stagger(false);
     return rdo::dispatch(
         [=](hipStream_t s) {
             auto go = [&](auto kern, int slot) -> int {
@@ -733,7 +854,8 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
                         return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_fwd_mfma) failed");
                     attr[slot].mark();
                 }
-                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv, windows, nitems);
+                const long grid = attn_grid(kern, lds, nitems, slot, false);
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv, windows, nitems, stagger);
                 return rdo::check_launch("window_attention_fwd");
             };
             if (!pf) return go(win_attn_fwd_mfma_kernel<false, 1>, 0);
@@ -771,9 +893,7 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
     static_assert(SS >= 64 + 1, "P must cover a 64-float row");
     const int nitems = windows * g.heads;
     const bool pf = ((g.hd | g.C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0;
-    const long resident = (long)256 * (160 * 1024 / (long)(lds + 1024));
-    long grid = nitems < resident ? nitems : resident / 8 * 8;
-    if (grid < 1) grid = 1;
+    const int stagger = attn_stagger(true);
     return rdo::dispatch(
         [=](hipStream_t s) {
             auto go = [&](auto kern, int slot) -> int {
@@ -783,7 +903,8 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
                         return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(win_attn_bwd_mfma) failed");
                     attr[slot].mark();
                 }
-                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, dout, g, dqkv, windows, nitems);
+                const long grid = attn_grid(kern, lds, nitems, slot, true);
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, dout, g, dqkv, windows, nitems, stagger);
                 return rdo::check_launch("window_attention_bwd");
             };
             if (!pf) return go(win_attn_bwd_mfma_kernel<false, 1>, 0);
