@@ -288,7 +288,7 @@ __device__ __forceinline__ void softmax_rows256(const AttnGeom& g, float* S, flo
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int j = part + 4 * k;
-        const float e = (rowok && j < g.N) ? expf(v[k] - mx) : 0.f;
+        const float e = (rowok && j < g.N) ? __expf(v[k] - mx) : 0.f;      // v_exp_f32(x log2 e): |error| <= ~|x| 2^-23 of e^x, x in [-100, 0]
         v[k] = e;
         sum += e;
     }
@@ -337,29 +337,43 @@ __device__ __forceinline__ void attn_item(int id, int windows, int heads, int& w
 // at the top of the next item).  Vector form only: head dim and channel offsets multiples of 4 (every Lu2022 shape).
 // TILE_IT = ceil(tokens x hd / 4 / 256): quads per thread and tile (hd <= 16: 1, <= 32: 2, <= 48: 3, <= 64: 4) -- a template parameter, the
 // prefetch registers of a kernel are 3 or 4 tiles x TILE_IT x 4
+// The thread's quads of a tile: token, channel offset, LDS offset -- the same for every tile and every item, computed ONCE per kernel
+// (per tile and item they cost two integer divisions by a run-time value each, in `fetch` and again in `stash`: a fifth of the
+// backward kernel went into issuing its twelve loads).
 template <int TILE_IT>
-__device__ __forceinline__ void tile_fetch(const AttnGeom& g, const float* src, int row_stride, int ch0, const int* pix, af4 (&r)[TILE_IT]) {
-    const int qpt = g.hd >> 2, nq = g.N * qpt;
-    // UNCONDITIONAL loads (a lane past the tile re-reads its last quad): a load behind a per-lane branch is a basic block of its own, and
-    // hipcc waits vmcnt(0) at every join -- twelve serial memory round trips per prefetch instead of one
+struct TileMap {
+    int tok[TILE_IT], ch[TILE_IT], lds[TILE_IT];
+    bool ok[TILE_IT];
+    __device__ __forceinline__ void init(const AttnGeom& g) {
+        const int qpt = g.hd >> 2, nq = g.N * qpt;
+#pragma unroll
+        for (int it = 0; it < TILE_IT; ++it) {
+            const int e0 = threadIdx.x + 256 * it;
+            ok[it] = e0 < nq;
+            const int e = ok[it] ? e0 : nq - 1;              // (a lane past the tile re-reads the last quad: loads stay unconditional)
+            tok[it] = e / qpt;
+            ch[it] = 4 * (e - tok[it] * qpt);
+            lds[it] = tok[it] * g.hs + ch[it];
+        }
+    }
+};
+// UNCONDITIONAL loads: a load behind a per-lane branch is a basic block of its own, and hipcc waits vmcnt(0) at every join -- twelve serial
+// memory round trips per prefetch instead of one.  `rowoff[it]` = pixel of the quad's token x row stride (one table lookup per quad and item)
+template <int TILE_IT>
+__device__ __forceinline__ void tile_fetch(const AttnGeom& g, const TileMap<TILE_IT>& m, const float* src, const long (&rowoff)[TILE_IT], int ch0,
+                                           af4 (&r)[TILE_IT]) {
 #pragma unroll
     for (int it = 0; it < TILE_IT; ++it) {
-        const int e0 = threadIdx.x + 256 * it;
-        const int e = e0 < nq ? e0 : nq - 1;
-        const int tok = e / qpt, dq = e - tok * qpt;
         if (ATTN_ABL(4)) { r[it] = af4{0.1f, 0.2f, -0.1f, 0.3f}; continue; }
-        r[it] = *reinterpret_cast<const af4*>(src + (long)pix[tok] * row_stride + ch0 + 4 * dq);
+        r[it] = *reinterpret_cast<const af4*>(src + rowoff[it] + ch0 + m.ch[it]);
     }
 }
 template <int TILE_IT>
-__device__ __forceinline__ void tile_stash(const AttnGeom& g, const af4 (&r)[TILE_IT], float* dst, float mul) {
-    const int qpt = g.hd >> 2, nq = g.N * qpt;
+__device__ __forceinline__ void tile_stash(const TileMap<TILE_IT>& m, const af4 (&r)[TILE_IT], float* dst, float mul) {
 #pragma unroll
     for (int it = 0; it < TILE_IT; ++it) {
-        const int e = threadIdx.x + 256 * it;
-        if (e < nq) {
-            const int tok = e / qpt, dq = e - tok * qpt;
-            float* d = dst + tok * g.hs + 4 * dq;              // (hs is odd: scalar LDS stores)
+        if (m.ok[it]) {
+            float* d = dst + m.lds[it];                      // (hs is odd: scalar LDS stores)
             d[0] = mul * r[it][0]; d[1] = mul * r[it][1]; d[2] = mul * r[it][2]; d[3] = mul * r[it][3];
         }
     }
@@ -394,10 +408,15 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
         }
     };
     af4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT];
+    TileMap<TILE_IT> tm;
+    tm.init(g);
     auto fetch = [&](int b, int head) {
-        tile_fetch(g, qkv, 3 * g.C, head * g.hd, pix[b], rq);
-        tile_fetch(g, qkv, 3 * g.C, g.C + head * g.hd, pix[b], rk);
-        tile_fetch(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix[b], rv);
+        long ro3[TILE_IT];
+#pragma unroll
+        for (int it = 0; it < TILE_IT; ++it) ro3[it] = (long)pix[b][tm.tok[it]] * (3 * g.C);
+        tile_fetch(g, tm, qkv, ro3, head * g.hd, rq);
+        tile_fetch(g, tm, qkv, ro3, g.C + head * g.hd, rk);
+        tile_fetch(g, tm, qkv, ro3, 2 * g.C + head * g.hd, rv);
     };
     int id = blockIdx.x, buf = 0, win, head;
     attn_item(id, windows, g.heads, win, head);
@@ -415,9 +434,9 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
             __syncthreads();
         }
         if (PF) {
-            tile_stash(g, rq, Q, g.scale);
-            tile_stash(g, rk, K, 1.f);
-            tile_stash(g, rv, V, 1.f);
+            tile_stash(tm, rq, Q, g.scale);
+            tile_stash(tm, rk, K, 1.f);
+            tile_stash(tm, rv, V, 1.f);
         } else {
             load_tile256(g, qkv, 3 * g.C, head * g.hd, pix[buf], Q, g.scale);
             load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix[buf], K, 1.f);
@@ -475,11 +494,20 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* 
         }
     };
     af4 rq[TILE_IT], rk[TILE_IT], rv[TILE_IT], ro[TILE_IT];
+    TileMap<TILE_IT> tm;
+    tm.init(g);
     auto fetch = [&](int b, int head) {
-        tile_fetch(g, qkv, 3 * g.C, head * g.hd, pix[b], rq);
-        tile_fetch(g, qkv, 3 * g.C, g.C + head * g.hd, pix[b], rk);
-        tile_fetch(g, qkv, 3 * g.C, 2 * g.C + head * g.hd, pix[b], rv);
-        tile_fetch(g, dout, g.C, head * g.hd, pix[b], ro);
+        long ro3[TILE_IT], ro1[TILE_IT];
+#pragma unroll
+        for (int it = 0; it < TILE_IT; ++it) {
+            const long px = pix[b][tm.tok[it]];
+            ro3[it] = px * (3 * g.C);
+            ro1[it] = px * g.C;
+        }
+        tile_fetch(g, tm, qkv, ro3, head * g.hd, rq);
+        tile_fetch(g, tm, qkv, ro3, g.C + head * g.hd, rk);
+        tile_fetch(g, tm, qkv, ro3, 2 * g.C + head * g.hd, rv);
+        tile_fetch(g, tm, dout, ro1, head * g.hd, ro);
     };
     int id = blockIdx.x, buf = 0, win, head;
     attn_item(id, windows, g.heads, win, head);
@@ -499,10 +527,10 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* 
             __syncthreads();
         }
         if (PF) {
-            tile_stash(g, rq, Q, g.scale);
-            tile_stash(g, rk, K, 1.f);
-            tile_stash(g, rv, V, 1.f);
-            tile_stash(g, ro, dO, 1.f);
+            tile_stash(tm, rq, Q, g.scale);
+            tile_stash(tm, rk, K, 1.f);
+            tile_stash(tm, rv, V, 1.f);
+            tile_stash(tm, ro, dO, 1.f);
         } else {
             load_tile256(g, qkv, 3 * g.C, head * g.hd, pix[buf], Q, g.scale);
             load_tile256(g, qkv, 3 * g.C, g.C + head * g.hd, pix[buf], K, 1.f);
