@@ -49,3 +49,16 @@ for rows, K, N, kind in [(65536, 192, 576, "act"), (65536, 192, 192, "act"), (65
     fl = 2.0 * rows * K * N
     print(f"{rows:6d} x {K:3d} -> {N:3d} {kind:4s}: linear_h2 {t2:7.1f} us ({fl / t2 * 1e-6:6.1f} TFLOP/s)  bf16x6 conv {t6:7.1f} us ({fl / t6 * 1e-6:6.1f})   "
           f"max err / token max: h2 {e2:.2e}  x6 {e6:.2e}", flush=True)
+
+# the GELU epilogues (Mlp.fc1 + GELU: 192 -> 384 with the pre-activation kept; fc2's input gradient through the GELU: 192 -> 384 reading the pre-activation)
+from hipops import _lib as L  # noqa: E402
+for rows in (65536, 16384):
+    x = torch.randn(rows, 192, device="cuda", generator=g)
+    w = torch.randn(384, 192, device="cuda", generator=g) / 192 ** 0.5
+    b = torch.randn(384, device="cuda", generator=g)
+    planes = ops.split_h2_linear(w)
+    pre, y, aux = torch.empty(rows, 384, device="cuda"), torch.empty(rows, 384, device="cuda"), torch.randn(rows, 384, device="cuda", generator=g)
+    t0 = timed(lambda: ops.linear_h2(x, planes, b, out=y))
+    t1 = timed(lambda: ops.linear_h2(x, planes, b, out=y, epilogue=L.EPI_GELU, pre=pre))
+    t2 = timed(lambda: ops.linear_h2(x, planes, None, out=y, epilogue=L.EPI_GELU_BWD, aux=aux))
+    print(f"{rows:6d} x 192 -> 384: plain {t0:6.1f} us   + GELU (pre kept) {t1:6.1f} us   GELU backward (aux read) {t2:6.1f} us", flush=True)
