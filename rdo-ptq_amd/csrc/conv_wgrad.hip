@@ -244,6 +244,8 @@ inline int tiles_total(const rdo_conv_desc* d) {
 }  // namespace
 
 int rdo_launch_wgrad_x6(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, int mchunk, hipStream_t s);
+bool rdo_linear_wgrad_h2_ok(const rdo_conv_desc* d, const float* x, const float* dy);                                   // conv_wgrad_h2.hip
+int rdo_launch_linear_wgrad_h2(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, int mchunk, hipStream_t s);
 bool rdo_conv_is_thin(const rdo_conv_desc* d, bool forward);                                                            // conv_thin.hip
 int rdo_launch_thin_wgrad(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, hipStream_t s);
 bool rdo_conv_is_thincout(const rdo_conv_desc* d, bool forward);                                                        // conv_thincout.hip
@@ -283,7 +285,8 @@ extern "C" int rdo_conv2d_wgrad_nsplit(const rdo_conv_desc* d) {
     const long max_by_m = rdo::ceil_div(M, 128);
     if (ns > max_by_m) ns = max_by_m;
     if (ns < 1) ns = 1;
-    const long cap = (g_force_big < 0 && one_tile_many_pixels(d)) ? 256 : 64;
+    // (token-matrix gradients on linear_wgrad_h2_kernel stream 48 KB per 32-token stage and workgroup: they want every CU, 128 slabs at two tiles)
+    const long cap = (g_force_big < 0 && one_tile_many_pixels(d)) ? 256 : ((g_force_big != 0 && rdo_linear_wgrad_h2_ok(d, nullptr, nullptr)) ? 128 : 64);
     if (ns > cap) ns = cap;
     return (int)ns;
 }
@@ -317,6 +320,14 @@ extern "C" int rdo_conv2d_wgrad(const rdo_conv_desc* d, const float* x, const fl
         return rdo::dispatch([=](hipStream_t s) { return rdo_launch_thin_wgrad(&dd, x, dy, slabs, nsplit, s); }, stream,
                              "conv_thin_wgrad", 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW,
                              4.0 * ((double)a.B * a.H * a.W * a.Cin + (double)a.M * a.Cout + (double)nsplit * a.Cout * a.KH * a.KW * a.Cin));
+    }
+    // token-matrix gradients (1 x 1, channel counts in blocks of 192) straight from fp32 on split-fp16 MFMA with a per-stage scale
+    if (g_force_big != 0 && rdo_linear_wgrad_h2_ok(d, x, dy) && (long)nsplit * a.mchunk >= a.M) {
+        const rdo_conv_desc dd = *d;
+        const int mchunk = a.mchunk;
+        return rdo::dispatch([=](hipStream_t s) { return rdo_launch_linear_wgrad_h2(&dd, x, dy, slabs, nsplit, mchunk, s); }, stream,
+                             "linear_wgrad_h2", 2.0 * a.M * (double)a.Cout * a.Cin,
+                             4.0 * ((double)a.M * a.Cin + (double)a.M * a.Cout + (double)nsplit * a.Cout * a.Cin));
     }
     if (vec && rdo_conv2d_wgrad_uses_bf16x6(d)) {
         const rdo_conv_desc dd = *d;

@@ -270,6 +270,233 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_h2_kernel(WgPArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------------------
+// Token-matrix weight gradient from FP32 operands (round 5):  dW[n][k] = sum_t dY[t][n] X[t][k]  -- the weight gradients of the
+// trainable Linears of the Lu2022 blocks (quant_layer.py:119 wrapped nn.Linear; 1 x 1 "convs" over [tokens][channels]) and the gamma
+// gradient of a GDN (X = the squared input, quant_layer.py:147).  They ran on the split-bf16 kernel (conv_wgrad_x6.hip: six products,
+// both operands split and transposed in registers by its loader -- 112 us for the 576 x 192 gradient over 64 K tokens, 1.8 TB/s).
+// Here: the MFMA side of conv_wgrad_h2_kernel above unchanged (LDS images [pixel][channel] of two fp16 planes, transposed reads, three
+// products) behind a loader that takes fp32 rows, scales a 32-token stage by a power of two and splits it in registers.
+// Scale: the reduction runs over tokens, so a scale has to be common to all 32 tokens of a stage (one MFMA sums them); it is taken from
+// the largest magnitude of the stage (-> [2^13, 2^14)), never larger than the scale of the stages before it, and the accumulators are
+// multiplied by the (exact, <= 1) ratio when a new largest stage arrives: products of small stages carry the running scale -- their
+// low bits fall below the fp32 accumulator's own resolution for the sum, like the small terms of any fp32 accumulation.
+// Pipeline per 32-token stage (one barrier): split stage s+1 (registers -> the other LDS image) | request stage s+3 | largest magnitude
+// of stage s+2 (landed) -> LDS slots | products of stage s.  Requests are inline asm with counted waits (see linear_h2.hip).
+struct LwArgs {
+    const float* x;      // [M][Cin]
+    const float* dy;     // [M][Cout]
+    float* slabs;        // [nsplit][Cout][Cin]
+    int M, Cin, Cout, mchunk, nsplit, tiles_co, tiles_ci;
+};
+
+typedef float lw4 __attribute__((ext_vector_type(4)));
+typedef _Float16 lwh8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float lw_pow2(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+
+template <bool SQ>
+__global__ __launch_bounds__(512, 2) void linear_wgrad_h2_kernel(LwArgs a) {
+    constexpr int T = 192;
+    constexpr int TM = 3, TN = 6;
+    extern __shared__ __attribute__((aligned(16))) char smem[];          // [2][STAGEB], then the small tables
+    float* amax_slot = reinterpret_cast<float*>(smem + 2 * STAGEB);      // [2 (stage parity)][2 (dY, X)][4 waves]
+    int* stage_exp = reinterpret_cast<int*>(amax_slot + 16);             // [4 (stage & 3)][2]: log2 of the scale of (dY, X)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l16 = lane & 15, lc = lane >> 4;
+    const int wco0 = (wave >> 1) * 48, wci0 = (wave & 1) * 96;
+
+    const int nwg = gridDim.x * gridDim.y;
+    const int lin = blockIdx.x + gridDim.x * blockIdx.y;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = lin & 7;
+    const int lid = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+    const int chunk = lid / gridDim.y;
+    int t = lid - chunk * gridDim.y;
+    const int tci = t % a.tiles_ci;
+    const int tco = t / a.tiles_ci;
+    const int co0 = tco * T, ci0 = tci * T;
+    const int mbeg = chunk * a.mchunk;
+    const int mend = min(a.M, mbeg + a.mchunk);
+    const int nsteps = mend > mbeg ? (mend - mbeg) / PK : 0;             // (M and mchunk are multiples of 32)
+
+    // ---- loader roles: waves 0-3 take dY, waves 4-7 take X; thread -> token row (t >> 3) of the stage, 8-channel chunk (t & 7) of each of
+    // the three 64-channel sub-tiles: two float4 per chunk
+    const bool ldx = wave >= 4;
+    const int lt = tid & 255, prow = lt >> 3, cpos = lt & 7;
+    const int Cop = ldx ? a.Cin : a.Cout;
+    const float* const rowbase = (ldx ? a.x + ci0 : a.dy + co0) + (long)(mbeg + prow) * Cop + 8 * cpos;
+    char* const ldst = smem + (ldx ? OPB : 0) + prow * 128 + ((cpos ^ (2 * ((prow >> 1) & 3))) * 16);
+    lw4 R[2][6];
+    auto request = [&](lw4 (&r)[6], int stage) {
+        const int st = stage < nsteps ? stage : (nsteps > 0 ? nsteps - 1 : 0);      // past the end: a valid stage again (never multiplied)
+        const float* src = rowbase + (long)st * PK * Cop;
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[0]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r[1]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(r[2]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:272" : "=v"(r[3]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(r[4]) : "v"(src) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:528" : "=v"(r[5]) : "v"(src) : "memory");
+    };
+    // the six requests issued BEFORE the youngest six have landed -> largest magnitude of the stage into this wave's slot
+    auto landed_amax = [&](lw4 (&r)[6], int parity) {
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 6; ++k) asm volatile("" : "+v"(r[k]));
+        float m = 0.f;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+            if (SQ && ldx) r[k] *= r[k];
+            m = fmaxf(m, fmaxf(fmaxf(fabsf(r[k][0]), fabsf(r[k][1])), fmaxf(fabsf(r[k][2]), fabsf(r[k][3]))));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+        if (lane == 0) amax_slot[parity * 8 + (ldx ? 4 : 0) + (wave & 3)] = m;
+    };
+    int erun = 100;                                                      // log2 of this operand's running scale (never grows)
+    auto split = [&](lw4 (&r)[6], int stage) {
+        const float* sl = amax_slot + (stage & 1) * 8 + (ldx ? 4 : 0);
+        const float m = fmaxf(fmaxf(sl[0], sl[1]), fmaxf(sl[2], sl[3]));
+        const int e = (int)((__builtin_bit_cast(unsigned, m) >> 23) & 0xFF) - 127;
+        int own = e < -100 ? 100 : 13 - e;                               // zeros / denormals: any scale; inf / NaN propagate through fp16
+        own = own < -100 ? -100 : own;
+        erun = own < erun ? own : erun;
+        if (lt == 0) stage_exp[(stage & 3) * 2 + (ldx ? 1 : 0)] = erun;
+        const float sc = lw_pow2(erun);
+        char* dst = ldst + (stage & 1) * STAGEB;
+#pragma unroll
+        for (int sub = 0; sub < 3; ++sub) {
+            const lw4 v0 = r[2 * sub] * sc, v1 = r[2 * sub + 1] * sc;
+            lwh8 hi, lo;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                hi[k] = (_Float16)v0[k];
+                hi[4 + k] = (_Float16)v1[k];
+                lo[k] = (_Float16)(v0[k] - (float)hi[k]);
+                lo[4 + k] = (_Float16)(v1[k] - (float)hi[4 + k]);
+            }
+            *reinterpret_cast<lwh8*>(dst + sub * SUBB) = hi;
+            *reinterpret_cast<lwh8*>(dst + PLANEB + sub * SUBB) = lo;
+        }
+    };
+
+    f32x4acc acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = f32x4acc{0.f, 0.f, 0.f, 0.f};
+
+    // ---- fragment addresses (as conv_wgrad_h2_kernel)
+    const int fr = 4 * lc + ((lane >> 2) & 3);
+    const int p4 = lane & 3;
+    const int fsw = 2 * ((fr >> 1) & 3);
+    int fa_off[TM], fb_off[TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int c = wco0 + 16 * i;
+        const int chunkpos = (2 * ((c & 63) >> 4) + (p4 >> 1)) ^ fsw;
+        fa_off[i] = (c >> 6) * SUBB + fr * 128 + chunkpos * 16 + (p4 & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int c = wci0 + 16 * j;
+        const int chunkpos = (2 * ((c & 63) >> 4) + (p4 >> 1)) ^ fsw;
+        fb_off[j] = OPB + (c >> 6) * SUBB + fr * 128 + chunkpos * 16 + (p4 & 1) * 8;
+    }
+    constexpr int PA[3] = {1, 0, 0};             // (dy2, x1) (dy1, x2) (dy1, x1): small terms first
+    constexpr int PB[3] = {0, 1, 0};
+
+    int Ey = 200, Ex = 200;                      // log2 of the scales the accumulators carry
+    if (nsteps > 0) {                            // (uniform; a chunk past the end of the tokens writes a slab of zeros)
+    // ---- prologue: stage 0 split, stage 1 measured, stage 2 requested
+    request(R[0], 0);
+    request(R[1], 1);
+    landed_amax(R[0], 0);
+    __syncthreads();
+    split(R[0], 0);
+    request(R[0], 2);
+    landed_amax(R[1], 1);
+
+    f16x8 fa[NP][TM], fb[2][NP][2];
+    auto read_b = [&](auto setc, const char* st, int third) {
+        constexpr int S = decltype(setc)::value;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) fb[S][p][j] = tr_pair(st + p * PLANEB + fb_off[2 * third + j]);
+    };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    auto stage = [&](auto parc, int s) {
+        constexpr int PAR = decltype(parc)::value;                       // s & 1: stage s + 1 sits in R[PAR ^ 1], stage s + 2 in R[PAR]
+        __syncthreads();                                                 // image s, its scales and the slots of stage s + 1 are complete
+        split(R[PAR ^ 1], s + 1);
+        request(R[PAR ^ 1], s + 3);
+        landed_amax(R[PAR], s & 1);                                      // stage s + 2 (parity (s + 2) & 1)
+        // accumulators follow the running scale (a new largest stage: exact ratio <= 1)
+        const int ey = stage_exp[(s & 3) * 2], ex = stage_exp[(s & 3) * 2 + 1];
+        if (ey + ex != Ey + Ex) {                                        // (uniform)
+            int d = (ey + ex) - (Ey + Ex);
+            d = d < -126 ? -126 : d;
+            const float ratio = s == 0 ? 1.f : lw_pow2(d);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) acc[i][j] *= ratio;
+            Ey = ey; Ex = ex;
+        }
+        const char* st = smem + (s & 1) * STAGEB;
+#pragma unroll
+        for (int p = 0; p < NP; ++p)
+#pragma unroll
+            for (int i = 0; i < TM; ++i) fa[p][i] = tr_pair(st + p * PLANEB + fa_off[i]);
+        read_b(S0{}, st, 0);
+        [&]<int... SL>(std::integer_sequence<int, SL...>) {
+            (([&] {
+                 constexpr int T3 = SL / 3, Q = SL % 3, SET = T3 & 1;
+                 if constexpr (Q == 0) {
+                     tr_wait();
+                     if constexpr (T3 < 2) {
+                         if constexpr (SET == 0) read_b(S1{}, st, T3 + 1);
+                         else read_b(S0{}, st, T3 + 1);
+                     }
+                 }
+#pragma unroll
+                 for (int i = 0; i < TM; ++i)
+#pragma unroll
+                     for (int j = 0; j < 2; ++j)
+                         acc[i][2 * T3 + j] =
+                             __builtin_amdgcn_mfma_f32_16x16x32_f16(fa[PA[Q]][i], fb[SET][PB[Q]][j], acc[i][2 * T3 + j], 0, 0, 0);
+                 __builtin_amdgcn_sched_barrier(0);
+             }()),
+             ...);
+        }
+        (std::make_integer_sequence<int, 9>{});
+    };
+    for (int s = 0; s < nsteps; s += 2) {
+        stage(S0{}, s);
+        if (s + 1 < nsteps) stage(S1{}, s + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                    // (the clamped tail requests)
+    } else {
+        Ey = Ex = 0;
+    }
+
+    const float fy = lw_pow2(-Ey), fx = lw_pow2(-Ex);                   // |E| <= 100 each: two exact factors
+    float* slab = a.slabs + (long)chunk * a.Cout * a.Cin;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int ci = ci0 + wci0 + j * 16 + l16;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wco0 + i * 16 + 4 * lc + r;
+                slab[(long)co * a.Cin + ci] = (acc[i][j][r] * fy) * fx;
+            }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
 // Row variant for 3 x 3 / stride 1 / pad 1 with Wo a multiple of 32 and Cin a multiple of 64: a workgroup owns the THREE kw taps of one
 // kh for a block of 64 input channels -- still a 192 x 192 output tile (192 co x [3 taps x 64 ci]) -- and a stage is 32 consecutive
 // pixels of ONE output row.  The three taps read the same input row shifted by one pixel, so the X image of a stage is 34 pixels x 64
@@ -775,6 +1002,36 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
             return rdo::check_launch("conv_wgrad_h2");
         },
         stream, "conv_wgrad_h2_192x192", flops, bytes);
+}
+
+// ---- fp32 token-matrix weight gradient (linear_wgrad_h2_kernel): called by rdo_conv2d_wgrad (conv_wgrad.hip) in front of the split-bf16 kernel
+bool rdo_linear_wgrad_h2_ok(const rdo_conv_desc* d, const float* x, const float* dy) {
+    static const int on = [] { const char* e = getenv("RDO_LIN_WGRAD_H2"); return e ? atoi(e) : 1; }();
+    if (!on || !d) return false;
+    const long M = (long)d->B * d->Ho * d->Wo;
+    return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 192 == 0 && d->Cout % 192 == 0 && M % 32 == 0 && M >= 8192 &&
+           ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
+}
+
+int rdo_launch_linear_wgrad_h2(const rdo_conv_desc* d, const float* x, const float* dy, float* slabs, int nsplit, int mchunk, hipStream_t s) {
+    LwArgs a{};
+    a.x = x; a.dy = dy; a.slabs = slabs;
+    a.M = d->B * d->Ho * d->Wo; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.mchunk = mchunk; a.nsplit = nsplit;
+    a.tiles_co = a.Cout / 192; a.tiles_ci = a.Cin / 192;
+    if ((long)nsplit * mchunk < a.M || mchunk % 32 != 0) return rdo::set_error(RDO_EINVAL, "linear_wgrad_h2: bad chunking (%d x %d over %d tokens)", nsplit, mchunk, a.M);
+    constexpr size_t lds = (size_t)2 * STAGEB + 16 * sizeof(float) + 8 * sizeof(int);
+    static rdo::PerDevice attr;
+    if (!attr.done()) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_wgrad_h2_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(linear_wgrad_h2_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+            return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(linear_wgrad_h2) failed");
+        attr.mark();
+    }
+    dim3 grid((unsigned)nsplit, (unsigned)(a.tiles_co * a.tiles_ci));
+    if (d->square_input) hipLaunchKernelGGL((linear_wgrad_h2_kernel<true>), grid, dim3(512), lds, s, a);
+    else hipLaunchKernelGGL((linear_wgrad_h2_kernel<false>), grid, dim3(512), lds, s, a);
+    return rdo::check_launch("linear_wgrad_h2");
 }
 
 #ifdef RDO_DIAG

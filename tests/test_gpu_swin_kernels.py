@@ -243,3 +243,30 @@ def test_linear_h2_gelu_epilogues(rows, K, N):
     lin = ops.linear_h2(x, planes, None)
     sep = ops.gelu_bwd(lin.view(-1), aux.view(-1)).view_as(lin)
     assert float((got - sep).abs().max()) <= 1e-6 * float(sep.abs().max())
+
+
+@pytest.mark.parametrize("rows,cin,cout", [(4 * 128 * 128, 192, 576), (4 * 64 * 64, 384, 192), (4096, 192, 192), (4 * 64 * 64 + 32 * 5, 576, 192)])
+@pytest.mark.parametrize("kind", ["act", "grad", "zero_blocks", "square"])
+def test_linear_weight_gradient_h2_matches_float64(rows, cin, cout, kind):
+    """The token-matrix weight gradient dW = dY^T X straight from fp32 operands on split-fp16 MFMA (linear_wgrad_h2_kernel behind
+    rdo_conv2d_wgrad: 1 x 1, channel counts in blocks of 192, >= 4096 tokens) against float64: activation-like operands, gradient-like
+    ones (1e-6 and below, magnitudes differing by e^(+-9) from token to token -- the per-stage power-of-two scale follows the largest
+    stage seen so far), whole stages of zeros in front of and between the data, and the squared input of the GDN gamma gradient.
+    Error against the largest gradient entry: 2e-6 (the split-bf16 kernel it replaces: 1e-6; an fp32 accumulation over 64 K terms: 4e-6)."""
+    from hipops import ops
+    g = torch.Generator().manual_seed(rows + cin + cout)
+    x = torch.randn(rows, cin, generator=g)
+    dy = torch.randn(rows, cout, generator=g)
+    if kind == "grad":
+        dy = dy * 1e-6 * torch.exp(3 * torch.randn(rows, 1, generator=g))
+    if kind == "zero_blocks":
+        dy[:96] = 0.0
+        x[:64] = 0.0
+        dy[1024:1024 + 320] = 0.0
+        dy[2000] = 0.0
+    sq = kind == "square"
+    slabs = ops.conv2d_wgrad(x.view(1, 1, rows, cin).cuda(), dy.view(1, 1, rows, cout).cuda(), (cout, 1, 1, cin), 1, 0, square_input=sq)
+    got = slabs.double().sum(0).view(cout, cin).cpu()
+    xin = x.double() ** 2 if sq else x.double()
+    want = dy.double().t() @ xin
+    assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max())
