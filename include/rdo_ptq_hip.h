@@ -167,6 +167,11 @@ typedef struct rdo_ada_step_item {
     void *wq_planes /* nullable */, *wd_planes /* nullable */;
     float* dalpha;      /* modes 1 (out) and 2 (in): this tensor's slice of the data-parallel gradient bucket */
     float wq_plane_scale, wd_plane_scale;   /* 0: bf16 three-way planes, > 0: fp16 two-way planes of w * scale (see rdo_adaround_step) */
+    /* nullable: fp16 two-way planes of the new soft weight [rows][inner] * lin_plane_scale in the fragment order of rdo_linear_h2
+     * (what rdo_split_h2_linear would make of wq), and of its transpose (of wd: the input-gradient Linear) -- a Linear / GDN gamma
+     * whose token matrices run on rdo_linear_h2 gets them from the step itself instead of two more launches.  rows, inner % 32 == 0. */
+    void *lin_fwd_planes, *lin_bwd_planes;
+    float lin_plane_scale;
 } rdo_ada_step_item;
 int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
                             const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,

@@ -44,7 +44,23 @@ struct AdaArgs {
     unsigned short* wd_planes;   // optional: the same for the dgrad layout wd
     float wq_pscale, wd_pscale;
     int* ovf;                    // sticky fp16 overflow flag (rdo_h2_overflow)
+    unsigned short* lin_fwd;     // optional: planes of wq * lin_pscale in rdo_linear_h2's fragment order ([plane][inner/32][rows/16][lane][8])
+    unsigned short* lin_bwd;     // optional: the same of the transpose (rows and inner swapped)
+    float lin_pscale;
 };
+
+// element (n, k) of W [rows][inner] in the fragment order of rdo_linear_h2 (linear_h2.hip, rdo_split_h2_linear): half index inside a plane
+__device__ __forceinline__ long lin_frag_index(int n, int k, int nblk) {
+    return ((((long)(k >> 5) * nblk + (n >> 4)) * 64 + (n & 15) + 16 * ((k & 31) >> 3)) << 3) + (k & 7);
+}
+__device__ __forceinline__ void lin_split(float v, float scale, unsigned short& hi, unsigned short& lo, int& bad) {
+    const float x = v * scale;
+    const _Float16 h = (_Float16)x;
+    const _Float16 l = (_Float16)(x - (float)h);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, l);
+    if (!(fabsf(x) <= 65504.f)) bad = 1;
+}
 
 // exact three-way bf16 split (hardware RNE conversions), as rdo_split_bf16x3
 __device__ __forceinline__ void split3_store(float v, unsigned short* planes, long n, long i) {
@@ -209,6 +225,26 @@ __device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, 
             *reinterpret_cast<vec_t*>(a.v + e0) = v4;
             *reinterpret_cast<vec_t*>(a.alpha + e0) = al4;
             *reinterpret_cast<vec_t*>(a.wq + e0) = o4;
+            if (a.lin_fwd || a.lin_bwd) {                      // planes for rdo_linear_h2 (a Linear / GDN gamma on large token matrices)
+                const int in_ = (int)inner, nr = d.rows;
+                const long plane = (long)nr * in_;
+                int bad = 0;
+#pragma unroll
+                for (int k = 0; k < W; ++k) {
+                    const int n = rows[k], kk = (int)(e0 + k - (long)n * in_);
+                    unsigned short hi, lo;
+                    lin_split(o4[k], a.lin_pscale, hi, lo, bad);
+                    if (a.lin_fwd) {
+                        const long f = lin_frag_index(n, kk, nr >> 4);
+                        a.lin_fwd[f] = hi; a.lin_fwd[plane + f] = lo;
+                    }
+                    if (a.lin_bwd) {
+                        const long f = lin_frag_index(kk, n, in_ >> 4);
+                        a.lin_bwd[f] = hi; a.lin_bwd[plane + f] = lo;
+                    }
+                }
+                rdo::h2_report(bad, a.ovf);
+            }
             if (a.wq_planes && a.wq_pscale > 0.f) {            // fp16 two-way split of wq * scale, fragment order
                 int bad = 0;
                 if constexpr (W == 4) {
@@ -562,6 +598,13 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
         a.wq_planes = static_cast<unsigned short*>(it.wq_planes);
         a.wd_planes = it.wd ? static_cast<unsigned short*>(it.wd_planes) : nullptr;
         a.wq_pscale = it.wq_plane_scale; a.wd_pscale = it.wd_plane_scale; a.ovf = rdo::h2_overflow_flag();
+        if (mode != 1 && (it.lin_fwd_planes || it.lin_bwd_planes)) {
+            RDO_REQUIRE(it.d.rows % 32 == 0 && (it.d.numel / it.d.rows) % 32 == 0 && it.lin_plane_scale > 0.f,
+                        "rdo_adaround_step_batch: item %d: Linear planes need rows and inner in blocks of 32 and a positive scale", i);
+            a.lin_fwd = static_cast<unsigned short*>(it.lin_fwd_planes);
+            a.lin_bwd = static_cast<unsigned short*>(it.lin_bwd_planes);
+            a.lin_pscale = it.lin_plane_scale;
+        }
         blocks += (int)grid_for((it.nsplit >= w1_min && mode != 2) ? it.d.numel : it.d.numel / 4);
         b.blk_end[i] = blocks;
         bytes += 4.0 * it.d.numel * ((mode == 2 ? 1 : it.nsplit) + (mode == 1 ? 3.0 : 9.0));

@@ -27,7 +27,8 @@ class AdaStepItem(C.Structure):
     _fields_ = [("d", AdaDesc), ("w", C.c_void_p), ("delta", C.c_void_p), ("zp", C.c_void_p), ("slabs", C.c_void_p),
                 ("nsplit", C.c_int32), ("alpha", C.c_void_p), ("adam_m", C.c_void_p), ("adam_v", C.c_void_p), ("wq", C.c_void_p),
                 ("wd", C.c_void_p), ("wq_planes", C.c_void_p), ("wd_planes", C.c_void_p), ("dalpha", C.c_void_p),
-                ("wq_plane_scale", C.c_float), ("wd_plane_scale", C.c_float)]
+                ("wq_plane_scale", C.c_float), ("wd_plane_scale", C.c_float),
+                ("lin_fwd_planes", C.c_void_p), ("lin_bwd_planes", C.c_void_p), ("lin_plane_scale", C.c_float)]
 
 
 class AttnDesc(C.Structure):

@@ -222,7 +222,7 @@ def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_
 
 
 def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None, mode=0, iter_shadow=None):
-    """items: list of dicts(d, w, delta, zp, slabs, alpha, m, v, wq, wd, wq_planes, wd_planes[, dalpha]) -- one launch for every
+    """items: list of dicts(d, w, delta, zp, slabs, alpha, m, v, wq, wd, wq_planes, wd_planes[, dalpha, lin_fwd, lin_bwd]) -- one launch for every
     weight tensor of a unit (<= 8, numel % 4 == 0): mode 0 the fused AdaRound step, 1 the data gradient into `dalpha`, 2 the update
     from an (all-reduced) `dalpha`; `advance_iter`: the device iteration counter to increment afterwards."""
     _bind_out(None)            # weight planes raise the enclosing block's word
@@ -237,6 +237,9 @@ def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_
         a.wq_planes, a.wd_planes = dp(it.get("wq_planes")), dp(it.get("wd_planes"))
         a.wq_plane_scale, a.wd_plane_scale = _pscale(it.get("wq_planes")), _pscale(it.get("wd_planes"))
         a.dalpha = dp(it.get("dalpha"))
+        lf, lb = it.get("lin_fwd"), it.get("lin_bwd")      # H2 planes in rdo_linear_h2's fragment order, written by the step itself
+        a.lin_fwd_planes, a.lin_bwd_planes = dp(lf), dp(lb)
+        a.lin_plane_scale = float((lf if lf is not None else lb).scale) if (lf is not None or lb is not None) else 0.0
     L.check(L.lib().rdo_adaround_step_batch(arr, len(items), int(mode), grad_scale, round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(round_log),
                                             _ptr(advance_iter), _ptr(iter_shadow), _stream()), "rdo_adaround_step_batch")
 

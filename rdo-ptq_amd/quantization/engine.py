@@ -507,11 +507,14 @@ class UnitEngine:
         ops.conv2d_wgrad(x, self.t["dyp"], op.wp4, 1, ph.pad, slabs=op.slabs_p)
         ops.tconv_fold(op.slabs_p, ph, op.rows, op.w4[3], out=op.slabs)
 
-    def _after_step(self):
-        """recorded right behind the AdaRound step: phase weights of transposed convs follow the new soft weights"""
+    def _after_step(self, lin_done=False):
+        """recorded right behind the AdaRound step: phase weights of transposed convs follow the new soft weights (lin_done: the batched
+        step has written the rdo_linear_h2 planes itself)"""
         for op in self.ops.values():
             if op.tc_phase is not None:
                 op.expand_phase()
+            if lin_done:
+                continue
             if op.lin_fwd is not None:                     # Linears on rdo_linear_h2: fragment-ordered planes of the new soft weights
                 ops.split_h2_linear(op.wq4(), planes=op.lin_fwd)
             if op.lin_bwd is not None:
@@ -1070,16 +1073,34 @@ class UnitEngine:
         self._wgrad(g, xin, tbuf, square=True)                        # dgamma'[k][i] = sum_m t_k x_i^2
 
     def _items(self, opl):
+        # (lin_fwd / lin_bwd: the fragment-ordered planes of a Linear / GDN gamma on rdo_linear_h2 -- written by the step's own launch)
         return [dict(d=op.desc, w=op.w, delta=op.delta, zp=op.zp, slabs=op.slabs, alpha=op.alpha, m=op.m, v=op.v, wq=op.wq, wd=op.wd,
-                     wq_planes=op.wq_planes, wd_planes=op.wd_planes, dalpha=getattr(op, "dalpha", None)) for op in opl]
+                     wq_planes=op.wq_planes, wd_planes=op.wd_planes, dalpha=getattr(op, "dalpha", None),
+                     lin_fwd=op.lin_fwd, lin_bwd=op.lin_bwd) for op in opl]
+
+    STEP_BATCH = 8          # weight tensors per rdo_adaround_step_batch launch (kMaxBatch of adaround.hip)
 
     def _batchable(self, opl):
-        return self.batch_step and 1 <= len(opl) <= 8 and all(op.numel() % 4 == 0 for op in opl)
+        """The tensors can go through rdo_adaround_step_batch: in ONE launch up to STEP_BATCH of them, else in ceil(n / STEP_BATCH) launches
+        (an RSTB with six blocks has 37 trainable tensors: 37 single-tensor steps, 24 transposes and 48 plane splits per iteration before)."""
+        return self.batch_step and len(opl) >= 1 and all(op.numel() % 4 == 0 for op in opl)
+
+    def _step_batches(self, opl, scale, mode):
+        """The batched step (mode 0) / update (mode 2) of `opl`; the iteration counter moves with the last launch."""
+        single = len(opl) <= self.STEP_BATCH
+        for i in range(0, len(opl), self.STEP_BATCH):
+            last = i + self.STEP_BATCH >= len(opl)
+            if single and self._handover:
+                ops.adaround_step_batch(self._items(opl), scale, self.weight, self.sched, self.it, self.round_log, mode=mode, iter_shadow=self.it_shadow)
+            else:
+                ops.adaround_step_batch(self._items(opl[i:i + self.STEP_BATCH]), scale, self.weight, self.sched, self.it, self.round_log, mode=mode,
+                                        advance_iter=self.it if last else None)
 
     @property
     def _handover(self):
         """The counter hand-over needs the step of the whole unit in one batched launch (it is that launch that fills the shadow)."""
-        return self.fold_iter and self._batchable(list(self.ops.values()))
+        opl = list(self.ops.values())
+        return self.fold_iter and self._batchable(opl) and len(opl) <= self.STEP_BATCH
 
     def _it_src(self):
         return self.it_shadow if self._handover else self.it
@@ -1090,7 +1111,8 @@ class UnitEngine:
     def _grad_ops(self, names):
         opl = [self.ops[n] for n in names]
         if self._batchable(opl):
-            ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, mode=1)
+            for i in range(0, len(opl), self.STEP_BATCH):
+                ops.adaround_step_batch(self._items(opl[i:i + self.STEP_BATCH]), 1.0, self.weight, self.sched, self.it, self.round_log, mode=1)
             return
         for op in opl:
             ops.adaround_grad(op.desc, op.w, op.alpha, op.delta, op.zp, op.slabs, op.dalpha)
@@ -1100,11 +1122,8 @@ class UnitEngine:
         tensors allow it, else one launch per op.  The bf16 planes of the new weights are written by the same launches."""
         opl = list(self.ops.values())
         if self._batchable(opl):
-            if self._handover:
-                ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, iter_shadow=self.it_shadow)
-            else:
-                ops.adaround_step_batch(self._items(opl), 1.0, self.weight, self.sched, self.it, self.round_log, advance_iter=self.it)
-            self._after_step()
+            self._step_batches(opl, 1.0, 0)
+            self._after_step(lin_done=True)
             return
         for op in opl:
             ops.adaround_step(op.desc, op.w, op.delta, op.zp, op.slabs, 1.0, self.weight, self.sched, self.it,
@@ -1145,15 +1164,14 @@ class UnitEngine:
             with self.plan_b.record():
                 opl = list(self.ops.values())
                 if self._batchable(opl):
-                    ops.adaround_step_batch(self._items(opl), self.bucket.scale, self.weight, self.sched, self.it, self.round_log,
-                                            advance_iter=None if self._handover else self.it, mode=2,
-                                            iter_shadow=self.it_shadow if self._handover else None)
+                    self._step_batches(opl, self.bucket.scale, 2)
+                    self._after_step(lin_done=True)
                 else:
                     for op in opl:
                         ops.adaround_apply(op.desc, op.w, op.delta, op.zp, op.dalpha, self.bucket.scale, self.weight, self.sched,
                                            self.it, op.alpha, op.m, op.v, op.wq, op.wd, self.round_log, op.wq_planes, op.wd_planes)
                     ops.iter_advance(self.it)
-                self._after_step()
+                    self._after_step()
 
     # ------------------------------------------------------------------------------------------------------------------
     def run(self, n_iters=None, idle=None):
