@@ -1005,11 +1005,15 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
 }
 
 // ---- fp32 token-matrix weight gradient (linear_wgrad_h2_kernel): called by rdo_conv2d_wgrad (conv_wgrad.hip) in front of the split-bf16 kernel
+static long lw_min_tokens() {
+    static const long v = [] { const char* e = getenv("RDO_LIN_WGRAD_H2_MIN"); return e ? atol(e) : 4096L; }();
+    return v;
+}
 bool rdo_linear_wgrad_h2_ok(const rdo_conv_desc* d, const float* x, const float* dy) {
     static const int on = [] { const char* e = getenv("RDO_LIN_WGRAD_H2"); return e ? atoi(e) : 1; }();
     if (!on || !d) return false;
     const long M = (long)d->B * d->Ho * d->Wo;
-    return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 192 == 0 && d->Cout % 192 == 0 && M % 32 == 0 && M >= 8192 &&
+    return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 192 == 0 && d->Cout % 192 == 0 && M % 32 == 0 && M >= lw_min_tokens() &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
 }
 

@@ -26,7 +26,8 @@ def timed(fn, n=30):
 
 g = torch.Generator(device="cuda").manual_seed(0)
 for rows, cin, cout, sq in [(65536, 192, 576, False), (65536, 192, 192, False), (65536, 192, 384, False), (65536, 384, 192, False),
-                            (16384, 192, 576, False), (16384, 384, 192, False), (65536, 192, 192, True), (16384, 192, 192, True), (4096, 192, 192, True)]:
+                            (16384, 192, 576, False), (16384, 384, 192, False), (65536, 192, 192, True), (16384, 192, 192, True), (4096, 192, 192, True),
+                            (4096, 192, 576, False), (4096, 192, 192, False), (4096, 384, 192, False), (4096, 192, 384, False)]:
     x = torch.randn(1, 1, rows, cin, device="cuda", generator=g)
     dy = torch.randn(1, 1, rows, cout, device="cuda", generator=g)
     ws = (cout, 1, 1, cin)
