@@ -270,3 +270,29 @@ def test_linear_weight_gradient_h2_matches_float64(rows, cin, cout, kind):
     xin = x.double() ** 2 if sq else x.double()
     want = dy.double().t() @ xin
     assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max())
+
+
+def test_round5_kernels_are_run_to_run_deterministic():
+    """linear_wgrad_h2_kernel (LDS slot hand-over of the per-stage scale, two register sets in flight), the weight-stationary linear kernel
+    (two LDS panels, hand-counted waits) and the attention kernels (persistent workgroups with a register prefetch) give the same bits on
+    every run -- a race in one of those hand-overs would show here first (tools/determinism_check.py: the longer version)."""
+    from hipops import ops
+    g = torch.Generator(device="cuda").manual_seed(0)
+
+    def same(fn, n=4):
+        ref = fn().clone()
+        return all(torch.equal(fn(), ref) for _ in range(n))
+
+    x = torch.randn(1, 1, 65536, 192, device="cuda", generator=g)
+    dy = torch.randn(1, 1, 65536, 576, device="cuda", generator=g) * torch.exp(3 * torch.randn(1, 1, 65536, 1, device="cuda", generator=g))
+    assert same(lambda: ops.conv2d_wgrad(x, dy, (576, 1, 1, 192), 1, 0))
+    w = torch.randn(576, 192, device="cuda", generator=g) / 192 ** 0.5
+    pl = ops.split_h2_linear(w)
+    assert same(lambda: ops.linear_h2(x.view(-1, 192), pl, None))
+    for B, H, heads, shift in [(4, 128, 4, 4), (4, 64, 8, 0)]:
+        d = ops.attn_desc(B, H, H, 192, heads, 8, shift)
+        qkv = torch.randn(B, H, H, 576, device="cuda", generator=g)
+        bias = torch.randn(heads, 64, 64, device="cuda", generator=g)
+        dout = torch.randn(B, H, H, 192, device="cuda", generator=g)
+        assert same(lambda: ops.window_attention(d, qkv, bias))
+        assert same(lambda: ops.window_attention_bwd(d, qkv, bias, dout))
