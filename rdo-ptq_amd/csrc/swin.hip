@@ -389,7 +389,7 @@ __device__ __forceinline__ void tile_stash(const TileMap<TILE_IT>& m, const af4 
 // products.  PF = false (head dims that are not multiples of 4): tiles loaded in place, no prefetch.
 template <bool PF, int TILE_IT>
 __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* qkv, const float* bias, AttnGeom g, float* out, float* probs,
-                                                                int no_pv, int windows, int nitems, int stagger) {
+                                                                int no_pv, int windows, int nitems) {
     constexpr int NDB = PF ? TILE_IT : 4;                     // 16-channel blocks of a head (TILE_IT = ceil(hd / 16) on the vector path)
     extern __shared__ float lds[];
     float* V = lds;
@@ -423,11 +423,6 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
     tables(0, win);
     __syncthreads();
     if (PF) fetch(0, head);
-    if (stagger > 0) {                                        // residency slot of this workgroup on its CU (guess: ids go over 8 XCDs x 32 CUs first)
-        const int st = stagger & 0xFFFF, key = stagger >> 16;
-        const int slot = key == 0 ? (blockIdx.x >> 8) : (int)((blockIdx.x >> 3) % (unsigned)(key + 1));
-        for (int k = slot * st; k > 0; k -= 100) __builtin_amdgcn_s_sleep(100);
-    }
     for (;;) {
         if (!full) {
             zero_lds(lds, 3 * 64 * g.hs);
@@ -473,7 +468,7 @@ __global__ __launch_bounds__(256, 3) void win_attn_fwd_mfma_kernel(const float* 
 
 template <bool PF, int TILE_IT>
 __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* qkv, const float* bias, const float* dout, AttnGeom g,
-                                                                float* dqkv, int windows, int nitems, int stagger) {
+                                                                float* dqkv, int windows, int nitems) {
     constexpr int NDB = PF ? TILE_IT : 4;
     extern __shared__ float lds[];
     float* Q = lds;                       // pre-scaled
@@ -514,11 +509,6 @@ __global__ __launch_bounds__(256, 2) void win_attn_bwd_mfma_kernel(const float* 
     tables(0, win);
     __syncthreads();
     if (PF) fetch(0, head);
-    if (stagger > 0) {                                        // residency slot of this workgroup on its CU (guess: ids go over 8 XCDs x 32 CUs first)
-        const int st = stagger & 0xFFFF, key = stagger >> 16;
-        const int slot = key == 0 ? (blockIdx.x >> 8) : (int)((blockIdx.x >> 3) % (unsigned)(key + 1));
-        for (int k = slot * st; k > 0; k -= 100) __builtin_amdgcn_s_sleep(100);
-    }
     for (;;) {
         f32x16 sd[2];                                                                              // scores Q K^T (from bias + mask) and dP = dO V^T, stepped together
         score_init(g, bias, reg[buf], head, ti, tj, sd[0]);
@@ -848,17 +838,6 @@ static long attn_grid(K kern, size_t lds, int nitems, int slot, bool bwd) {
     return nitems < m.resident ? nitems : m.resident;
 }
 
-// co-resident workgroups start in step and stay in step (same work, same contention): every phase of one collides with the same phase
-// of the other -- tools/attn_ablate.py: the costs of loads, products, softmax rows and stores ADD UP to the kernel time.  Workgroups of
-// the second (third) residency slot of a CU (launch ids are dealt round-robin over the XCDs, then over a XCD's CUs) start late by
-// `stagger` x 64 cycles per slot: their product phase then runs under the other's row / store phases.  Tuning only: a wrong guess
-// about the placement costs the delay once.
-static int attn_stagger(bool bwd) {
-    static const int v[2] = {[] { const char* e = getenv("RDO_ATTN_STAGGER_FWD"); return e ? atoi(e) : 0; }(),
-                             [] { const char* e = getenv("RDO_ATTN_STAGGER_BWD"); return e ? atoi(e) : 0; }()};
-    return v[bwd ? 1 : 0];
-}
-
 extern "C" {
 
 int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const float* bias, float* out, float* probs, void* stream) {
@@ -872,7 +851,6 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
     const int no_pv = out == nullptr;
     const int nitems = windows * g.heads;
     const bool pf = ((g.hd | g.C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv)) & 15) == 0;
-    const int stagger = attn_stagger(false);
     return rdo::dispatch(
         [=](hipStream_t s) {
             auto go = [&](auto kern, int slot) -> int {
@@ -883,7 +861,7 @@ int rdo_window_attention_fwd(const rdo_attn_desc* d, const float* qkv, const flo
                     attr[slot].mark();
                 }
                 const long grid = attn_grid(kern, lds, nitems, slot, false);
-                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv, windows, nitems, stagger);
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, g, out, probs, no_pv, windows, nitems);
                 return rdo::check_launch("window_attention_fwd");
             };
             if (!pf) return go(win_attn_fwd_mfma_kernel<false, 1>, 0);
@@ -921,7 +899,6 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
     static_assert(SS >= 64 + 1, "P must cover a 64-float row");
     const int nitems = windows * g.heads;
     const bool pf = ((g.hd | g.C) & 3) == 0 && ((reinterpret_cast<uintptr_t>(qkv) | reinterpret_cast<uintptr_t>(dout)) & 15) == 0;
-    const int stagger = attn_stagger(true);
     return rdo::dispatch(
         [=](hipStream_t s) {
             auto go = [&](auto kern, int slot) -> int {
@@ -932,7 +909,7 @@ int rdo_window_attention_bwd(const rdo_attn_desc* d, const float* qkv, const flo
                     attr[slot].mark();
                 }
                 const long grid = attn_grid(kern, lds, nitems, slot, true);
-                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, dout, g, dqkv, windows, nitems, stagger);
+                hipLaunchKernelGGL(kern, dim3((unsigned)grid), dim3(256), lds, s, qkv, bias, dout, g, dqkv, windows, nitems);
                 return rdo::check_launch("window_attention_bwd");
             };
             if (!pf) return go(win_attn_bwd_mfma_kernel<false, 1>, 0);
