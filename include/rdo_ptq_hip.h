@@ -383,6 +383,10 @@ int rdo_conv2d_fwd_h2_tail(const rdo_conv_desc* d, const void* x_planes, float x
 /* rdo_conv2d_wgrad with both operands as H2 planes (x: [B*H*W][Cin], dy: [B*Ho*Wo][Cout]); same slabs, same nsplit rule
  * (rdo_conv2d_wgrad_nsplit).  Supported for the shapes of rdo_conv2d_wgrad_uses_bf16x6 with Cin % 16 == Cout % 16 == 0, no square_input. */
 int rdo_conv2d_wgrad_h2_supported(const rdo_conv_desc* d);
+/* ... and additionally k x k (k > 1) shapes with 64 <= Cin, Cout (multiples of 16) over >= 8192 output pixels -- the weight gradient of a
+ * layer unit on planes (quant_layer.py:123 under autograd; the 3 x 3 96 -> 96 convs of Cheng2020-attn's attention blocks): the general
+ * plane kernel with its 192 x 192 tile masked.  rdo_conv2d_wgrad_h2 accepts every shape one of the two predicates accepts. */
+int rdo_conv2d_wgrad_h2_layer_supported(const rdo_conv_desc* d);
 int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes, float x_scale, const void* dy_planes, float dy_scale, float* slabs,
                         int nsplit, void* stream);
 /* rdo_gather_qdrop writing the mini-batch as H2 planes (and as fp32 when `out` != NULL) */

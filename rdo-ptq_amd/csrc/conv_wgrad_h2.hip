@@ -905,10 +905,17 @@ extern "C" int rdo_conv2d_wgrad_h2_supported(const rdo_conv_desc* d) {
     return rdo_conv2d_wgrad_uses_bf16x6(d);
 }
 
+extern "C" int rdo_conv2d_wgrad_h2_layer_supported(const rdo_conv_desc* d) {
+    if (!d || d->square_input || d->Cin % 16 != 0 || d->Cout % 16 != 0) return 0;
+    if ((double)d->B * d->H * d->W * d->Cin >= 2147483648.0 - 64.0 || (double)d->B * d->Ho * d->Wo * d->Cout >= 2147483648.0 - 64.0) return 0;
+    if (rdo_conv2d_wgrad_h2_supported(d)) return 1;
+    return d->KH * d->KW > 1 && d->Cin >= 64 && d->Cout >= 64 && (long)d->B * d->Ho * d->Wo >= 8192;
+}
+
 extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes, float x_scale, const void* dy_planes, float dy_scale,
                                    float* slabs, int nsplit, void* stream) {
     RDO_REQUIRE(d && x_planes && dy_planes && slabs && nsplit >= 1, "rdo_conv2d_wgrad_h2: bad argument");
-    RDO_REQUIRE(rdo_conv2d_wgrad_h2_supported(d), "rdo_conv2d_wgrad_h2: shape not on the split-precision plane path (rdo_conv2d_wgrad_h2_supported)");
+    RDO_REQUIRE(rdo_conv2d_wgrad_h2_layer_supported(d), "rdo_conv2d_wgrad_h2: shape not on the split-precision plane path (rdo_conv2d_wgrad_h2_supported / _layer_supported)");
     constexpr int T = 192;
     WgPArgs a{};
     a.xp = reinterpret_cast<const u16*>(x_planes);
@@ -935,7 +942,8 @@ extern "C" int rdo_conv2d_wgrad_h2(const rdo_conv_desc* d, const void* x_planes,
     const double flops = 2.0 * a.M * (double)a.Cout * a.Cin * a.KH * a.KW;
     const double bytes = 4.0 * (a.xplane + a.yplane) + 4.0 * nsplit * (double)a.Cout * a.KH * a.KW * a.Cin;
     // 3 x 3 / stride 1 / pad 1 over whole 32-pixel row segments, Cin in blocks of 64: the three kw taps share one input image
-    if (rdo::tuning(rdo::T_WGRAD_P3_ROW) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Wo % 32 == 0 && a.Cin % 64 == 0 &&
+    // (shapes only the layer predicate accepts -- narrow channel counts -- stay on the general kernel, whose loader and epilogue mask the tile)
+    if (rdo_conv2d_wgrad_h2_supported(d) && rdo::tuning(rdo::T_WGRAD_P3_ROW) && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.Wo % 32 == 0 && a.Cin % 64 == 0 &&
         a.Wo == a.W && a.Ho == a.H && (long)(a.M / 32) >= nsplit) {
         WgPArgs b = a;
         b.tiles_ci = a.Cin / 64;

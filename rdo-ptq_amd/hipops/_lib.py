@@ -113,6 +113,7 @@ _SIGS = {
     "rdo_conv2d_fwd_h2_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_fwd_h2": (C.c_int, [C.POINTER(ConvDesc), P, C.c_float, P, C.c_float, P, P, P, P, P, P, P, C.c_float, P, C.c_int64, P]),
     "rdo_conv2d_wgrad_h2_supported": (C.c_int, [C.POINTER(ConvDesc)]),
+    "rdo_conv2d_wgrad_h2_layer_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_wgrad_h2": (C.c_int, [C.POINTER(ConvDesc), P, C.c_float, P, C.c_float, P, C.c_int, P]),
     "rdo_conv2d_fwd_h2_tail_supported": (C.c_int, [C.POINTER(ConvDesc)]),
     "rdo_conv2d_fwd_h2_tail": (C.c_int, [C.POINTER(ConvDesc), P, C.c_float, P, C.c_float, P, P, C.c_float, P, P, P, C.c_int32, C.c_float, C.c_int32, P,

@@ -967,6 +967,13 @@ def wgrad_h2_supported(x_shape, w_shape, stride, pad):
     return bool(L.lib().rdo_conv2d_wgrad_h2_supported(C.byref(d)))
 
 
+def wgrad_h2_layer_supported(x_shape, w_shape, stride, pad):
+    """rdo_conv2d_wgrad_h2 takes this shape when it is the weight gradient of a layer unit on planes (narrower channel counts than the
+    block units' 192: the general plane kernel masks its 192 x 192 tile)."""
+    d = conv_desc(x_shape, w_shape, stride, pad)
+    return bool(L.lib().rdo_conv2d_wgrad_h2_layer_supported(C.byref(d)))
+
+
 def conv2d_wgrad_h2(xp, x_shape, dyp, w_shape, stride=1, pad=0, slabs=None):
     """Weight-gradient slabs from H2 operands (planes of x [B,H,W,Cin] and of dy [B,Ho,Wo,Cout])."""
     d = conv_desc(x_shape, w_shape, stride, pad)

@@ -587,6 +587,7 @@ class UnitEngine:
     # plane-input kernels from this many output elements of the conv (pixels x channels) on
     H2_MIN_OUT = int(os.environ.get("RDO_H2_MIN_OUT", 4096 * 192))
     h2_lean = os.environ.get("RDO_H2_LEAN", "1") != "0"     # tensors whose only readers take planes are not also written as fp32
+    layer_h2 = os.environ.get("RDO_LAYER_H2", "1") != "0"   # plain k x k layer units over enough pixels on the plane kernels (plan "layer")
 
     OVF_PAIRS = 8
 
@@ -640,6 +641,11 @@ class UnitEngine:
             if (op.tc_phase is not None and op.tc_phase.stride == 2 and xs[-1] % 16 == 0 and ops.conv_h2_supported(xs, op.wp4, 1, op.tc_phase.pad)
                     and ops.wgrad_h2_supported(xs, op.wp4, 1, op.tc_phase.pad) and xs[0] * xs[1] * xs[2] * op.wp4[0] >= self.H2_MIN_OUT):
                 return "tconv"
+            # a plain k x k conv (k > 1) over enough pixels -- the 3 x 3 96 -> 96 convs of Cheng2020-attn's attention blocks at 64^2 (BASELINE
+            # config 3; fp32 MFMA 50 + 65 us forward + weight gradient, planes 40 + 32: tools/bench_layer96.py): input and dL/dpre as planes
+            if (self.layer_h2 and op.tconv is None and not op.is_gdn and op.qm.kind == "conv" and op.K > 1 and xs[-1] % 16 == 0
+                    and "dpre" in self.t and self._conv_ok_h2(op, xs) and ops.wgrad_h2_layer_supported(xs, op.w4, op.stride, op.pad)):
+                return "layer"
             return None
         if k == "rb" and "skip" not in o:
             c1, c2 = o["conv1"], o["conv2"]
@@ -776,7 +782,7 @@ class UnitEngine:
                 self._wgrad(c1, x, t["dh1"])
 
     # activation buffers a plan may keep as planes (all probed: a scale that is never used costs nothing)
-    H2_PROBED = {"tconv": ("x", "dpre"), "rb": ("x", "h1", "dpre2", "dh1"), "rbws": ("x", "h1", "t", "dc2", "dh1"), "rbu": ("x", "h1", "t", "dc", "dup", "dsp")}
+    H2_PROBED = {"tconv": ("x", "dpre"), "layer": ("x", "dpre"), "rb": ("x", "h1", "dpre2", "dh1"), "rbws": ("x", "h1", "t", "dc2", "dh1"), "rbu": ("x", "h1", "t", "dc", "dup", "dsp")}
 
     def _probe_amax(self, names):
         """One eager iteration of the unit on fp32 activations and the plain fp32 kernels (no planes, no AdaRound step) at the CURRENT
@@ -934,7 +940,7 @@ class UnitEngine:
             return self._fb_rb_h2()
         if self.h2_plan in ("rbws", "rbu"):
             return self._fb_gdn_block_h2()
-        if self.h2_plan != "tconv":                           # (that plan gathers straight into planes)
+        if self.h2_plan not in ("tconv", "layer"):            # (those plans gather straight into planes)
             ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
                              iter_publish=self._it_pub())
         if self.kind == "layer" and o["layer"].is_gdn:
@@ -957,7 +963,16 @@ class UnitEngine:
             if epi is None and self.include_act and type(op.qm.activation_function).__name__ != "StraightThrough":
                 raise NotImplementedError("calibration engine: only LeakyReLU(0.01) or ReLU may be fused into a layer unit")
             act = {None: ops.ACT_NONE, L.EPI_LRELU: ops.ACT_LRELU, L.EPI_RELU: ops.ACT_RELU}[epi]
-            if self.h2_plan == "tconv":                      # ... with the phase conv and its weight gradient on H2 tensors
+            if self.h2_plan == "layer":                      # conv, tail and weight gradient on H2 tensors (x and dL/dpre exist as planes only)
+                xs = tuple(x.shape)
+                xp, dpp = self._h2("x", x), self._h2("dpre", t["dpre"])
+                ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None, xp, self.batch_offset,
+                                    iter_publish=self._it_pub())
+                self._conv_h2(op, xp, xs, out=t["y"])                                               # pre-activation
+                self._task_is_rec = True
+                ops.loss_act_bwd(t["y"], None, self.co, self.idx, self.it, 2.0, act, self.loss_log, dpre_planes=dpp)
+                self._wgrad_h2(op, xp, xs, dpp)
+            elif self.h2_plan == "tconv":                    # ... with the phase conv and its weight gradient on H2 tensors
                 ph, xs = op.tc_phase, tuple(x.shape)
                 xp, dypp = self._h2("x", x), self._h2("dpre", t["dyp"])
                 if op.wp_h2 is None:

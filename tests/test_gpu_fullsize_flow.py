@@ -71,6 +71,10 @@ def test_small_layer_units_n192_match_oracle(cheng192, name):
     np.testing.assert_array_equal(e.zp.cpu().numpy(), op.zp.reshape(-1).numpy())
     eng.run()
     torch.cuda.synchronize()
+    if name == "g_a.3.conv_a.0.conv.2":                      # the 3 x 3 96 -> 96 conv at 64^2: conv, tail and weight gradient on H2 planes (plan "layer")
+        assert eng.h2_plan == "layer" and eng.use_h2
+    else:
+        assert eng.h2_plan is None
     total, rt, rd = eng.logs()
     a_gpu, a_ref = eng.alpha_of("layer").cpu(), op.alpha
     if iters > 50:
