@@ -744,6 +744,11 @@ static int h2_halo_shape(const rdo_conv_desc* d) {
     if (h2_ksplit(d) == 1) return 1;
     const long patches = (long)d->B * d->H * d->W / 256;
     if (rdo::tuning(rdo::T_X6P_HALO) != 2 && d->Cout % 64 == 0 && patches * (d->Cout / 64) >= 160) return 2;    // "x6p_halo" = 2: wide tile only
+    // 3 = the 256 x 48 tile of the K32 kernel for output channel counts in blocks of 48 but not of 64 (the 3 x 3 96 -> 96 convs of
+    // Cheng2020-attn's attention blocks at 64^2: 128 tiles, nothing wasted -- the per-tap kernel's 256 x 192 tile ran them half empty)
+    if (rdo::tuning(rdo::T_X6P_HALO) != 2 && rdo::tuning(rdo::T_H2_K32) && d->Cout % 48 == 0 && d->Cout % 64 != 0 && d->Cin % 32 == 0 &&
+        patches * (d->Cout / 48) >= 96)
+        return 3;
     return 0;
 }
 
@@ -821,7 +826,7 @@ static int conv2d_fwd_h2_impl(const rdo_conv_desc* d, const void* x_planes, floa
         }
     }
     // ... in its 32-channel-stage / 16x16x32 form where the shape allows (conv_fwd_h2k.hip; tuning key "h2_k32")
-    if (halo && rdo::tuning(rdo::T_H2_K32) && (halo == 2 || ks == 1)) {
+    if (halo && rdo::tuning(rdo::T_H2_K32) && (halo >= 2 || ks == 1)) {
         H2Args k = a;
         k.ksplit = 1;
         k.partial = nullptr;
@@ -906,7 +911,8 @@ extern "C" int rdo_conv2d_fwd_h2(const rdo_conv_desc* d, const void* x_planes, f
 }
 
 extern "C" int rdo_conv2d_fwd_h2_tail_supported(const rdo_conv_desc* d) {
-    return d && rdo_conv2d_fwd_h2_supported(d) && h2_halo_shape(d) != 0 && d->epilogue == RDO_EPI_NONE && !d->add_residual;
+    const int hs = d ? h2_halo_shape(d) : 0;
+    return d && rdo_conv2d_fwd_h2_supported(d) && (hs == 1 || hs == 2) && d->epilogue == RDO_EPI_NONE && !d->add_residual;
 }
 
 // Last conv of a unit + its tail in ONE launch (halo kernel): the epilogue forms out = act(conv + bias) + residual, the loss against
