@@ -300,7 +300,8 @@ int rdo_add3(const float* a, const float* b, const float* c, int64_t n, float* o
 /* Token-matrix Linear  out[M][N] = x[M][K] W^T + bias  (F.linear of the Swin blocks, models/layers.py:44-47,147,163; quant_layer.py:119;
  * its input gradient is the same entry on the planes of W^T) on fp16 two-way-split MFMA with a PER-TOKEN dynamic power-of-two scale
  * taken inside the kernel: no probed scale, no overflow flag (csrc/linear_h2.hip).  `wplanes`: rdo_split_h2_linear of W [N][K] * wscale
- * (2 * N * K halfs, fragment order).  rdo_linear_h2_supported: M % 64 == 0, K % 192 == 0, N % 192 == 0. */
+ * (2 * N * K halfs, fragment order).  rdo_linear_h2_supported: M % 64 == 0; K and N each a multiple of 192, or 96 (the 192 <-> 96 1x1 convs
+ * of Cheng2020-attn's attention blocks as token matrices). */
 int rdo_linear_h2_supported(int64_t M, int32_t K, int32_t N);
 int rdo_split_h2_linear(const float* w, int32_t N, int32_t K, float scale, void* planes, void* stream);
 int rdo_linear_h2(const float* x, int64_t M, int32_t K, int32_t N, const void* wplanes, float wscale, const float* bias,

@@ -324,18 +324,27 @@ __global__ __launch_bounds__(512, 2) void linear_wgrad_h2_kernel(LwArgs a) {
     const bool ldx = wave >= 4;
     const int lt = tid & 255, prow = lt >> 3, cpos = lt & 7;
     const int Cop = ldx ? a.Cin : a.Cout;
-    const float* const rowbase = (ldx ? a.x + ci0 : a.dy + co0) + (long)(mbeg + prow) * Cop + 8 * cpos;
+    // channel counts that do not fill the 192-wide tile (96: the 1 x 1 convs of Cheng2020-attn's attention blocks): chunks past the tensor
+    // re-read the row's first chunk (the request count per wave stays six) and are zeroed when they land
+    const int cbase = (ldx ? ci0 : co0) + 8 * cpos;
+    bool cok[3];
+#pragma unroll
+    for (int sub = 0; sub < 3; ++sub) cok[sub] = cbase + 64 * sub < Cop;
+    const float* const rowbase = (ldx ? a.x : a.dy) + (long)(mbeg + prow) * Cop;
     char* const ldst = smem + (ldx ? OPB : 0) + prow * 128 + ((cpos ^ (2 * ((prow >> 1) & 3))) * 16);
     lw4 R[2][6];
     auto request = [&](lw4 (&r)[6], int stage) {
         const int st = stage < nsteps ? stage : (nsteps > 0 ? nsteps - 1 : 0);      // past the end: a valid stage again (never multiplied)
-        const float* src = rowbase + (long)st * PK * Cop;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[0]) : "v"(src) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r[1]) : "v"(src) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:256" : "=v"(r[2]) : "v"(src) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:272" : "=v"(r[3]) : "v"(src) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:512" : "=v"(r[4]) : "v"(src) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off offset:528" : "=v"(r[5]) : "v"(src) : "memory");
+        const float* row = rowbase + (long)st * PK * Cop;
+        const float* s0 = row + (cok[0] ? cbase : 0);
+        const float* s1 = row + (cok[1] ? cbase + 64 : 0);
+        const float* s2 = row + (cok[2] ? cbase + 128 : 0);
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[0]) : "v"(s0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r[1]) : "v"(s0) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[2]) : "v"(s1) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r[3]) : "v"(s1) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r[4]) : "v"(s2) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off offset:16" : "=v"(r[5]) : "v"(s2) : "memory");
     };
     // the six requests issued BEFORE the youngest six have landed -> largest magnitude of the stage into this wave's slot
     auto landed_amax = [&](lw4 (&r)[6], int parity) {
@@ -345,6 +354,7 @@ __global__ __launch_bounds__(512, 2) void linear_wgrad_h2_kernel(LwArgs a) {
         float m = 0.f;
 #pragma unroll
         for (int k = 0; k < 6; ++k) {
+            if (!cok[k >> 1]) r[k] = lw4{0.f, 0.f, 0.f, 0.f};
             if (SQ && ldx) r[k] *= r[k];
             m = fmaxf(m, fmaxf(fmaxf(fabsf(r[k][0]), fabsf(r[k][1])), fmaxf(fabsf(r[k][2]), fabsf(r[k][3]))));
         }
@@ -486,12 +496,13 @@ __global__ __launch_bounds__(512, 2) void linear_wgrad_h2_kernel(LwArgs a) {
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int ci = ci0 + wci0 + j * 16 + l16;
+        if (ci >= a.Cin) continue;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + wco0 + i * 16 + 4 * lc + r;
-                slab[(long)co * a.Cin + ci] = (acc[i][j][r] * fy) * fx;
+                if (co < a.Cout) slab[(long)co * a.Cin + ci] = (acc[i][j][r] * fy) * fx;
             }
     }
 }
@@ -1021,7 +1032,9 @@ bool rdo_linear_wgrad_h2_ok(const rdo_conv_desc* d, const float* x, const float*
     static const int on = [] { const char* e = getenv("RDO_LIN_WGRAD_H2"); return e ? atoi(e) : 1; }();
     if (!on || !d) return false;
     const long M = (long)d->B * d->Ho * d->Wo;
-    return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && d->Cin % 192 == 0 && d->Cout % 192 == 0 && M % 32 == 0 && M >= lw_min_tokens() &&
+    // channel counts in blocks of 192, or 96 (a half tile, masked)
+    const bool cin_ok = d->Cin % 192 == 0 || d->Cin == 96, cout_ok = d->Cout % 192 == 0 || d->Cout == 96;
+    return d->KH == 1 && d->KW == 1 && d->stride == 1 && d->pad == 0 && cin_ok && cout_ok && M % 32 == 0 && M >= lw_min_tokens() &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0;
 }
 
@@ -1030,7 +1043,7 @@ int rdo_launch_linear_wgrad_h2(const rdo_conv_desc* d, const float* x, const flo
     a.x = x; a.dy = dy; a.slabs = slabs;
     a.M = d->B * d->Ho * d->Wo; a.Cin = d->Cin; a.Cout = d->Cout;
     a.mchunk = mchunk; a.nsplit = nsplit;
-    a.tiles_co = a.Cout / 192; a.tiles_ci = a.Cin / 192;
+    a.tiles_co = (a.Cout + 191) / 192; a.tiles_ci = (a.Cin + 191) / 192;
     if ((long)nsplit * mchunk < a.M || mchunk % 32 != 0) return rdo::set_error(RDO_EINVAL, "linear_wgrad_h2: bad chunking (%d x %d over %d tokens)", nsplit, mchunk, a.M);
     constexpr size_t lds = (size_t)2 * STAGEB + 16 * sizeof(float) + 8 * sizeof(int);
     static rdo::PerDevice attr;

@@ -59,13 +59,19 @@ struct LinArgs {
 
 __device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
 
-template <int EPI>
+// PART: K = 96 or N = 96 (half a panel / half a chunk) -- an instantiation of its own, the full shapes keep their register budget
+template <int EPI, bool PART = false>
 __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* scl = reinterpret_cast<float*>(smem + 2 * PLANE);          // [2][BM]: 1 / scale of the token for K block (kb & 1)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l16 = lane & 15, kg = lane >> 4;
-    const int nkb = a.K / KB, nchunks = a.N / NC, nblk = a.N / 16, ksteps = a.K / 32;
+    // K a multiple of 192, or 96 (half a panel: lanes past the row re-read it and are zeroed, three K steps); N a multiple of 192, or 96
+    // (half a chunk: waves 2 and 3 only keep the barriers)
+    const int nkb = PART ? (a.K + KB - 1) / KB : a.K / KB, nchunks = PART ? (a.N + NC - 1) / NC : a.N / NC, nblk = a.N / 16, ksteps = a.K / 32;
+    const int kvalid4 = PART ? (a.K < KB ? a.K : KB) >> 2 : KB / 4;           // float4 per row of a K block
+    const int nks = PART ? (ksteps < KB / 32 ? ksteps : KB / 32) : KB / 32;   // K steps per block
+    const bool wave_live = !PART || a.N >= NC || wave * 48 < a.N;             // (N = 96: channels 0-95 = waves 0, 1)
     int wg_tile, wg_chunk;
     {
         const int ntiles = a.M / BM;
@@ -93,8 +99,16 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
 #ifdef RDO_DIAG
                 if (a.diag & 4) { v[pass][k] = f32x4{1.f, 2.f, 3.f, 4.f}; continue; }
 #endif
-                v[pass][k] = src[l16 + 16 * k];
+                const int c4 = l16 + 16 * k;
+                v[pass][k] = src[(!PART || c4 < kvalid4) ? c4 : 0];     // (unconditional: a load behind a per-lane branch costs a vmcnt(0) at the join)
             }
+        }
+        if (PART && kvalid4 < KB / 4) {                      // (uniform) K = 96: zero what lies past the row
+#pragma unroll
+            for (int pass = 0; pass < BM / 16; ++pass)
+#pragma unroll
+                for (int k = 0; k < 3; ++k)
+                    if (l16 + 16 * k >= kvalid4) v[pass][k] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
         if (a.square) {
 #pragma unroll
@@ -135,7 +149,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
     // ---- weight fragments: plane p, K step ks, 16-channel block b -> 1 KiB at ((p * ksteps + ks) * nblk + b) * 512 halfs; lane -> 16 bytes
     const u32x4* wbase = reinterpret_cast<const u32x4*>(a.wp) + lane;
     auto load_w = [&](f16x8 (&fw)[2][3], int ks, int chunk) {
-        const long b0 = (long)chunk * (NC / 16) + wave * 3;
+        const long b0 = wave_live ? (long)chunk * (NC / 16) + wave * 3 : 0;        // (idle waves of a half chunk read block 0, unused)
 #pragma unroll
         for (int p = 0; p < 2; ++p)
 #pragma unroll
@@ -179,10 +193,11 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
             }
 #pragma unroll
             for (int ksl = 0; ksl < KB / 32; ++ksl) {
+                if (PART && ksl >= nks) break;                 // (uniform; K = 96: three steps)
                 // the next K step's weight fragments are requested HERE, a whole step (36 MFMAs) ahead of their first use: left to itself
                 // hipcc sinks each of the six loads to a few instructions in front of the MFMA that needs it (`global_load; s_waitcnt
                 // vmcnt(1); v_mfma` -- the L2 latency exposed six times per step)
-                if (ksl + 1 < KB / 32) load_w(fw[(ksl + 1) & 1], kb * (KB / 32) + ksl + 1, chunk);
+                if (ksl + 1 < KB / 32 && (!PART || ksl + 1 < nks)) load_w(fw[(ksl + 1) & 1], kb * (KB / 32) + ksl + 1, chunk);
                 __builtin_amdgcn_sched_barrier(0);
 #ifdef RDO_DIAG
                 if (a.diag & 2) continue;
@@ -207,6 +222,7 @@ __global__ __launch_bounds__(256, 3) void linear_h2_kernel(LinArgs a) {
             }
         }
         // ---- epilogue: y = acc / (token scale * weight scale) + bias, four consecutive channels of one token per lane
+        if (!wave_live) return;                                // (no barrier follows)
         const float* inv_s = scl + ((nkb - 1) & 1) * BM;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -490,7 +506,7 @@ bool pow2(float s) {
 }  // namespace
 
 extern "C" int rdo_linear_h2_supported(int64_t M, int32_t K, int32_t N) {
-    return M > 0 && M % BM == 0 && K > 0 && K % KB == 0 && N > 0 && N % NC == 0 && (double)M * (K > N ? K : N) * 4.0 < 4.0e9;
+    return M > 0 && M % BM == 0 && K > 0 && (K % KB == 0 || K == 96) && N > 0 && (N % NC == 0 || N == 96) && (double)M * (K > N ? K : N) * 4.0 < 4.0e9;
 }
 
 // tuning: 1 (default) = the weight-stationary kernel for one K block (K = 192) when every workgroup gets at least four token tiles (the
@@ -552,7 +568,7 @@ extern "C" int rdo_linear_h2_epi(const float* x, int64_t M, int32_t K, int32_t N
     RDO_REQUIRE(epilogue != RDO_EPI_GELU || pre, "rdo_linear_h2: RDO_EPI_GELU needs the pre-activation output");
     RDO_REQUIRE(epilogue != RDO_EPI_GELU_BWD || aux, "rdo_linear_h2: RDO_EPI_GELU_BWD needs aux");
     RDO_REQUIRE(((reinterpret_cast<uintptr_t>(pre) | reinterpret_cast<uintptr_t>(aux)) & 15) == 0, "rdo_linear_h2: pointers must be 16-byte aligned");
-    RDO_REQUIRE(rdo_linear_h2_supported(M, K, N), "rdo_linear_h2: shape %ld x %d -> %d is not supported (M %% 64, K %% 192, N %% 192)", (long)M, K, N);
+    RDO_REQUIRE(rdo_linear_h2_supported(M, K, N), "rdo_linear_h2: shape %ld x %d -> %d is not supported (M %% 64; K and N multiples of 192, or 96)", (long)M, K, N);
     RDO_REQUIRE(pow2(wscale), "rdo_linear_h2: weight scale %g is not a power of two", (double)wscale);
     RDO_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wplanes) | reinterpret_cast<uintptr_t>(bias) |
                   reinterpret_cast<uintptr_t>(out)) & 15) == 0, "rdo_linear_h2: pointers must be 16-byte aligned");
@@ -565,11 +581,11 @@ extern "C" int rdo_linear_h2_epi(const float* x, int64_t M, int32_t K, int32_t N
     { const char* e = getenv("RDO_LIN_DIAG"); a.diag = e ? atoi(e) : 0; }
 #endif
     const double flops = 2.0 * (double)M * K * N;
-    const int nkb = K / KB;
+    const int nkb = K % KB == 0 ? K / KB : 0;                // (0: the half panel K = 96 -- streaming kernel only)
     const int slots = cu_count() / 8;
     bool stat = false;
     // (not with RDO_EPI_GELU_BWD: its aux reads sit behind the products and their wait drains the panel prefetch -- 83 against 79 us)
-    if (lin_stationary() && nkb == 1 && N / NC <= slots && (a.epi != 2 || lin_stationary() == 2)) stat = (M / BM) / (8 * (slots / (N / NC))) >= 4;
+    if (lin_stationary() && nkb == 1 && N % NC == 0 && N / NC <= slots && (a.epi != 2 || lin_stationary() == 2)) stat = (M / BM) / (8 * (slots / (N / NC))) >= 4;
     else if (lin_stationary() == 2 && (nkb == 2 || nkb == 3) && a.epi == 0 && N / 64 <= slots) stat = true;
     return rdo::dispatch(
         [a, stat, nkb, slots](hipStream_t s) {
@@ -582,10 +598,15 @@ extern "C" int rdo_linear_h2_epi(const float* x, int64_t M, int32_t K, int32_t N
                 if (nkb == 2) return launch_w<1, 2, 0>(a, slots, s);
                 return launch_w<1, 3, 0>(a, slots, s);
             }
-            const unsigned grid = (unsigned)(rdo::ceil_div(a.M / BM, 8) * 8 * (a.N / NC));
-            if (a.epi == 0) hipLaunchKernelGGL(linear_h2_kernel<0>, dim3(grid), dim3(256), LDS_BYTES, s, a);
-            else if (a.epi == 1) hipLaunchKernelGGL(linear_h2_kernel<1>, dim3(grid), dim3(256), LDS_BYTES, s, a);
-            else hipLaunchKernelGGL(linear_h2_kernel<2>, dim3(grid), dim3(256), LDS_BYTES, s, a);
+            const unsigned grid = (unsigned)(rdo::ceil_div(a.M / BM, 8) * 8 * rdo::ceil_div(a.N, NC));
+            const bool part = a.K % KB != 0 || a.N % NC != 0;
+            if (part) {
+                if (a.epi == 0) hipLaunchKernelGGL((linear_h2_kernel<0, true>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+                else if (a.epi == 1) hipLaunchKernelGGL((linear_h2_kernel<1, true>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+                else hipLaunchKernelGGL((linear_h2_kernel<2, true>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+            } else if (a.epi == 0) hipLaunchKernelGGL((linear_h2_kernel<0, false>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+            else if (a.epi == 1) hipLaunchKernelGGL((linear_h2_kernel<1, false>), dim3(grid), dim3(256), LDS_BYTES, s, a);
+            else hipLaunchKernelGGL((linear_h2_kernel<2, false>), dim3(grid), dim3(256), LDS_BYTES, s, a);
             return rdo::check_launch("linear_h2");
         },
         stream, "linear_h2", flops, 4.0 * ((double)M * K + (double)M * N + (double)K * N));

@@ -174,8 +174,8 @@ class _Op:
     def lin_planes(self, fwd: bool):
         """Planes of this Linear's soft weight (fwd) / of its transpose (input gradient) for rdo_linear_h2: allocated on first use -- while
         the plan is being recorded --, filled by `refresh_planes` (eagerly after the recording, then inside the plan behind every step)."""
-        if self.qm.kind not in ("linear", "gdn"):
-            raise RuntimeError("lin_planes: a Linear or the 1x1 pool of a GDN")
+        if self.qm.kind not in ("linear", "gdn") and not (self.qm.kind == "conv" and self.K == 1):
+            raise RuntimeError("lin_planes: a Linear, a 1x1 conv or the 1x1 pool of a GDN")
         co, _, _, ci = self.w4
         if fwd:
             if self.lin_fwd is None:
@@ -442,8 +442,21 @@ class UnitEngine:
         return op.slabs
 
     # ------------------------------------------------------------------------------------------------------------------
+    lin_conv = os.environ.get("RDO_CONV1X1_LIN_H2", "1") != "0"
+
+    def _lin_conv_ok(self, op, x):
+        """A 1 x 1 / stride 1 conv over a large pixel matrix is a token-matrix Linear: rdo_linear_h2 (per-pixel dynamic scale, no probed scale)
+        instead of the fp32 / split-bf16 conv kernels -- the 192 <-> 96 convs of Cheng2020-attn's attention blocks (BASELINE config 3)."""
+        if not (self.lin_conv and not self._probing and op.qm.kind == "conv" and op.K == 1 and op.stride == 1 and op.pad == 0 and op.tconv is None):
+            return False
+        C = x.shape[-1]
+        rows = x.numel() // C
+        return rows >= self.LIN_GDN_MIN_ROWS and ops.linear_h2_supported(rows, C, op.w4[0])
+
     def _conv(self, op, x, out, epilogue=L.EPI_NONE, aux=None, residual=None, pre=None, square=False, bias=True):
         b = (op.beta if op.is_gdn else op.bias) if bias else None
+        if epilogue == L.EPI_NONE and aux is None and residual is None and pre is None and not square and self._lin_conv_ok(op, x):
+            return ops.linear_h2(x.view(-1, x.shape[-1]), op.lin_planes(True), b, out=out.view(-1, out.shape[-1]))
         if ops.uses_bf16x6(tuple(x.shape), op.w4, op.stride, op.pad):
             op.enable_planes(True, False)
         return ops.conv2d_fwd(x, op.wq4(), b, op.stride, op.pad, epilogue=epilogue, aux=aux, residual=residual,
@@ -563,6 +576,10 @@ class UnitEngine:
     def _conv_tail(self, op, x, pre, res, act, dpre, gout=None):
         """Last conv of a unit + its fused tail.  When the conv is split over K, its second pass (sum the partial slabs, add the
         bias) moves into the tail's first load: one launch and one round trip of the pre-activation tensor less."""
+        if self._lin_conv_ok(op, x):                           # a 1 x 1 conv over a large pixel matrix: rdo_linear_h2, then the tail
+            self._conv(op, x, pre)
+            self._tail_act(pre, res, act, dpre, gout=gout)
+            return
         if ops.uses_bf16x6(tuple(x.shape), op.w4, op.stride, op.pad):
             op.enable_planes(True, False)
         ks, _ = ops.conv_fwd_ksplit(tuple(x.shape), op.w4, op.stride, op.pad, op.wq_planes is not None, self.dev)

@@ -183,7 +183,9 @@ def test_gelu_epilogues_of_the_linear_kernels(rows, cin, cout, planes):
 
 @pytest.mark.parametrize("rows,K,N", [(64, 192, 192), (4 * 64 * 64, 192, 576), (4 * 128 * 128, 384, 192), (16384, 576, 192), (640, 192, 384),
                                       # the weight-stationary kernel (>= 4 token tiles per workgroup; a tile count the XCDs do not share evenly)
-                                      (4 * 128 * 128 + 192, 192, 192), (24576, 192, 576), (32768 + 64, 192, 384)])
+                                      (4 * 128 * 128 + 192, 192, 192), (24576, 192, 576), (32768 + 64, 192, 384),
+                                      # half a panel / half a chunk (the 192 <-> 96 1x1 convs of Cheng2020-attn's attention blocks)
+                                      (4 * 64 * 64, 192, 96), (4 * 64 * 64, 96, 192), (4096 + 64, 96, 96)])
 @pytest.mark.parametrize("kind", ["act", "grad", "zero_rows"])
 def test_linear_h2_per_token_scale_matches_float64(rows, K, N, kind):
     """rdo_linear_h2 (csrc/linear_h2.hip): Y = X W^T + b on fp16 two-way-split MFMA with a per-token dynamic power-of-two scale, against
@@ -201,7 +203,7 @@ def test_linear_h2_per_token_scale_matches_float64(rows, K, N, kind):
         x[1, 5] = 1e-30
     w = torch.randn(N, K, generator=g) / K ** 0.5
     b = torch.randn(N, generator=g)
-    assert ops.linear_h2_supported(rows, K, N) and not ops.linear_h2_supported(rows + 1, K, N) and not ops.linear_h2_supported(rows, K + 32, N)
+    assert ops.linear_h2_supported(rows, K, N) and not ops.linear_h2_supported(rows + 1, K, N) and not ops.linear_h2_supported(rows, K + 64, N)
     planes = ops.split_h2_linear(w.cuda())
     want = x.double() @ w.double().t()
     tok = want.abs().amax(1, keepdim=True)
@@ -245,7 +247,8 @@ def test_linear_h2_gelu_epilogues(rows, K, N):
     assert float((got - sep).abs().max()) <= 1e-6 * float(sep.abs().max())
 
 
-@pytest.mark.parametrize("rows,cin,cout", [(4 * 128 * 128, 192, 576), (4 * 64 * 64, 384, 192), (4096, 192, 192), (4 * 64 * 64 + 32 * 5, 576, 192)])
+@pytest.mark.parametrize("rows,cin,cout", [(4 * 128 * 128, 192, 576), (4 * 64 * 64, 384, 192), (4096, 192, 192), (4 * 64 * 64 + 32 * 5, 576, 192),
+                                           (4 * 64 * 64, 192, 96), (4 * 64 * 64, 96, 192), (8192 + 96, 96, 96)])      # half tiles, masked
 @pytest.mark.parametrize("kind", ["act", "grad", "zero_blocks", "square"])
 def test_linear_weight_gradient_h2_matches_float64(rows, cin, cout, kind):
     """The token-matrix weight gradient dW = dY^T X straight from fp32 operands on split-fp16 MFMA (linear_wgrad_h2_kernel behind
