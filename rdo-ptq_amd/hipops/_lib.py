@@ -150,6 +150,10 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise RuntimeError(f"{LIB_PATH} not found: build it with `python __graft_entry__.py` or "
                                f"`make -C rdo-ptq_amd/csrc` (no CPU fallback exists)")
+        # PyTorch first: it brings its own copy of the HIP runtime, and the process must hold ONE -- loaded the other way round (this
+        # library, then torch: `python __graft_entry__.py smoke` runs build() before smoke()) the library's launches fail with
+        # "no ROCm-capable device is detected"
+        import torch  # noqa: F401
         h = C.CDLL(LIB_PATH)
         for name, (res, args) in _SIGS.items():
             fn = getattr(h, name)
