@@ -197,6 +197,8 @@ def gpu_leg(a, rank, world, device):
     dist = torch.distributed if (world > 1 or force_dp) else None
 
     def barrier():
+        for _, e_ in engines:
+            e_.dp_drain()                        # captured data-parallel replays: wait on the heartbeat (stall deadline), then synchronise
         torch.cuda.synchronize()
         if dist:
             dist.barrier()
@@ -349,7 +351,8 @@ def gpu_leg(a, rank, world, device):
                 torch.cuda.empty_cache()
     # which data-parallel loop ran: "graph" (iteration + collectives replayed from one graph) or "host" (plan / all-reduce / plan)
     dp_paths = sorted({e.dp_path for _, e in engines if e.dp_path is not None})
-    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, h2_units=h2_units, dp_paths=dp_paths,
+    dp_fallbacks = sum(e.dp_fallbacks for _, e in engines)
+    return dict(dt=dt, n_units=len(engines), per_tag=per_tag, t_cache=t_cache, windows=windows, h2_units=h2_units, dp_paths=dp_paths, dp_fallbacks=dp_fallbacks,
                 batch_extra=batch_extra, dp_units=dp_units)
 
 
@@ -470,29 +473,17 @@ def visible_gpu_count():
     return n
 
 
-def launch_ranks(a):
-    """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (one per GPU, rendezvous on 127.0.0.1)
-    and return the worst exit status.  The parent never initialises HIP (a process that has may neither fork GPU children safely
-    nor be replaced by exec): devices are counted from sysfs (`visible_gpu_count`).  It is also the watchdog: when one rank exits
-    non-zero (or is killed) the others -- which would wait in a collective for ever -- are terminated and the status is non-zero.
-    Only a single-rank `bench.py` may be run under rocprofv3 (the profiler's preload initialises the GPU in every process it starts).
-    RDO_BENCH_SHARE_GPU=1 (tests only, with RDO_BENCH_BACKEND=gloo): every rank uses cuda:0 -- RCCL refuses two ranks on one device,
-    gloo with device tensors does not -- so the N-rank code runs on a one-GPU box."""
-    import socket
-    import subprocess
-    share = os.environ.get("RDO_BENCH_SHARE_GPU") == "1"
-    have = visible_gpu_count()
-    if not share and have is not None and have < a.gpus:
-        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible on this box -- refusing to run a smaller world "
-                         f"under the label n_gpus={a.gpus}")
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
-    procs = []
-    for r in range(a.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share else str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
-                   MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+STALL_STATUS = 86                 # a rank whose captured data-parallel loop stopped making progress exits with this (engine.DpStallError)
+DEADLINE_S = float(os.environ.get("RDO_BENCH_DEADLINE_S", 1500))   # overall limit of an N > 1 run (the driver's own is 1 800 s)
+
+
+def _stall_marker(port):
+    return f"/tmp/rdo_bench_stall_{port}"
+
+
+def _watch(procs, deadline, what):
+    """Wait for the child processes: the first non-zero exit (or the deadline) stops the others -- they would wait in a collective for
+    ever.  Returns the worst status (signal s -> 128 + s; deadline -> 124)."""
     rc = 0
     try:
         while procs:
@@ -503,13 +494,103 @@ def launch_ranks(a):
                 procs.remove(p)
                 if c != 0:
                     rc = rc or (c if c > 0 else 128 - c)      # killed by signal s: Popen reports -s
-                    print(f"[bench] rank process {p.pid} ended with status {c}: stopping the other ranks", file=sys.stderr, flush=True)
-                    for q in procs:          # one rank failed: the others would wait in a collective for ever
+                    print(f"[bench] {what} {p.pid} ended with status {c}: stopping the other ranks", file=sys.stderr, flush=True)
+                    for q in procs:
                         q.terminate()
+            if procs and time.monotonic() > deadline:
+                print(f"[bench] deadline of {DEADLINE_S:.0f} s reached: stopping {len(procs)} {what}(s), no result line", file=sys.stderr, flush=True)
+                rc = rc or 124
+                for q in procs:
+                    q.terminate()
+                t_kill = time.monotonic() + 10
+                while any(q.poll() is None for q in procs) and time.monotonic() < t_kill:
+                    time.sleep(0.2)
+                break
             time.sleep(0.2)
     finally:
         for p in procs:
-            p.kill()
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def launch_ranks(a):
+    """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (one per GPU, rendezvous on 127.0.0.1)
+    and return the worst exit status.  The parent never initialises HIP (a process that has may neither fork GPU children safely
+    nor be replaced by exec): devices are counted from sysfs (`visible_gpu_count`).  It is also the watchdog: when one rank exits
+    non-zero (or is killed) the others -- which would wait in a collective for ever -- are terminated and the status is non-zero;
+    an overall deadline (RDO_BENCH_DEADLINE_S) ends a run that hangs where no rank exits; and when a rank reports that its CAPTURED
+    data-parallel loop stalled (status 86) the whole world is started once more, as fresh children, on the host-driven loop
+    (RDO_DP_GRAPH=0) -- never a re-exec of a process that touched the GPU.
+    Only a single-rank `bench.py` may be run under rocprofv3 (the profiler's preload initialises the GPU in every process it starts).
+    RDO_BENCH_SHARE_GPU=1 (tests only, with RDO_BENCH_BACKEND=gloo): every rank uses cuda:0 -- RCCL refuses two ranks on one device,
+    gloo with device tensors does not -- so the N-rank code runs on a one-GPU box."""
+    import socket
+    import subprocess
+    share = os.environ.get("RDO_BENCH_SHARE_GPU") == "1"
+    have = visible_gpu_count()
+    if not share and have is not None and have < a.gpus:
+        raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible on this box -- refusing to run a smaller world "
+                         f"under the label n_gpus={a.gpus}")
+    deadline = time.monotonic() + DEADLINE_S
+    rc = 0
+    for attempt in (0, 1):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        procs = []
+        for r in range(a.gpus):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK="0" if share else str(r), WORLD_SIZE=str(a.gpus), MASTER_ADDR="127.0.0.1",
+                       MASTER_PORT=str(port), RDO_BENCH_CHILD="1")
+            if attempt:
+                env["RDO_DP_GRAPH"] = "0"
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+        rc = _watch(procs, deadline, "rank process")
+        stalled = rc == STALL_STATUS or os.path.exists(_stall_marker(port))
+        try:
+            os.remove(_stall_marker(port))
+        except OSError:
+            pass
+        if rc == 0 or not stalled or attempt or os.environ.get("RDO_DP_GRAPH", "1") != "1":
+            break
+        print("[bench] the captured data-parallel loop stalled: starting the ranks again on the host-driven loop (RDO_DP_GRAPH=0)",
+              file=sys.stderr, flush=True)
+    return rc
+
+
+def supervise_rank():
+    """Launched by torch.distributed.run (RANK / WORLD_SIZE in the environment, N > 1): this process stays OFF the GPU and runs the
+    actual rank as a fresh child, so that a hang has a way out that is not a re-exec: the child's captured data-parallel loop is
+    watched by a heartbeat (engine.UnitEngine._hb_wait); when it stalls, the rank leaves a marker file and exits with status 86;
+    every rank's loop stalls with it (a collective blocks all of them) or its child is ended by torch's collective timeout.  Each
+    supervisor that finds the marker starts its rank ONCE more on the host-driven loop (RDO_DP_GRAPH=0) with the rendezvous port
+    moved by a fixed offset (all supervisors compute the same one).  An overall deadline ends a child that hangs anywhere else."""
+    import subprocess
+    port = int(os.environ.get("MASTER_PORT", "29517"))
+    deadline = time.monotonic() + DEADLINE_S
+    rc = 0
+    for attempt in (0, 1):
+        env = dict(os.environ, RDO_BENCH_CHILD="1")
+        if attempt:
+            env["RDO_DP_GRAPH"] = "0"
+            env["MASTER_PORT"] = str(1024 + (port + 101 - 1024) % (65536 - 1024))
+        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
+        rc = _watch([child], deadline, "rank process")
+        if rc == 0 or attempt or os.environ.get("RDO_DP_GRAPH", "1") != "1":
+            break
+        t_wait = time.monotonic() + 30                # another rank may be the one that saw the stall: give its marker a moment
+        while rc != STALL_STATUS and not os.path.exists(_stall_marker(port)) and time.monotonic() < t_wait:
+            time.sleep(0.5)
+        if rc != STALL_STATUS and not os.path.exists(_stall_marker(port)):
+            break
+        print(f"[bench] rank {os.environ.get('RANK')}: the captured data-parallel loop stalled: starting this rank again on the host-driven "
+              "loop (RDO_DP_GRAPH=0)", file=sys.stderr, flush=True)
+        time.sleep(3.0)                               # every supervisor reads the marker before rank 0 removes it
+    if os.environ.get("RANK", "0") == "0":
+        try:
+            os.remove(_stall_marker(port))
+        except OSError:
+            pass
     return rc
 
 
@@ -524,6 +605,8 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         raise SystemExit(f"bench.py: --gpus {a.gpus} contradicts WORLD_SIZE={world} (launch with --nproc-per-node {a.gpus})")
+    if world > 1 and os.environ.get("RDO_BENCH_CHILD") != "1":
+        sys.exit(supervise_rank())                   # launched by torch.distributed.run: the rank itself is a fresh child (see there)
     # The ONE JSON line goes to the real stdout; everything else that lands on fd 1 -- RCCL prints a version banner there when the
     # first communicator is created -- is sent to stderr.
     json_out = os.fdopen(os.dup(1), "w")
@@ -540,10 +623,28 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         # RDO_BENCH_BACKEND=gloo exists for the tests (two ranks on ONE GPU: RCCL refuses that); measurements use nccl = RCCL
         backend = os.environ.get("RDO_BENCH_BACKEND", "nccl")
+        # a collective that does not complete in 180 s ends the process (torch's watchdog): a mismatch on first contact must not cost
+        # the whole of the driver's time limit; collectives replayed from a captured graph are watched by the engine's heartbeat instead
+        import datetime
+        tmo = datetime.timedelta(seconds=float(os.environ.get("RDO_BENCH_COLL_TIMEOUT_S", 180)))
         if backend == "nccl":
-            torch.distributed.init_process_group("nccl", device_id=device, rank=rank, world_size=world)
+            torch.distributed.init_process_group("nccl", device_id=device, rank=rank, world_size=world, timeout=tmo)
         else:
-            torch.distributed.init_process_group(backend, rank=rank, world_size=world)
+            torch.distributed.init_process_group(backend, rank=rank, world_size=world, timeout=tmo)
+        from quantization import engine as _engine
+
+        def _stalled(exc_type, exc, tb, _prev=sys.excepthook):
+            """A stalled captured loop cannot be torn down (every synchronisation would hang with it): leave the marker for the
+            launcher / supervisors and end the process at once."""
+            if isinstance(exc, _engine.DpStallError):
+                print(f"[bench] {exc}", file=sys.stderr, flush=True)
+                try:
+                    open(_stall_marker(os.environ.get("MASTER_PORT", "29517")), "w").close()
+                except OSError:
+                    pass
+                os._exit(STALL_STATUS)
+            _prev(exc_type, exc, tb)
+        sys.excepthook = _stalled
     res = gpu_leg(a, rank, world, device)
     log("gpu leg done")
     n_units, dt = res["n_units"], res["dt"]
@@ -620,6 +721,8 @@ def main():
         if res["dp_paths"]:
             out["dp_graph"] = res["dp_paths"] == ["graph"]
             out["config"]["dp_loop"] = "+".join(res["dp_paths"])
+            out["config"]["dp_capture_fallbacks"] = res["dp_fallbacks"]      # units whose capture the ranks agreed to drop (host loop there)
+            out["config"]["dp_graph_env"] = os.environ.get("RDO_DP_GRAPH", "1")   # "0": the launcher's retry after a stalled captured loop
         if res["dp_units"]:
             du = res["dp_units"]
             out["dp"] = {"backend": torch.distributed.get_backend() if torch.distributed.is_initialized() else None,

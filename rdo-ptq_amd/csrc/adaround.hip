@@ -20,6 +20,16 @@ constexpr float kBeta1 = 0.9f, kBeta2 = 0.999f, kAdamEps = 1e-8f;
 
 __device__ __forceinline__ float sigmoidf_(float a) { return 1.0f / (1.0f + __expf(-a)); }
 
+// u^p for u in [0, 1], p in [1, 19] (the rounding regulariser's (2|h - 1/2|)^(b-1)) on the transcendental unit: exp2(p * log2 u).
+// HIP's __powf is the correctly rounded library pow -- ~190 instructions, more than the rest of an element's step together and
+// ~150 us of every calibration step of the Cheng2020 schedule (tools/ada_step_ablate.py, profiles/r06a_ada_step_ablate.md).  v_log_f32 /
+// v_exp_f32 are good to 1 ulp of their results: the power's relative error is <= 4e-8 * |p log2 u|, i.e. <= 3 ulp wherever the
+// result is above 1e-3 and an absolute error below 1e-9 everywhere else (the term is a regulariser's value and slope next to a data
+// gradient that carries the fp32 summation-order noise of 65 536-pixel reductions).
+__device__ __forceinline__ float pow_u(float u, float p) {
+    return (u > 0.f) ? __builtin_amdgcn_exp2f(__builtin_amdgcn_logf(u) * p) : 0.f;
+}
+
 struct AdaArgs {
     rdo_ada_desc d;
     const float* w;
@@ -48,6 +58,15 @@ struct AdaArgs {
     unsigned short* lin_bwd;     // optional: the same of the transpose (rows and inner swapped)
     float lin_pscale;
 };
+#ifdef RDO_DIAG
+// ablation mask of a diagnostic build (tools/ada_step_ablate.py; set by rdo_diag_ada_ablate, read by the kernels at run time so that
+// captured graphs follow it): 1 slab reads off, 2 plane writes off, 4 rounding term off, 8 Adam state off, 16 dgrad-layout work off,
+// 32 fp32 wq write off
+__device__ int g_ada_abl = 0;
+#define ADA_ABL(bit) ((g_ada_abl & (bit)) != 0)
+#else
+#define ADA_ABL(bit) false
+#endif
 
 // element (n, k) of W [rows][inner] in the fragment order of rdo_linear_h2 (linear_h2.hip, rdo_split_h2_linear): half index inside a plane
 __device__ __forceinline__ long lin_frag_index(int n, int k, int nblk) {
@@ -119,7 +138,7 @@ __device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, 
         vec_t g4 = wv4 * 0.f;
         if (a.mode == 2) {
             g4 = *reinterpret_cast<const vec_t*>(a.dalpha_in + e0);
-        } else {
+        } else if (!ADA_ABL(1)) {
             // eight slab loads in flight per thread: with ~5 waves per CU at these sizes a serial chain of nsplit dependent
             // loads (one L2 / fabric round trip each) was the whole kernel time
             const float* sp = a.slabs + e0;
@@ -147,7 +166,7 @@ __device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, 
             for (; s < a.nsplit; ++s) g4 += *reinterpret_cast<const vec_t*>(sp + (long)s * d.numel);
         }
         vec_t m4 = wv4 * 0.f, v4 = m4, o4 = m4;
-        if (a.mode != 1) {
+        if (a.mode != 1 && !ADA_ABL(8)) {
             m4 = *reinterpret_cast<const vec_t*>(a.m + e0);
             v4 = *reinterpret_cast<const vec_t*>(a.v + e0);
         }
@@ -194,9 +213,9 @@ __device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, 
             }
             // rounding regulariser (value of the current alpha, gradient through h)
             float g_total = g_alpha * a.grad_scale;
-            if (round_on != 0.f) {
+            if (round_on != 0.f && !ADA_ABL(4)) {
                 const float u = fabsf(h - 0.5f) * 2.f;
-                const float ub1 = (u > 0.f) ? __powf(u, b - 1.f) : 0.f;   // u^(b-1); u^b = u * u^(b-1)
+                const float ub1 = pow_u(u, b - 1.f);                       // u^(b-1); u^b = u * u^(b-1)
                 rl_local += a.round_weight * (1.f - u * ub1);
                 const float sgn = (h > 0.5f) ? 1.f : ((h < 0.5f) ? -1.f : 0.f);
                 g_total += (-a.round_weight * (b * ub1) * 2.f * sgn) * dh_da;
@@ -221,10 +240,13 @@ __device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, 
         if (a.mode == 1) {
             *reinterpret_cast<vec_t*>(a.dalpha_out + e0) = o4;
         } else {
-            *reinterpret_cast<vec_t*>(a.m + e0) = m4;
-            *reinterpret_cast<vec_t*>(a.v + e0) = v4;
+            if (!ADA_ABL(8)) {
+                *reinterpret_cast<vec_t*>(a.m + e0) = m4;
+                *reinterpret_cast<vec_t*>(a.v + e0) = v4;
+            }
             *reinterpret_cast<vec_t*>(a.alpha + e0) = al4;
-            *reinterpret_cast<vec_t*>(a.wq + e0) = o4;
+            if (!ADA_ABL(32)) *reinterpret_cast<vec_t*>(a.wq + e0) = o4;
+            if (ADA_ABL(2)) continue;
             if (a.lin_fwd || a.lin_bwd) {                      // planes for rdo_linear_h2 (a Linear / GDN gamma on large token matrices)
                 const int in_ = (int)inner, nr = d.rows;
                 const long plane = (long)nr * in_;
@@ -303,6 +325,238 @@ __device__ __forceinline__ void ada_step_body(const AdaArgs& a, const long bid, 
     }
 }
 
+
+// ---- tile form of the fused step (modes 0 and 2) -------------------------------------------------------------------------------------
+// One workgroup owns 32 rows (output channels) x 32 input channels of ONE tap of a conv weight [rows][KH][KW][Cin] (a GDN gamma or a
+// Linear is the one-tap case): thread (r = tid / 8, q = tid % 8) steps the four channels 4q .. 4q + 3 of row r -- every stream is read and
+// written in 128-byte row segments (eight lanes per segment), a thread's quantisation row is fixed (no index division per element) --
+// and the new soft weights go through a 32 x 32 LDS tile so that the SAME launch writes the dgrad layout wd[ci][KH-1-kh][KW-1-kw][co],
+// its planes and the transposed rdo_linear_h2 planes with 16-byte / 8-byte stores along co.  Until round 6 that was a second launch
+// (wd_transpose_batch_kernel) that re-read wq: 13 launches and ~0.1-0.2 ms of every calibration step of the Cheng2020 schedule
+// (profiles/r06a_ada_step_ablate.md).  Needs Cin % 4 == 0 and rows % 4 == 0; everything else stays on the flat form above.
+__device__ __forceinline__ void ada_step_tile_body(const AdaArgs& a, int bid) {
+    typedef float vec_t __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    const rdo_ada_desc d = a.d;
+    const int Cin = d.Cin, taps = d.KH * d.KW, nrows = d.rows;
+    const int ctiles = (Cin + 31) >> 5;
+    const int bid0 = bid;
+    const int ct = bid % ctiles; bid /= ctiles;
+    const int tap = bid % taps;
+    const int rt = bid / taps;
+    const int q = threadIdx.x & 7, r = threadIdx.x >> 3;
+    const int row = rt * 32 + r, ci = ct * 32 + 4 * q;
+    const bool live = row < nrows && ci < Cin;
+    const float Lm1 = (float)(d.n_levels - 1);
+    const int it = *a.iter_ptr;
+    const rdo_sched_row sc = a.sched[it];
+    const float b = sc.b, round_on = sc.round_on, step_size = sc.step_size, bc2 = sc.bc2_sqrt;
+    float rl_local = 0.f;
+    vec_t o4 = {0.f, 0.f, 0.f, 0.f};
+    const long e0 = ((long)row * taps + tap) * Cin + ci;
+    if (live) {
+        const vec_t wv4 = *reinterpret_cast<const vec_t*>(a.w + e0);
+        vec_t al4 = *reinterpret_cast<const vec_t*>(a.alpha + e0);
+        vec_t g4 = {0.f, 0.f, 0.f, 0.f};
+        if (a.mode == 2) {
+            g4 = *reinterpret_cast<const vec_t*>(a.dalpha_in + e0);
+        } else if (!ADA_ABL(1)) {
+            const float* sp = a.slabs + e0;                     // same summation order as the flat form
+            int s = 0;
+            for (; s + 16 <= a.nsplit; s += 16) {
+                vec_t t[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) t[u] = *reinterpret_cast<const vec_t*>(sp + (long)(s + u) * d.numel);
+                g4 += (((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]))) +
+                      (((t[8] + t[9]) + (t[10] + t[11])) + ((t[12] + t[13]) + (t[14] + t[15])));
+            }
+            for (; s + 8 <= a.nsplit; s += 8) {
+                vec_t t[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const vec_t*>(sp + (long)(s + u) * d.numel);
+                g4 += ((t[0] + t[1]) + (t[2] + t[3])) + ((t[4] + t[5]) + (t[6] + t[7]));
+            }
+            if (s + 4 <= a.nsplit) {
+                vec_t t[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) t[u] = *reinterpret_cast<const vec_t*>(sp + (long)(s + u) * d.numel);
+                g4 += (t[0] + t[1]) + (t[2] + t[3]);
+                s += 4;
+            }
+            for (; s < a.nsplit; ++s) g4 += *reinterpret_cast<const vec_t*>(sp + (long)s * d.numel);
+        }
+        vec_t m4 = {0.f, 0.f, 0.f, 0.f}, v4 = m4;
+        if (!ADA_ABL(8)) {
+            m4 = *reinterpret_cast<const vec_t*>(a.m + e0);
+            v4 = *reinterpret_cast<const vec_t*>(a.v + e0);
+        }
+        const float dl = a.delta[row], z = a.zp[row];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float al = al4[k];
+            const float xf = floorf(wv4[k] / dl);
+            const float sg = sigmoidf_(al);
+            const float hraw = sg * (kZeta - kGamma) + kGamma;
+            const float h = fminf(fmaxf(hraw, 0.f), 1.f);
+            const float xint = xf + h + z;
+            const float pass_h = (hraw >= 0.f && hraw <= 1.f) ? 1.f : 0.f;
+            const float dh_da = pass_h * ((kZeta - kGamma) * (sg * (1.f - sg)));
+            float g_alpha = g4[k];
+            if (a.mode != 2) {
+                float g = g4[k];
+                if (d.reparam) {
+                    const float qv = (fminf(fmaxf(xint, 0.f), Lm1) - z) * dl;
+                    const float lb = fmaxf(qv, d.reparam_bound);
+                    const float go = g * (2.f * lb);
+                    g = (qv >= d.reparam_bound || go < 0.f) ? go : 0.f;
+                }
+                const float pass_q = (xint >= 0.f && xint <= Lm1) ? 1.f : 0.f;
+                g_alpha = (g * dl) * pass_q * dh_da;
+            }
+            float g_total = g_alpha * a.grad_scale;
+            if (round_on != 0.f && !ADA_ABL(4)) {
+                const float u = fabsf(h - 0.5f) * 2.f;
+                const float ub1 = pow_u(u, b - 1.f);
+                rl_local += a.round_weight * (1.f - u * ub1);
+                const float sgn = (h > 0.5f) ? 1.f : ((h < 0.5f) ? -1.f : 0.f);
+                g_total += (-a.round_weight * (b * ub1) * 2.f * sgn) * dh_da;
+            }
+            float mm = m4[k], vv = v4[k];
+            mm = mm + (g_total - mm) * (1.f - kBeta1);
+            vv = vv * kBeta2 + (1.f - kBeta2) * g_total * g_total;
+            const float denom = sqrtf(vv) / bc2 + kAdamEps;
+            al = al - step_size * (mm / denom);
+            m4[k] = mm; v4[k] = vv; al4[k] = al;
+            const float sg2 = sigmoidf_(al);
+            const float h2 = fminf(fmaxf(sg2 * (kZeta - kGamma) + kGamma, 0.f), 1.f);
+            float o = (fminf(fmaxf(xf + h2 + z, 0.f), Lm1) - z) * dl;
+            if (d.reparam) {
+                const float lb = fmaxf(o, d.reparam_bound);
+                o = lb * lb - d.reparam_pedestal;
+            }
+            o4[k] = o;
+        }
+        if (!ADA_ABL(8)) {
+            *reinterpret_cast<vec_t*>(a.m + e0) = m4;
+            *reinterpret_cast<vec_t*>(a.v + e0) = v4;
+        }
+        *reinterpret_cast<vec_t*>(a.alpha + e0) = al4;
+        if (!ADA_ABL(32)) *reinterpret_cast<vec_t*>(a.wq + e0) = o4;
+        if (!ADA_ABL(2)) {
+            int bad = 0;
+            if (a.lin_fwd) {                                    // rdo_linear_h2 planes of W [rows][Cin]: four consecutive k = 8 bytes
+                unsigned hh, ll;
+                u32x2 ph, pl;
+                rdo::h2_split_pk(o4[0], o4[1], a.lin_pscale, hh, ll, bad); ph[0] = hh; pl[0] = ll;
+                rdo::h2_split_pk(o4[2], o4[3], a.lin_pscale, hh, ll, bad); ph[1] = hh; pl[1] = ll;
+                const long f = lin_frag_index(row, ci, nrows >> 4);
+                *reinterpret_cast<u32x2*>(a.lin_fwd + f) = ph;
+                *reinterpret_cast<u32x2*>(a.lin_fwd + (long)nrows * Cin + f) = pl;
+            }
+            if (a.wq_planes) {
+                const long f0 = (Cin & 15) ? e0 : (((((long)(ci >> 4) * taps + tap) * nrows + row) << 4) + (ci & 15));   // rdo::frag_index
+                if (a.wq_pscale > 0.f) {
+                    unsigned hh, ll;
+                    u32x2 ph, pl;
+                    rdo::h2_split_pk(o4[0], o4[1], a.wq_pscale, hh, ll, bad); ph[0] = hh; pl[0] = ll;
+                    rdo::h2_split_pk(o4[2], o4[3], a.wq_pscale, hh, ll, bad); ph[1] = hh; pl[1] = ll;
+                    *reinterpret_cast<u32x2*>(a.wq_planes + f0) = ph;
+                    *reinterpret_cast<u32x2*>(a.wq_planes + d.numel + f0) = pl;
+                } else {
+                    u16x4 ph, pm, pl;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const __bf16 hb = (__bf16)o4[k];
+                        const float r1 = o4[k] - (float)hb;
+                        const __bf16 mb = (__bf16)r1;
+                        const __bf16 lb = (__bf16)(r1 - (float)mb);
+                        ph[k] = __builtin_bit_cast(unsigned short, hb);
+                        pm[k] = __builtin_bit_cast(unsigned short, mb);
+                        pl[k] = __builtin_bit_cast(unsigned short, lb);
+                    }
+                    *reinterpret_cast<u16x4*>(a.wq_planes + f0) = ph;
+                    *reinterpret_cast<u16x4*>(a.wq_planes + d.numel + f0) = pm;
+                    *reinterpret_cast<u16x4*>(a.wq_planes + 2 * d.numel + f0) = pl;
+                }
+            }
+            rdo::h2_report(bad, a.ovf);
+        }
+    }
+    // ---- dgrad layout: transpose the tile's new soft weights through LDS (wave-uniform condition: the barrier is reached by all or none)
+    __shared__ float tile[32][33];
+    __shared__ float red[4];
+    if ((a.wd || a.lin_bwd) && !ADA_ABL(16)) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tile[r][4 * q + k] = o4[k];
+        __syncthreads();
+        const int ci2 = ct * 32 + r, co2 = rt * 32 + 4 * q;      // this thread now owns four consecutive output channels of one input channel
+        if (ci2 < Cin && co2 < nrows) {
+            vec_t t4;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) t4[k] = tile[4 * q + k][r];
+            const int kh = tap / d.KW, kw = tap - kh * d.KW;
+            const int tapf = (d.KH - 1 - kh) * d.KW + (d.KW - 1 - kw);
+            const long o = ((long)ci2 * taps + tapf) * nrows + co2;
+            if (a.wd) *reinterpret_cast<vec_t*>(a.wd + o) = t4;
+            int bad = 0;
+            if (a.lin_bwd && !ADA_ABL(2)) {
+                unsigned hh, ll;
+                u32x2 ph, pl;
+                rdo::h2_split_pk(t4[0], t4[1], a.lin_pscale, hh, ll, bad); ph[0] = hh; pl[0] = ll;
+                rdo::h2_split_pk(t4[2], t4[3], a.lin_pscale, hh, ll, bad); ph[1] = hh; pl[1] = ll;
+                const long f = lin_frag_index(ci2, co2, Cin >> 4);
+                *reinterpret_cast<u32x2*>(a.lin_bwd + f) = ph;
+                *reinterpret_cast<u32x2*>(a.lin_bwd + (long)nrows * Cin + f) = pl;
+            }
+            if (a.wd && a.wd_planes && !ADA_ABL(2)) {
+                // wd is the weight [Cin][KH][KW][Cout] of the dgrad conv: its planes go in THAT conv's fragment order (slices of 16 co)
+                const long f0 = (nrows & 15) ? o : (((((long)(co2 >> 4) * taps + tapf) * Cin + ci2) << 4) + (co2 & 15));
+                if (a.wd_pscale > 0.f) {
+                    unsigned hh, ll;
+                    u32x2 ph, pl;
+                    rdo::h2_split_pk(t4[0], t4[1], a.wd_pscale, hh, ll, bad); ph[0] = hh; pl[0] = ll;
+                    rdo::h2_split_pk(t4[2], t4[3], a.wd_pscale, hh, ll, bad); ph[1] = hh; pl[1] = ll;
+                    *reinterpret_cast<u32x2*>(a.wd_planes + f0) = ph;
+                    *reinterpret_cast<u32x2*>(a.wd_planes + d.numel + f0) = pl;
+                } else {
+                    u16x4 ph, pm, pl;
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const __bf16 hb = (__bf16)t4[k];
+                        const float r1 = t4[k] - (float)hb;
+                        const __bf16 mb = (__bf16)r1;
+                        const __bf16 lb = (__bf16)(r1 - (float)mb);
+                        ph[k] = __builtin_bit_cast(unsigned short, hb);
+                        pm[k] = __builtin_bit_cast(unsigned short, mb);
+                        pl[k] = __builtin_bit_cast(unsigned short, lb);
+                    }
+                    *reinterpret_cast<u16x4*>(a.wd_planes + f0) = ph;
+                    *reinterpret_cast<u16x4*>(a.wd_planes + d.numel + f0) = pm;
+                    *reinterpret_cast<u16x4*>(a.wd_planes + 2 * d.numel + f0) = pl;
+                }
+            }
+            rdo::h2_report(bad, a.ovf);
+        }
+    }
+    if (a.round_loss_out && round_on != 0.f) {
+        float vsum = rl_local;
+        for (int o = 32; o > 0; o >>= 1) vsum += __shfl_down(vsum, o, 64);
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = vsum;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t = red[0] + red[1] + red[2] + red[3];
+            if (t != 0.f) atomicAdd(a.round_loss_out + (long)it * RDO_LOG_SLOTS + (bid0 & (RDO_LOG_SLOTS - 1)), t);
+        }
+    }
+}
+
+// Does a tensor's fused step / apply run in the tile form?  (host side; the kernel gets the answer as `tile` in the batch descriptor)
+inline bool tile_ok(const rdo_ada_desc& d, int mode) {
+    return mode != 1 && d.Cin > 0 && d.Cin % 4 == 0 && d.rows % 4 == 0 && (long)d.rows * d.KH * d.KW * d.Cin == d.numel && d.numel < (1L << 31);
+}
+inline long tile_blocks(const rdo_ada_desc& d) { return rdo::ceil_div(d.rows, 32) * d.KH * d.KW * rdo::ceil_div(d.Cin, 32); }
+
 template <int W>
 __global__ __launch_bounds__(256) void ada_step_kernel(AdaArgs a) {
     ada_step_body<W>(a, blockIdx.x, gridDim.x);
@@ -317,6 +571,7 @@ struct AdaBatch {
     int32_t* iter_shadow;   // nullable: block 0 leaves *iter_ptr + 1 here (iteration-counter hand-over, rdo_ptq_hip.h)
     AdaArgs a[kMaxBatch];
     int blk_end[kMaxBatch];
+    unsigned char tile[kMaxBatch];   // this tensor runs the tile form (ada_step_tile_body): the dgrad layout is written by the same launch
     int n;
 };
 __global__ __launch_bounds__(256) void ada_step_batch_kernel(AdaBatch b) {
@@ -324,6 +579,7 @@ __global__ __launch_bounds__(256) void ada_step_batch_kernel(AdaBatch b) {
     int t = 0;
     while (t + 1 < b.n && (int)blockIdx.x >= b.blk_end[t]) ++t;
     const int beg = t ? b.blk_end[t - 1] : 0;
+    if (b.tile[t]) { ada_step_tile_body(b.a[t], (int)blockIdx.x - beg); return; }
     // many slabs over a small tensor (the 1x1 GDN gamma gradient, 256 slabs of 36 K elements): one element per thread -- four times
     // the threads walking the slab chain; same per-element summation order
     if (b.a[t].nsplit >= b.w1_min && b.a[t].mode != 2) ada_step_body<1>(b.a[t], (long)blockIdx.x - beg, (long)b.blk_end[t] - beg);
@@ -375,7 +631,7 @@ __global__ __launch_bounds__(256) void wd_transpose_batch_kernel(AdaBatch b, int
     int t = 0;
     while (t + 1 < b.n && (int)blockIdx.x >= b.blk_end[t]) ++t;
     const int beg = t ? b.blk_end[t - 1] : 0;
-    wd_transpose_body(b.a[t].d, b.a[t].wq, b.a[t].wd, b.a[t].wd_planes, b.a[t].wd_pscale, b.a[t].ovf, (int)blockIdx.x - beg);
+    if (!ADA_ABL(16)) wd_transpose_body(b.a[t].d, b.a[t].wq, b.a[t].wd, b.a[t].wd_planes, b.a[t].wd_pscale, b.a[t].ovf, (int)blockIdx.x - beg);
     if (advance && blockIdx.x == 0 && threadIdx.x == 0) *advance += 1;
 }
 
@@ -492,6 +748,12 @@ int run_step(AdaArgs a, void* stream) {
 
 extern "C" {
 
+#ifdef RDO_DIAG
+int rdo_diag_ada_ablate(int mask) {
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_ada_abl), &mask, sizeof mask) == hipSuccess ? RDO_OK : rdo::set_error(RDO_EHIP, "rdo_diag_ada_ablate");
+}
+#endif
+
 int rdo_adaround_init_alpha(const rdo_ada_desc* d, const float* w, const float* delta, float* alpha, void* stream) {
     if (int rc = check_desc(d, "rdo_adaround_init_alpha")) return rc;
     RDO_REQUIRE(w && delta && alpha, "rdo_adaround_init_alpha: null pointer");
@@ -605,10 +867,11 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
             a.lin_bwd = static_cast<unsigned short*>(it.lin_bwd_planes);
             a.lin_pscale = it.lin_plane_scale;
         }
-        blocks += (int)grid_for((it.nsplit >= w1_min && mode != 2) ? it.d.numel : it.d.numel / 4);
+        b.tile[i] = tile_ok(it.d, mode) ? 1 : 0;
+        blocks += b.tile[i] ? (int)tile_blocks(it.d) : (int)grid_for((it.nsplit >= w1_min && mode != 2) ? it.d.numel : it.d.numel / 4);
         b.blk_end[i] = blocks;
         bytes += 4.0 * it.d.numel * ((mode == 2 ? 1 : it.nsplit) + (mode == 1 ? 3.0 : 9.0));
-        if (mode != 1 && it.wd && it.d.Cin > 0) {
+        if (mode != 1 && it.wd && it.d.Cin > 0 && !b.tile[i]) {
             bw.a[bw.n] = a;
             wblocks += (int)(rdo::ceil_div(it.d.rows, 32) * it.d.KH * it.d.KW * rdo::ceil_div(it.d.Cin, 32));
             bw.blk_end[bw.n++] = wblocks;

@@ -36,6 +36,10 @@ from .quantizer import AdaRoundQuantizer, from_rows, to_rows
 UNIT_KINDS = ("layer", "rb", "rbws", "rbu", "rstb")
 
 
+class DpStallError(RuntimeError):
+    """The captured data-parallel loop stopped making progress (`UnitEngine._hb_wait`): a collective inside the graph hangs."""
+
+
 class IdxStream:
     """Mini-batch index tables drawn from torch's GLOBAL CPU generator exactly as the reference draws them -- one `torch.randperm(n)` per
     iteration (layer_opt.py:289) -- with the NEXT unit's table drawn ahead of time while the GPU runs the current unit's loop (20 000
@@ -305,6 +309,9 @@ class UnitEngine:
         self.split = self.world > 1 or force_dp_split
         self.dp_path = None                    # "graph" | "host" once a data-parallel run has started (_run_dp)
         self._dp_graph, self._dp_graph_failed = None, False
+        self.dp_fallbacks = 0                  # captures the ranks agreed to drop (this unit then runs the host loop on every rank)
+        self._hb_dev = self._hb_host = None    # heartbeat of the captured loop (`_dp_capture`)
+        self._hb_issued = 0
         self.rd_path = None                    # "graph" | "host" once an R + lambda*D run has started (_run_rd)
         self._rd_graph, self._rd_graph_failed = None, False
         # this unit's own fp16-overflow word (rdo_h2_bind_flag): raised by every H2 producer of its plans, polled during long runs
@@ -933,6 +940,7 @@ class UnitEngine:
         Restart ladder (`_recover`): H2_RESTARTS restarts on re-derived scales, then one on fp32 activations (`use_h2 = False`, no
         planes left, `_overflowed` is False by construction).  An overflow word raised with no plane tensor alive would be a library
         fault."""
+        self.dp_drain()
         if self._ovf_checked == self._done:
             return
         while self._overflowed():
@@ -1118,21 +1126,22 @@ class UnitEngine:
         return self.batch_step and len(opl) >= 1 and all(op.numel() % 4 == 0 for op in opl)
 
     def _step_batches(self, opl, scale, mode):
-        """The batched step (mode 0) / update (mode 2) of `opl`; the iteration counter moves with the last launch."""
-        single = len(opl) <= self.STEP_BATCH
+        """The batched step (mode 0) / update (mode 2) of `opl`.  The iteration counter moves by hand-over (the FIRST launch leaves
+        it + 1 in the shadow word -- every launch of the step only reads the counter --, the next gather publishes it) or, with the
+        hand-over switched off, with the last launch."""
         for i in range(0, len(opl), self.STEP_BATCH):
             last = i + self.STEP_BATCH >= len(opl)
-            if single and self._handover:
-                ops.adaround_step_batch(self._items(opl), scale, self.weight, self.sched, self.it, self.round_log, mode=mode, iter_shadow=self.it_shadow)
+            if self._handover:
+                ops.adaround_step_batch(self._items(opl[i:i + self.STEP_BATCH]), scale, self.weight, self.sched, self.it, self.round_log, mode=mode,
+                                        iter_shadow=self.it_shadow if i == 0 else None)
             else:
                 ops.adaround_step_batch(self._items(opl[i:i + self.STEP_BATCH]), scale, self.weight, self.sched, self.it, self.round_log, mode=mode,
                                         advance_iter=self.it if last else None)
 
     @property
     def _handover(self):
-        """The counter hand-over needs the step of the whole unit in one batched launch (it is that launch that fills the shadow)."""
-        opl = list(self.ops.values())
-        return self.fold_iter and self._batchable(opl) and len(opl) <= self.STEP_BATCH
+        """The counter hand-over needs the unit's step as batched launches (it is the first of them that fills the shadow)."""
+        return self.fold_iter and self._batchable(list(self.ops.values()))
 
     def _it_src(self):
         return self.it_shadow if self._handover else self.it
@@ -1233,6 +1242,8 @@ class UnitEngine:
                 self._done += k
                 if idle is not None:
                     idle()                                      # host work while the GPU has the enqueued iterations to do
+                if self._done < target and self.P and self.H2_POLL > 0:
+                    self.dp_drain()
                 if self._done < target and self._overflowed():
                     self._recover()                  # back to iteration 0 with new scales / on fp32 activations
         return n
@@ -1251,6 +1262,48 @@ class UnitEngine:
         else:
             self.plan_b.run_then(self.plan_a, graph=graph)
 
+    # backends whose collectives can be captured into a graph (torch's "nccl" = RCCL on ROCm); a test adds "gloo" to exercise the agreement
+    DP_GRAPH_BACKENDS = ("nccl",)
+    DP_HB_BATCH = 32                                                   # captured replays between two looks at the heartbeat
+    DP_STALL_S = float(os.environ.get("RDO_DP_STALL_S", 120))          # no heartbeat for this long = the captured loop hangs
+
+    def _dp_capture(self):
+        """One data-parallel iteration -- the recorded kernels of the plans AND the collectives -- as one graph, closed by the heartbeat:
+        a device counter incremented and copied to pinned host memory by the graph's last two nodes.  torch's NCCL watchdog does not see
+        collectives replayed from a graph; the heartbeat is what tells the host that replays still complete (`_hb_wait`)."""
+        if self._hb_dev is None:
+            self._hb_dev = torch.zeros(1, dtype=torch.int64, device=self.dev)
+            self._hb_host = torch.zeros(1, dtype=torch.int64).pin_memory()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self._dp_iteration(False)
+            self._hb_dev.add_(1)
+            self._hb_host.copy_(self._hb_dev, non_blocking=True)
+        return g
+
+    def _hb_wait(self, target):
+        """Block until `target` captured replays have completed (heartbeat in pinned memory: no device synchronisation, which would hang
+        with the loop).  No progress for DP_STALL_S seconds -> `DpStallError`: the process cannot recover a hung collective; the
+        application decides (bench.py exits with status 86 and its launcher / supervisor starts FRESH children on the host loop)."""
+        import time
+        if self._hb_host is None or target <= 0:
+            return
+        seen, t_last = int(self._hb_host[0]), time.monotonic()
+        while seen < target:
+            time.sleep(0.0005)
+            now = int(self._hb_host[0])
+            if now != seen:
+                seen, t_last = now, time.monotonic()
+            elif time.monotonic() - t_last > self.DP_STALL_S:
+                raise DpStallError(f"rank {self._rank()}: the captured data-parallel loop made no progress for {self.DP_STALL_S:.0f} s "
+                                   f"({seen} of {self._hb_issued} replays completed) -- a collective inside the graph hangs")
+
+    def dp_drain(self):
+        """Wait (heartbeat, with the stall deadline) for every captured replay issued so far: call it before anything that synchronises
+        the device behind a data-parallel run -- a plain synchronisation behind a hung graph would never return."""
+        if self._dp_graph is not None:
+            self._hb_wait(self._hb_issued)
+
     def _run_dp(self, n):
         """n data-parallel iterations.  With the RCCL backend (round 5: the DEFAULT; `RDO_DP_GRAPH=0` keeps the host loop) the whole
         iteration -- the recorded kernels of the three plans AND the collectives -- is captured once per unit into ONE graph
@@ -1259,20 +1312,22 @@ class UnitEngine:
         the sixteen <= 50-us units cannot hide (+13 % on one rank against +5 % captured, `extra.dp_overhead_one_rank` of the bench
         line re-measures both on every run).  The ranks AGREE on the outcome of the capture (MIN all-reduce of an "ok" flag) before
         anyone replays: a rank never replays a graph with collectives while another runs the host loop; a unit whose capture fails
-        on any rank runs the host loop on every rank.  Other backends (gloo in the CPU / one-GPU tests): host loop.  `self.dp_path`
-        says which loop ran ("graph" / "host"); every rank logs it, the bench line carries it per unit."""
+        on any rank runs the host loop on every rank (`dp_fallbacks` counts them).  The eager iteration in front of the capture is
+        OUTSIDE the try: it is an ordinary iteration on every rank whatever the capture does afterwards, so all ranks run the same
+        number of iterations (an exception in it is a real failure and propagates).  Replays are watched through a heartbeat
+        (`_dp_capture`, `_hb_wait`).  Other backends (gloo in the CPU / one-GPU tests): host loop.  `self.dp_path` says which loop
+        ran ("graph" / "host"); every rank logs it, the bench line carries it per unit."""
         import logging
         dist = torch.distributed
         comm = self.world > 1 or (dist.is_available() and dist.is_initialized())
-        want = self.use_graph and os.environ.get("RDO_DP_GRAPH", "1") == "1" and comm and dist.get_backend(self.group) == "nccl"
+        want = (self.use_graph and os.environ.get("RDO_DP_GRAPH", "1") == "1" and comm
+                and dist.get_backend(self.group) in self.DP_GRAPH_BACKENDS)
         if want and self._dp_graph is None and not self._dp_graph_failed and n > 1:
-            ok = 1
+            self._dp_iteration(False)                               # one eager iteration: warms RCCL and every lazy initialisation
+            n -= 1
+            ok, g = 1, None
             try:
-                self._dp_iteration(False)                           # one eager iteration: warms RCCL and every lazy initialisation
-                n -= 1
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    self._dp_iteration(False)
+                g = self._dp_capture()
             except Exception as e:      # pragma: no cover - depends on the RCCL / driver stack
                 logging.warning("rank %s: data-parallel iteration could not be captured into a graph (%s)", self._rank(), e)
                 ok = 0
@@ -1282,9 +1337,13 @@ class UnitEngine:
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
                 ok = int(flag.item())
             if ok:
-                self._dp_graph = g
+                self._dp_graph, self._hb_issued = g, 0
+                self._hb_dev.zero_()
+                self._hb_host.zero_()
             else:
                 self._dp_graph_failed = True
+                self.dp_fallbacks += 1
+                del g
         path = "graph" if self._dp_graph is not None else "host"
         if self.dp_path != path:
             self.dp_path = path
@@ -1292,6 +1351,9 @@ class UnitEngine:
         if self._dp_graph is not None:
             for _ in range(n):
                 self._dp_graph.replay()
+                self._hb_issued += 1
+                if self._hb_issued % self.DP_HB_BATCH == 0:         # at most two batches queued: the GPU stays fed, a hang is seen
+                    self._hb_wait(self._hb_issued - self.DP_HB_BATCH)
             return
         merge = self.use_graph and os.environ.get("RDO_DP_MERGE", "1") != "0"
         for i in range(n):

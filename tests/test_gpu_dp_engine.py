@@ -32,7 +32,7 @@ def _gidx(iters):
     return np.array([[i % 3, 3 + (2 * i) % 3] for i in range(iters)], dtype=np.int64)   # one image from each rank's shard
 
 
-def _rank(rank, world, port, golden, tag, kind, overlap, out_q):
+def _rank(rank, world, port, golden, tag, kind, overlap, out_q, break_capture=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for p in (root, os.path.join(root, "rdo-ptq_amd"), os.path.join(root, "tests")):
@@ -54,19 +54,41 @@ def _rank(rank, world, port, golden, tag, kind, overlap, out_q):
                          batch_size=1, iters=ITERS, input_prob=0.5, seed=SEED, idx_table=idx, batch_offset=rank, dp_overlap=overlap)
         assert eng.world == 2 and eng.split
         assert (eng.plan_a2 is not None) == (overlap and kind != "layer")
+        if break_capture:
+            # the capture path with gloo standing in for RCCL: rank 0's capture raises, rank 1's "succeeds" (a stand-in object: gloo
+            # collectives cannot be captured) -- the MIN agreement must put BOTH ranks on the host loop with the same iteration count
+            class _Fake:
+                def replay(self):
+                    raise AssertionError("a graph was replayed although another rank's capture failed")
+
+            def capture(self):
+                if rank == 0:
+                    raise RuntimeError("capture refused (injected)")
+                return _Fake()
+            UnitEngine.DP_GRAPH_BACKENDS = ("nccl", "gloo")
+            UnitEngine._dp_capture = capture
         eng.run()
         torch.cuda.synchronize()
         total = eng.logs()[0]
+        if break_capture:
+            assert eng.dp_path == "host" and eng._dp_graph is None and eng._dp_graph_failed and eng.dp_fallbacks == 1
+            assert eng._done == ITERS and int(eng._it2.max().item()) == ITERS     # (hand-over: the counter's shadow word is ahead by one)
         if rank == 0:
             out_q.put(({n_: eng.alpha_of(n_).cpu().numpy() for n_ in eng.ops}, total.numpy()))
         dist.barrier()
+    except BaseException as e:          # the parent must not wait out its queue timeout for a rank that failed
+        out_q.put(("error", f"rank {rank}: {e!r}"))
+        raise
     finally:
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("tag,kind,overlap", [("g_a.1", "rb", True), ("g_a.1", "rb", False), ("g_a.0", "rbws", True),
-                                              ("g_s.1", "rbu", True), ("g_a.6", "layer", True)])
-def test_two_rank_engine_equals_single_rank(golden_dir, tag, kind, overlap):
+@pytest.mark.parametrize("tag,kind,overlap,break_capture", [("g_a.1", "rb", True, False), ("g_a.1", "rb", False, False), ("g_a.0", "rbws", True, False),
+                                                            ("g_s.1", "rbu", True, False), ("g_a.6", "layer", True, False),
+                                                            ("g_a.1", "rb", True, True)])
+def test_two_rank_engine_equals_single_rank(golden_dir, tag, kind, overlap, break_capture):
+    """break_capture: one rank's graph capture of the data-parallel iteration fails: both ranks must
+    finish on the host loop, having run the same number of iterations, with the single-rank result."""
     from helpers import nhwc, product_unit
     from quantization.engine import UnitEngine
     golden = os.path.join(golden_dir, "recon_toy.npz")
@@ -82,14 +104,15 @@ def test_two_rank_engine_equals_single_rank(golden_dir, tag, kind, overlap):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_rank, args=(r, 2, port, golden, tag, kind, overlap, q)) for r in range(2)]
+    procs = [ctx.Process(target=_rank, args=(r, 2, port, golden, tag, kind, overlap, q, break_capture)) for r in range(2)]
     for p in procs:
         p.start()
     try:
-        got_alpha, got_total = q.get(timeout=600)
+        got_alpha, got_total = q.get(timeout=180)
+        assert not isinstance(got_alpha, str), got_total
     finally:
         for p in procs:
-            p.join(timeout=120)
+            p.join(timeout=60)
             if p.is_alive():
                 p.kill()
     assert all(p.exitcode == 0 for p in procs)
