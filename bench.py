@@ -514,6 +514,11 @@ def _watch(procs, deadline, what):
     return rc
 
 
+def _rank_cmd():
+    """the command of one rank process (a function so that the tests of the launcher can stand a stub in)"""
+    return [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
+
+
 def launch_ranks(a):
     """`python bench.py --gpus N` without a launcher: start N ranks as fresh child processes (one per GPU, rendezvous on 127.0.0.1)
     and return the worst exit status.  The parent never initialises HIP (a process that has may neither fork GPU children safely
@@ -544,7 +549,7 @@ def launch_ranks(a):
                        MASTER_PORT=str(port), RDO_BENCH_CHILD="1")
             if attempt:
                 env["RDO_DP_GRAPH"] = "0"
-            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+            procs.append(subprocess.Popen(_rank_cmd(), env=env))
         rc = _watch(procs, deadline, "rank process")
         stalled = rc == STALL_STATUS or os.path.exists(_stall_marker(port))
         try:
@@ -574,7 +579,7 @@ def supervise_rank():
         if attempt:
             env["RDO_DP_GRAPH"] = "0"
             env["MASTER_PORT"] = str(1024 + (port + 101 - 1024) % (65536 - 1024))
-        child = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env)
+        child = subprocess.Popen(_rank_cmd(), env=env)
         rc = _watch([child], deadline, "rank process")
         if rc == 0 or attempt or os.environ.get("RDO_DP_GRAPH", "1") != "1":
             break

@@ -134,3 +134,72 @@ def minnen_product_module(fx, tag, dev="cuda"):
     if int(fx[f"{tag}/act"]):
         qm.activation_function = nn.LeakyReLU(inplace=True) if int(fx[f"{tag}/act"]) == 1 else nn.ReLU(inplace=True)
     return qm
+
+
+# ---- natural-image statistics (VERDICT round 5, missing 3 / next 3) ---------------------------------------------------------------------
+def kodak_crops(golden_dir, n=None):
+    """[n, 3, 256, 256] floats in [0, 1]: the committed crops of the reference's Kodak images (tools/make_kodak_fixture.py), divided by 255
+    as the reference's ToTensor does (datasets/dataset.py:8-12)."""
+    import os
+    crops = np.load(os.path.join(golden_dir, "kodak_crops.npz"))["crops"]
+    x = torch.from_numpy(crops[: n or len(crops)].astype(np.float32) / 255.0)
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def trained_like_(ref, g, decades=2.5, probe=None):
+    """'Trained-like' parameters for an oracle model (oracle/lic_oracle.py; the product side copies the state): there are no checkpoints
+    offline (ReadMe.md:56-57), so the properties of trained codecs that matter to the plane path are drawn instead --
+      * conv weights with Laplace tails (a few weights per channel far outside the bulk: they set delta = range / 255 and push most
+        weights into a handful of levels) and per-output-channel scales spread log-uniformly over `decades` decades (channel-wise
+        ranges over orders of magnitude), normalised so that the layer as a whole preserves the activation variance (He);
+      * biases of the order of the activations;
+      * GDN: a NON-diagonal gamma (diagonal 0.05-0.4, off-diagonal mass of the same order with Laplace tails) and beta log-uniform in
+        [0.1, 10] -- stored through the re-parametrisation sqrt(. + 2^-36) like a trained CompressAI state.  An IGDN MULTIPLIES by
+        sqrt(beta + gamma . x^2): a decoder that does not explode keeps gamma . x^2 of the order of beta, so with `probe` (a batch of
+        images) every IGDN's gamma is scaled by the power of two that puts its mean gamma . x^2 at ~1 for the activations the model
+        itself produces on that batch (one forward pass, in execution order; a power of two so that the last bits of the probe
+        activations on another CPU do not change the parameters).
+    Heavy-tailed activations behind the GDNs and smooth image regions then do the rest.  Seeded: both sides draw the same model."""
+    from oracle import lic_oracle as L
+    ped = 2.0 ** -36
+
+    def laplace(shape):
+        u = torch.rand(shape, generator=g) - 0.5
+        return -torch.sign(u) * torch.log1p(-2 * u.abs().clamp(max=0.4999999))
+
+    with torch.no_grad():
+        for name, p in ref.named_parameters():
+            if "entropy_bottleneck" in name:
+                continue
+            if p.dim() == 4:
+                co, fan = p.shape[0], p[0].numel()
+                s = 10.0 ** ((torch.rand(co, generator=g) - 0.5) * decades)
+                s = s / s.pow(2).mean().sqrt()
+                gain = 0.5 if name.startswith("g_s") else 1.0       # (a synthesis transform contracts towards [0, 1] pixels)
+                p.copy_(laplace(p.shape) / 2 ** 0.5 * gain * (2.0 / fan) ** 0.5 * s.view(-1, 1, 1, 1))
+            elif p.dim() == 1 and name.endswith("bias"):
+                p.copy_(0.1 * laplace(p.shape))
+        for m in ref.modules():
+            if isinstance(m, L.GDN):
+                c = m.gamma.shape[0]
+                diag = 0.05 * 8.0 ** torch.rand(c, generator=g)
+                off = (0.3 / c) * laplace((c, c)).abs() * 10.0 ** ((torch.rand(c, 1, generator=g) - 0.5) * 1.5)
+                m.gamma.copy_(torch.sqrt(torch.diag(diag) + off + ped))
+                m.beta.copy_(torch.sqrt(10.0 ** (2.0 * torch.rand(c, generator=g) - 1.0) + ped))
+        cp = getattr(ref, "context_prediction", None)
+        if cp is not None:
+            cp.weight.data *= cp.mask          # a trained checkpoint carries the masked weight; the wrapper never re-applies the mask
+        if probe is not None:
+            import math
+
+            def tame(m, args):
+                x = args[0]
+                gam = m.gamma.pow(2) - ped
+                pool = float((x.pow(2).mean(dim=(0, 2, 3)) * gam.mean(dim=0)).sum())     # mean over rows of gamma . E[x^2]
+                m.gamma.copy_(torch.sqrt(gam * 2.0 ** -round(math.log2(max(pool, 1e-30))) + ped))
+            hooks = [m.register_forward_pre_hook(tame) for m in ref.modules() if isinstance(m, L.GDN) and m.inverse]
+            try:
+                ref(probe)
+            finally:
+                for h in hooks:
+                    h.remove()
