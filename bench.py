@@ -44,15 +44,47 @@ PEAK_HBM_GBS = 8000.0
 MEASURED_F16_MFMA_SUSTAINED_TFLOPS = 1709.0   # tools/micro/mfma_power.hip on MI355X, 16x16x32 f16, random operand bits, every CU busy
 
 
+ACHIEVABLE_HBM_GBS = 6300.0       # same guide: 6.29 TB/s measured with a float4 copy (79 % of the 8 TB/s specification)
+
+# Kernel FAMILY (prefix of the executor's op tag) -> the MFMA arithmetic it executes.  By family, not by substring: "linear_h2" and
+# "linear_wgrad_h2" END in "_h2" and were priced against the fp32 peak by the substring test of rounds 2-5.
+_H2 = (PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent MAC")
+_X6 = (PEAK_BF16_MFMA_TFLOPS / 6.0, "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent MAC")
+_F32 = (PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak")
+KERNEL_FAMILIES = (("conv_fwd_h2", _H2), ("conv_wgrad_h2", _H2), ("linear_h2", _H2), ("linear_wgrad_h2", _H2), ("win_attn_h2", _H2),
+                   ("conv_fwd_x6", _X6), ("conv_wgrad_x6", _X6))
+
+
 def kernel_peak(tag):
-    """Dense MFMA peak for the arithmetic a conv kernel family executes, in ALGORITHMIC (fp32-equivalent) TFLOP/s:
-    the *_x6_* kernels issue 6 bf16 MFMA products per fp32 product (exact 3-way operand split), the *_h2_* kernels 3 fp16 products
-    (two-way fp16 split of the power-of-two-scaled operands, include/rdo_ptq_hip.h)."""
-    if "_h2_" in tag:
-        return PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent MAC"
-    if "_x6_" in tag:
-        return PEAK_BF16_MFMA_TFLOPS / 6.0, "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent MAC"
-    return PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak"
+    """Dense MFMA peak for the arithmetic a kernel family executes, in ALGORITHMIC (fp32-equivalent) TFLOP/s: the *_x6 kernels issue 6
+    bf16 MFMA products per fp32 product (exact 3-way operand split), the *_h2 kernels 3 fp16 products (two-way fp16 split of the
+    power-of-two-scaled operands, include/rdo_ptq_hip.h); everything else multiplies on fp32 MFMA."""
+    for prefix, peak in KERNEL_FAMILIES:
+        if tag == prefix or tag.startswith(prefix + "_"):
+            return peak
+    return _F32
+
+
+def kernel_row(tag, launches, ms, flops, nbytes):
+    """One row of the line's `kernels` table.  A kernel whose algorithmic intensity (FLOP per algorithmic byte) lies below the ridge
+    of ITS pipe -- peak FLOP/s over the achievable HBM rate -- is memory-side: it is reported against bytes (`bound: "hbm"`, fraction
+    of the 8 TB/s specification and of the 6.3 TB/s a copy achieves), not against an MFMA peak it cannot reach."""
+    row = {"launches_per_step": launches, "ms_per_step": round(ms, 4),
+           "tflops": round(flops / (ms * 1e-3) / 1e12, 2) if flops else None,
+           "gbs": round(nbytes / (ms * 1e-3) / 1e9, 1) if nbytes else None}
+    peak = kernel_peak(tag)[0]
+    ridge = peak * 1e12 / (ACHIEVABLE_HBM_GBS * 1e9)
+    if flops and nbytes and flops / nbytes >= ridge:
+        row.update(bound="mfma", frac_of_peak=round(flops / (ms * 1e-3) / 1e12 / peak, 4), peak_tflops=round(peak, 1))
+    elif nbytes:
+        gbs = nbytes / (ms * 1e-3) / 1e9
+        row.update(bound="hbm", frac_of_peak=round(gbs / PEAK_HBM_GBS, 4), frac_of_achievable_hbm=round(gbs / ACHIEVABLE_HBM_GBS, 4))
+        if flops:
+            row.update(flop_per_byte=round(flops / nbytes, 1), ridge_flop_per_byte=round(ridge, 1),
+                       frac_of_mfma_peak=round(flops / (ms * 1e-3) / 1e12 / peak, 4))
+    else:
+        row.update(bound=None, frac_of_peak=None)
+    return row
 
 
 def log(*a):
@@ -660,11 +692,7 @@ def main():
         cnt, ms, fl, _ = conv[dom]
         achieved = fl / (ms * 1e-3) / 1e12
         peak, peak_note = kernel_peak(dom)
-        kernels = {t: {"launches_per_step": v[0], "ms_per_step": round(v[1], 4),
-                       "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 2) if v[2] else None,
-                       "frac_of_peak": round(v[2] / (v[1] * 1e-3) / 1e12 / kernel_peak(t)[0], 4) if v[2] else None,
-                       "gbs": round(v[3] / (v[1] * 1e-3) / 1e9, 1) if v[3] else None}
-                   for t, v in sorted(res["per_tag"].items(), key=lambda kv: -kv[1][1])}
+        kernels = {t: kernel_row(t, *v) for t, v in sorted(res["per_tag"].items(), key=lambda kv: -kv[1][1])}
         traffic, traffic_src = None, None
         for tf in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM-side bytes per launch of the dominant kernel, last committed --pmc passes
             try:
@@ -704,8 +732,8 @@ def main():
                          "algorithmic_gflop_per_launch": round(fl / cnt / 1e9, 3),
                          # what the board's power limit lets nothing-but-MFMA code reach on random fp16 operands (tools/micro/mfma_power.hip,
                          # DESIGN 3): 1709 TFLOP/s of v_mfma_f32_16x16x32_f16 at 1.72 GHz -- informative, `frac` stays against the nominal peak
-                         "power_limited_peak_measured": round(MEASURED_F16_MFMA_SUSTAINED_TFLOPS / 3.0, 1) if "_h2_" in dom else None,
-                         "frac_of_power_limited_peak": round(achieved / (MEASURED_F16_MFMA_SUSTAINED_TFLOPS / 3.0), 4) if "_h2_" in dom else None},
+                         "power_limited_peak_measured": round(MEASURED_F16_MFMA_SUSTAINED_TFLOPS / 3.0, 1) if kernel_peak(dom) is _H2 else None,
+                         "frac_of_power_limited_peak": round(achieved / (MEASURED_F16_MFMA_SUSTAINED_TFLOPS / 3.0), 4) if kernel_peak(dom) is _H2 else None},
             "kernels": kernels,
         }
         if res["windows"]:
@@ -757,7 +785,8 @@ def main():
             sys.path.insert(0, os.path.join(ROOT, "tools"))
             import bench_configs
             for key, fn in (("config3_attn_w10", bench_configs.attn_w10), ("config4_lu2022_g_a1", bench_configs.lu2022_unit),
-                            ("config4_lu2022_schedule", bench_configs.lu2022_schedule), ("config5_mbt2018_w8a8_eval", bench_configs.mbt2018_eval)):
+                            ("config4_lu2022_schedule", bench_configs.lu2022_schedule), ("config5_mbt2018_w8a8_eval", bench_configs.mbt2018_eval),
+                            ("rd_mode", bench_configs.rd_mode)):
                 try:
                     torch.cuda.empty_cache()
                     extra[key] = fn(log=log)

@@ -178,6 +178,35 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
                             int32_t* iter_shadow /* nullable alternative to advance_iter: receives *iter_ptr + 1 (hand-over above) */,
                             void* stream);
 
+/* Round 6: the step launch of iteration i also ASSEMBLES THE MINI-BATCH OF ITERATION i + 1 (gather + QDrop, rdo_gather_qdrop /
+ * rdo_gather_qdrop_h2 below: same index arithmetic, counter RNG and plane split -- csrc/gather_body.h) in extra workgroups behind the
+ * step's own: the step is latency-bound, the gather a plain stream, both run behind every reader of the current mini-batch, and the
+ * iteration loses a launch (layer_opt.py:289-292 moved behind :307 of the previous pass; iteration 0's mini-batch is assembled by
+ * a stand-alone gather before the loop).  The gather reads row *iter_ptr + 1 of idx_table and is skipped when that row does not exist
+ * (n_iters).  Counter hand-over with this entry: the loss / tail launch of an iteration reads the real counter and publishes it into
+ * a second word (rdo_iter_bind_publish); this launch is given iter_ptr = that word and iter_shadow = the real counter, into which its
+ * first thread stores *iter_ptr + 1 -- no thread of the launch reads the word another thread of it writes. */
+typedef struct rdo_gather_desc {
+    const float *cache_q, *cache_fp;
+    const int32_t* idx_table;           /* [n_iters][B] */
+    int32_t n_iters, B, batch_offset;
+    int64_t per_image;
+    int32_t C;                          /* plane form only */
+    float prob;
+    uint32_t seed;
+    float* out;                         /* fp32 mini-batch; nullable when out_planes is given */
+    void* out_planes;                   /* nullable: H2 planes [2][B * per_image] of out * out_scale (rdo_gather_qdrop_h2) */
+    float out_scale;
+    int32_t* overflow_flag;             /* nullable: the overflow word pair of out_planes (NULL: the word bound by rdo_h2_bind_flag / the default) */
+} rdo_gather_desc;
+int rdo_adaround_step_batch_gather(const rdo_ada_step_item* items, int32_t n, int32_t mode /* 0 or 2 */, float grad_scale, float round_weight,
+                                   const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* iter_shadow,
+                                   const rdo_gather_desc* next, void* stream);
+/* The NEXT loss / tail launch issued (or recorded) on this thread -- rdo_lp2_loss_grad, rdo_lp_loss_grad, rdo_loss_act_bwd(_splitk),
+ * rdo_loss_gdn_bwd, rdo_conv2d_fwd_h2_tail -- stores the iteration number it read to *publish (its first thread), then the binding is
+ * gone.  Returns 1 when an earlier binding was still pending (never consumed), else 0; publish = NULL only clears. */
+int rdo_iter_bind_publish(int32_t* publish);
+
 /* only the data-gradient half (slab reduce + chain rule -> dalpha_data), for the all-reduce bucket of the DP path */
 int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,
                       const float* slabs, int nsplit, float* dalpha, void* stream);

@@ -10,6 +10,7 @@
 //   quant_layer.py:142-146 (GDN gamma): gamma' = max(w~, bound)^2 - pedestal, LowerBound gradient rule (CompressAI)
 // This file is built with -ffp-contract=off so products and sums round separately, as the reference's op chain does.
 #include "rdo_common.h"
+#include "gather_body.h"
 
 namespace {
 
@@ -573,9 +574,21 @@ struct AdaBatch {
     int blk_end[kMaxBatch];
     unsigned char tile[kMaxBatch];   // this tensor runs the tile form (ada_step_tile_body): the dgrad layout is written by the same launch
     int n;
+    // Round 6: the launch also assembles the NEXT iteration's mini-batch (rdo_adaround_step_batch_gather): blocks from `gather_beg` on run
+    // the gather for iteration *iter_ptr + 1 -- two memory streams that share no data in one launch, one launch less per iteration.
+    int gather_beg;                  // first gather block (= the number of step blocks; no gather: never reached)
+    rdo::gq::Gather g;
 };
 __global__ __launch_bounds__(256) void ada_step_batch_kernel(AdaBatch b) {
     if (b.iter_shadow && blockIdx.x == 0 && threadIdx.x == 0) *b.iter_shadow = *b.a[0].iter_ptr + 1;
+    if ((int)blockIdx.x >= b.gather_beg) {                   // the next iteration's mini-batch (nothing behind the last iteration)
+        const int it1 = *b.a[0].iter_ptr + 1;
+        if (it1 < b.g.n_iters) {
+            if (b.g.planes.p) rdo::gq::gather_h2_body(b.g, it1, (long)blockIdx.x - b.gather_beg, (long)gridDim.x - b.gather_beg);
+            else rdo::gq::gather_fp32_body(b.g, it1, (long)blockIdx.x - b.gather_beg, (long)gridDim.x - b.gather_beg);
+        }
+        return;
+    }
     int t = 0;
     while (t + 1 < b.n && (int)blockIdx.x >= b.blk_end[t]) ++t;
     const int beg = t ? b.blk_end[t - 1] : 0;
@@ -831,9 +844,9 @@ int rdo_adaround_step(const rdo_ada_desc* d, const float* w, const float* delta,
     return run_step(a, stream);
 }
 
-int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
-                            const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
-                            int32_t* iter_shadow, void* stream) {
+static int step_batch_impl(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
+                           const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
+                           int32_t* iter_shadow, const rdo_gather_desc* next, void* stream) {
     RDO_REQUIRE(items && n >= 1 && n <= kMaxBatch, "rdo_adaround_step_batch: bad argument (1 <= n <= %d)", kMaxBatch);
     RDO_REQUIRE(mode >= 0 && mode <= 2, "rdo_adaround_step_batch: mode %d (0 fused step, 1 gradient only, 2 apply)", mode);
     RDO_REQUIRE(mode == 1 || (sched && iter_ptr), "rdo_adaround_step_batch: schedule / iteration counter missing");
@@ -879,6 +892,29 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
     }
     b.n = n;
     b.iter_shadow = iter_shadow;
+    b.gather_beg = blocks;
+    if (next) {
+        RDO_REQUIRE(mode != 1 && iter_ptr, "rdo_adaround_step_batch_gather: the gather rides on a fused step or an apply launch");
+        RDO_REQUIRE(next->cache_q && next->cache_fp && next->idx_table && (next->out || next->out_planes) && next->n_iters > 0,
+                    "rdo_adaround_step_batch_gather: null pointer in the gather descriptor");
+        RDO_REQUIRE(next->B > 0 && next->batch_offset >= 0 && next->per_image > 0 && next->per_image % 4 == 0 &&
+                    (long)(next->batch_offset + next->B) * next->per_image < (1L << 32), "rdo_adaround_step_batch_gather: bad gather shape");
+        RDO_REQUIRE(!next->out_planes || (next->C > 0 && next->C % 16 == 0 && next->per_image % next->C == 0 && next->out_scale > 0.f),
+                    "rdo_adaround_step_batch_gather: the plane form needs C %% 16 == 0 and a positive power-of-two scale");
+        RDO_REQUIRE(next->out_planes || next->out, "rdo_adaround_step_batch_gather: no destination");
+        RDO_REQUIRE(next->prob >= 0.f && next->prob <= 1.f, "rdo_adaround_step_batch_gather: prob out of [0,1]");
+        const double t = floor((double)next->prob * 4294967296.0);
+        const unsigned long long thr = (unsigned long long)(t > 4294967296.0 ? 4294967296.0 : t);
+        b.g = rdo::gq::Gather{next->cache_q, next->cache_fp, next->idx_table, next->n_iters, next->B, next->batch_offset, (long)next->per_image,
+                              next->C, thr, next->seed, next->out,
+                              rdo::gq::H2Out{static_cast<unsigned short*>(next->out_planes), next->out_scale,
+                                             next->overflow_flag ? reinterpret_cast<int*>(next->overflow_flag) : rdo::h2_overflow_flag()}};
+        long gb = rdo::gq::gather_blocks(b.g);
+        const long cap = b.g.planes.p ? 8192 : 2048;            // the grids of the stand-alone gather kernels
+        blocks += (int)(gb > cap ? cap : gb);
+        bytes += (8.0 + (next->out ? 4.0 : 0.0) + (next->out_planes ? 4.0 : 0.0)) * next->B * (double)next->per_image;
+    }
+    const char* tag = next ? "ada_step_gather" : "ada_step";
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(ada_step_batch_kernel, dim3((unsigned)blocks), dim3(256), 0, s, b);
@@ -888,7 +924,20 @@ int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t m
                 hipLaunchKernelGGL(iter_advance1_kernel, dim3(1), dim3(1), 0, s, advance_iter);
             return rdo::check_launch("ada_step_batch");
         },
-        stream, "ada_step", 0.0, bytes);
+        stream, tag, 0.0, bytes);
+}
+
+int rdo_adaround_step_batch(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
+                            const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* advance_iter,
+                            int32_t* iter_shadow, void* stream) {
+    return step_batch_impl(items, n, mode, grad_scale, round_weight, sched, iter_ptr, round_loss_out, advance_iter, iter_shadow, nullptr, stream);
+}
+
+int rdo_adaround_step_batch_gather(const rdo_ada_step_item* items, int32_t n, int32_t mode, float grad_scale, float round_weight,
+                                   const rdo_sched_row* sched, const int32_t* iter_ptr, float* round_loss_out, int32_t* iter_shadow,
+                                   const rdo_gather_desc* next, void* stream) {
+    RDO_REQUIRE(next != nullptr, "rdo_adaround_step_batch_gather: null gather descriptor");
+    return step_batch_impl(items, n, mode, grad_scale, round_weight, sched, iter_ptr, round_loss_out, nullptr, iter_shadow, next, stream);
 }
 
 int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,

@@ -572,6 +572,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2h_kernel(H2Args a) {
         for (int o = 32; o > 0; o >>= 1) tail_loss += __shfl_down(tail_loss, o, 64);
         if (lane == 0) red[wave] = tail_loss;
         __syncthreads();
+        if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && a.tail_pub) *a.tail_pub = *a.tail_iter;
         if (tid == 0 && a.tail_loss)
             atomicAdd(a.tail_loss + (long)(*a.tail_iter) * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)),
                       (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) * (a.tail_inv_npix * a.tail_coef));
@@ -788,7 +789,7 @@ static int conv2d_fwd_h2_impl(const rdo_conv_desc* d, const void* x_planes, floa
     a.ablate = rdo::tuning(rdo::T_X6P_ABLATE);
 #endif
     if (tail) {
-        a.tail_tgt = tail->tail_tgt; a.tail_idx = tail->tail_idx; a.tail_iter = tail->tail_iter; a.tail_resp = tail->tail_resp;
+        a.tail_tgt = tail->tail_tgt; a.tail_idx = tail->tail_idx; a.tail_iter = tail->tail_iter; a.tail_pub = tail->tail_pub; a.tail_resp = tail->tail_resp;
         a.tail_res_inv = tail->tail_res_inv;
         a.tail_loss = tail->tail_loss; a.tail_per_image = tail->tail_per_image; a.tail_B = tail->tail_B; a.tail_act = tail->tail_act;
         a.tail_coef = tail->tail_coef; a.tail_inv_npix = tail->tail_inv_npix;
@@ -927,7 +928,7 @@ extern "C" int rdo_conv2d_fwd_h2_tail(const rdo_conv_desc* d, const void* x_plan
     RDO_REQUIRE(B == d->B && act >= 0 && act <= 2, "rdo_conv2d_fwd_h2_tail: B must be the conv's batch, act in 0..2");
     RDO_REQUIRE(!residual_planes || pow2_scale(residual_scale), "rdo_conv2d_fwd_h2_tail: residual_scale %g is not a power of two", (double)residual_scale);
     H2Args t{};
-    t.tail_tgt = tgt_cache; t.tail_idx = idx_table; t.tail_iter = iter_ptr; t.tail_resp = reinterpret_cast<const u16*>(residual_planes);
+    t.tail_tgt = tgt_cache; t.tail_idx = idx_table; t.tail_iter = iter_ptr; t.tail_pub = rdo::take_iter_publish(); t.tail_resp = reinterpret_cast<const u16*>(residual_planes);
     t.tail_res_inv = residual_planes ? 1.f / residual_scale : 1.f;
     t.tail_loss = loss_out; t.tail_per_image = (long)d->Ho * d->Wo * d->Cout; t.tail_B = B; t.tail_act = act; t.tail_coef = coef;
     t.tail_inv_npix = (float)(1.0 / ((double)B * d->Ho * d->Wo));

@@ -426,6 +426,7 @@ __global__ __launch_bounds__(512, 2) void conv_fwd_h2k_kernel(H2Args a) {
         for (int o = 32; o > 0; o >>= 1) tail_loss += __shfl_down(tail_loss, o, 64);
         if (lane == 0) red[wave] = tail_loss;
         __syncthreads();
+        if (tid == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && a.tail_pub) *a.tail_pub = *a.tail_iter;
         if (tid == 0 && a.tail_loss)
             atomicAdd(a.tail_loss + (long)(*a.tail_iter) * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)),
                       (((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]))) * (a.tail_inv_npix * a.tail_coef));

@@ -946,6 +946,10 @@ static int fwd_bf16x6_impl(const rdo_conv_desc* d, const float* x, const void* w
             const size_t lds = (size_t)2 * 3 * (128 + 192) * 32 + (ver == 5 ? 0 : 4096);
             dim3 grid((unsigned)rdo::ceil_div(a.M, 128), (unsigned)rdo::ceil_div(a.Cout, 192), (unsigned)a.ksplit);
 #ifdef RDO_DIAG
+            // the diagnostic build has only the plain instantiations: an unsplit launch with a GELU epilogue would return the
+            // pre-activation without a word (conv_fwd.hip rejects the equivalent case the same way)
+            if (a.epilogue >= RDO_EPI_GELU && a.ksplit == 1)
+                return rdo::set_error(RDO_EINVAL, "rdo_conv2d_fwd_bf16x6: the GELU epilogues of an unsplit launch are not compiled into a diagnostic build");
             const void* kern = ver == 3 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<false>)
                              : ver == 4 ? reinterpret_cast<const void*>(conv_fwd_x6v3_kernel<true>)
                                         : reinterpret_cast<const void*>(conv_fwd_x6v5_kernel<false>);

@@ -36,6 +36,7 @@ struct H2Args {
     const float* tail_tgt;    // nullptr: no tail
     const int32_t* tail_idx;
     const int32_t* tail_iter;
+    int32_t* tail_pub;        // rdo_iter_bind_publish: the launch's first thread leaves *tail_iter there (nullable)
     const unsigned short* tail_resp;     // residual as H2 planes of [M][Cout] (nullable)
     float tail_res_inv;       // 1 / s of that tensor
     float* tail_loss;

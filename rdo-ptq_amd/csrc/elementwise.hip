@@ -2,49 +2,32 @@
 // 16-byte (float4) accesses, grid-stride loops capped at ~2048 workgroups (MI355X: 256 CUs x 8).
 // Built with -ffp-contract=off (products and sums round separately, like the reference's op chains).
 #include "rdo_common.h"
+#include "gather_body.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using rdo::gq::f32x4;
 
 inline unsigned grid_for(long n, int per_thread = 1) {
     long g = rdo::ceil_div(n, 256L * per_thread);
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
-__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
-}
+using rdo::gq::lowbias32;
 
-// ---- K7: gather + QDrop (layer_opt.py:289-292).  keep = u32(seed, iter, i) < floor(p * 2^32) takes the quantised-prefix input.
-__global__ __launch_bounds__(256) void gather_qdrop_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
-                                                           const int32_t* iter_ptr, int B, int batch_offset, long per_image,
-                                                           unsigned long long thr, uint32_t seed, float* out, int32_t* iter_publish) {
+// ---- K7: gather + QDrop (layer_opt.py:289-292; gather_body.h).  keep = u32(seed, iter, i) < floor(p * 2^32) takes the quantised-prefix input.
+__global__ __launch_bounds__(256) void gather_qdrop_kernel(rdo::gq::Gather g, const int32_t* iter_ptr, int32_t* iter_publish) {
     const int it = *iter_ptr;
     if (iter_publish && blockIdx.x == 0 && threadIdx.x == 0) *iter_publish = it;      // rdo_ptq_hip.h: iteration-counter hand-over
-    const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
-    const long quads = per_image / 4;
-    const long total = (long)B * quads;
-    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int b = (int)(t / quads);
-        const long off = (t - (long)b * quads) * 4;
-        const long src = (long)idx_table[(long)it * B + b] * per_image + off;
-        const f32x4 q = *reinterpret_cast<const f32x4*>(cq + src);
-        const f32x4 f = *reinterpret_cast<const f32x4*>(cfp + src);
-        const uint32_t i0 = (uint32_t)((long)(batch_offset + b) * per_image + off);     // element index in the GLOBAL mini-batch
-        f32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = ((unsigned long long)lowbias32((i0 + e) ^ key) < thr) ? q[e] : f[e];
-        *reinterpret_cast<f32x4*>(out + (long)b * per_image + off) = o;
-    }
+    rdo::gq::gather_fp32_body(g, it, blockIdx.x, gridDim.x);
 }
 
 // ---- K8: p=2 lp_loss forward + gradient against the cached FP target rows
 __global__ __launch_bounds__(256) void lp2_kernel(const float* pred, const float* tgt, const int32_t* idx_table,
                                                   const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef,
-                                                  float* grad, float* loss_out) {
+                                                  float* grad, float* loss_out, int32_t* iter_pub) {
     const int it = *iter_ptr;
+    if (iter_pub && blockIdx.x == 0 && threadIdx.x == 0) *iter_pub = it;       // rdo_iter_bind_publish
     const long quads = per_image / 4;
     const long total = (long)B * quads;
     float acc = 0.f;
@@ -72,8 +55,9 @@ __global__ __launch_bounds__(256) void lp2_kernel(const float* pred, const float
 // task term with main2.py's --task_loss exponent (layer_opt.py:133,150) in one pass
 __global__ __launch_bounds__(256) void lp_kernel(const float* pred, const float* tgt, const int32_t* idx_table,
                                                  const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef2,
-                                                 float coefp, float pw, float* grad, float* loss_out, float* loss_out_p) {
+                                                 float coefp, float pw, float* grad, float* loss_out, float* loss_out_p, int32_t* iter_pub) {
     const int it = *iter_ptr;
+    if (iter_pub && blockIdx.x == 0 && threadIdx.x == 0) *iter_pub = it;
     const long quads = per_image / 4;
     const long total = (long)B * quads;
     float acc = 0.f, accp = 0.f;                                 // the p = 2 term and the |d|^p term, logged apart on request
@@ -413,10 +397,10 @@ int rdo_gather_qdrop(const float* cache_q, const float* cache_fp, const int32_t*
     RDO_REQUIRE(prob >= 0.f && prob <= 1.f, "rdo_gather_qdrop: prob out of [0,1]");
     double t = floor((double)prob * 4294967296.0);
     const unsigned long long thr = (unsigned long long)(t > 4294967296.0 ? 4294967296.0 : t);
+    const rdo::gq::Gather g{cache_q, cache_fp, idx_table, 0, B, batch_offset, (long)per_image, 0, thr, seed, out, rdo::gq::H2Out{nullptr, 0.f, nullptr}};
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(gather_qdrop_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, cache_q, cache_fp,
-                               idx_table, iter_ptr, B, batch_offset, (long)per_image, thr, seed, out, iter_publish);
+            hipLaunchKernelGGL(gather_qdrop_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, g, iter_ptr, iter_publish);
             return rdo::check_launch("gather_qdrop");
         },
         stream, "gather_qdrop", 0.0, 12.0 * B * per_image);
@@ -427,10 +411,11 @@ int rdo_lp2_loss_grad(const float* pred, const float* tgt_cache, const int32_t* 
     RDO_REQUIRE(pred && tgt_cache && idx_table && iter_ptr && grad, "rdo_lp2_loss_grad: null pointer");
     RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_lp2_loss_grad: bad shape");
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
+    int32_t* const pub = rdo::take_iter_publish();
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(lp2_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, pred, tgt_cache, idx_table,
-                               iter_ptr, B, (long)per_image, inv_npix, coef, grad, loss_out);
+                               iter_ptr, B, (long)per_image, inv_npix, coef, grad, loss_out, pub);
             return rdo::check_launch("lp2_loss_grad");
         },
         stream, "lp2_loss_grad", 0.0, 12.0 * B * per_image);
@@ -443,10 +428,11 @@ int rdo_lp_loss_grad(const float* pred, const float* tgt_cache, const int32_t* i
     RDO_REQUIRE(B > 0 && C > 0 && per_image > 0 && per_image % 4 == 0 && per_image % C == 0, "rdo_lp_loss_grad: bad shape");
     RDO_REQUIRE(p >= 1.f, "rdo_lp_loss_grad: exponent %g < 1 has no finite gradient at zero", (double)p);
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
+    int32_t* const pub = rdo::take_iter_publish();
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(lp_kernel, dim3(grid_for((long)B * per_image / 4)), dim3(256), 0, s, pred, tgt_cache, idx_table,
-                               iter_ptr, B, (long)per_image, inv_npix, coef2, coefp, p, grad, loss_out, loss_out_p);
+                               iter_ptr, B, (long)per_image, inv_npix, coef2, coefp, p, grad, loss_out, loss_out_p, pub);
             return rdo::check_launch("lp_loss_grad");
         },
         stream, "lp_loss_grad", 0.0, 12.0 * B * per_image);

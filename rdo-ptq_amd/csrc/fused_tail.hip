@@ -13,10 +13,11 @@
 // and the file is built with -ffp-contract=off like them: fused and unfused paths produce the same bits except for the order in
 // which the loss partial sums are added.
 #include "rdo_common.h"
+#include "gather_body.h"
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
+using namespace rdo::gq;          // f32x4, u32x4, H2Out / H2In, the pixel-major work split (Oct), lowbias32, the gather bodies
 typedef unsigned short u16;
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
@@ -32,22 +33,9 @@ inline unsigned grid_for(long n) {
     return (unsigned)(g < 1 ? 1 : (g > 2048 ? 2048 : g));
 }
 
-__device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
-    x ^= x >> 16; x *= 0x7FEB352Du; x ^= x >> 15; x *= 0x846CA68Bu; x ^= x >> 16;
-    return x;
-}
-
-struct H2Out {          // planes of an H2 tensor being written: [2][M*C] fp16, values times `s`
-    unsigned short* p;
-    float s;
-    int* ovf;           // sticky overflow flag (rdo_h2_overflow)
-};
-struct H2In {           // planes being read back as fp32: (h1 + h2) * inv
-    const unsigned short* p;
-    float inv;
-};
-
-__device__ __forceinline__ void block_loss_add(float acc, float scale, float* loss_out, int it) {
+// (pub: rdo_iter_bind_publish -- the launch's first thread leaves the iteration number there for the AdaRound step of the same iteration)
+__device__ __forceinline__ void block_loss_add(float acc, float scale, float* loss_out, int it, int32_t* pub) {
+    if (pub && blockIdx.x == 0 && threadIdx.x == 0) *pub = it;
     __shared__ float red[4];
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -56,44 +44,6 @@ __device__ __forceinline__ void block_loss_add(float acc, float scale, float* lo
         atomicAdd(loss_out + (long)it * RDO_LOG_SLOTS + (blockIdx.x & (RDO_LOG_SLOTS - 1)), (red[0] + red[1] + red[2] + red[3]) * scale);
 }
 
-// ---- pixel-major work split of the kernels that write (or read) planes ----------------------------------------------------------
-// A virtual block covers 64 pixels x one group of 32 channels (one 128-byte line of the fp32 tensors per pixel); a thread owns 8
-// consecutive channels of one pixel (quads at c0 and c0 + 4): two 16-byte fp32 accesses per tensor and ONE 16-byte access per plane.
-// Lanes 4p..4p+3 hold pixel p, so the plane stores of a wave are two runs of 16 consecutive 32-byte records (slices 2g and 2g+1)
-// instead of 8-byte pieces scattered over twelve slices, which is what a channel-major thread order produces.  (Measured at
-// 4 x 128^2 x 192, tools/bench_tails.py: 16-byte plane stores in this order 35 us for gather + planes; 8-byte stores -- channel-major,
-// or pixel-major with the two quads 16 channels apart so that the fp32 side is sector-complete -- 42-56 us.)
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-constexpr int Q2 = 4;       // channel distance between the two quads of a thread
-
-struct Oct {
-    long m;     // pixel
-    int c0;     // first of the 8 channels
-};
-__device__ __forceinline__ bool oct_of(long vb, int ngroups, long M, int C, Oct& o) {
-    const int grp = (int)(vb % ngroups);
-    o.m = (vb / ngroups) * 64 + (threadIdx.x >> 2);
-    o.c0 = grp * 32 + (threadIdx.x & 3) * 8;
-    return o.m < M && o.c0 < C;          // C % 16 == 0: the 8 channels exist together
-}
-inline long oct_blocks(long M, int C) { return rdo::ceil_div(M, 64L) * rdo::ceil_div(C, 32); }
-inline unsigned oct_grid(long M, int C) {
-    const long g = oct_blocks(M, C);
-    return (unsigned)(g > 8192 ? 8192 : g);
-}
-
-__device__ __forceinline__ void store_h2_oct(const H2Out& pl, long M, int C, const Oct& o, const f32x4& a, const f32x4& b, int& bad) {
-    const long pstride = M * C;
-    const long e = ((long)(o.c0 >> 4) * M + o.m) * 16 + (o.c0 & 15);
-    u32x4 hi, lo;
-    unsigned h, l;
-    rdo::h2_split_pk(a[0], a[1], pl.s, h, l, bad); hi[0] = h; lo[0] = l;
-    rdo::h2_split_pk(a[2], a[3], pl.s, h, l, bad); hi[1] = h; lo[1] = l;
-    rdo::h2_split_pk(b[0], b[1], pl.s, h, l, bad); hi[2] = h; lo[2] = l;
-    rdo::h2_split_pk(b[2], b[3], pl.s, h, l, bad); hi[3] = h; lo[3] = l;
-    *reinterpret_cast<u32x4*>(pl.p + e) = hi;
-    *reinterpret_cast<u32x4*>(pl.p + pstride + e) = lo;
-}
 // fp32 values of the thread's 8 channels from planes: (h1 + h2) / s -- the sum is exact in fp32, the value is the original to 2^-24
 __device__ __forceinline__ void load_h2_oct(const H2In& pl, long M, int C, const Oct& o, f32x4& a, f32x4& b) {
     const long pstride = M * C;
@@ -107,50 +57,11 @@ __device__ __forceinline__ void load_h2_oct(const H2In& pl, long M, int C, const
               (h2_hi(h[3]) + h2_hi(l[3])) * pl.inv};
 }
 
-__device__ __forceinline__ const f32x4& ldq(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void stq(float* p, const f32x4& v) { *reinterpret_cast<f32x4*>(p) = v; }
-
-// ---- gather + QDrop ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ f32x4 qdrop_quad(const float* cq, const float* cfp, long src, uint32_t i0, uint32_t key, unsigned long long thr) {
-    const f32x4 q = ldq(cq + src), f = ldq(cfp + src);
-    f32x4 o;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = ((unsigned long long)lowbias32((i0 + e) ^ key) < thr) ? q[e] : f[e];
-    return o;
-}
-
-__global__ __launch_bounds__(256) void gather_qdrop_h2_kernel(const float* cq, const float* cfp, const int32_t* idx_table,
-                                                              const int32_t* iter_ptr, int B, int batch_offset, long per_image, int C,
-                                                              unsigned long long thr, uint32_t seed, float* out, H2Out planes,
-                                                              int32_t* iter_publish) {
-    int bad = 0;
+// ---- gather + QDrop (gather_body.h) ---------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gather_qdrop_h2_kernel(Gather g, const int32_t* iter_ptr, int32_t* iter_publish) {
     const int it = *iter_ptr;
     if (iter_publish && blockIdx.x == 0 && threadIdx.x == 0) *iter_publish = it;
-    const uint32_t key = lowbias32((uint32_t)it + seed * 0x9E3779B9u);
-    const long ppi = per_image / C, M = (long)B * ppi;
-    const int ngroups = (C + 31) / 32;
-    const long nvb = ((M + 63) / 64) * ngroups;
-    for (long vb = blockIdx.x; vb < nvb; vb += gridDim.x) {
-        Oct o;
-        if (!oct_of(vb, ngroups, M, C, o)) continue;
-        const int b = (int)(o.m / ppi);
-        const long row = (long)idx_table[(long)it * B + b] * per_image;
-        f32x4 v[2];
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = o.c0 + k * Q2;
-            const long off = (o.m - (long)b * ppi) * C + c;                           // element offset inside the image
-            const uint32_t i0 = (uint32_t)((long)(batch_offset + b) * per_image + off);   // the element's RNG counter (elementwise.hip)
-            v[k] = qdrop_quad(cq, cfp, row + off, i0, key, thr);
-        }
-        // all loads before any store (the stores may alias the inputs as far as the compiler knows)
-        if (out) {
-            stq(out + o.m * C + o.c0, v[0]);
-            stq(out + o.m * C + o.c0 + Q2, v[1]);
-        }
-        store_h2_oct(planes, M, C, o, v[0], v[1], bad);
-    }
-    rdo::h2_report(bad, planes.ovf);
+    gather_h2_body(g, it, blockIdx.x, gridDim.x);
 }
 
 // ---- conv activation + loss + gradient + activation backward ------------------------------------------------------------------------
@@ -179,7 +90,7 @@ __device__ __forceinline__ float loss_act_quad(const f32x4& p, const f32x4& y, c
 __global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, const float* partial, int ks, long slab, const float* bias,
                                                            int C, const float* res, const float* tgt, const int32_t* idx_table,
                                                            const int32_t* iter_ptr, int B, long per_image, float inv_npix, float coef,
-                                                           int act, float* out, float* gout, float* dpre, float* loss_out) {
+                                                           int act, float* out, float* gout, float* dpre, float* loss_out, int32_t* iter_pub) {
     const int it = *iter_ptr;
     const long quads = per_image / 4;
     const long total = (long)B * quads;
@@ -206,14 +117,14 @@ __global__ __launch_bounds__(256) void loss_act_bwd_kernel(const float* pre, con
         if (gout) stq(gout + e, g);
         if (dpre) stq(dpre + e, dp);
     }
-    block_loss_add(acc, inv_npix * coef, loss_out, it);
+    block_loss_add(acc, inv_npix * coef, loss_out, it, iter_pub);
 }
 
 // with planes on either side (dL/dpre out, residual in): pixel-major
 __global__ __launch_bounds__(256) void loss_act_bwd_pix_kernel(const float* pre, const float* res, H2In res_planes, const float* tgt,
                                                                const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
                                                                int C, float inv_npix, float coef, int act, float* out, float* gout,
-                                                               float* dpre, H2Out dpre_planes, float* loss_out) {
+                                                               float* dpre, H2Out dpre_planes, float* loss_out, int32_t* iter_pub) {
     int bad = 0;
     const int it = *iter_ptr;
     const long ppi = per_image / C, M = (long)B * ppi;
@@ -246,7 +157,7 @@ __global__ __launch_bounds__(256) void loss_act_bwd_pix_kernel(const float* pre,
         if (dpre_planes.p) store_h2_oct(dpre_planes, M, C, oc, d[0], d[1], bad);
     }
     if (dpre_planes.p) rdo::h2_report(bad, dpre_planes.ovf);
-    block_loss_add(acc, inv_npix * coef, loss_out, it);
+    block_loss_add(acc, inv_npix * coef, loss_out, it, iter_pub);
 }
 
 // ---- GDN / IGDN epilogue + loss + gradient + dL/dnorm ----------------------------------------------------------------------------------
@@ -270,7 +181,7 @@ __device__ __forceinline__ float loss_gdn_quad(const f32x4& xv, const f32x4& nv,
 __global__ __launch_bounds__(256) void loss_gdn_bwd_kernel(const float* x, const float* nrm, const float* res, const float* tgt,
                                                            const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
                                                            float inv_npix, float coef, int inverse, float* out, float* gout, float* tbuf,
-                                                           float* loss_out) {
+                                                           float* loss_out, int32_t* iter_pub) {
     const int it = *iter_ptr;
     const long quads = per_image / 4;
     const long total = (long)B * quads;
@@ -288,13 +199,13 @@ __global__ __launch_bounds__(256) void loss_gdn_bwd_kernel(const float* x, const
         stq(gout + e, g);
         stq(tbuf + e, tv);
     }
-    block_loss_add(acc, inv_npix * coef, loss_out, it);
+    block_loss_add(acc, inv_npix * coef, loss_out, it, iter_pub);
 }
 
 __global__ __launch_bounds__(256) void loss_gdn_bwd_pix_kernel(const float* x, const float* nrm, const float* res, const float* tgt,
                                                                const int32_t* idx_table, const int32_t* iter_ptr, int B, long per_image,
                                                                int C, float inv_npix, float coef, int inverse, float* out, float* gout,
-                                                               float* tbuf, H2Out t_planes, float* loss_out) {
+                                                               float* tbuf, H2Out t_planes, float* loss_out, int32_t* iter_pub) {
     int bad = 0;
     const int it = *iter_ptr;
     const long ppi = per_image / C, M = (long)B * ppi;
@@ -325,7 +236,7 @@ __global__ __launch_bounds__(256) void loss_gdn_bwd_pix_kernel(const float* x, c
         store_h2_oct(t_planes, M, C, oc, tv[0], tv[1], bad);
     }
     rdo::h2_report(bad, t_planes.ovf);
-    block_loss_add(acc, inv_npix * coef, loss_out, it);
+    block_loss_add(acc, inv_npix * coef, loss_out, it, iter_pub);
 }
 
 // ---- GDN backward: dx -------------------------------------------------------------------------------------------------------------------
@@ -492,10 +403,10 @@ int rdo_gather_qdrop_h2(const float* cache_q, const float* cache_fp, const int32
     const unsigned long long thr = (unsigned long long)(t > 4294967296.0 ? 4294967296.0 : t);
     RDO_REQUIRE(out_scale > 0.f, "rdo_gather_qdrop_h2: out_scale must be a positive power of two");
     const H2Out pl{reinterpret_cast<u16*>(out_planes), out_scale, rdo::h2_overflow_flag()};
+    const Gather g{cache_q, cache_fp, idx_table, 0, B, batch_offset, (long)per_image, C, thr, seed, out, pl};
     return rdo::dispatch(
         [=](hipStream_t s) {
-            hipLaunchKernelGGL(gather_qdrop_h2_kernel, dim3(oct_grid((long)B * (per_image / C), C)), dim3(256), 0, s, cache_q, cache_fp,
-                               idx_table, iter_ptr, B, batch_offset, (long)per_image, C, thr, seed, out, pl, iter_publish);
+            hipLaunchKernelGGL(gather_qdrop_h2_kernel, dim3(oct_grid((long)B * (per_image / C), C)), dim3(256), 0, s, g, iter_ptr, iter_publish);
             return rdo::check_launch("gather_qdrop_h2");
         },
         stream, "gather_qdrop_h2", 0.0, (8.0 + (out ? 4.0 : 0.0) + 4.0) * B * per_image);
@@ -512,17 +423,18 @@ int rdo_loss_act_bwd(const float* pre, const float* residual, const void* residu
     RDO_REQUIRE(act >= 0 && act <= 2, "rdo_loss_act_bwd: act %d (0 none, 1 LeakyReLU(0.01), 2 ReLU)", act);
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
     const H2Out pl{reinterpret_cast<u16*>(dpre_planes), dpre_scale, rdo::h2_overflow_flag()};
+    int32_t* const pub = rdo::take_iter_publish();
     const double n = (double)B * per_image;
     return rdo::dispatch(
         [=](hipStream_t s) {
             if (pl.p || rpl.p)
                 hipLaunchKernelGGL(loss_act_bwd_pix_kernel, dim3(loss_grid(oct_blocks((long)B * (per_image / C), C))), dim3(256), 0, s, pre, residual, rpl,
                                    tgt_cache, idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, act, out, grad_out, dpre, pl,
-                                   loss_out);
+                                   loss_out, pub);
             else
                 hipLaunchKernelGGL(loss_act_bwd_kernel, dim3(loss_grid(rdo::ceil_div((long)B * per_image / 4, 256L))), dim3(256), 0, s, pre,
                                    (const float*)nullptr, 0, 0L, (const float*)nullptr, C, residual, tgt_cache, idx_table, iter_ptr, B,
-                                   (long)per_image, inv_npix, coef, act, out, grad_out, dpre, loss_out);
+                                   (long)per_image, inv_npix, coef, act, out, grad_out, dpre, loss_out, pub);
             return rdo::check_launch("loss_act_bwd");
         },
         stream, "loss_act_bwd", 0.0,
@@ -537,12 +449,13 @@ int rdo_loss_act_bwd_splitk(const float* partial, int32_t ksplit, const float* b
     RDO_REQUIRE(act >= 0 && act <= 2, "rdo_loss_act_bwd_splitk: act %d (0 none, 1 LeakyReLU(0.01), 2 ReLU)", act);
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
     const long slab = (long)B * per_image;
+    int32_t* const pub = rdo::take_iter_publish();
     const double n = (double)B * per_image;
     return rdo::dispatch(
         [=](hipStream_t s) {
             hipLaunchKernelGGL(loss_act_bwd_kernel, dim3(loss_grid(rdo::ceil_div((long)B * per_image / 4, 256L))), dim3(256), 0, s,
                                (const float*)nullptr, partial, ksplit, slab, bias, C, residual, tgt_cache, idx_table, iter_ptr, B,
-                               (long)per_image, inv_npix, coef, act, out, grad_out, dpre, loss_out);
+                               (long)per_image, inv_npix, coef, act, out, grad_out, dpre, loss_out, pub);
             return rdo::check_launch("loss_act_bwd_splitk");
         },
         stream, "loss_act_bwd", 0.0,
@@ -558,16 +471,17 @@ int rdo_loss_gdn_bwd(const float* x, const float* norm, const float* residual, c
     RDO_REQUIRE(!t_planes || t_scale > 0.f, "rdo_loss_gdn_bwd: t_scale must be a positive power of two");
     const float inv_npix = (float)(1.0 / ((double)B * (double)(per_image / C)));
     const H2Out pl{reinterpret_cast<u16*>(t_planes), t_scale, rdo::h2_overflow_flag()};
+    int32_t* const pub = rdo::take_iter_publish();
     const double n = (double)B * per_image;
     return rdo::dispatch(
         [=](hipStream_t s) {
             if (pl.p)
                 hipLaunchKernelGGL(loss_gdn_bwd_pix_kernel, dim3(loss_grid(oct_blocks((long)B * (per_image / C), C))), dim3(256), 0, s, x, norm, residual,
                                    tgt_cache, idx_table, iter_ptr, B, (long)per_image, C, inv_npix, coef, inverse, out, grad_out, t, pl,
-                                   loss_out);
+                                   loss_out, pub);
             else
                 hipLaunchKernelGGL(loss_gdn_bwd_kernel, dim3(loss_grid(rdo::ceil_div((long)B * per_image / 4, 256L))), dim3(256), 0, s, x, norm, residual, tgt_cache,
-                                   idx_table, iter_ptr, B, (long)per_image, inv_npix, coef, inverse, out, grad_out, t, loss_out);
+                                   idx_table, iter_ptr, B, (long)per_image, inv_npix, coef, inverse, out, grad_out, t, loss_out, pub);
             return rdo::check_launch("loss_gdn_bwd");
         },
         stream, "loss_gdn_bwd", 0.0,

@@ -302,6 +302,9 @@ __global__ __launch_bounds__(512, 1) void linear_h2w_kernel(LinArgs a) {
     };
     // behind = vector-memory instructions issued after the loads that have to be back (the counter retires in order): -1 = all of them
     auto landed = [&](int behind) {
+#ifdef RDO_DIAG
+        behind = -1;            // a diagnostic build's ablations change how many stores sit behind the loads: never count, wait for all
+#endif
         if (behind < 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (behind == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (behind == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -513,9 +516,9 @@ extern "C" int rdo_linear_h2_supported(int64_t M, int32_t K, int32_t N) {
 // 128^2 maps: 192 -> 576 over 64 K tokens 67 -> 63 us, -> 384 48 -> 38.5, -> 192 29 -> 26; over 16 K tokens the one-time weight load and the
 // tile quantisation lose: 23.6 against 20.0), 2 = also for K = 384 / 576 (16 channels x K per wave: LDS-read-bound, measured 60 / 102 us
 // against 44 / 61 -- kept for A/B runs), 0 = always one (token tile, chunk) per workgroup with the weights streamed from L2
-static int lin_stationary() {
-    static const int v = [] { const char* e = getenv("RDO_LIN_H2_STATIONARY"); return e ? atoi(e) : 1; }();
-    return v;
+static int lin_stationary() {      // read per call (calls are recorded once per plan): a test compares the two kernels in one process
+    const char* e = getenv("RDO_LIN_H2_STATIONARY");
+    return e ? atoi(e) : 1;
 }
 static int cu_count() {
     static const int v = [] {

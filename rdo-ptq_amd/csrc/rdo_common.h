@@ -96,6 +96,7 @@ inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 // bf16 six-product form and 1.8e-7 for an fp32 fma chain; MFMA honours fp16 denormals).  |x s| > 65504 cannot be represented: the
 // producers raise a sticky device flag (rdo_h2_overflow) instead of failing silently.
 int* h2_overflow_flag();                   // device pointer of the sticky flag on the current device (allocated on first use)
+int32_t* take_iter_publish();              // the word bound by rdo_iter_bind_publish for the next loss / tail launch (and clears the binding)
 
 #if defined(__HIPCC__)
 typedef _Float16 h2_f16x2 __attribute__((ext_vector_type(2)));

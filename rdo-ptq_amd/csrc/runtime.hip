@@ -62,6 +62,14 @@ int tuning(Tune t) {
 // rdo_h2_bind_flag: the caller's own flag word for the launches of this thread (nullptr: the per-device default below)
 static thread_local int* t_h2_bound = nullptr;
 
+// rdo_iter_bind_publish: where the NEXT loss / tail launch of this thread leaves the iteration number it read (nullptr: nowhere)
+static thread_local int32_t* t_iter_pub = nullptr;
+int32_t* take_iter_publish() {
+    int32_t* p = t_iter_pub;
+    t_iter_pub = nullptr;
+    return p;
+}
+
 int* h2_overflow_flag() {
     if (t_h2_bound) return t_h2_bound;
     static std::mutex mu;
@@ -123,6 +131,12 @@ int rdo_get_tuning(const char* key) {
     if (i < 0) return -1;
     rdo::tune_init();
     return rdo::g_tune[i].load();
+}
+
+int rdo_iter_bind_publish(int32_t* publish) {
+    const int pending = rdo::t_iter_pub != nullptr;      // 1: an earlier binding was never consumed (no loss launch followed it)
+    rdo::t_iter_pub = publish;
+    return pending;
 }
 
 int rdo_h2_bind_flag(int32_t* flag) {

@@ -31,6 +31,12 @@ class AdaStepItem(C.Structure):
                 ("lin_fwd_planes", C.c_void_p), ("lin_bwd_planes", C.c_void_p), ("lin_plane_scale", C.c_float)]
 
 
+class GatherDesc(C.Structure):
+    _fields_ = [("cache_q", C.c_void_p), ("cache_fp", C.c_void_p), ("idx_table", C.c_void_p), ("n_iters", C.c_int32), ("B", C.c_int32),
+                ("batch_offset", C.c_int32), ("per_image", C.c_int64), ("C", C.c_int32), ("prob", C.c_float), ("seed", C.c_uint32),
+                ("out", C.c_void_p), ("out_planes", C.c_void_p), ("out_scale", C.c_float), ("overflow_flag", C.c_void_p)]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("B", "H", "W", "C", "heads", "window", "shift")] + [("scale", C.c_float)]
 
@@ -60,6 +66,8 @@ _SIGS = {
     "rdo_adaround_fwd": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, P, P, P]),
     "rdo_adaround_step": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_int, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, C.c_float, C.c_float, P]),
     "rdo_adaround_step_batch": (C.c_int, [C.POINTER(AdaStepItem), C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, P, P, P, P]),
+    "rdo_adaround_step_batch_gather": (C.c_int, [C.POINTER(AdaStepItem), C.c_int32, C.c_int32, C.c_float, C.c_float, P, P, P, P, C.POINTER(GatherDesc), P]),
+    "rdo_iter_bind_publish": (C.c_int, [P]),
     "rdo_adaround_grad": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, C.c_int, P, P]),
     "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, C.c_float, C.c_float, P]),
     "rdo_uaq_fakequant": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, P]),

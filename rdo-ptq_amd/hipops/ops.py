@@ -221,10 +221,18 @@ def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_
                                       _stream()), "rdo_adaround_step")
 
 
-def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None, mode=0, iter_shadow=None):
+def iter_bind_publish(word):
+    """The next loss / tail launch of this thread leaves the iteration number it read in `word` (a one-element int32 tensor; None clears).
+    Returns True when an earlier binding was still pending (include/rdo_ptq_hip.h: rdo_iter_bind_publish)."""
+    return bool(L.lib().rdo_iter_bind_publish(_ptr(word)))
+
+
+def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_log, advance_iter=None, mode=0, iter_shadow=None, gather=None):
     """items: list of dicts(d, w, delta, zp, slabs, alpha, m, v, wq, wd, wq_planes, wd_planes[, dalpha, lin_fwd, lin_bwd]) -- one launch for every
     weight tensor of a unit (<= 8, numel % 4 == 0): mode 0 the fused AdaRound step, 1 the data gradient into `dalpha`, 2 the update
-    from an (all-reduced) `dalpha`; `advance_iter`: the device iteration counter to increment afterwards."""
+    from an (all-reduced) `dalpha`; `advance_iter`: the device iteration counter to increment afterwards.
+    `gather`: dict(cache_q, cache_fp, idx_table, B, batch_offset, prob, seed, out, out_planes) -- the launch also assembles the NEXT
+    iteration's mini-batch (rdo_adaround_step_batch_gather)."""
     _bind_out(None)            # weight planes raise the enclosing block's word
     arr = (L.AdaStepItem * len(items))()
     dp = lambda t: None if t is None else _ptr(t).value
@@ -240,6 +248,19 @@ def adaround_step_batch(items, grad_scale, round_weight, sched, iter_ptr, round_
         lf, lb = it.get("lin_fwd"), it.get("lin_bwd")      # H2 planes in rdo_linear_h2's fragment order, written by the step itself
         a.lin_fwd_planes, a.lin_bwd_planes = dp(lf), dp(lb)
         a.lin_plane_scale = float((lf if lf is not None else lb).scale) if (lf is not None or lb is not None) else 0.0
+    if gather is not None:
+        if advance_iter is not None:
+            raise ValueError("adaround_step_batch: the gather form moves the counter by hand-over (iter_shadow), not advance_iter")
+        cq, pl = gather["cache_q"], gather.get("out_planes")
+        g = L.GatherDesc()
+        g.cache_q, g.cache_fp, g.idx_table = dp(cq), dp(gather["cache_fp"]), dp(gather["idx_table"])
+        g.n_iters, g.B, g.batch_offset = int(gather["idx_table"].shape[0]), int(gather["B"]), int(gather.get("batch_offset", 0))
+        g.per_image, g.C, g.prob, g.seed = cq[0].numel(), int(cq.shape[-1]), float(gather["prob"]), int(gather["seed"])
+        g.out, g.out_planes, g.out_scale = dp(gather.get("out")), dp(pl), (float(pl.scale) if pl is not None else 0.0)
+        g.overflow_flag = dp(getattr(pl, "flag", None))      # the gathered planes raise their own overflow word
+        L.check(L.lib().rdo_adaround_step_batch_gather(arr, len(items), int(mode), grad_scale, round_weight, _ptr(sched), _ptr(iter_ptr),
+                                                       _ptr(round_log), _ptr(iter_shadow), C.byref(g), _stream()), "rdo_adaround_step_batch_gather")
+        return
     L.check(L.lib().rdo_adaround_step_batch(arr, len(items), int(mode), grad_scale, round_weight, _ptr(sched), _ptr(iter_ptr), _ptr(round_log),
                                             _ptr(advance_iter), _ptr(iter_shadow), _stream()), "rdo_adaround_step_batch")
 

@@ -267,6 +267,10 @@ class UnitEngine:
         self.fuse_splitk = os.environ.get("RDO_FUSE_SPLITK", "1") != "0"   # split-K conv + unit tail: the conv's second pass inside the tail
         self.fuse_h2_tail = os.environ.get("RDO_H2_TAIL", "1") != "0"       # last conv of a H2 ResidualBlock unit + its tail in one launch
         self.fold_iter = os.environ.get("RDO_FOLD_ITER", "1") != "0"     # iteration-counter hand-over instead of an increment launch
+        # round 6: the NEXT iteration's mini-batch is assembled by the AdaRound-step launch (rdo_adaround_step_batch_gather) -- one launch
+        # less per iteration, the gather's stream under the step's latency; iteration 0's mini-batch by a stand-alone gather (`_prime`)
+        self.fold_gather = os.environ.get("RDO_GATHER_IN_STEP", "1") != "0"
+        self._next_gather = None
         # opt-in R + lambda*D task loss (loss_mode='rd'): dict(model=QuantModel, unit=module, cali=calibration images NCHW on the GPU,
         # lmbda=float).  The unit output of every iteration is pushed through the REST of the wrapped model on torch's tape
         # (hipops.autograd) and losses.RateDistortionLoss is differentiated back to it; rec_loss stays the lp term.
@@ -331,6 +335,7 @@ class UnitEngine:
             self._record()
             for op in self.ops.values():
                 op.refresh_planes()      # initial soft weights -> bf16 planes (eager, before the first iteration)
+            self._prime()                # folded gather: the mini-batch of iteration 0
 
     # ------------------------------------------------------------------------------------------------------------------
     def _build_ops(self):
@@ -693,8 +698,7 @@ class UnitEngine:
         lean = self.h2_lean
         # lean: x and h1 exist as planes only -- the residual add of the tail sums the three planes back (exactly), the LeakyReLU
         # mask of the dgrad epilogue reads the sign off plane 0
-        ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None if lean else x, xp,
-                            self.batch_offset, iter_publish=self._it_pub())
+        self._gather(None if lean else x, xp)
         self._conv_h2(c1, xp, x.shape, out=None if lean else t["h1"], out_planes=h1p, epilogue=L.EPI_LRELU)
         self._task_is_rec = True
         if self.fuse_h2_tail and ops.conv_h2_tail_supported(tuple(t["h1"].shape), c2.w4, c2.stride, c2.pad):
@@ -735,12 +739,7 @@ class UnitEngine:
         h1p, dcp = self._h2("h1", t["h1"]), self._h2(dname, t["h1"])
         tp = self._h2("t", t["h1"]) if g_h2 else None
         xp = self._h2("x", x) if x_h2 else None
-        if x_h2:
-            ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, xp, self.batch_offset,
-                                iter_publish=self._it_pub())
-        else:
-            ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
-                             iter_publish=self._it_pub())
+        self._gather(x, xp if x_h2 else None)
         lean_h1 = self.h2_lean and (rbu or x_h2)          # h1 exists as planes only (its LeakyReLU mask is read off plane 0)
         if rbu:
             r = self.r
@@ -931,6 +930,7 @@ class UnitEngine:
         self._record()
         for op in self.ops.values():
             op.refresh_planes()
+        self._prime()
 
     def _check_overflow(self):
         """Where results leave the engine: an overflow not yet seen by the polls of `run` is handled here.  COLLECTIVE under data
@@ -966,8 +966,7 @@ class UnitEngine:
         if self.h2_plan in ("rbws", "rbu"):
             return self._fb_gdn_block_h2()
         if self.h2_plan not in ("tconv", "layer"):            # (those plans gather straight into planes)
-            ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
-                             iter_publish=self._it_pub())
+            self._gather(x)
         if self.kind == "layer" and o["layer"].is_gdn:
             # a GDN / IGDN that is its own unit (sequential Minnen2018-style coders): only gamma is trained, no dx needed
             op = o["layer"]
@@ -991,8 +990,7 @@ class UnitEngine:
             if self.h2_plan == "layer":                      # conv, tail and weight gradient on H2 tensors (x and dL/dpre exist as planes only)
                 xs = tuple(x.shape)
                 xp, dpp = self._h2("x", x), self._h2("dpre", t["dpre"])
-                ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None, xp, self.batch_offset,
-                                    iter_publish=self._it_pub())
+                self._gather(None, xp)
                 self._conv_h2(op, xp, xs, out=t["y"])                                               # pre-activation
                 self._task_is_rec = True
                 ops.loss_act_bwd(t["y"], None, self.co, self.idx, self.it, 2.0, act, self.loss_log, dpre_planes=dpp)
@@ -1002,8 +1000,7 @@ class UnitEngine:
                 xp, dypp = self._h2("x", x), self._h2("dpre", t["dyp"])
                 if op.wp_h2 is None:
                     op.wp_h2 = ops.H2(torch.empty((2,) + tuple(op.wp4), device=self.dev, dtype=torch.int16), op.wscale)
-                ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, None, xp, self.batch_offset,
-                                    iter_publish=self._it_pub())
+                self._gather(None, xp)
                 ops.conv2d_fwd_h2(xp, xs, op.wp4, op.wp_h2, op.bias_p, 1, ph.pad, out=t["yp"])
                 self._shuffle(t["yp"], 2, t["y"])
                 self._tail_act(t["y"], None, act, t["dpre"])
@@ -1131,7 +1128,11 @@ class UnitEngine:
         hand-over switched off, with the last launch."""
         for i in range(0, len(opl), self.STEP_BATCH):
             last = i + self.STEP_BATCH >= len(opl)
-            if self._handover:
+            if self._folded:
+                # every launch of the step reads the published word; the LAST one carries the next mini-batch and moves the real counter
+                ops.adaround_step_batch(self._items(opl[i:i + self.STEP_BATCH]), scale, self.weight, self.sched, self.it_shadow, self.round_log, mode=mode,
+                                        iter_shadow=self.it if last else None, gather=self._next_gather if last else None)
+            elif self._handover:
                 ops.adaround_step_batch(self._items(opl[i:i + self.STEP_BATCH]), scale, self.weight, self.sched, self.it, self.round_log, mode=mode,
                                         iter_shadow=self.it_shadow if i == 0 else None)
             else:
@@ -1143,11 +1144,45 @@ class UnitEngine:
         """The counter hand-over needs the unit's step as batched launches (it is the first of them that fills the shadow)."""
         return self.fold_iter and self._batchable(list(self.ops.values()))
 
+    @property
+    def _folded(self):
+        """The step launch of iteration i assembles the mini-batch of iteration i + 1.  Counter words then: the loss / tail launch reads
+        the real counter `it` and publishes it into `it_shadow` (ops.iter_bind_publish); the step reads `it_shadow` and its first thread
+        stores it + 1 into `it` -- nobody reads a word that another thread of the same launch writes (include/rdo_ptq_hip.h)."""
+        return self.fold_gather and self._handover and self.rd is None
+
     def _it_src(self):
-        return self.it_shadow if self._handover else self.it
+        return self.it_shadow if (self._handover and not self._folded) else self.it
 
     def _it_pub(self):
-        return self.it if self._handover else None
+        return self.it if (self._handover and not self._folded) else None
+
+    def _gather(self, x, xp=None):
+        """The unit's mini-batch for the current iteration: x_q / x_fp rows mixed by the QDrop mask into `x` (fp32, may be None with
+        planes) and / or the planes `xp`.  Recorded as the iteration's first kernel -- or, folded, handed to the step launch of the
+        PREVIOUS iteration (`_step_batches`) with `_prime` covering iteration 0."""
+        if self._folded and not self._probing:
+            self._next_gather = dict(cache_q=self.cq, cache_fp=self.cf, idx_table=self.idx, B=self.B, batch_offset=self.batch_offset,
+                                     prob=self.input_prob, seed=self.seed, out=x, out_planes=xp)
+            return
+        if xp is not None:
+            ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, xp, self.batch_offset,
+                                iter_publish=self._it_pub())
+        else:
+            ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
+                             iter_publish=self._it_pub())
+
+    def _prime(self):
+        """Folded gather: the mini-batch of the iteration the counter stands at, assembled eagerly (before the first iteration of a
+        run and after a restart; every later one comes from the previous iteration's step launch)."""
+        g = self._next_gather
+        if g is None:
+            return
+        self.it_shadow.copy_(self.it)
+        if g["out_planes"] is not None:
+            ops.gather_qdrop_h2(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, g["out"], g["out_planes"], self.batch_offset)
+        else:
+            ops.gather_qdrop(self.cq, self.cf, self.idx, self.it, self.B, self.input_prob, self.seed, g["out"], self.batch_offset)
 
     def _grad_ops(self, names):
         opl = [self.ops[n] for n in names]
@@ -1189,8 +1224,13 @@ class UnitEngine:
         self.plan_a2 = self.plan_b = self.plan_rd = None
         self._rec_ctx = self.plan_a.record()
         self._rec_ctx.__enter__()
+        self._next_gather = None
         try:
+            if self._folded:
+                ops.iter_bind_publish(self.it_shadow)          # consumed by the iteration's first loss / tail launch
             self._forward_backward()
+            if self._folded and (ops.iter_bind_publish(None) or self._next_gather is None):
+                raise RuntimeError("calibration engine: the folded gather needs exactly one loss / tail launch and one gather per iteration")
             if not self.split:
                 self._step_ops()
             elif self.plan_a2 is not None:

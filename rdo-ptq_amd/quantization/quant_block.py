@@ -197,6 +197,11 @@ class QuantWindowAttention(BaseQuantBlock):
         d = ops.attn_desc(B, H, W, C, self.num_heads, window, shift, self.scale)
         bias = self.position_bias()
         if self.use_act_quant and self.trained:
+            if _tracked(qkv):
+                # the activation-quantised attention below runs raw kernels (no grad_fn): under torch's tape (loss_mode='rd' behind a unit,
+                # a second calibration pass) the gradient through the attention path would be cut silently
+                raise NotImplementedError("QuantWindowAttention: a trained, activation-quantised attention cannot sit on torch's tape "
+                                          "(its quantised probabilities carry no gradient); run the R + lambda*D task loss with act_quant=False")
             n = window * window
             probs = torch.empty((B * (H // window) * (W // window), n, n, self.num_heads), device=qkv.device, dtype=torch.float32)
             ops.window_attention(d, qkv, bias, probs=probs, compute_out=False)

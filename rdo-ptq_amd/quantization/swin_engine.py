@@ -21,6 +21,7 @@ import torch
 
 from hipops import _lib as L
 from hipops import ops
+from hipops.autograd import LIN_H2_MIN_ROWS
 from hipops.plan import Plan
 
 from . import dp
@@ -227,8 +228,12 @@ class TapeEngine(UnitEngine):
         y = self._buf(*x.shape[:-1], cout)
         x4, y4 = x.view(1, 1, rows, cin), y.view(1, 1, rows, cout)
         pre = None
-        lin_f = self.lin_h2 and ops.linear_h2_supported(rows, cin, cout)          # large token matrices: per-token-scaled fp16-split kernel
-        lin_b = self.lin_h2 and ops.linear_h2_supported(rows, cout, cin)
+        # large token matrices: per-token-scaled fp16-split kernel -- from the same token count as the tape's Linears (hipops.autograd) and
+        # the engine's GDN GEMMs: below it the launch is a few dozen workgroups that each stream the whole weight chunk and the conv
+        # kernels' split-K forms win (and the tape path and this one would use different arithmetic for the same layer shape)
+        big = rows >= LIN_H2_MIN_ROWS
+        lin_f = self.lin_h2 and big and ops.linear_h2_supported(rows, cin, cout)
+        lin_b = self.lin_h2 and big and ops.linear_h2_supported(rows, cout, cin)
         bias_of = lambda: p.bias
         fuse_here = lambda xs, w4, has_planes: self.fuse_gelu == 2 or (
             self.fuse_gelu == 1 and ops.conv_fwd_ksplit(tuple(xs), tuple(w4), 1, 0, has_planes, self.dev)[0] >= 2)
@@ -482,8 +487,7 @@ class TapeEngine(UnitEngine):
         from .quant_block import QuantRSTB
         self.tape, self.G = [], {}
         x = self.x_in
-        ops.gather_qdrop(self.cq, self.cf, self.idx, self._it_src(), self.B, self.input_prob, self.seed, x, self.batch_offset,
-                         iter_publish=self._it_pub())
+        self._gather(x)
         y = self._unit_forward(x)
         n_unit = len(self.tape)
         plain = not self.tail and not self.tail_round                 # fp_out is the identity: task == rec (coef 2)

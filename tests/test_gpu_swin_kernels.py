@@ -275,6 +275,34 @@ def test_linear_weight_gradient_h2_matches_float64(rows, cin, cout, kind):
     assert float((got - want).abs().max()) < 2e-6 * float(want.abs().max())
 
 
+@pytest.mark.parametrize("rows,N,epi", [(4 * 128 * 128, 192, "none"), (4 * 128 * 128 + 192, 384, "none"), (32768 + 64, 576, "gelu")])
+def test_linear_h2_stationary_kernel_equals_streaming_kernel(rows, N, epi, monkeypatch):
+    """The weight-stationary kernel (linear_h2w_kernel: inline-asm prefetch waited for with hand-counted `s_waitcnt vmcnt(n)`, n = the
+    number of vector-memory instructions the compiler emits for an epilogue) against the streaming kernel on the same inputs, bit for
+    bit: a compiler upgrade that changes that count makes the stationary kernel read its registers before the loads have landed --
+    silently -- and shows here."""
+    from hipops import _lib as L, ops
+    g = torch.Generator().manual_seed(rows + N)
+    x = (torch.randn(rows, 192, generator=g) * torch.exp(torch.randn(rows, 1, generator=g))).cuda()
+    w = (torch.randn(N, 192, generator=g) / 192 ** 0.5).cuda()
+    b = torch.randn(N, generator=g).cuda()
+    planes = ops.split_h2_linear(w)
+
+    def run():
+        if epi == "gelu":
+            pre = torch.empty(rows, N, device="cuda")
+            return ops.linear_h2(x, planes, b, epilogue=L.EPI_GELU, pre=pre), pre
+        return ops.linear_h2(x, planes, b), None
+    monkeypatch.setenv("RDO_LIN_H2_STATIONARY", "0")
+    y0, p0 = run()
+    monkeypatch.setenv("RDO_LIN_H2_STATIONARY", "1")
+    for _ in range(3):                                     # (a late load is a race: look more than once)
+        y1, p1 = run()
+        assert torch.equal(y0, y1)
+        if p0 is not None:
+            assert torch.equal(p0, p1)
+
+
 def test_round5_kernels_are_run_to_run_deterministic():
     """linear_wgrad_h2_kernel (LDS slot hand-over of the per-stage scale, two register sets in flight), the weight-stationary linear kernel
     (two LDS panels, hand-counted waits) and the attention kernels (persistent workgroups with a register prefetch) give the same bits on

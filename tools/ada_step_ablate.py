@@ -66,7 +66,7 @@ def main():
         e = UnitEngine(kind, mods, cq, cf, co, batch_size=4, iters=iters, weight=0.01, b_range=(20, 2), warmup=0.0, input_prob=0.5, seed=1005,
                        idx_table=idx)
         info = e.plan_a.op_info()
-        sel = [i for i, (tag, _, _) in enumerate(info) if tag == "ada_step"]
+        sel = [i for i, (tag, _, _) in enumerate(info) if tag in ("ada_step", "ada_step_gather")]
         params = sum(op.numel() for op in e.ops.values())
         tensors = {n: dict(numel=op.numel(), nsplit=int(op.slabs.shape[0]), dgrad=op.wd is not None,
                            planes=("h2" if isinstance(op.wq_planes, ops.H2) else ("bf16x3" if op.wq_planes is not None else None)),

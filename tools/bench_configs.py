@@ -19,11 +19,13 @@ def attn_w10(images=16, iters=60, batch=4, log=print):
     """BASELINE config 3 on one GPU: Cheng2020-attn N=192, W10 channel-wise weights, the whole recon_model schedule (108 units) for a few
     iterations per unit through the public API; ms per step (one iteration of every unit) from the loop share of the wall."""
     from full_schedule import run_schedule
-    r = run_schedule(images=images, iters=iters, batch=batch, log=log, quality=False, arch="attn", w_bits=10, a_bits=10, per_unit_log=False)
+    r = run_schedule(images=images, iters=iters, batch=batch, log=log, quality=False, arch="attn", w_bits=10, a_bits=10, per_unit_log=False, roofline=True)
+    rf = r["roofline"]
+    rf.pop("units", None)                       # (the full per-unit table: tools/full_schedule.py --roofline, profiles/)
     return {"workload": f"Cheng2020-attn N=192 W10A10 channel-wise, {r['n_units']} units, {images} images 256x256, batch {batch}, {iters} iterations per unit "
                         "(graph capture inside the loop time)",
             "units": r["n_units"], "ms_per_step": round(r["loop_s"] / iters * 1e3, 3),
-            "images_per_s": round(r["n_units"] * batch * iters / r["loop_s"], 1), "wall_s": round(r["recon_model_wall_s"], 2)}
+            "images_per_s": round(r["n_units"] * batch * iters / r["loop_s"], 1), "wall_s": round(r["recon_model_wall_s"], 2), "roofline": rf}
 
 
 def lu2022_unit(name="g_a1", log=print):
@@ -83,13 +85,63 @@ def lu2022_schedule(images=8, iters=30, batch=4, log=print):
     the context conv and the three entropy-parameter convs: main2.py:227-253 on models/nic_cvt.py) through the public API for a few
     iterations each; ms per step (one iteration of every unit) from the loop share of the wall, the slowest units by name."""
     from full_schedule import run_schedule
-    r = run_schedule(images=images, iters=iters, batch=batch, log=log, quality=False, arch="lu2022", per_unit_log=False)
+    r = run_schedule(images=images, iters=iters, batch=batch, log=log, quality=False, arch="lu2022", per_unit_log=False, roofline=True)
+    rf = r["roofline"]
+    rf.pop("units", None)
     slow = sorted(r["units"], key=lambda u: -u["loop_ms_per_iter"])[:6]
     return {"workload": f"Lu2022 (embed 192, latent 320), {r['n_units']} units, {images} images 256x256, batch {batch}, {iters} iterations per unit "
                         "(graph capture inside the loop time)",
             "units": r["n_units"], "ms_per_step": round(r["loop_s"] / iters * 1e3, 3),
             "images_per_s": round(r["n_units"] * batch * iters / r["loop_s"], 1), "wall_s": round(r["recon_model_wall_s"], 2),
-            "slowest_units_ms_per_iteration": {u["unit"]: u["loop_ms_per_iter"] for u in slow}}
+            "slowest_units_ms_per_iteration": {u["unit"]: u["loop_ms_per_iter"] for u in slow}, "roofline": rf}
+
+
+def rd_mode(units=("g_a.0", "g_a.6", "g_s.5"), batch=4, images=16, iters=24, log=print):
+    """The opt-in R + lambda*D task loss (`loss_mode='rd'`; north_star names the R + lambda*D loss / backward as part of the hot path): ms
+    per calibration iteration of three units of the headline model -- the first analysis block, the last analysis conv (whose tail is the
+    whole hyper-path + synthesis transform) and the 128^2 synthesis block -- with the model behind the unit evaluated on torch's tape
+    (hipops.autograd) inside the captured iteration, next to the same unit's default (lp) iteration."""
+    import lic
+    from quantization import QuantModel
+    from quantization.engine import UnitEngine
+    from quantization.recon import _unit_modules
+    wq = {"n_bits": 8, "channel_wise": True, "scale_method": "max"}
+    out = {"workload": f"Cheng2020-anchor N=192, batch {batch}, 256x256, {iters} iterations behind 8 warm-up iterations", "units": {}}
+    torch.manual_seed(0)
+    cali = torch.rand(images, 3, 256, 256).cuda()
+    for name in units:
+        row = {}
+        for mode in ("lp", "rd"):
+            torch.manual_seed(1)
+            qnn = QuantModel(lic.Cheng2020Anchor(N=192).eval().cuda(), wq, dict(wq, leaf_param=False), is_cheng=True).cuda().eval()
+            qnn.set_quant_state(False, False)
+            unit = qnn.model
+            for part in name.split("."):
+                unit = unit[int(part)] if part.isdigit() else getattr(unit, part)
+            store = {"inps": [], "outs": []}
+            h = unit.register_forward_hook(lambda m, i, o: (store["inps"].append(i[0].detach().clone()), store["outs"].append(o.detach().clone())))
+            with torch.no_grad():
+                for i in range(0, images, batch):
+                    qnn(cali[i:i + batch])
+            h.remove()
+            nh = lambda ts: torch.cat(ts).permute(0, 2, 3, 1).contiguous()
+            inp, tgt = nh(store["inps"]), nh(store["outs"])
+            k, mods = _unit_modules(unit)
+            rd = None if mode == "lp" else dict(model=qnn, unit=unit, cali=cali, lmbda=0.0483)
+            eng = UnitEngine(k, mods, inp, inp, tgt, batch_size=batch, iters=8 + iters, seed=1, rd=rd)
+            eng.run(8)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            eng.run(iters)
+            torch.cuda.synchronize()
+            row[f"{mode}_ms_per_iteration"] = round((time.perf_counter() - t0) / iters * 1e3, 3)
+            if rd is not None:
+                row["rd_loop"] = eng.rd_path
+            del eng, qnn
+            torch.cuda.empty_cache()
+        log(f"rd mode {name}: {row}")
+        out["units"][name] = row
+    return out
 
 
 def mbt2018_eval(hw=(512, 768), n=6, log=print):
@@ -124,6 +176,6 @@ def mbt2018_eval(hw=(512, 768), n=6, log=print):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "lu2022", "lu2022_schedule", "mbt2018"]
-    fns = {"attn": attn_w10, "lu2022": lu2022_unit, "lu2022_schedule": lu2022_schedule, "mbt2018": mbt2018_eval}
+    fns = {"attn": attn_w10, "lu2022": lu2022_unit, "lu2022_schedule": lu2022_schedule, "mbt2018": mbt2018_eval, "rd": rd_mode}
     for w in which:
         print(w, fns[w]())

@@ -21,8 +21,46 @@ sys.path.insert(0, os.path.join(ROOT, "rdo-ptq_amd"))
 sys.path.insert(0, ROOT)
 
 
+def schedule_roofline(engines, loop_s, iters, top=8):
+    """Algorithmic-FLOP accounting of a finished schedule (missing 2 / next 2a): every recorded op of every unit's
+    plans carries its algorithmic FLOPs (2 M N K of its GEMM: unit forward, input and weight gradients, the full-precision tail's
+    forward and input gradient, the attention products) and bytes; ONE more eager iteration of every unit with a hipEvent pair around
+    every op (rdo_plan_profile) gives the time per kernel family.  -> per-unit GFLOP per iteration against the unit's loop time, the
+    schedule's achieved TFLOP/s, and the kernel families by time, each against the peak of ITS pipe or -- below the ridge -- against bytes."""
+    import bench
+    per_tag, units = {}, []
+    for (name, e), t_loop in zip(engines, loop_s):
+        e.dp_drain()
+        e._it2.fill_(max(0, e.iters - 1))      # the profiled iteration stays inside the unit's index / schedule tables
+        fl_u = ms_u = 0.0
+        for p in (e.plan_a, getattr(e, "plan_a2", None), getattr(e, "plan_rd", None), getattr(e, "plan_b", None)):
+            if p is None:
+                continue
+            for (tag, fl, by), ms in zip(p.op_info(), p.profile()):
+                d = per_tag.setdefault(tag, [0, 0.0, 0.0, 0.0])
+                d[0] += 1; d[1] += ms; d[2] += fl; d[3] += by
+                fl_u += fl; ms_u += ms
+        it_ms = t_loop / iters * 1e3
+        units.append(dict(unit=name, kind=e.kind, gflop_per_iteration=round(fl_u / 1e9, 2), loop_ms_per_iteration=round(it_ms, 4),
+                          tflops=round(fl_u / (it_ms * 1e-3) / 1e12, 1) if it_ms > 0 else None, profiled_kernel_ms=round(ms_u, 4)))
+    step_ms = sum(loop_s) / iters * 1e3
+    flops = sum(v[2] for v in per_tag.values())
+    rows = {t: bench.kernel_row(t, *v) for t, v in sorted(per_tag.items(), key=lambda kv: -kv[1][1])}
+    mm = {t: v for t, v in per_tag.items() if v[2] > 0}
+    dom = max(mm, key=lambda t: mm[t][1]) if mm else None
+    ach = flops / (step_ms * 1e-3) / 1e12
+    split_peak = bench.PEAK_BF16_MFMA_TFLOPS / 3.0
+    return {"bound": "mfma", "unit": "TFLOP/s", "achieved": round(ach, 2), "peak": round(split_peak, 1),
+            "peak_note": "whole schedule against the fp16-split ceiling 2500 / 3 (the pipe the bulk of its FLOPs run on); per kernel family below",
+            "frac": round(ach / split_peak, 4), "frac_of_fp32_mfma_peak": round(ach / bench.PEAK_F32_MFMA_TFLOPS, 3),
+            "algorithmic_gflop_per_step": round(flops / 1e9, 1), "ms_per_step": round(step_ms, 3),
+            "dominant_kernel": dom, "dominant_kernel_row": rows.get(dom),
+            "kernels": dict(list(rows.items())[:top]),
+            "units_by_time": sorted(units, key=lambda u: -u["loop_ms_per_iteration"])[:top], "units": units}
+
+
 def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2, log=print, quality=True, arch="anchor", w_bits=8,
-                 a_bits=8, per_unit_log=True):
+                 a_bits=8, per_unit_log=True, roofline=False):
     """arch: "anchor" | "attn" (Cheng2020-attn, BASELINE config 3) | "lu2022" (BASELINE config 4: NIC embed 192 / latent 320, the 25
     units of main2.py's recon_model on the tape engine); w_bits / a_bits: weight grid and dynamic activation grid."""
     import math
@@ -122,6 +160,11 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
             log(f"  {name:24s} {e.kind:5s} loop {t['loop_s']:7.2f} s = {t['loop_s'] / iters * 1e3:7.3f} ms/it  cache {t['cache_s']:5.2f} s  record {t['record_s']:5.2f} s  "
                 f"soft targets in {{0,1}}: {100 * done / tot:6.2f} %  rec {float(rec[0]):.4e} -> {float(rec[-1]):.4e}  round {float(rnd[-1]):.3e}")
     res["units"] = units
+    if roofline:
+        res["roofline"] = schedule_roofline(engines, [t["loop_s"] for t in timing], iters)
+        r = res["roofline"]
+        log(f"roofline: {r['algorithmic_gflop_per_step']:.0f} GFLOP per step in {r['ms_per_step']:.2f} ms = {r['achieved']:.0f} TFLOP/s = "
+            f"{r['frac']:.3f} of {r['peak']:.0f}; dominant kernel {r['dominant_kernel']}: {r['dominant_kernel_row']}")
     if quality:
         qnn.set_quant_state(True, False)
         res["w8"] = evaluate_images(qnn.eval(), test_imgs) + (fidelity(qnn),)
@@ -147,7 +190,15 @@ if __name__ == "__main__":
     ap.add_argument("--no-quality", action="store_true")
     ap.add_argument("--w-bits", type=int, default=8)
     ap.add_argument("--a-bits", type=int, default=8)
+    ap.add_argument("--roofline", action="store_true", help="algorithmic-FLOP table per unit and kernel-family fractions (one more profiled iteration per unit)")
     a = ap.parse_args()
-    r = run_schedule(a.images, a.iters, a.batch, arch=a.arch, quality=not a.no_quality, w_bits=a.w_bits, a_bits=a.a_bits)
+    r = run_schedule(a.images, a.iters, a.batch, arch=a.arch, quality=not a.no_quality, w_bits=a.w_bits, a_bits=a.a_bits, roofline=a.roofline)
+    if a.roofline:
+        print("| unit | kind | GFLOP / iteration | ms / iteration | TFLOP/s |\n|---|---|---|---|---|")
+        for u in r["roofline"]["units"]:
+            print(f"| {u['unit']} | {u['kind']} | {u['gflop_per_iteration']} | {u['loop_ms_per_iteration']} | {u['tflops']} |")
+        print("\n| kernel family | launches | ms | TFLOP/s | GB/s | bound | fraction |\n|---|---|---|---|---|---|---|")
+        for t, k in r["roofline"]["kernels"].items():
+            print(f"| {t} | {k['launches_per_step']} | {k['ms_per_step']} | {k['tflops']} | {k['gbs']} | {k['bound']} | {k['frac_of_peak']} |")
     if a.json:
         json.dump(r, open(a.json, "w"), indent=1)

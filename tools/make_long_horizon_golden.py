@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""tests/golden/long_horizon.npz: the ORACLE's long-horizon trajectories of the Cheng2020-anchor N=192 block units (VERDICT round 5,
+weak 2 / next 7) for the seeded input sets of tests/long_horizon_common.py -- losses at the pick points, final hard decisions as packed
+bits, the fraction of decisions moved, a signature of the caches.  The inputs are seeded, so the oracle side is a constant; computing
+it inside the GPU suite cost ~300 s of the driver's 1 200 s limit on the GPU box's host cores.  Units in `LIVE` are recomputed by the
+test itself in every run (one per unit class) and are stored here as well (the test cross-checks the two when both exist).
+
+Runs anywhere the repository does (no reference needed: the oracle is the pinned restatement, see oracle/rdo_oracle.py):
+    python tools/make_long_horizon_golden.py [--only kodak] [--out tests/golden/long_horizon.npz]
+About 40 minutes on 8 cores for everything."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import long_horizon_common as C  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(C.GOLDEN, "long_horizon.npz"))
+    ap.add_argument("--only", default=None, help="one input set (uniform / kodak) or one 'stats/unit'; the rest of an existing file is kept")
+    a = ap.parse_args()
+    out = dict(np.load(a.out)) if os.path.exists(a.out) else {}
+    built = {}
+    for (stats, name), (iters, every) in C.RUNS.items():
+        if a.only and a.only not in (stats, f"{stats}/{name}"):
+            continue
+        if stats not in built:
+            built[stats] = C.build(stats)
+        flow, cali, _ = built[stats]
+        t0 = time.time()
+        log, u, caches = C.oracle_run(flow, cali, name, iters)
+        for k, v in C.summary(log, u, iters, every, caches).items():
+            out[f"{stats}/{name}/{k}"] = v
+        out[f"{stats}/{name}/iters"] = np.array([iters, every])
+        print(f"{stats}/{name}: {iters} iterations in {time.time() - t0:.0f} s; total {log.total[0]:.5g} -> {log.total[-1]:.5g}, moved "
+              + ", ".join(f"{n} {float(out[f'{stats}/{name}/moved/{n}']):.4f}" for n in u.ops), flush=True)
+        np.savez_compressed(a.out, **out)
+    print(f"{a.out}: {os.path.getsize(a.out) / 1e6:.2f} MB, {len(out)} arrays")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(max(1, len(os.sched_getaffinity(0))))
+    main()

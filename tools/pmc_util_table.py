@@ -5,7 +5,11 @@
 
 Only hot-loop dispatches are counted (same rule as tools/summarize_rocprof.py).  Columns, per kernel, means over its dispatches:
   * duration (us) of the dispatch in that pass,
-  * clock = GRBM_GUI_ACTIVE / 8 XCDs / duration (MI355X_MICROARCH.md, DVFS give-back: reads high on dispatches shorter than ~0.3 ms),
+  * clock = GRBM_GUI_ACTIVE / 8 XCDs / duration -- printed ONLY for kernels whose dispatches average >= 100 us: the counter's window is
+    wider than the dispatch (it includes the command processor's work around it), so the quotient read 3-6 GHz on a 2.4 GHz part for
+    every short kernel in rounds 4-5.  Even at 100 us it over-reads by a few per cent; the in-kernel
+    clock64 / wall_clock64 stamps of tools/h2k_stamps.py and tools/wgrad_ablate.py are the evidence for the power-limit reading
+    of the dominant kernels, this column is a cross-check,
   * MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / 1024 SIMDs / (GRBM_GUI_ACTIVE / 8): the share of the kernel's cycles in which a SIMD's
     matrix pipe was busy, averaged over the chip (the counter sums cycles over all SIMDs; it counts cycles, not quad-cycles),
   * SQ busy = SQ_BUSY_CYCLES / 32 shader engines / (GRBM_GUI_ACTIVE / 8) (a sanity column: ~1 for kernels that keep every SE busy)."""
@@ -47,4 +51,6 @@ for k, (n, cyc, ns) in sorted(g.items(), key=lambda kv: -kv[1][2]):
     b = per.get("SQ_BUSY_CYCLES", {}).get(k)
     mf = (m[1] / m[0]) / 1024.0 / xcd_cyc if m else float("nan")
     sq = (b[1] / b[0]) / 32.0 / xcd_cyc if b else float("nan")      # summed over the 32 shader engines
-    print(f"| {k} | {n} | {us:.1f} | {clk:.2f} | {mf * 100:.1f} % | {sq:.2f} |")
+    print(f"| {k} | {n} | {us:.1f} | {f'{clk:.2f}' if us >= 100.0 else '-'} | {mf * 100:.1f} % | {sq:.2f} |")
+print("\n(clock: only for dispatches of >= 100 us, see the docstring; MFMA busy and SQ busy are relative to the counter's own window and "
+      "therefore UNDER-read on short dispatches)")
