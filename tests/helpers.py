@@ -203,3 +203,45 @@ def trained_like_(ref, g, decades=2.5, probe=None):
             finally:
                 for h in hooks:
                     h.remove()
+
+
+def trained_like_nic_(model, g, decades=2.0):
+    """The same idea for the Lu2022 `NIC` (lic/nic.py; Swin blocks): Laplace-tailed conv / transposed-conv / Linear weights with
+    per-output-channel scales over `decades` decades (variance-preserving per layer), LayerNorm gains log-uniform in [0.3, 3] with small
+    offsets, relative-position tables and biases with mass.  The residual + LayerNorm structure keeps the activations bounded."""
+    import torch.nn as nn
+
+    def laplace(shape):
+        u = torch.rand(shape, generator=g) - 0.5
+        return -torch.sign(u) * torch.log1p(-2 * u.abs().clamp(max=0.4999999))
+
+    def scales(n, dec):
+        s = 10.0 ** ((torch.rand(n, generator=g) - 0.5) * dec)
+        return s / s.pow(2).mean().sqrt()
+
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if "entropy_bottleneck" in name:
+                continue
+            if isinstance(m, nn.ConvTranspose2d):
+                cin, cout, k, _ = m.weight.shape
+                fan = cin * k * k / (m.stride[0] * m.stride[1])
+                m.weight.copy_(laplace(m.weight.shape) / 2 ** 0.5 * (1.0 / fan) ** 0.5 * scales(cout, decades).view(1, -1, 1, 1))
+            elif isinstance(m, nn.Conv2d):
+                fan = m.weight[0].numel()
+                m.weight.copy_(laplace(m.weight.shape) / 2 ** 0.5 * (1.0 / fan) ** 0.5 * scales(m.weight.shape[0], decades).view(-1, 1, 1, 1))
+                if hasattr(m, "mask"):
+                    m.weight.mul_(m.mask)
+            elif isinstance(m, nn.Linear):
+                m.weight.copy_(laplace(m.weight.shape) / 2 ** 0.5 * (1.0 / m.weight.shape[1]) ** 0.5 * scales(m.weight.shape[0], 0.75 * decades).view(-1, 1))
+            elif isinstance(m, nn.LayerNorm):
+                m.weight.copy_(10.0 ** (torch.rand(m.weight.shape, generator=g) - 0.5))
+                m.bias.copy_(0.1 * laplace(m.bias.shape))
+                continue
+            else:
+                continue
+            if getattr(m, "bias", None) is not None:
+                m.bias.copy_(0.05 * laplace(m.bias.shape))
+        for n, p in model.named_parameters():
+            if n.endswith("relative_position_bias_table"):
+                p.copy_(0.5 * torch.randn(p.shape, generator=g))

@@ -325,19 +325,24 @@ def test_engine_ten_bit_weights_match_oracle(golden_dir):
 
 
 @pytest.mark.parametrize("tag,kind", RECON_UNITS)
-def test_fused_tails_and_batched_step_change_nothing(recon, tag, kind):
-    """The fused unit tails (csrc/fused_tail.hip) and the one-launch AdaRound step execute the same fp32 operations as the chains
-    of separate kernels they replace: trained alphas are bit-identical, the logged loss differs only in summation order."""
+def test_fused_tails_and_batched_step_change_nothing(recon, tag, kind, monkeypatch):
+    """The fused unit tails (csrc/fused_tail.hip), the one-launch AdaRound step (tile form: dgrad layout in the same launch) and the
+    next iteration's gather riding in that launch (round 6: rdo_adaround_step_batch_gather, counter published by the tail) execute
+    the same fp32 operations as the chains of separate kernels they replace: trained alphas are bit-identical, the logged loss
+    differs only in summation order."""
     from quantization.engine import UnitEngine
     fx = recon
     _, _, B, iters = (int(v) for v in fx["meta"])
     idx = torch.from_numpy(fx[f"{tag}/idx"])
     res = []
-    for fuse, batch in ((True, True), (False, False), (True, False)):
+    for fuse, batch, fold in ((True, True, True), (False, False, True), (True, False, True), (True, True, False)):
+        monkeypatch.setenv("RDO_GATHER_IN_STEP", "1" if fold else "0")
         unit, k, mods = product_unit(fx, tag, kind)
         eng = UnitEngine(k, mods, nhwc(fx[f"{tag}/inp_q"]), nhwc(fx[f"{tag}/inp_fp"]), nhwc(fx[f"{tag}/out"]), batch_size=B,
                          iters=iters, input_prob=0.5, seed=SEED, idx_table=idx, fuse_tail=fuse, batch_step=batch)
-        assert eng.fused == fuse
+        assert eng.fused == fuse and eng._folded == (fold and batch)
+        assert any(t == "ada_step_gather" for t, _, _ in eng.plan_a.op_info()) == eng._folded
+        assert any(t.startswith("gather_qdrop") for t, _, _ in eng.plan_a.op_info()) != eng._folded
         eng.run()
         torch.cuda.synchronize()
         res.append(({n: eng.alpha_of(n).clone() for n in eng.ops}, eng.logs()[0]))

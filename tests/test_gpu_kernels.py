@@ -560,3 +560,59 @@ def test_plan_run_then_equals_two_runs(ops):
     torch.cuda.synchronize()
     t = torch.nn.functional.leaky_relu(a0 + b, 0.01)
     torch.testing.assert_close(a, (t + a0) + b, rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("planes", [False, True])
+def test_step_launch_assembles_the_next_mini_batch(planes):
+    """rdo_adaround_step_batch_gather (round 6): the step launch of iteration i leaves in `out` / `out_planes` exactly what a stand-alone
+    rdo_gather_qdrop(_h2) produces for iteration i + 1, steps the weights exactly as rdo_adaround_step_batch does, moves the counter by
+    the hand-over (reads the published word, stores it + 1 into the real counter), and skips the gather behind the last row of the
+    index table."""
+    from hipops import ops
+    g = torch.Generator().manual_seed(5)
+    n_img, B, H, C, iters = 6, 2, 8, 32, 3
+    cq = torch.randn(n_img, H, H, C, generator=g).cuda()
+    cf = torch.randn(n_img, H, H, C, generator=g).cuda()
+    idx = torch.stack([torch.randperm(n_img, generator=g)[:B] for _ in range(iters)]).to(torch.int32).cuda()
+    shape = (32, 3, 3, 32)
+    w = (torch.randn(shape, generator=g) * 0.1).cuda()
+    delta, zp = ops.uaq_init_minmax(w.reshape(shape[0], -1), 256)
+    d = ops.ada_desc(w)
+    slabs = (torch.randn((3,) + shape, generator=g) * 1e-2).cuda()
+    sched = torch.tensor([[10.0, 1.0, 1e-3, 1.0]] * iters, device="cuda")
+
+    def fresh():
+        alpha = ops.adaround_init_alpha(d, w, delta)
+        return dict(d=d, w=w, delta=delta, zp=zp, slabs=slabs, alpha=alpha, m=torch.zeros_like(w), v=torch.zeros_like(w), wq=torch.empty_like(w),
+                    wd=torch.empty_like(w))
+    for it0 in (0, iters - 1):
+        a, b = fresh(), fresh()
+        word = torch.full((2,), it0, dtype=torch.int32, device="cuda")                 # [real counter, published copy]
+        log_a, log_b = torch.zeros(iters, 32, device="cuda"), torch.zeros(iters, 32, device="cuda")
+        out = torch.full((B, H, H, C), 7.0, device="cuda")
+        xp = ops.h2_empty(out.shape, out.device, 4.0) if planes else None
+        if planes:
+            xp.t.fill_(77)
+        ops.adaround_step_batch([a], 1.0, 0.01, sched, word[1:2], log_a, iter_shadow=word[0:1],
+                                gather=dict(cache_q=cq, cache_fp=cf, idx_table=idx, B=B, batch_offset=0, prob=0.5, seed=99, out=out, out_planes=xp))
+        ref_word = torch.full((1,), it0, dtype=torch.int32, device="cuda")
+        ops.adaround_step_batch([b], 1.0, 0.01, sched, ref_word, log_b)
+        torch.cuda.synchronize()
+        for k in ("alpha", "m", "v", "wq", "wd"):
+            assert torch.equal(a[k], b[k]), k
+        assert torch.equal(log_a, log_b)
+        assert word.tolist() == [it0 + 1, it0]
+        if it0 + 1 < iters:
+            nxt = torch.full((1,), it0 + 1, dtype=torch.int32, device="cuda")
+            want = torch.empty_like(out)
+            if planes:
+                wp = ops.h2_empty(out.shape, out.device, 4.0)
+                ops.gather_qdrop_h2(cq, cf, idx, nxt, B, 0.5, 99, want, wp)
+                torch.cuda.synchronize()
+                assert torch.equal(xp.t, wp.t)
+            else:
+                ops.gather_qdrop(cq, cf, idx, nxt, B, 0.5, 99, want)
+            torch.cuda.synchronize()
+            assert torch.equal(out, want)
+        else:
+            assert bool((out == 7.0).all()) and (xp is None or bool((xp.t == 77).all()))     # behind the last iteration: nothing is gathered

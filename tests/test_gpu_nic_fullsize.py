@@ -54,6 +54,29 @@ def nic_full():
     return model, state, cali
 
 
+@pytest.fixture(scope="module")
+def nic_full_kodak(golden_dir):
+    """The same model class with natural-image statistics (missing 3 / next 3): crops of the reference's Kodak images
+    (tests/golden/kodak_crops.npz) and 'trained-like' parameters (helpers.trained_like_nic_: Laplace-tailed weights, per-channel scales
+    over two decades, LayerNorm gains in [0.3, 3]) -- activations with kurtosis 8-20 and magnitudes growing to 10^2-10^3 through the
+    residual stacks, where the per-token scales of rdo_linear_h2 and the probed plane scales of the conv units are exercised."""
+    import lic
+    from helpers import kodak_crops, trained_like_nic_
+    torch.manual_seed(1005)
+    model = lic.NIC(CFG).eval()
+    g = torch.Generator().manual_seed(7)
+    trained_like_nic_(model, g)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    return model, state, kodak_crops(golden_dir, N_IMG)
+
+
+@pytest.mark.parametrize("name", ["g_a1", "g_s4"])
+def test_lu2022_full_size_units_natural_statistics(nic_full_kodak, name):
+    """g_a1 (RSTB at 128^2 + the rest of g_a + round_ste) and g_s4 (RSTB at 64^2 + transposed-conv / RSTB tail) on Kodak crops with
+    trained-like parameters: same comparison, same tolerances as on uniform noise."""
+    test_lu2022_full_size_units_match_oracle(nic_full_kodak, name)
+
+
 def _logical(op, g):
     """engine gradient buffer (kernel layout) -> the oracle's logical weight shape"""
     g = g.reshape(op.alpha.shape)

@@ -119,7 +119,10 @@ def rd_mode(units=("g_a.0", "g_a.6", "g_s.5"), batch=4, images=16, iters=24, log
             for part in name.split("."):
                 unit = unit[int(part)] if part.isdigit() else getattr(unit, part)
             store = {"inps": [], "outs": []}
-            h = unit.register_forward_hook(lambda m, i, o: (store["inps"].append(i[0].detach().clone()), store["outs"].append(o.detach().clone())))
+            def keep(m, i, o, store=store):
+                store["inps"].append(i[0].detach().clone())
+                store["outs"].append(o.detach().clone())
+            h = unit.register_forward_hook(keep)
             with torch.no_grad():
                 for i in range(0, images, batch):
                     qnn(cali[i:i + batch])
