@@ -62,6 +62,41 @@ def build(stats):
     return flow, cali, mods
 
 
+def latents(flow, cali):
+    """The rounded latents y_hat = round(g_a(x)) of the calibration images in the two states a synthesis unit's caches are built from
+    (full precision / hard-quantised prefix), as int16.  Rounding is a discontinuity: a latent within fp32 noise of x.5 rounds the
+    other way on another CPU and moves every cache behind it by a whole quantisation step (observed between the authoring container
+    and the GPU box's host: 1.7e-3 of g_s.0's first loss).  The committed trajectories of the g_s units therefore come WITH the
+    latents they were computed from, and the test builds the caches of those units from the stored latents (`caches`)."""
+    out = {}
+    with torch.no_grad():
+        for state in ("fp", "prefix"):
+            flow._set_modes(state)
+            y = flow._run("g_a", cali, False, None)
+            yh = flow.model.gaussian_conditional.quantize(y, "dequantize")
+            assert float(yh.abs().max()) < 32000 and bool((yh == yh.round()).all())
+            out[state] = yh.to(torch.int16).numpy()
+    return out
+
+
+def caches(flow, cali, name, lat=None):
+    """(x_q, x_fp, target) of unit `name`: FlowOracle.caches, or -- for a synthesis unit when the latents are given -- the synthesis
+    prefix alone run from them (same modules, same batch: bit-identical to FlowOracle.caches on the machine the latents come from)."""
+    if lat is None or not name.startswith("g_s"):
+        return flow.caches(name, cali)
+    from oracle.flow_oracle import _Tap
+    got = {}
+    with torch.no_grad():
+        for state in ("fp", "prefix"):
+            flow._set_modes(state)
+            try:
+                flow._run("g_s", torch.from_numpy(lat[state]).float(), False, name)
+                raise RuntimeError(f"unit {name} was not reached")
+            except _Tap as t:
+                got[state] = (t.inp.clone(), t.out.clone())
+    return got["prefix"][0], got["fp"][0], got["fp"][1]
+
+
 def idx_stream(iters):
     return np.stack([np.random.RandomState(500 + i).permutation(N_IMG)[:B] for i in range(iters)])
 
@@ -75,11 +110,14 @@ def cache_signature(xq, xf, tg):
     return np.array([float(t.double().sum()) for t in (xq, xf, tg)] + [float(t.double().abs().sum()) for t in (xq, xf, tg)])
 
 
-def oracle_run(flow, cali, name, iters):
+def oracle_run(flow, cali, name, iters, lat=None):
     """the oracle's trajectory of unit `name` (block_opt.py:287-311 restated, torch CPU fp32) -> (log, unit, caches)"""
+    import copy
     from oracle import rdo_oracle as O
-    u = flow.by_name[name]
-    xq, xf, tg = flow.caches(name, cali)
+    xq, xf, tg = caches(flow, cali, name, lat)
+    # a COPY of the unit is trained: the flow stays what `build` made it (every unit at nearest rounding), so the caches of a unit do
+    # not depend on which other units were run before it -- in the generator or in the test, in any order or selection
+    u = copy.deepcopy(flow.by_name[name])
     for op in u.ops.values():
         op.init_scale()
     log = O.reconstruct_unit(u.kind, u.ops, xq, xf, tg, iters=iters, batch_size=B, idx_stream=idx_stream(iters),

@@ -26,9 +26,21 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(C.GOLDEN, "long_horizon.npz"))
     ap.add_argument("--only", default=None, help="one input set (uniform / kodak) or one 'stats/unit'; the rest of an existing file is kept")
+    ap.add_argument("--latents-only", action="store_true", help="only (re)write the rounded latents the synthesis units' caches start from")
     a = ap.parse_args()
     out = dict(np.load(a.out)) if os.path.exists(a.out) else {}
     built = {}
+    for stats in sorted({s for s, _ in C.RUNS}):
+        if a.only and not a.only.startswith(stats):
+            continue
+        if f"{stats}/y_hat/fp" not in out or a.latents_only:
+            built[stats] = C.build(stats)
+            for k, v in C.latents(built[stats][0], built[stats][1]).items():
+                out[f"{stats}/y_hat/{k}"] = v
+            print(f"{stats}: latents stored ({out[f'{stats}/y_hat/fp'].shape}, |y_hat| <= {int(np.abs(out[f'{stats}/y_hat/fp']).max())})", flush=True)
+            np.savez_compressed(a.out, **out)
+    if a.latents_only:
+        return
     for (stats, name), (iters, every) in C.RUNS.items():
         if a.only and a.only not in (stats, f"{stats}/{name}"):
             continue
@@ -36,7 +48,7 @@ def main():
             built[stats] = C.build(stats)
         flow, cali, _ = built[stats]
         t0 = time.time()
-        log, u, caches = C.oracle_run(flow, cali, name, iters)
+        log, u, caches = C.oracle_run(flow, cali, name, iters, lat={k: out[f"{stats}/y_hat/{k}"] for k in ("fp", "prefix")})
         for k, v in C.summary(log, u, iters, every, caches).items():
             out[f"{stats}/{name}/{k}"] = v
         out[f"{stats}/{name}/iters"] = np.array([iters, every])
