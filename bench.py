@@ -694,7 +694,7 @@ def main():
         peak, peak_note = kernel_peak(dom)
         kernels = {t: kernel_row(t, *v) for t, v in sorted(res["per_tag"].items(), key=lambda kv: -kv[1][1])}
         traffic, traffic_src = None, None
-        for tf in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM-side bytes per launch of the dominant kernel, last committed --pmc passes
+        for tf in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):   # HBM-side bytes per launch of the dominant kernel, last committed --pmc passes
             try:
                 tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
                 if dom in tj:
