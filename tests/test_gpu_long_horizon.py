@@ -65,7 +65,7 @@ def test_long_horizon_unit_matches_oracle(built, golden, stats, name):
         want = {k[len(key) + 1:]: golden[k] for k in golden.files if k.startswith(key + "/")}
         xq, xf, tg = C.caches(flow, cali, name, lat)
         np.testing.assert_allclose(C.cache_signature(xq, xf, tg), want["cache_sig"], rtol=1e-5, err_msg="caches differ from the fixture's")
-    assert float((xq - xf).abs().max()) > 0.0            # the prefix really is quantised
+    assert name == "g_a.0" or float((xq - xf).abs().max()) > 0.0      # the prefix really is quantised (the first unit has none)
     pm = _product_unit(u.kind, mods[name])
     nh = lambda t: t.permute(0, 2, 3, 1).contiguous().cuda()
     eng = UnitEngine(u.kind, pm, nh(xq), nh(xf), nh(tg), batch_size=C.B, iters=iters, weight=0.01, b_range=(20, 2), warmup=0.2,

@@ -100,7 +100,6 @@ def test_lu2022_full_size_long_horizon(nic_full, name):
     test_lu2022_full_size_units_match_oracle(nic_full, name, iters=LONG[name], long=True)
 
 
-@pytest.mark.parametrize("name", list(ITERS))
 def _oracle_first_gradient(state, dtype, name, inp_q, inp_fp, out_fp, idx, seed, zr_fixed):
     """d(rec + task)/d alpha of every weight tensor of unit `name` in the FIRST iteration from the oracle evaluated in `dtype` (float32:
     the reference's arithmetic; float64: the value both fp32 implementations approximate) on the given caches.  zr_fixed (units in g_a):
@@ -130,6 +129,7 @@ def _oracle_first_gradient(state, dtype, name, inp_q, inp_fp, out_fp, idx, seed,
     return list(ops2), grads, seen["flips"]
 
 
+@pytest.mark.parametrize("name", list(ITERS))
 def test_lu2022_full_size_units_match_oracle(nic_full, name, iters=None, long=False, natural=False):
     import copy
     from oracle import rdo_oracle as O, swin_oracle as S
