@@ -239,6 +239,7 @@ def gpu_leg(a, rank, world, device):
     log("engines recorded; warm-up")
     for _, e in engines:
         e.run(a.warmup)
+        e.prepare(a.steps)                       # graph capture of the timed call's replay units is set-up, like the recording
     barrier()
     log("timed region")
     t0 = time.perf_counter()

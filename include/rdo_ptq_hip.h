@@ -466,6 +466,8 @@ int rdo_plan_end_record(rdo_plan* p);
 int rdo_plan_suspend_record(int on);
 int rdo_plan_num_ops(const rdo_plan* p);
 int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream);
+/* capture + instantiate the graph(s) a later rdo_plan_run(p, n_iters, 1, .) replays, launching nothing (set-up work, like recording) */
+int rdo_plan_prepare(rdo_plan* p, int n_iters);
 /* one iteration of `p` then one of `q` as ONE graph launch (cached per partner): "apply of iteration i + forward/backward of iteration
  * i + 1" between two collectives of the data-parallel host loop */
 int rdo_plan_run_then(rdo_plan* p, rdo_plan* q, int use_graph, void* stream);

@@ -222,7 +222,15 @@ static int run_ops(rdo_plan* p, hipStream_t s) {
     return RDO_OK;
 }
 
-int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream) {
+static int plan_run_impl(rdo_plan* p, int n_iters, int use_graph, void* stream, bool launch);
+
+int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream) { return plan_run_impl(p, n_iters, use_graph, stream, true); }
+
+// Capture and instantiate the graphs a later rdo_plan_run(p, n_iters, 1, .) will replay, without launching anything: graph building
+// is set-up work (like recording); a caller that times its loop does it here instead of inside the first timed call.
+int rdo_plan_prepare(rdo_plan* p, int n_iters) { return plan_run_impl(p, n_iters, 1, nullptr, false); }
+
+static int plan_run_impl(rdo_plan* p, int n_iters, int use_graph, void* stream, bool launch) {
     RDO_REQUIRE(p != nullptr && !p->recording, "plan is null or still recording");
     RDO_REQUIRE(n_iters >= 0, "n_iters < 0");
     hipStream_t s = reinterpret_cast<hipStream_t>(stream);
@@ -265,13 +273,14 @@ int rdo_plan_run(rdo_plan* p, int n_iters, int use_graph, void* stream) {
             p->unroll_k = unroll;
         }
         for (; i + unroll <= n_iters; i += unroll) {
+            if (!launch) continue;
             hipError_t e = hipGraphLaunch(p->exec_k, s);
             if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
         }
     }
     if (i < n_iters && !p->exec)
         if (int rc = capture(1, &p->graph, &p->exec)) return rc;
-    for (; i < n_iters; ++i) {
+    for (; i < n_iters && launch; ++i) {
         hipError_t e = hipGraphLaunch(p->exec, s);
         if (e != hipSuccess) return rdo::set_error(RDO_EHIP, "hipGraphLaunch: %s", hipGetErrorString(e));
     }

@@ -142,6 +142,7 @@ _SIGS = {
     "rdo_plan_suspend_record": (C.c_int, [C.c_int]),
     "rdo_plan_num_ops": (C.c_int, [P]),
     "rdo_plan_run": (C.c_int, [P, C.c_int, C.c_int, P]),
+    "rdo_plan_prepare": (C.c_int, [P, C.c_int]),
     "rdo_plan_run_then": (C.c_int, [P, P, C.c_int, P]),
     "rdo_plan_op_info": (C.c_int, [P, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "rdo_plan_profile": (C.c_int, [P, C.POINTER(C.c_float), P]),

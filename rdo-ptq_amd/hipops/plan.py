@@ -43,6 +43,10 @@ class Plan:
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         L.check(L.lib().rdo_plan_run(self._h, int(n_iters), int(bool(graph)), s), "rdo_plan_run")
 
+    def prepare(self, n_iters):
+        """Build the graph(s) `run(n_iters)` will replay now, launching nothing (set-up work: a timed loop should not pay for it)."""
+        L.check(L.lib().rdo_plan_prepare(self._h, int(n_iters)), "rdo_plan_prepare")
+
     def run_then(self, other, graph=True):
         """One iteration of this plan followed by one of `other` in one graph launch."""
         s = C.c_void_p(torch.cuda.current_stream().cuda_stream)

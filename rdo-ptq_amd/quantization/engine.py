@@ -1288,6 +1288,17 @@ class UnitEngine:
                     self._recover()                  # back to iteration 0 with new scales / on fp32 activations
         return n
 
+    def prepare(self, n_iters=None):
+        """Capture the graphs a `run(n_iters)` (default: the rest of the unit's iterations) will replay -- set-up work like the recording;
+        `run` does it lazily otherwise (inside its first call).  Single-GPU plans only: the data-parallel and `rd` loops capture in
+        their own first call (they need an eager iteration in front)."""
+        if self.use_graph and not self.split and self.plan_rd is None:
+            n = self.iters - self._done if n_iters is None else int(n_iters)
+            k = min(n, self.H2_POLL) if (self.P and self.H2_POLL > 0) else n
+            self.plan_a.prepare(k)
+            if n % k:
+                self.plan_a.prepare(n % k)
+
     def _dp_iteration(self, graph, first=True, last=True):
         """One data-parallel iteration on the current stream: plan A -> all-reduce of the front of the bucket (asynchronous, on the
         process group's stream) overlapped with plan A2 = the last weight gradient -> all-reduce of the rest -> plan B.
