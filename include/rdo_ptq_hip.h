@@ -207,6 +207,17 @@ int rdo_adaround_step_batch_gather(const rdo_ada_step_item* items, int32_t n, in
  * gone.  Returns 1 when an earlier binding was still pending (never consumed), else 0; publish = NULL only clears. */
 int rdo_iter_bind_publish(int32_t* publish);
 
+/* ---- the data path of a 1 x 1 LAYER unit's iteration in ONE launch (round 6): pre = x W~^T + b (quant_layer.py:113-123), out = act(pre),
+ * loss += coef * lp_loss(out, target[idx]) (layer_opt.py:133,150), dpre = act'(pre) dL/dout, and the weight-gradient slabs dpre^T x --
+ * rdo_conv2d_fwd + rdo_loss_act_bwd + rdo_conv2d_wgrad for the 1x1 192 <-> 96 convs of Cheng2020-attn's attention blocks, exact fp32
+ * arithmetic (fp32 MFMA).  x [M][K], w [N][K]; tokens % 32 == 0, 32 <= K <= 192, K % 32 == 0, N % 32 == 0; slabs [nslab][N][K] with
+ * nslab = rdo_unit1x1_nslab(M, N) (<= 256).  A loss / tail launch in the sense of rdo_iter_bind_publish. */
+int rdo_unit1x1_supported(int64_t M, int32_t K, int32_t N);
+int rdo_unit1x1_nslab(int64_t M, int32_t N);
+int rdo_unit1x1(const float* x, int64_t M, int32_t K, int32_t N, const float* w, const float* bias, const float* tgt_cache,
+                const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, float coef, int32_t act /* 0 none, 1 LeakyReLU(0.01), 2 ReLU */,
+                float* slabs, int32_t nslab, float* loss_out, void* stream);
+
 /* only the data-gradient half (slab reduce + chain rule -> dalpha_data), for the all-reduce bucket of the DP path */
 int rdo_adaround_grad(const rdo_ada_desc* d, const float* w, const float* alpha, const float* delta, const float* zp,
                       const float* slabs, int nsplit, float* dalpha, void* stream);

@@ -221,6 +221,23 @@ def adaround_step(d, w, delta, zp, slabs, grad_scale, round_weight, sched, iter_
                                       _stream()), "rdo_adaround_step")
 
 
+def unit1x1_supported(M, K, N):
+    return bool(L.lib().rdo_unit1x1_supported(int(M), int(K), int(N)))
+
+
+def unit1x1_nslab(M, N):
+    return int(L.lib().rdo_unit1x1_nslab(int(M), int(N)))
+
+
+def unit1x1(x, w, bias, tgt_cache, idx_table, iter_ptr, coef, act, loss_log, slabs):
+    """One launch for a 1 x 1 layer unit's data path (include/rdo_ptq_hip.h: rdo_unit1x1): x [B, H, W, K] mini-batch, w [N, 1, 1, K] soft
+    weights -> loss into `loss_log`, weight-gradient slabs [nslab, N, 1, 1, K]."""
+    K, N = int(x.shape[-1]), int(w.shape[0])
+    M = x.numel() // K
+    L.check(L.lib().rdo_unit1x1(_ptr(x), M, K, N, _ptr(w), _ptr(bias), _ptr(tgt_cache), _ptr(idx_table), _ptr(iter_ptr), int(x.shape[0]),
+                                float(coef), int(act), _ptr(slabs), int(slabs.shape[0]), _ptr(loss_log), _stream()), "rdo_unit1x1")
+
+
 def iter_bind_publish(word):
     """The next loss / tail launch of this thread leaves the iteration number it read in `word` (a one-element int32 tensor; None clears).
     Returns True when an earlier binding was still pending (include/rdo_ptq_hip.h: rdo_iter_bind_publish)."""

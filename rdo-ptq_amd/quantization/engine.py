@@ -465,6 +465,20 @@ class UnitEngine:
         rows = x.numel() // C
         return rows >= self.LIN_GDN_MIN_ROWS and ops.linear_h2_supported(rows, C, op.w4[0])
 
+    unit1x1 = os.environ.get("RDO_UNIT1X1", "1") != "0"
+
+    def _unit1x1_ok(self, op, x):
+        """A plain 1 x 1 / stride-1 conv as a LAYER unit with the default objective: rdo_unit1x1 (forward + tail + weight-gradient slabs in
+        one launch, exact fp32) -- the 192 <-> 96 convs of Cheng2020-attn's attention blocks (BASELINE config 3)."""
+        if not (self.unit1x1 and self.fused and self.include_act and self.kind == "layer" and op.qm.kind == "conv" and op.K == 1
+                and op.stride == 1 and op.pad == 0 and op.tconv is None and not op.is_gdn):
+            return False
+        M, K = x.numel() // x.shape[-1], x.shape[-1]
+        # where it wins (per unit-iteration inside the config-3 schedule, us, three launches -> one): 16^2 maps 31 -> 29 (192 -> 96), 29 -> 22
+        # (96 -> 192), 32 -> 30 (192 -> 192); 64^2 maps 54 -> 47 at K = 96 but 54 -> 58 / 58 -> 70 at K = 192, where the fp32 MFMAs of its
+        # two GEMMs (157 TFLOP/s peak) lose to rdo_linear_h2 + linear_wgrad_h2 on split fp16
+        return (M <= 4096 or K <= 96) and ops.unit1x1_supported(M, K, op.w4[0])
+
     def _conv(self, op, x, out, epilogue=L.EPI_NONE, aux=None, residual=None, pre=None, square=False, bias=True):
         b = (op.beta if op.is_gdn else op.bias) if bias else None
         if epilogue == L.EPI_NONE and aux is None and residual is None and pre is None and not square and self._lin_conv_ok(op, x):
@@ -1024,6 +1038,11 @@ class UnitEngine:
                         (ops.lrelu_bwd if epi == L.EPI_LRELU else ops.relu_bwd)(t["dy"], t["y"], t["dpre"])
                         g = t["dpre"]
                     self._tconv_wgrad(op, x, g)
+            elif self._unit1x1_ok(op, x):                    # a 1 x 1 conv: forward, tail and weight-gradient slabs in one launch
+                if op.slabs is None:
+                    op.slabs = self._buf(ops.unit1x1_nslab(x.numel() // x.shape[-1], op.w4[0]), *op.w4)
+                self._task_is_rec = True
+                ops.unit1x1(x, op.wq4(), op.bias, self.co, self.idx, self.it, 2.0, act, self.loss_log, op.slabs)
             elif self.fused:
                 self._conv_tail(op, x, t["y"], None, act, t["dpre"])                              # t["y"]: pre-activation, if it is stored
                 self._wgrad(op, x, t["dpre"])

@@ -616,3 +616,39 @@ def test_step_launch_assembles_the_next_mini_batch(planes):
             assert torch.equal(out, want)
         else:
             assert bool((out == 7.0).all()) and (xp is None or bool((xp.t == 77).all()))     # behind the last iteration: nothing is gathered
+
+
+@pytest.mark.parametrize("B,H,K,N,act", [(4, 16, 192, 96, 2), (4, 16, 96, 192, 0), (2, 8, 96, 96, 1), (4, 64, 192, 96, 2), (4, 64, 192, 192, 0),
+                                         (3, 16, 64, 32, 1)])
+def test_unit1x1_matches_float64(B, H, K, N, act):
+    """rdo_unit1x1 (round 6): forward of a 1 x 1 conv with bias, activation, 2 x lp_loss against the cached target rows picked by the
+    device index table, activation backward and the weight-gradient slabs in one launch, against float64 -- loss to 1e-6 relative, the
+    summed slabs to 2e-6 of the largest gradient entry (exact fp32 MFMA: an fmaf chain per accumulator)."""
+    from hipops import ops
+    import torch.nn.functional as F
+    g = torch.Generator().manual_seed(B + H + K + N)
+    n_img = B + 2
+    x = torch.randn(B, H, H, K, generator=g)
+    w = torch.randn(N, 1, 1, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    tgt = torch.randn(n_img, H, H, N, generator=g)
+    idx = torch.stack([torch.randperm(n_img, generator=g)[:B] for _ in range(3)]).to(torch.int32)
+    it = torch.tensor([1], dtype=torch.int32)
+    assert ops.unit1x1_supported(B * H * H, K, N)
+    ns = ops.unit1x1_nslab(B * H * H, N)
+    slabs = torch.full((ns, N, 1, 1, K), 7.0, device="cuda")
+    log = torch.zeros(3, 32, device="cuda")
+    ops.unit1x1(x.cuda(), w.cuda(), b.cuda(), tgt.cuda(), idx.cuda(), it.cuda(), 2.0, act, log, slabs)
+    torch.cuda.synchronize()
+    x64 = x.double().reshape(-1, K)
+    w64 = w.double().reshape(N, K).requires_grad_(True)
+    pre = x64 @ w64.t() + b.double()
+    out = {0: pre, 1: F.leaky_relu(pre, 0.01), 2: F.relu(pre)}[act]
+    y = tgt[idx[1].long()].double().reshape(-1, N)
+    loss = 2.0 * ((out - y) ** 2).sum(1).mean()
+    loss.backward()
+    got_loss = float(log[1].sum())
+    assert float(log[0].abs().sum()) == 0.0 and float(log[2].abs().sum()) == 0.0
+    assert abs(got_loss - float(loss)) <= 1e-6 * abs(float(loss)) + 1e-9
+    gw = slabs.double().sum(0).reshape(N, K).cpu()
+    assert float((gw - w64.grad).abs().max()) <= 2e-6 * float(w64.grad.abs().max())
