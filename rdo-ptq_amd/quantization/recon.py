@@ -213,6 +213,7 @@ def _reconstruct(model, unit, unit_name, cali_data, batch_size=32, iters=20000, 
                          task_cache=task_cache, **common)
     else:
         eng = UnitEngine(kind, mods, _nhwc(inp_q), _nhwc(inp_fp), _nhwc(out_fp), **common)
+    eng.prepare()                # graph capture belongs to the set-up ("recording + graph capture" of the timing split), not to the loop
     t2 = _mark()
     # the next unit's index table is drawn while this unit's loop runs on the GPU (engine.IdxStream: adopted only if the next request
     # matches and nobody touched the CPU generator in between)
