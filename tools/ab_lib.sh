@@ -5,6 +5,6 @@ L=$R/rdo-ptq_amd/lib
 mkdir -p $L/ab; cp $L/librdoptq_hip.so /tmp/lib_keep.so
 for v in old new old new; do
   cp $L/ab/librdoptq_hip_$v.so $L/librdoptq_hip.so
-  python3 $R/bench.py --no-cpu-baseline --sustain-steps 300 2>&1 >/dev/null | tail -1 | sed "s/^/$v /"
+  python3 $R/bench.py --no-cpu-baseline --no-extras --recon-iters 0 --sustain-steps 300 2>&1 >/dev/null | grep sustained | tail -1 | sed "s/^/$v /"
 done
 cp /tmp/lib_keep.so $L/librdoptq_hip.so
