@@ -1257,6 +1257,7 @@ class UnitEngine:
             else:
                 self._grad_ops(list(self.ops))
         finally:
+            ops.iter_bind_publish(None)        # (a recording that raised must not leave its word bound for the next engine's loss launch)
             self._rec_ctx.__exit__(None, None, None)
             self._rec_ctx = None
         if self.split:

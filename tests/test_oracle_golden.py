@@ -378,3 +378,33 @@ def test_nic_whole_model_oracle_matches_reference_forward(golden_dir):
         y1 = mo.nic.run(["g_a0", "g_a1"], x)
         o2 = mo.forward(x, substitute=("g_a1", y1))
     np.testing.assert_allclose(o2["x_hat"].numpy(), o["x_hat"].numpy(), rtol=0, atol=0)
+
+
+def test_committed_oracle_trajectories_cover_the_test_tables(golden_dir):
+    """tests/golden/long_horizon.npz and flow_n192.npz (tools/make_long_horizon_golden.py, tools/make_flow_golden.py) hold an entry for every
+    run the GPU tests look up, with the iteration counts the tests use -- a stale fixture fails here, on the CPU, not on the GPU box."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import flow_common as F
+    import long_horizon_common as C
+    lh = np.load(os.path.join(golden_dir, "long_horizon.npz"))
+    for (stats, name), (iters, every) in C.RUNS.items():
+        key = f"{stats}/{name}"
+        assert tuple(lh[f"{key}/iters"]) == (iters, every), key
+        n = len(C.picks(iters, every))
+        assert lh[f"{key}/total"].shape == (n,) and lh[f"{key}/rt"].shape == (n,) and lh[f"{key}/round"].shape == (n,), key
+        assert lh[f"{key}/cache_sig"].shape == (6,) and np.isfinite(lh[f"{key}/total"]).all(), key
+        assert any(k.startswith(f"{key}/bits/") for k in lh.files), key
+    for stats in ("uniform", "kodak"):
+        assert lh[f"{stats}/y_hat/fp"].shape == (C.N_IMG, 192, 16, 16) and lh[f"{stats}/y_hat/prefix"].dtype == np.int16
+    fl = np.load(os.path.join(golden_dir, "flow_n192.npz"))
+    for stats in ("uniform", "kodak"):
+        units = list(fl[f"{stats}/units"])
+        assert len(units) == 29 and units[0] == "g_a.0"
+        for u in units:
+            assert fl[f"{stats}/{u}/idx"].shape == (F.iters_of(u), F.B), (stats, u)
+            assert fl[f"{stats}/{u}/total_first_last"].shape == (2,)
+        assert fl[f"{stats}/w8"].shape == (2,) and fl[f"{stats}/w8a8"].shape == (2,)
+    crops = np.load(os.path.join(golden_dir, "kodak_crops.npz"))["crops"]
+    assert crops.shape == (16, 256, 256, 3) and crops.dtype == np.uint8
