@@ -547,6 +547,38 @@ def _watch(procs, deadline, what):
     return rc
 
 
+def _die_with_parent():
+    """preexec_fn of the rank children: the kernel sends them SIGKILL when the launcher / supervisor that started them dies (a
+    supervisor killed with SIGKILL cannot forward anything) -- no orphaned rank keeps a GPU.  Runs between fork and exec in a
+    process that never touched the GPU."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGKILL)          # PR_SET_PDEATHSIG
+    except Exception:
+        pass
+
+
+def _forward_signals(procs):
+    """SIGTERM / SIGINT to the launcher or supervisor (torch.distributed.run stops its workers that way) end the rank children too."""
+    import signal
+
+    def handler(signum, frame):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        time.sleep(1.0)
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+        os._exit(128 + signum)
+    for sig in (signal.SIGTERM, signal.SIGINT):
+        try:
+            signal.signal(sig, handler)
+        except ValueError:           # not the main thread (tests): the parent-death signal still covers the children
+            pass
+
+
 def _rank_cmd():
     """the command of one rank process (a function so that the tests of the launcher can stand a stub in)"""
     return [sys.executable, os.path.abspath(__file__)] + sys.argv[1:]
@@ -582,7 +614,8 @@ def launch_ranks(a):
                        MASTER_PORT=str(port), RDO_BENCH_CHILD="1")
             if attempt:
                 env["RDO_DP_GRAPH"] = "0"
-            procs.append(subprocess.Popen(_rank_cmd(), env=env))
+            procs.append(subprocess.Popen(_rank_cmd(), env=env, preexec_fn=_die_with_parent))
+        _forward_signals(procs)
         rc = _watch(procs, deadline, "rank process")
         stalled = rc == STALL_STATUS or os.path.exists(_stall_marker(port))
         try:
@@ -612,7 +645,8 @@ def supervise_rank():
         if attempt:
             env["RDO_DP_GRAPH"] = "0"
             env["MASTER_PORT"] = str(1024 + (port + 101 - 1024) % (65536 - 1024))
-        child = subprocess.Popen(_rank_cmd(), env=env)
+        child = subprocess.Popen(_rank_cmd(), env=env, preexec_fn=_die_with_parent)
+        _forward_signals([child])
         rc = _watch([child], deadline, "rank process")
         if rc == 0 or attempt or os.environ.get("RDO_DP_GRAPH", "1") != "1":
             break

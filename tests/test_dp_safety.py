@@ -43,6 +43,7 @@ with open(log, "a") as f:
     f.write(f"{os.environ['RANK']} {os.environ.get('RDO_DP_GRAPH', '1')} {os.environ['MASTER_PORT']} {os.environ.get('RDO_BENCH_CHILD')}\n")
 if os.environ.get("RDO_DP_GRAPH", "1") == "1" and os.environ["STUB_MODE"] == "stall":
     if os.environ["RANK"] == "0":
+        import time; time.sleep(1.0)          # (the other rank is up and has written its line before this one reports the stall)
         open(f"/tmp/rdo_bench_stall_{os.environ['MASTER_PORT']}", "w").close()
         sys.exit(86)
     import time; time.sleep(120)          # the other rank hangs in its collective until the launcher ends it
@@ -111,3 +112,28 @@ def test_heartbeat_wait_returns_on_progress_and_raises_on_a_stall():
     with pytest.raises(DpStallError):
         UnitEngine._hb_wait(eng, 9)
     assert 0.25 < time.monotonic() - t0 < 5
+
+
+def test_supervisor_takes_its_rank_down_with_it(tmp_path):
+    """torch.distributed.run stops its workers -- here the supervisors -- with SIGTERM (and SIGKILL after a grace period): the actual
+    rank, a child of the supervisor, must not survive either (signal forwarding; PR_SET_PDEATHSIG for the SIGKILL case)."""
+    import signal
+    import psutil
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for sig in (signal.SIGTERM, signal.SIGKILL):
+        code = ("import sys, os; sys.path.insert(0, %r); import bench; "
+                "bench._rank_cmd = lambda: [sys.executable, '-c', 'import time; time.sleep(120)']; "
+                "os.environ.update(RANK='0', WORLD_SIZE='2', MASTER_ADDR='127.0.0.1', MASTER_PORT='29872'); "
+                "sys.exit(bench.supervise_rank())") % root
+        sup = subprocess.Popen([sys.executable, "-c", code])
+        kids, t0 = [], time.time()
+        while not kids and time.time() - t0 < 60:
+            kids = psutil.Process(sup.pid).children()
+            time.sleep(0.1)
+        assert len(kids) == 1
+        os.kill(sup.pid, sig)
+        sup.wait(timeout=30)
+        t0 = time.time()
+        while time.time() - t0 < 15 and kids[0].is_running() and kids[0].status() != psutil.STATUS_ZOMBIE:
+            time.sleep(0.1)
+        assert not (kids[0].is_running() and kids[0].status() != psutil.STATUS_ZOMBIE), f"the rank survived its supervisor ({sig!r})"
