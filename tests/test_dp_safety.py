@@ -82,7 +82,8 @@ def test_launcher_retries_on_the_host_loop_after_a_stall(stub, monkeypatch):
 def test_launcher_does_not_retry_an_ordinary_failure(stub, monkeypatch):
     monkeypatch.setenv("STUB_MODE", "crash")
     rc = bench.launch_ranks(types.SimpleNamespace(gpus=2))
-    assert rc == 3 and len(_rows(stub)) == 2
+    rows = _rows(stub)
+    assert rc == 3 and 1 <= len(rows) <= 2 and all(r[1] == "1" for r in rows)      # one attempt only (a rank may be stopped before it logs)
 
 
 def test_supervisor_retries_its_rank_after_a_stall(stub, monkeypatch):
