@@ -59,15 +59,32 @@ __global__ __launch_bounds__(256) void unit1x1_kernel(U1Args a) {
     const int kq = K >> 2;
     const int mfirst = chunk * a.T * BM;
     // the weight block (once) and the first token tile
-    for (int q = tid; q < NB * kq; q += 256) {
-        const int r = q / kq, c = (q - r * kq) * 4;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (r < nrows) v = *reinterpret_cast<const f32x4*>(a.w + (long)(nb0 + r) * K + c);
-        *reinterpret_cast<f32x4*>(Ws + r * S + c) = v;
-    }
-    for (int q = tid; q < BM * kq; q += 256) {
-        const int r = q / kq, c = (q - r * kq) * 4;
-        *reinterpret_cast<f32x4*>(Xs + r * S + c) = *reinterpret_cast<const f32x4*>(a.x + (long)(mfirst + r) * K + c);
+    // Eight lanes per row, each taking the quads (lane & 7) + 8 j of its row: no index division, and every request of the block is issued
+    // before the first LDS store (the plain "load, store" loop compiled to 18 serial round trips: load, s_waitcnt vmcnt(0), ds_write).
+    const int kq8 = kq >> 3;                                 // quads per lane and row: 1 .. 6
+    {
+        const int r0 = tid >> 3, c0 = (tid & 7) * 4;
+        f32x4 wv[3][6], xv[6];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 6; ++j) {
+                wv[p][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (j < kq8 && 32 * p + r0 < nrows) wv[p][j] = *reinterpret_cast<const f32x4*>(a.w + (long)(nb0 + 32 * p + r0) * K + c0 + 32 * j);
+            }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            xv[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < kq8) xv[j] = *reinterpret_cast<const f32x4*>(a.x + (long)(mfirst + r0) * K + c0 + 32 * j);
+        }
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int j = 0; j < 6; ++j)
+                if (j < kq8) *reinterpret_cast<f32x4*>(Ws + (32 * p + r0) * S + c0 + 32 * j) = wv[p][j];
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            if (j < kq8) *reinterpret_cast<f32x4*>(Xs + r0 * S + c0 + 32 * j) = xv[j];
     }
 
     // weight-gradient accumulators: tiles t = wave, wave + 4, ... of the 3 x (K / 32) grid (row block t % 3, column block t / 3)
@@ -91,9 +108,20 @@ __global__ __launch_bounds__(256) void unit1x1_kernel(U1Args a) {
             const int m1 = m0 + BM;
             if (tt + 1 < a.T && m1 < a.M) {
                 float* Xn = Xs + ((tt + 1) & 1) * BM * S;
-                for (int q = lane; q < BM * kq; q += 64) {
-                    const int r = q / kq, c = (q - r * kq) * 4;
-                    *reinterpret_cast<f32x4*>(Xn + r * S + c) = *reinterpret_cast<const f32x4*>(a.x + (long)(m1 + r) * K + c);
+                const int r1 = lane >> 3, c1 = (lane & 7) * 4;          // eight rows per pass, four passes, in two halves of <= 12 requests
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    f32x4 pv[2][6];
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j)
+                            if (j < kq8) pv[p][j] = *reinterpret_cast<const f32x4*>(a.x + (long)(m1 + 8 * (2 * half + p) + r1) * K + c1 + 32 * j);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int j = 0; j < 6; ++j)
+                            if (j < kq8) *reinterpret_cast<f32x4*>(Xn + (8 * (2 * half + p) + r1) * S + c1 + 32 * j) = pv[p][j];
                 }
             }
         } else if (wave * 32 < nrows) {

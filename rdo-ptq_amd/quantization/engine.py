@@ -465,7 +465,7 @@ class UnitEngine:
         rows = x.numel() // C
         return rows >= self.LIN_GDN_MIN_ROWS and ops.linear_h2_supported(rows, C, op.w4[0])
 
-    unit1x1 = os.environ.get("RDO_UNIT1X1", "1") != "0"
+    unit1x1 = int(os.environ.get("RDO_UNIT1X1", "2"))       # 0 off, 1 only 16^2 maps and K = 96, 2 wherever the shape is supported (default)
 
     def _unit1x1_ok(self, op, x):
         """A plain 1 x 1 / stride-1 conv as a LAYER unit with the default objective: rdo_unit1x1 (forward + tail + weight-gradient slabs in
@@ -474,10 +474,11 @@ class UnitEngine:
                 and op.stride == 1 and op.pad == 0 and op.tconv is None and not op.is_gdn):
             return False
         M, K = x.numel() // x.shape[-1], x.shape[-1]
-        # where it wins (per unit-iteration inside the config-3 schedule, us, three launches -> one): 16^2 maps 31 -> 29 (192 -> 96), 29 -> 22
-        # (96 -> 192), 32 -> 30 (192 -> 192); 64^2 maps 54 -> 47 at K = 96 but 54 -> 58 / 58 -> 70 at K = 192, where the fp32 MFMAs of its
-        # two GEMMs (157 TFLOP/s peak) lose to rdo_linear_h2 + linear_wgrad_h2 on split fp16
-        return (M <= 4096 or K <= 96) and ops.unit1x1_supported(M, K, op.w4[0])
+        # per unit-iteration inside the config-3 schedule (us, three launches -> one): 16^2 maps 31 -> 29 (192 -> 96), 29 -> 22 (96 -> 192),
+        # 32 -> 30 (192 -> 192); 64^2 maps 54 -> 47 at K = 96; at K = 192 on the 64^2 maps the first version (serial load / store loops) lost to
+        # rdo_linear_h2 + linear_wgrad_h2 (54 -> 58), with its loads batched it wins there too: schedule 9.13 (off) / 8.81 (K = 96 and 16^2
+        # only: RDO_UNIT1X1=1) / 8.76 ms per step (everywhere: the default, 2)
+        return (self.unit1x1 == 2 or M <= 4096 or K <= 96) and ops.unit1x1_supported(M, K, op.w4[0])
 
     def _conv(self, op, x, out, epilogue=L.EPI_NONE, aux=None, residual=None, pre=None, square=False, bias=True):
         b = (op.beta if op.is_gdn else op.bias) if bias else None
