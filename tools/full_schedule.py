@@ -60,7 +60,7 @@ def schedule_roofline(engines, loop_s, iters, top=8):
 
 
 def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2, log=print, quality=True, arch="anchor", w_bits=8,
-                 a_bits=8, per_unit_log=True, roofline=False):
+                 a_bits=8, per_unit_log=True, roofline=False, model=None, cali=None):
     """arch: "anchor" | "attn" (Cheng2020-attn, BASELINE config 3) | "lu2022" (BASELINE config 4: NIC embed 192 / latent 320, the 25
     units of main2.py's recon_model on the tape engine); w_bits / a_bits: weight grid and dynamic activation grid."""
     import math
@@ -77,13 +77,19 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
         torch.manual_seed(1005)
         model = lic.NIC(dict(height=256, width=256, in_chans=3, embed_dim=192, latent_dim=320, window_size=8, mlp_ratio=2.0, qkv_bias=True,
                              qk_scale=None, drop_rate=0.0, attn_drop_rate=0.0, drop_path_rate=0.1, use_checkpoint=False)).to(dev).eval()
+    elif model is not None:        # the caller's model and calibration images (tests/run_kodak_schedule.py: natural-image statistics)
+        model = model.to(dev).eval()
     else:
         model = bench.seeded_model(192, 1005, dev, arch=arch)
         with torch.no_grad():      # variance-preserving conv weights: the signal (and the quantisation error) reaches the output
             for name, p_ in model.named_parameters():
                 if p_.dim() == 4 and "entropy_bottleneck" not in name:
                     p_.copy_(((torch.rand(p_.shape, generator=g) - 0.5) * 2 * (3.0 / p_[0].numel()) ** 0.5).to(dev))
-    cali = torch.rand(images, 3, 256, 256, generator=g).to(dev)
+    if cali is not None:
+        cali = cali.to(dev)
+        images = cali.shape[0]
+    else:
+        cali = torch.rand(images, 3, 256, 256, generator=g).to(dev)
     test_imgs = [torch.rand(1, 3, eval_hw[0], eval_hw[1], generator=g) for _ in range(n_eval)]
     probe = torch.rand(4, 3, 256, 256, generator=g).to(dev)
     res = {}
@@ -153,12 +159,13 @@ def run_schedule(images=256, iters=20000, batch=4, eval_hw=(512, 768), n_eval=2,
             done += int(((h == 0) | (h == 1)).sum())
             tot += h.numel()
         rec, task, rnd, b = e.logs_terms()
-        units.append(dict(unit=name, kind=e.kind, loop_ms_per_iter=round(t["loop_s"] / iters * 1e3, 4), loop_s=round(t["loop_s"], 3), cache_s=round(t["cache_s"], 3), record_s=round(t["record_s"], 3),
+        units.append(dict(unit=name, kind=e.kind, h2_plan=getattr(e, "h2_plan", None), h2_restarts=e.h2_restarts, use_h2=bool(e.use_h2), loop_ms_per_iter=round(t["loop_s"] / iters * 1e3, 4), loop_s=round(t["loop_s"], 3), cache_s=round(t["cache_s"], 3), record_s=round(t["record_s"], 3),
                           hard_frac=done / tot, loss_first=float(rec[0] + task[0] + rnd[0]), loss_last=float(rec[-1] + task[-1] + rnd[-1]),
                           rec_first=float(rec[0]), rec_last=float(rec[-1]), round_last=float(rnd[-1])))
         if per_unit_log:
             log(f"  {name:24s} {e.kind:5s} loop {t['loop_s']:7.2f} s = {t['loop_s'] / iters * 1e3:7.3f} ms/it  cache {t['cache_s']:5.2f} s  record {t['record_s']:5.2f} s  "
-                f"soft targets in {{0,1}}: {100 * done / tot:6.2f} %  rec {float(rec[0]):.4e} -> {float(rec[-1]):.4e}  round {float(rnd[-1]):.3e}")
+                f"soft targets in {{0,1}}: {100 * done / tot:6.2f} %  rec {float(rec[0]):.4e} -> {float(rec[-1]):.4e}  round {float(rnd[-1]):.3e}"
+                f"  plan {getattr(e, 'h2_plan', None)} restarts {e.h2_restarts}")
     res["units"] = units
     if roofline:
         res["roofline"] = schedule_roofline(engines, [t["loop_s"] for t in timing], iters)
