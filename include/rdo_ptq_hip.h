@@ -209,11 +209,16 @@ int rdo_iter_bind_publish(int32_t* publish);
 
 /* ---- the data path of a 1 x 1 LAYER unit's iteration in ONE launch (round 6): pre = x W~^T + b (quant_layer.py:113-123), out = act(pre),
  * loss += coef * lp_loss(out, target[idx]) (layer_opt.py:133,150), dpre = act'(pre) dL/dout, and the weight-gradient slabs dpre^T x --
- * rdo_conv2d_fwd + rdo_loss_act_bwd + rdo_conv2d_wgrad for the 1x1 192 <-> 96 convs of Cheng2020-attn's attention blocks, exact fp32
- * arithmetic (fp32 MFMA).  x [M][K], w [N][K]; tokens % 32 == 0, 32 <= K <= 192, K % 32 == 0, N % 32 == 0; slabs [nslab][N][K] with
+ * rdo_conv2d_fwd + rdo_loss_act_bwd + rdo_conv2d_wgrad for the 1x1 192 <-> 96 convs of Cheng2020-attn's attention blocks.  Two forms:
+ * split-fp16 MFMA with scales taken on the fly (per output channel, per token, per tile of dL/dpre: nothing probed, nothing that can
+ * overflow) where Cout is a multiple of 96, and exact fp32 arithmetic (fp32 MFMA) for every other shape or after rdo_unit1x1_form(0).
+ * x [M][K], w [N][K]; tokens % 32 == 0, 32 <= K <= 192, K % 32 == 0, N % 32 == 0; slabs [nslab][N][K] with
  * nslab = rdo_unit1x1_nslab(M, N) (<= 256).  A loss / tail launch in the sense of rdo_iter_bind_publish. */
 int rdo_unit1x1_supported(int64_t M, int32_t K, int32_t N);
 int rdo_unit1x1_nslab(int64_t M, int32_t N);
+/* 1 (default): the split-fp16 form where the shape allows it; 0: always the exact form.  Returns the previous setting.  Process-wide, and
+ * rdo_unit1x1_nslab follows it: switch before a unit's slabs are sized. */
+int rdo_unit1x1_form(int32_t form);
 int rdo_unit1x1(const float* x, int64_t M, int32_t K, int32_t N, const float* w, const float* bias, const float* tgt_cache,
                 const int32_t* idx_table, const int32_t* iter_ptr, int32_t B, float coef, int32_t act /* 0 none, 1 LeakyReLU(0.01), 2 ReLU */,
                 float* slabs, int32_t nslab, float* loss_out, void* stream);

@@ -16,6 +16,9 @@
 // bias / activation / loss / activation backward on the accumulators (the arithmetic of loss_act_quad, fused_tail.hip, element by
 // element) and leave dpre in LDS; then all four waves multiply the 3 x (K / 32) tiles of dpre^T x over the tile's 32 tokens into
 // accumulators that live across the T tiles, and store them as this chunk's slab.  Needs K <= 192, K % 32 == 0, Cout % 32 == 0, tokens % 32 == 0.
+#include <algorithm>
+#include <type_traits>
+
 #include "rdo_common.h"
 
 namespace {
@@ -200,6 +203,295 @@ __global__ __launch_bounds__(256) void unit1x1_kernel(U1Args a) {
                   (red[0] + red[1] + red[2] + red[3]) * a.loss_scale);
 }
 
+// ---- split-fp16 form (round 6) -------------------------------------------------------------------------------------------------------
+// The fp32 MFMAs above are the kernel's time at 64^2 (6.5-7.4 us per token tile measured by varying T: 96 + 80 v_mfma_f32_32x32x2_f32 of
+// 64 cycles per wave).  This form runs both GEMMs on v_mfma_f32_16x16x32_f16 in the H2 arithmetic of linear_h2.hip (x s = h1 + h2 in fp16,
+// three products h1 g1 + h1 g2 + h2 g1, fp32 accumulate) with scales computed on the fly -- nothing probed, nothing that can overflow:
+//   * weights: one power-of-two scale per OUTPUT CHANNEL (row of W); the wave's 3 x (K / 32) fragments of both planes stay in registers for
+//     all T token tiles (A operand = weights: a lane's four accumulator values are four consecutive channels of one token);
+//   * inputs: one scale per TOKEN (as rdo_linear_h2): split once per tile into LDS, row-major for the forward and transposed for the weight
+//     gradient;
+//   * dL/dpre: the token's input scale is divided out of its row first (exact: a power of two), then ONE scale per tile (the block's
+//     largest magnitude): dW~ += (dpre / sx)^T (x sx) needs no per-token factor behind the sum over tokens.
+// Forward: wave w owns tokens [16 (w & 1), +16) x channels [48 (w >> 1), +48): 3 tiles, K / 32 steps, 9 MFMAs per step.  Weight gradient:
+// wave w owns the 16-column blocks w, w + 4, w + 8 of K x all six 16-row blocks of the 96 channels (18 tiles of ONE 32-token step).
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+constexpr int ST = BM + 8;   // halfs per row of the transposed tiles (32 tokens + 16 bytes: fragment reads of 16 consecutive rows are conflict free)
+
+__device__ __forceinline__ float pow2f(int e) { return __builtin_bit_cast(float, (unsigned)(e + 127) << 23); }
+// exponent of the power-of-two scale that puts a largest magnitude `amax` into [2^7, 2^8); 0 where there is nothing to keep
+__device__ __forceinline__ int scale_exp(float amax) {
+    const int e = (int)((__builtin_bit_cast(unsigned, amax) >> 23) & 0xFFu) - 127;
+    return e < -100 ? 0 : 7 - e;
+}
+__device__ __forceinline__ float amax4(const f32x4& v, float m) {
+    return fmaxf(fmaxf(fmaxf(__builtin_fabsf(v[0]), __builtin_fabsf(v[1])), fmaxf(__builtin_fabsf(v[2]), __builtin_fabsf(v[3]))), m);
+}
+// workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for the tile prefetched for the NEXT iteration
+// (measured: 3.4 us per token tile with everything but the loads and the barriers switched off)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ void split1(float x, _Float16& h, _Float16& l) {
+    h = (_Float16)x;
+    l = (_Float16)(x - (float)h);
+}
+
+template <int NKS>        // K / 32: 3 or 6 (compile-time loop bounds: guarded loops became branches, serial loads and 800 AGPR moves)
+__global__ __launch_bounds__(256) void unit1x1_h2_kernel(U1Args a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_h2[];
+    constexpr int K = 32 * NKS, SX = K + 8;                           // halfs per row of the row-major tile
+    constexpr int xh_halfs = 2 * BM * SX, buf_halfs = xh_halfs + 2 * K * ST;
+    _Float16* const base = reinterpret_cast<_Float16*>(smem_h2);   // two buffers of { Xh [2][BM][SX], XT [2][K][ST] }
+    _Float16* const DT = base + 2 * buf_halfs;               // [2][NB][ST]: (dpre / sx) sd, transposed
+    float* const scl = reinterpret_cast<float*>(DT + 2 * NB * ST);   // [2][BM]: 1 / sx of the buffer's tokens
+    float* const red = scl + 2 * BM;                         // [4]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l16 = lane & 15, kg = lane >> 4;
+    const int tt = wave & 1, cg = wave >> 1;
+    const int chunk = blockIdx.x, nb0 = blockIdx.y * NB;
+    const int it = *a.iter;
+    if (a.pub && blockIdx.x == 0 && blockIdx.y == 0 && tid == 0) *a.pub = it;
+    const int mfirst = chunk * a.T * BM;
+    const int r0 = tid >> 3, c0 = (tid & 7) * 4;             // loader role: row r0, quads at c0 + 32 j
+
+    f32x4 xv[NKS];
+    auto request = [&](int m0) {
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) xv[j] = *reinterpret_cast<const f32x4*>(a.x + (long)(m0 + r0) * K + c0 + 32 * j);
+    };
+    // the loader's row: largest magnitude over its eight lanes, split by the token's scale into both layouts of buffer `b`
+    auto deposit = [&](int b) {
+        float m = 0.f;
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) m = amax4(xv[j], m);
+        m = fmaxf(m, __shfl_xor(m, 1, 64)); m = fmaxf(m, __shfl_xor(m, 2, 64)); m = fmaxf(m, __shfl_xor(m, 4, 64));
+        const int e = scale_exp(m);
+        const float s = pow2f(e);
+        _Float16* xh = base + b * buf_halfs;
+        _Float16* xt = xh + xh_halfs;
+        if ((tid & 7) == 0) scl[b * BM + r0] = pow2f(-e);
+#pragma unroll
+        for (int j = 0; j < NKS; ++j) {
+            f16x4 h, l;
+#pragma unroll
+            for (int e4 = 0; e4 < 4; ++e4) {
+                _Float16 hh, ll;
+                split1(xv[j][e4] * s, hh, ll);
+                h[e4] = hh; l[e4] = ll;
+                const int k = c0 + 32 * j + e4;
+                xt[k * ST + r0] = hh;
+                xt[(K + k) * ST + r0] = ll;
+            }
+            *reinterpret_cast<f16x4*>(xh + r0 * SX + c0 + 32 * j) = h;
+            *reinterpret_cast<f16x4*>(xh + (BM + r0) * SX + c0 + 32 * j) = l;
+        }
+    };
+
+    // Every global load inside the tile loop is unconditional and independent of other loads (the index row sits in LDS, the bias in
+    // registers, the tiles behind the last one are re-requests of the last): straight-line code whose waits the compiler can count --
+    // with a dependent index load, guarded requests and bias loads in the loop every tile began with s_waitcnt vmcnt(0), i.e. paid the
+    // full latency of the tile prefetched for the next iteration (2 us per tile with everything else switched off).
+    __shared__ int sidx[256];
+    if (tid < a.B) sidx[tid] = a.idx[(long)it * a.B + tid];
+    const int ntw = min(a.T, (a.M - mfirst) / BM);           // token tiles of this workgroup (>= 1)
+    auto tile_m = [&](int t) { return mfirst + min(t, ntw - 1) * BM; };
+    f32x4 yn[3];
+    auto request_y = [&](int m0, bool first = false) {      // (first: before the index row is in LDS)
+        const int m = m0 + 16 * tt + l16, bimg = m / a.ppi;
+        const int img = first ? a.idx[(long)it * a.B + bimg] : sidx[bimg];
+        const float* yrow = a.tgt + ((long)img * a.ppi + (m - bimg * a.ppi)) * a.N + nb0 + 48 * cg + 4 * kg;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) yn[ct] = *reinterpret_cast<const f32x4*>(yrow + 16 * ct);
+    };
+    request(mfirst);
+    request_y(mfirst, true);
+    f32x4 bvr[3];
+#pragma unroll
+    for (int ct = 0; ct < 3; ++ct) {
+        bvr[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.bias) bvr[ct] = *reinterpret_cast<const f32x4*>(a.bias + nb0 + 48 * cg + 16 * ct + 4 * kg);
+    }
+    // ---- the wave's weight fragments: rows nb0 + 48 cg + 16 ct + l16, k = 32 ks + 8 kg + {0..7}; one scale per row
+    f16x8 wf[3][NKS][2];
+    float isw[3][4];
+    {
+        f32x4 wr[3][NKS][2];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+                    const float* src = a.w + (long)(nb0 + 48 * cg + 16 * ct + l16) * K + 32 * ks + 8 * kg;
+                    wr[ct][ks][0] = *reinterpret_cast<const f32x4*>(src);
+                    wr[ct][ks][1] = *reinterpret_cast<const f32x4*>(src + 4);
+                }
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+            float m = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) m = amax4(wr[ct][ks][1], amax4(wr[ct][ks][0], m));
+            m = fmaxf(m, __shfl_xor(m, 16, 64)); m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const int e = scale_exp(m);
+            const float s = pow2f(e), inv = pow2f(-e);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) isw[ct][i] = __shfl(inv, 4 * kg + i, 64);      // the accumulator rows of this lane: channels 4 kg + i
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+                for (int e8 = 0; e8 < 8; ++e8) {
+                    _Float16 hh, ll;
+                    split1(wr[ct][ks][e8 >> 2][e8 & 3] * s, hh, ll);
+                    wf[ct][ks][0][e8] = hh; wf[ct][ks][1][e8] = ll;
+                }
+            }
+        }
+    }
+    deposit(0);
+    if (ntw > 1) request(tile_m(1));
+    lds_barrier();                                           // the index row and tile 0
+
+    constexpr int ktiles = K >> 4, KU = (ktiles + 3) / 4;      // 16-column blocks of K; per wave at most KU of them
+    f32x4 gacc[KU][6];
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) gacc[u][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float slope = a.act == 1 ? 0.01f : 0.f;
+    float lsum = 0.f;
+    int de = 0;                                              // exponent of the accumulators' running scale
+    // one token tile; `last_c`: the workgroup's last (nothing behind it to request or deposit -- at 16^2 the only one)
+    auto tile = [&](int ti, auto last_c) {
+        constexpr bool LAST = decltype(last_c)::value;
+        const int cur = ti & 1;
+        const _Float16* xh = base + cur * buf_halfs;
+        const _Float16* xt = xh + xh_halfs;
+        // ---- forward.  The targets of this tile were requested behind the previous tile's tail (one workgroup per CU and one wave per
+        // SIMD: nothing else would hide their latency -- the products of a tile are 0.4 us).
+        const int tok = 16 * tt + l16;
+        f32x4 acc[3];
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) acc[ct] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const _Float16* xrow = xh + tok * SX + 8 * kg;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const f16x8 b1 = *reinterpret_cast<const f16x8*>(xrow + 32 * ks), b2 = *reinterpret_cast<const f16x8*>(xrow + BM * SX + 32 * ks);
+#pragma unroll
+            for (int ct = 0; ct < 3; ++ct) {
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ct][ks][0], b1, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ct][ks][0], b2, acc[ct], 0, 0, 0);
+                acc[ct] = __builtin_amdgcn_mfma_f32_16x16x32_f16(wf[ct][ks][1], b1, acc[ct], 0, 0, 0);
+            }
+        }
+        // ---- tail on the accumulators (the arithmetic of the fp32 form, element by element); dpre leaves with the token's input scale divided out
+        const float isx = scl[cur * BM + tok];
+        float dmax = 0.f;
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float p = acc[ct][i] * (isw[ct][i] * isx) + bvr[ct][i];
+                float o = p;
+                if (a.act) o = p > 0.f ? p : slope * p;
+                const float dd = o - yn[ct][i];
+                const float g = dd * a.gs;
+                const float d = (a.act ? (p > 0.f ? g : slope * g) : g) * isx;
+                acc[ct][i] = d;
+                dmax = fmaxf(dmax, __builtin_fabsf(d));
+                lsum += dd * dd;
+            }
+        }
+        if constexpr (!LAST) request_y(tile_m(ti + 1));
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dmax = fmaxf(dmax, __shfl_xor(dmax, o, 64));
+        if (lane == 0) red[wave] = dmax;
+        lds_barrier();                                       // (B) the tile's largest |dpre / sx|
+        // The gradient accumulators carry ONE running scale 2^de: a tile keeps it while its largest magnitude lands in [2^0, 2^15) under it
+        // (fp16 split: 22 bits down to 2^-3 of that, absolute 2^-25 below), else the accumulators move to the tile's own scale (exact).
+        {
+            const float tmax = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+            const int et = scale_exp(tmax), pos = 7 - et + de;            // floor(log2(tmax 2^de))
+            if (ti == 0) de = et;
+            else if (tmax > 0.f && (pos < 0 || pos > 14)) {
+                const int d = et - de;
+                const float r1 = pow2f(d / 2), r2 = pow2f(d - d / 2);
+#pragma unroll
+                for (int u = 0; u < KU; ++u)
+#pragma unroll
+                    for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) gacc[u][nt][i] = gacc[u][nt][i] * r1 * r2;
+                de = et;
+            }
+        }
+        const float sd = pow2f(de);
+#pragma unroll
+        for (int ct = 0; ct < 3; ++ct)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                _Float16 hh, ll;
+                split1(acc[ct][i] * sd, hh, ll);
+                const int nl = 48 * cg + 16 * ct + 4 * kg + i;
+                DT[nl * ST + tok] = hh;
+                DT[(NB + nl) * ST + tok] = ll;
+            }
+        // the next tile (requested one iteration ago) goes into the other buffer; the one behind it is requested
+        if constexpr (!LAST) {
+            deposit(cur ^ 1);
+            request(tile_m(ti + 2));
+        }
+        lds_barrier();                                       // (C) DT complete, the next tile in place
+        // ---- weight gradient of the tile: D[n][k] = sum over the 32 tokens DT[n][t] XT[k][t]
+        f16x8 bx[KU][2];
+#pragma unroll
+        for (int u = 0; u < KU; ++u) {
+            const int kt = (wave + 4 * u < ktiles) ? wave + 4 * u : wave;          // (a wave without a u-th block re-reads its first)
+            bx[u][0] = *reinterpret_cast<const f16x8*>(xt + (16 * kt + l16) * ST + 8 * kg);
+            bx[u][1] = *reinterpret_cast<const f16x8*>(xt + (K + 16 * kt + l16) * ST + 8 * kg);
+        }
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt) {
+            const f16x8 d1 = *reinterpret_cast<const f16x8*>(DT + (16 * nt + l16) * ST + 8 * kg);
+            const f16x8 d2 = *reinterpret_cast<const f16x8*>(DT + (NB + 16 * nt + l16) * ST + 8 * kg);
+#pragma unroll
+            for (int u = 0; u < KU; ++u) {
+                if (ktiles % 4 != 0 && wave + 4 * u >= ktiles) break;
+                gacc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bx[u][0], gacc[u][nt], 0, 0, 0);
+                gacc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d1, bx[u][1], gacc[u][nt], 0, 0, 0);
+                gacc[u][nt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(d2, bx[u][0], gacc[u][nt], 0, 0, 0);
+            }
+        }
+        // (no barrier here: the next writes to `red`, DT and this X buffer all come behind barrier (B) of the next iteration)
+    };
+    for (int ti = 0; ti + 1 < ntw; ++ti) tile(ti, std::false_type{});
+    tile(ntw - 1, std::true_type{});
+    // ---- this chunk's slab: lane holds rows 16 nt + 4 kg + i, column 16 kt + l16
+    float* slab = a.slabs + (long)chunk * a.N * K;
+    const float inv_run = pow2f(-de);
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+        const int kt = wave + 4 * u;
+        if (ktiles % 4 != 0 && kt >= ktiles) break;
+#pragma unroll
+        for (int nt = 0; nt < 6; ++nt)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) slab[(long)(nb0 + 16 * nt + 4 * kg + i) * K + 16 * kt + l16] = gacc[u][nt][i] * inv_run;
+    }
+    for (int o = 32; o > 0; o >>= 1) lsum += __shfl_down(lsum, o, 64);
+    __syncthreads();                                         // `red` was the amax exchange
+    if (lane == 0) red[wave] = lsum;
+    __syncthreads();
+    if (tid == 0 && a.loss)
+        atomicAdd(a.loss + (long)it * RDO_LOG_SLOTS + ((blockIdx.x + gridDim.x * blockIdx.y) & (RDO_LOG_SLOTS - 1)),
+                  (red[0] + red[1] + red[2] + red[3]) * a.loss_scale);
+}
+
+size_t h2_lds_bytes(int K) {
+    return sizeof(_Float16) * (2 * (size_t)(2 * BM * (K + 8) + 2 * K * ST) + 2 * (size_t)NB * ST) + sizeof(float) * (2 * BM + 4);
+}
+
+int g_form = 1;          // 1: split-fp16 where the shape allows it (Cout in blocks of 96); 0: always the exact fp32 form
+
 }  // namespace
 
 extern "C" {
@@ -211,10 +503,15 @@ int rdo_unit1x1_supported(int64_t M, int32_t K, int32_t N) {
                : 0;
 }
 
-// token tiles per workgroup: as few as keep the launch at one workgroup per CU (256 CUs; the kernel's LDS allows one per CU)
+static bool h2_form(int32_t N, int32_t K, int32_t B) { return g_form != 0 && N % NB == 0 && (K == 96 || K == 192) && B <= 256; }
+
+// token tiles per workgroup: as few as keep the launch at one workgroup per CU (256 CUs; the kernels' LDS allows one per CU).  The
+// split-fp16 form's tiles are cheap enough to cap the slabs at 128 as well (Cout = 96 at 4 x 64^2: four tiles on 128 workgroups instead
+// of two on 256 -- the step has half the slabs to sum: 42 -> 40 us per unit-iteration; eight tiles lose again).
 static int tiles_per_wg(int64_t M, int32_t N) {
     const int64_t tiles = M / BM, nblk = (N + NB - 1) / NB;
-    const int64_t T = (tiles * nblk + 255) / 256;
+    int64_t T = (tiles * nblk + 255) / 256;
+    if (g_form != 0 && N % NB == 0) T = std::max<int64_t>(T, (tiles + 127) / 128);
     return (int)(T < 1 ? 1 : T);
 }
 
@@ -222,6 +519,14 @@ static int tiles_per_wg(int64_t M, int32_t N) {
 int rdo_unit1x1_nslab(int64_t M, int32_t N) {
     const int64_t tiles = M / BM, T = tiles_per_wg(M, N);
     return (int)((tiles + T - 1) / T);
+}
+
+// 1 (default): Cout in blocks of 96 runs the split-fp16 form; 0: always the exact fp32 form.  Returns the previous setting.  Process-wide;
+// rdo_unit1x1_nslab follows it, so switch before the slabs of a unit are sized, not between a unit's launches.
+int rdo_unit1x1_form(int32_t form) {
+    const int was = g_form;
+    if (form == 0 || form == 1) g_form = form;
+    return was;
 }
 
 int rdo_unit1x1(const float* x, int64_t M, int32_t K, int32_t N, const float* w, const float* bias, const float* tgt_cache,
@@ -241,23 +546,30 @@ int rdo_unit1x1(const float* x, int64_t M, int32_t K, int32_t N, const float* w,
     const float inv_npix = (float)(1.0 / (double)M);
     a.gs = coef * 2.f * inv_npix;
     a.loss_scale = inv_npix * coef;
-    const size_t lds = sizeof(float) * ((size_t)(2 * BM + NB) * (K + 4) + (size_t)BM * (NB + 4));
+    const bool h2 = h2_form(N, K, B);
+    const size_t lds = h2 ? h2_lds_bytes(K) : sizeof(float) * ((size_t)(2 * BM + NB) * (K + 4) + (size_t)BM * (NB + 4));
     const double flops = 4.0 * (double)M * K * N;
     const double bytes = 4.0 * ((double)M * K + (double)M * N + (double)N * K * (1.0 + nslab));
     return rdo::dispatch(
-        [a, lds, nslab](hipStream_t s) {
+        [a, lds, nslab, h2](hipStream_t s) {
             static rdo::PerDevice attr;
             if (!attr.done()) {
                 if (hipFuncSetAttribute(reinterpret_cast<const void*>(unit1x1_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(sizeof(float) * ((size_t)(2 * BM + NB) * (KMAX + 4) + (size_t)BM * (NB + 4)))) != hipSuccess)
+                                        (int)(sizeof(float) * ((size_t)(2 * BM + NB) * (KMAX + 4) + (size_t)BM * (NB + 4)))) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(unit1x1_h2_kernel<6>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)h2_lds_bytes(192)) != hipSuccess ||
+                    hipFuncSetAttribute(reinterpret_cast<const void*>(unit1x1_h2_kernel<3>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)h2_lds_bytes(96)) != hipSuccess)
                     return rdo::set_error(RDO_EHIP, "hipFuncSetAttribute(unit1x1) failed");
                 attr.mark();
             }
             dim3 grid((unsigned)nslab, (unsigned)rdo::ceil_div(a.N, NB));
-            hipLaunchKernelGGL(unit1x1_kernel, grid, dim3(256), lds, s, a);
+            if (h2 && a.K == 192) hipLaunchKernelGGL(unit1x1_h2_kernel<6>, grid, dim3(256), lds, s, a);
+            else if (h2) hipLaunchKernelGGL(unit1x1_h2_kernel<3>, grid, dim3(256), lds, s, a);
+            else hipLaunchKernelGGL(unit1x1_kernel, grid, dim3(256), lds, s, a);
             return rdo::check_launch("unit1x1");
         },
-        stream, "unit1x1", flops, bytes);
+        stream, h2 ? "unit1x1_h2" : "unit1x1", flops, bytes);
 }
 
 }  // extern "C"

@@ -70,6 +70,7 @@ _SIGS = {
     "rdo_iter_bind_publish": (C.c_int, [P]),
     "rdo_unit1x1_supported": (C.c_int, [C.c_int64, C.c_int32, C.c_int32]),
     "rdo_unit1x1_nslab": (C.c_int, [C.c_int64, C.c_int32]),
+    "rdo_unit1x1_form": (C.c_int, [C.c_int32]),
     "rdo_unit1x1": (C.c_int, [P, C.c_int64, C.c_int32, C.c_int32, P, P, P, P, P, C.c_int32, C.c_float, C.c_int32, P, C.c_int32, P, P]),
     "rdo_adaround_grad": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, P, C.c_int, P, P]),
     "rdo_adaround_apply": (C.c_int, [C.POINTER(AdaDesc), P, P, P, P, C.c_float, C.c_float, P, P, P, P, P, P, P, P, P, P, C.c_float, C.c_float, P]),

@@ -229,6 +229,11 @@ def unit1x1_nslab(M, N):
     return int(L.lib().rdo_unit1x1_nslab(int(M), int(N)))
 
 
+def unit1x1_form(form):
+    """1: split-fp16 form of rdo_unit1x1 where Cout is a multiple of 96 (default); 0: always the exact fp32 form.  -> previous setting."""
+    return int(L.lib().rdo_unit1x1_form(int(form)))
+
+
 def unit1x1(x, w, bias, tgt_cache, idx_table, iter_ptr, coef, act, loss_log, slabs):
     """One launch for a 1 x 1 layer unit's data path (include/rdo_ptq_hip.h: rdo_unit1x1): x [B, H, W, K] mini-batch, w [N, 1, 1, K] soft
     weights -> loss into `loss_log`, weight-gradient slabs [nslab, N, 1, 1, K]."""

@@ -618,12 +618,15 @@ def test_step_launch_assembles_the_next_mini_batch(planes):
             assert bool((out == 7.0).all()) and (xp is None or bool((xp.t == 77).all()))     # behind the last iteration: nothing is gathered
 
 
-@pytest.mark.parametrize("B,H,K,N,act", [(4, 16, 192, 96, 2), (4, 16, 96, 192, 0), (2, 8, 96, 96, 1), (4, 64, 192, 96, 2), (4, 64, 192, 192, 0),
-                                         (3, 16, 64, 32, 1)])
-def test_unit1x1_matches_float64(B, H, K, N, act):
+@pytest.mark.parametrize("form", [1, 0])
+@pytest.mark.parametrize("B,H,K,N,act,spread", [(4, 16, 192, 96, 2, 0), (4, 16, 96, 192, 0, 0), (2, 8, 96, 96, 1, 1), (4, 64, 192, 96, 2, 1),
+                                                (4, 64, 192, 192, 0, 0), (4, 64, 96, 192, 1, 1), (3, 16, 64, 32, 1, 0), (4, 32, 160, 288, 2, 1)])
+def test_unit1x1_matches_float64(B, H, K, N, act, spread, form):
     """rdo_unit1x1 (round 6): forward of a 1 x 1 conv with bias, activation, 2 x lp_loss against the cached target rows picked by the
     device index table, activation backward and the weight-gradient slabs in one launch, against float64 -- loss to 1e-6 relative, the
-    summed slabs to 2e-6 of the largest gradient entry (exact fp32 MFMA: an fmaf chain per accumulator)."""
+    summed slabs to 2e-6 of the largest gradient entry.  Both forms: split-fp16 with on-the-fly scales (Cout in blocks of 96) and exact
+    fp32 MFMA (an fmaf chain per accumulator).  `spread`: token magnitudes over several decades, channel scales over two, targets 1e-2 from
+    the outputs (small residuals) -- what per-token / per-channel / per-tile scales are for."""
     from hipops import ops
     import torch.nn.functional as F
     g = torch.Generator().manual_seed(B + H + K + N)
@@ -633,13 +636,24 @@ def test_unit1x1_matches_float64(B, H, K, N, act):
     b = torch.randn(N, generator=g) * 0.1
     tgt = torch.randn(n_img, H, H, N, generator=g)
     idx = torch.stack([torch.randperm(n_img, generator=g)[:B] for _ in range(3)]).to(torch.int32)
+    if spread:
+        x = x * torch.exp(2.5 * torch.randn(B, H, H, 1, generator=g))
+        w = w * torch.exp(1.5 * torch.randn(N, 1, 1, 1, generator=g))
+        with torch.no_grad():
+            pre = (x.double().reshape(-1, K) @ w.double().reshape(N, K).t() + b.double()).reshape(B, H, H, N)
+            out = {0: pre, 1: F.leaky_relu(pre, 0.01), 2: F.relu(pre)}[act]
+            tgt[idx[1].long()] = (out * (1 + 1e-2 * torch.randn(out.shape, generator=g, dtype=torch.float64))).float()
     it = torch.tensor([1], dtype=torch.int32)
     assert ops.unit1x1_supported(B * H * H, K, N)
-    ns = ops.unit1x1_nslab(B * H * H, N)
-    slabs = torch.full((ns, N, 1, 1, K), 7.0, device="cuda")
-    log = torch.zeros(3, 32, device="cuda")
-    ops.unit1x1(x.cuda(), w.cuda(), b.cuda(), tgt.cuda(), idx.cuda(), it.cuda(), 2.0, act, log, slabs)
-    torch.cuda.synchronize()
+    was = ops.unit1x1_form(form)
+    try:
+        ns = ops.unit1x1_nslab(B * H * H, N)
+        slabs = torch.full((ns, N, 1, 1, K), 7.0, device="cuda")
+        log = torch.zeros(3, 32, device="cuda")
+        ops.unit1x1(x.cuda(), w.cuda(), b.cuda(), tgt.cuda(), idx.cuda(), it.cuda(), 2.0, act, log, slabs)
+        torch.cuda.synchronize()
+    finally:
+        ops.unit1x1_form(was)
     x64 = x.double().reshape(-1, K)
     w64 = w.double().reshape(N, K).requires_grad_(True)
     pre = x64 @ w64.t() + b.double()
@@ -649,6 +663,10 @@ def test_unit1x1_matches_float64(B, H, K, N, act):
     loss.backward()
     got_loss = float(log[1].sum())
     assert float(log[0].abs().sum()) == 0.0 and float(log[2].abs().sum()) == 0.0
-    assert abs(got_loss - float(loss)) <= 1e-6 * abs(float(loss)) + 1e-9
+    # (with targets 1e-2 from the outputs the residual itself carries the fp32 rounding of `out`: the loss is a sum of squares of
+    # differences of nearly equal numbers, so its bar is looser there -- for both forms alike)
+    assert abs(got_loss - float(loss)) <= (2e-4 if spread else 1e-6) * abs(float(loss)) + 1e-9, (got_loss, float(loss))
     gw = slabs.double().sum(0).reshape(N, K).cpu()
-    assert float((gw - w64.grad).abs().max()) <= 2e-6 * float(w64.grad.abs().max())
+    err = float((gw - w64.grad).abs().max()) / float(w64.grad.abs().max())
+    print(f"form {form} B {B} {H}x{H} {K}->{N} act {act} spread {spread}: loss rel {abs(got_loss - float(loss)) / abs(float(loss)):.2e}, grad {err:.2e}")
+    assert err <= (2e-4 if spread else 2e-6)

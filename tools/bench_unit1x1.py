@@ -32,8 +32,13 @@ for B, H, K, N in [(4, 64, 192, 96), (4, 64, 96, 192), (4, 64, 192, 192), (4, 16
     idx = torch.stack([torch.randperm(B + 4)[:B] for _ in range(2)]).to(torch.int32).cuda()
     it = torch.zeros(1, dtype=torch.int32, device="cuda")
     log = torch.zeros(2, 32, device="cuda")
-    slabs = torch.empty(ops.unit1x1_nslab(B * H * H, N), N, 1, 1, K, device="cuda")
-    t1 = timeit(lambda: ops.unit1x1(x, w, b, tgt, idx, it, 2.0, 2, log, slabs))
+    ts = {}
+    for form in (0, 1):
+        was = ops.unit1x1_form(form)
+        slabs = torch.empty(ops.unit1x1_nslab(B * H * H, N), N, 1, 1, K, device="cuda")
+        ts[form] = timeit(lambda: ops.unit1x1(x, w, b, tgt, idx, it, 2.0, 2, log, slabs))
+        ops.unit1x1_form(was)
+    t1 = ts[0]
     y, dpre = torch.empty(B, H, H, N, device="cuda"), torch.empty(B, H, H, N, device="cuda")
 
     def three():
@@ -41,4 +46,4 @@ for B, H, K, N in [(4, 64, 192, 96), (4, 64, 96, 192), (4, 64, 192, 192), (4, 16
         ops.loss_act_bwd(y, None, tgt, idx, it, 2.0, ops.ACT_RELU, log, dpre=dpre)
         ops.conv2d_wgrad(x, dpre, tuple(w.shape), 1, 0)
     t3 = timeit(three)
-    print(f"B {B} {H}x{H} {K}->{N}: unit1x1 {t1:6.1f} us ({slabs.shape[0]} slabs) | conv + tail + wgrad {t3:6.1f} us (back to back, eager)")
+    print(f"B {B} {H}x{H} {K}->{N}: unit1x1 fp32 {t1:6.1f} us, split-fp16 {ts[1]:6.1f} us ({slabs.shape[0]} slabs) | conv + tail + wgrad {t3:6.1f} us (back to back, eager)")
