@@ -51,7 +51,7 @@ ACHIEVABLE_HBM_GBS = 6300.0       # same guide: 6.29 TB/s measured with a float4
 _H2 = (PEAK_BF16_MFMA_TFLOPS / 3.0, "fp16 dense MFMA peak 2500 TFLOP/s / 3 products per fp32-equivalent MAC")
 _X6 = (PEAK_BF16_MFMA_TFLOPS / 6.0, "bf16 dense MFMA peak 2500 TFLOP/s / 6 products per fp32-equivalent MAC")
 _F32 = (PEAK_F32_MFMA_TFLOPS, "fp32 MFMA peak")
-KERNEL_FAMILIES = (("conv_fwd_h2", _H2), ("conv_wgrad_h2", _H2), ("linear_h2", _H2), ("linear_wgrad_h2", _H2), ("win_attn_h2", _H2),
+KERNEL_FAMILIES = (("conv_fwd_h2", _H2), ("conv_wgrad_h2", _H2), ("linear_h2", _H2), ("linear_wgrad_h2", _H2), ("win_attn_h2", _H2), ("unit1x1_h2", _H2),
                    ("conv_fwd_x6", _X6), ("conv_wgrad_x6", _X6))
 
 
