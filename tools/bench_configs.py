@@ -15,9 +15,11 @@ for p in (os.path.join(ROOT, "rdo-ptq_amd"), ROOT, os.path.join(ROOT, "tools")):
         sys.path.insert(0, p)
 
 
-def attn_w10(images=16, iters=60, batch=4, log=print):
-    """BASELINE config 3 on one GPU: Cheng2020-attn N=192, W10 channel-wise weights, the whole recon_model schedule (108 units) for a few
-    iterations per unit through the public API; ms per step (one iteration of every unit) from the loop share of the wall."""
+def attn_w10(images=16, iters=320, batch=4, log=print):
+    """BASELINE config 3 on one GPU: Cheng2020-attn N=192, W10 channel-wise weights, the whole recon_model schedule (105 units) for a few
+    hundred iterations per unit through the public API; ms per step (one iteration of every unit) from the loop share of the wall.
+    (320 iterations since round 6: with 60, the first replay of each of the 105 captured graphs -- the upload of the graph -- was 0.25 ms
+    of the 8.6 ms "step"; the reference's schedule runs 20 000 per unit, tools/full_schedule.py times that: 8.375.)"""
     from full_schedule import run_schedule
     r = run_schedule(images=images, iters=iters, batch=batch, log=log, quality=False, arch="attn", w_bits=10, a_bits=10, per_unit_log=False, roofline=True)
     rf = r["roofline"]
