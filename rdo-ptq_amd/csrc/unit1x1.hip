@@ -233,6 +233,19 @@ __device__ __forceinline__ float amax4(const f32x4& v, float m) {
 // workgroup barrier for LDS traffic only: __syncthreads() also drains vmcnt, i.e. waits for the tile prefetched for the NEXT iteration
 // (measured: 3.4 us per token tile with everything but the loads and the barriers switched off)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ unsigned pk2(_Float16 a, _Float16 b) { return __builtin_bit_cast(unsigned, f16x2{a, b}); }
+// Transposed stores two tokens at a time.  Lane `odd` and its partner (DPP control `CTRL`: the lane whose token is the neighbour) each hold
+// the values v0 v1 | v2 v3 of ONE token for four consecutive rows; after one exchange the even lane owns rows 0, 1 and the odd lane rows
+// 2, 3 for BOTH tokens: w0 / w1 = (even token, odd token) of the lane's two rows -- two ds_write_b32 instead of four ds_write_b16.
+template <int CTRL>
+__device__ __forceinline__ void pair_rows(unsigned p01, unsigned p23, bool odd, unsigned& w0, unsigned& w1) {
+    const unsigned send = odd ? p01 : p23;
+    const unsigned recv = (unsigned)__builtin_amdgcn_update_dpp(0, (int)send, CTRL, 0xf, 0xf, false);
+    const unsigned keep = odd ? p23 : p01;
+    const unsigned ev = odd ? recv : keep, od = odd ? keep : recv;
+    w0 = (ev & 0xffffu) | (od << 16);
+    w1 = (ev >> 16) | (od & 0xffff0000u);
+}
 __device__ __forceinline__ void split1(float x, _Float16& h, _Float16& l) {
     h = (_Float16)x;
     l = (_Float16)(x - (float)h);
@@ -280,12 +293,22 @@ __global__ __launch_bounds__(256) void unit1x1_h2_kernel(U1Args a) {
                 _Float16 hh, ll;
                 split1(xv[j][e4] * s, hh, ll);
                 h[e4] = hh; l[e4] = ll;
-                const int k = c0 + 32 * j + e4;
-                xt[k * ST + r0] = hh;
-                xt[(K + k) * ST + r0] = ll;
             }
             *reinterpret_cast<f16x4*>(xh + r0 * SX + c0 + 32 * j) = h;
             *reinterpret_cast<f16x4*>(xh + (BM + r0) * SX + c0 + 32 * j) = l;
+            // transposed: rows k, tokens (r0 & ~1, r0 | 1) as one dword at position r0 >> 1, its 16-byte group XORed with (k >> 4) & 3
+            // (lanes q and q + 4 of a row write rows 16 apart = the same bank otherwise); row_ror:8 = the lane of the neighbouring token
+            const bool odd = (r0 & 1) != 0;
+            const int k = c0 + 32 * j + (odd ? 2 : 0), tp = r0 >> 1;
+            const int pos = ((((tp >> 2) ^ (k >> 4)) & 3) << 2) | (tp & 3);
+            unsigned w0, w1;
+            pair_rows<0x128>(pk2(h[0], h[1]), pk2(h[2], h[3]), odd, w0, w1);
+            unsigned* xt32 = reinterpret_cast<unsigned*>(xt);
+            xt32[k * (ST / 2) + pos] = w0;
+            xt32[(k + 1) * (ST / 2) + pos] = w1;
+            pair_rows<0x128>(pk2(l[0], l[1]), pk2(l[2], l[3]), odd, w0, w1);
+            xt32[(K + k) * (ST / 2) + pos] = w0;
+            xt32[(K + k + 1) * (ST / 2) + pos] = w1;
         }
     };
 
@@ -426,15 +449,22 @@ __global__ __launch_bounds__(256) void unit1x1_h2_kernel(U1Args a) {
         }
         const float sd = pow2f(de);
 #pragma unroll
-        for (int ct = 0; ct < 3; ++ct)
+        for (int ct = 0; ct < 3; ++ct) {
+            _Float16 hh[4], ll[4];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                _Float16 hh, ll;
-                split1(acc[ct][i] * sd, hh, ll);
-                const int nl = 48 * cg + 16 * ct + 4 * kg + i;
-                DT[nl * ST + tok] = hh;
-                DT[(NB + nl) * ST + tok] = ll;
-            }
+            for (int i = 0; i < 4; ++i) split1(acc[ct][i] * sd, hh[i], ll[i]);
+            // rows 4 kg + {0..3}, tokens (tok & ~1, tok | 1) as one dword (quad_perm [1,0,3,2] = the lane of the neighbouring token)
+            const bool odd = (l16 & 1) != 0;
+            const int nl = 48 * cg + 16 * ct + 4 * kg + (odd ? 2 : 0), tp = tok >> 1;
+            unsigned w0, w1;
+            unsigned* dt32 = reinterpret_cast<unsigned*>(DT);
+            pair_rows<0xB1>(pk2(hh[0], hh[1]), pk2(hh[2], hh[3]), odd, w0, w1);
+            dt32[nl * (ST / 2) + tp] = w0;
+            dt32[(nl + 1) * (ST / 2) + tp] = w1;
+            pair_rows<0xB1>(pk2(ll[0], ll[1]), pk2(ll[2], ll[3]), odd, w0, w1);
+            dt32[(NB + nl) * (ST / 2) + tp] = w0;
+            dt32[(NB + nl + 1) * (ST / 2) + tp] = w1;
+        }
         // the next tile (requested one iteration ago) goes into the other buffer; the one behind it is requested
         if constexpr (!LAST) {
             deposit(cur ^ 1);
@@ -446,8 +476,8 @@ __global__ __launch_bounds__(256) void unit1x1_h2_kernel(U1Args a) {
 #pragma unroll
         for (int u = 0; u < KU; ++u) {
             const int kt = (wave + 4 * u < ktiles) ? wave + 4 * u : wave;          // (a wave without a u-th block re-reads its first)
-            bx[u][0] = *reinterpret_cast<const f16x8*>(xt + (16 * kt + l16) * ST + 8 * kg);
-            bx[u][1] = *reinterpret_cast<const f16x8*>(xt + (K + 16 * kt + l16) * ST + 8 * kg);
+            bx[u][0] = *reinterpret_cast<const f16x8*>(xt + (16 * kt + l16) * ST + 8 * ((kg ^ kt) & 3));
+            bx[u][1] = *reinterpret_cast<const f16x8*>(xt + (K + 16 * kt + l16) * ST + 8 * ((kg ^ kt) & 3));
         }
 #pragma unroll
         for (int nt = 0; nt < 6; ++nt) {
