@@ -173,6 +173,9 @@ def test_attention_block_layer_units_n192_w10_match_oracle(attn192, name, act, i
     np.testing.assert_array_equal(e.zp.cpu().numpy(), op.zp.reshape(-1).numpy())
     eng.run()
     torch.cuda.synchronize()
+    tags = [t for t, _, _ in eng.plan_a.op_info()]
+    if mod.kernel_size == (1, 1):        # the 1 x 1 units run the one-launch kernel in its split-fp16 form (round 6), nothing else in front of the step
+        assert "unit1x1_h2" in tags and not any(t.startswith("conv_") or t.startswith("loss_") for t in tags), tags
     total, rt, rd = eng.logs()
     a_gpu, a_ref = eng.alpha_of("layer").cpu(), op.alpha
     if iters > 50:
