@@ -5,4 +5,4 @@ R=$GRAFT_REPO_ROOT
 mkdir -p $R/gpurun_out/prof_attn
 timeout 900 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_attn -o attn --output-format csv -- python3 $R/tools/full_schedule.py --arch attn --w-bits 10 --a-bits 10 --images 16 --iters 200 --no-quality --json $R/gpurun_out/prof_attn/schedule.json > $R/gpurun_out/prof_attn/log.txt 2>&1
 echo rc=$?
-cp $(find $R/gpurun_out/prof_attn -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r05_attn_w10_kernel_stats.csv
+cp $(find $R/gpurun_out/prof_attn -name "*kernel_stats.csv" | head -1) $R/gpurun_out/r06f_attn_w10_kernel_stats.csv
