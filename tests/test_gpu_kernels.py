@@ -670,3 +670,41 @@ def test_unit1x1_matches_float64(B, H, K, N, act, spread, form):
     err = float((gw - w64.grad).abs().max()) / float(w64.grad.abs().max())
     print(f"form {form} B {B} {H}x{H} {K}->{N} act {act} spread {spread}: loss rel {abs(got_loss - float(loss)) / abs(float(loss)):.2e}, grad {err:.2e}")
     assert err <= (2e-4 if spread else 2e-6)
+
+
+@pytest.mark.parametrize("form", [1, 0])
+def test_unit1x1_ragged_last_chunk(form):
+    """290 token tiles over chunks of 3 (97 slabs, the last chunk holds two tiles) and a second block of output channels: the workgroups of
+    the last chunk stop behind their tokens (the split-fp16 form re-requests its last tile instead of reading past the mini-batch), every
+    slab is written, and the summed gradient is float64's."""
+    from hipops import ops
+    B, Hh, Ww, K, N = 5, 32, 58, 192, 192
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, Hh, Ww, K, generator=g)
+    w = torch.randn(N, 1, 1, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g) * 0.1
+    tgt = torch.randn(B + 1, Hh, Ww, N, generator=g)
+    idx = torch.stack([torch.randperm(B + 1, generator=g)[:B] for _ in range(2)]).to(torch.int32)
+    it = torch.tensor([1], dtype=torch.int32)
+    M = B * Hh * Ww
+    was = ops.unit1x1_form(form)
+    try:
+        ns = ops.unit1x1_nslab(M, N)
+        assert (M // 32) % ((M // 32 + ns - 1) // ns) != 0           # the last chunk really is short
+        slabs = torch.full((ns, N, 1, 1, K), float("nan"), device="cuda")
+        guard = torch.full((4096,), 3.0, device="cuda")              # (allocated right behind x on the device: not a proof, a tripwire)
+        xg = x.cuda()
+        log = torch.zeros(2, 32, device="cuda")
+        ops.unit1x1(xg, w.cuda(), b.cuda(), tgt.cuda(), idx.cuda(), it.cuda(), 2.0, 1, log, slabs)
+        torch.cuda.synchronize()
+    finally:
+        ops.unit1x1_form(was)
+    assert bool(torch.isfinite(slabs).all()) and bool((guard == 3.0).all())
+    x64, w64 = x.double().reshape(-1, K), w.double().reshape(N, K).requires_grad_(True)
+    pre = x64 @ w64.t() + b.double()
+    out = torch.nn.functional.leaky_relu(pre, 0.01)
+    loss = 2.0 * ((out - tgt[idx[1].long()].double().reshape(-1, N)) ** 2).sum(1).mean()
+    loss.backward()
+    assert abs(float(log[1].sum()) - float(loss)) <= 1e-6 * float(loss)
+    gw = slabs.double().sum(0).reshape(N, K).cpu()
+    assert float((gw - w64.grad).abs().max()) <= 2e-6 * float(w64.grad.abs().max())
