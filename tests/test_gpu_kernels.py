@@ -696,6 +696,10 @@ def test_unit1x1_ragged_last_chunk(form):
         xg = x.cuda()
         log = torch.zeros(2, 32, device="cuda")
         ops.unit1x1(xg, w.cuda(), b.cuda(), tgt.cuda(), idx.cuda(), it.cuda(), 2.0, 1, log, slabs)
+        again = torch.empty_like(slabs)
+        for _ in range(3):                                           # fixed summation order: the slabs are bit-reproducible
+            ops.unit1x1(xg, w.cuda(), b.cuda(), tgt.cuda(), idx.cuda(), it.cuda(), 2.0, 1, torch.zeros_like(log), again)
+            assert torch.equal(again, slabs)
         torch.cuda.synchronize()
     finally:
         ops.unit1x1_form(was)
